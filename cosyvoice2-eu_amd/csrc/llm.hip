@@ -1,0 +1,561 @@
+// Stage 1 on MI355X: Qwen2-0.5B speech-token LM decode (replaces cosyvoice/llm/llm.py:575-719 and the HF
+// Qwen2ForCausalLM forward it calls at llm.py:107-117).
+//
+// One decode step = 5 kernels per layer + head + sampler, captured in a hipGraph per batch size:
+//   k_qkv    : [sum partials -> x] RMSNorm -> QKV skinny GEMM -> +bias -> RoPE -> q buffer / KV cache write
+//   k_attn   : GQA decode attention over the fp32 KV cache
+//   k_oproj  : O projection (output kept separate; the residual add happens in k_gateup's prologue)
+//   k_gateup : [x + o -> x_mid] RMSNorm -> gate/up skinny GEMM -> SiLU(g)*u
+//   k_down   : down projection, split-K partials (summed by the next k_qkv / k_head prologue)
+//   k_head   : final RMSNorm -> llm_decoder GEMV + bias -> logits
+//   k_sample : log-softmax, EOS rules, greedy or RAS draw, token bookkeeping, next input embedding gather
+// All are HBM-bound weight streams (skinny.h); the per-step algorithmic traffic is the bf16 weights once
+// (727.6 MB at the real dims) plus the KV read.
+#include "skinny.h"
+#include "../../include/cv2_amd.h"
+#include <map>
+#include <stdarg.h>
+#include <vector>
+
+thread_local std::string g_cv2_err;
+int cv2_fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_cv2_err = buf;
+    return -1;
+}
+extern "C" const char* cv2_last_error(void) { return g_cv2_err.c_str(); }
+extern "C" int cv2_version(void) { return 1; }
+
+#define ST CV2_LLM_STATE_STRIDE
+
+struct RowMap {          // row r of a launch -> (sequence slot, position)
+    const int* state;    // decode: seq = r, pos = state[r][POS]
+    int prefill;         // prefill: seq = seq0, pos = pos0 + r
+    int seq0, pos0;
+    __device__ __forceinline__ void get(int r, int& seq, int& pos) const {
+        if (prefill) { seq = seq0; pos = pos0 + r; }
+        else { seq = r; pos = state[r * ST + CV2_ST_POS]; }
+    }
+};
+
+// ------------------------------------------------------------------ k_qkv
+struct QkvArgs {
+    const uint16_t* W; const float* bias;
+    SkinnyX X; int KS, rows, K;
+    int n_q, n_kv;
+    const float* cosT; const float* sinT;       // [max_pos][32]
+    float* q;                                   // [rows][n_q*64]
+    float* kc; float* vc;                       // this layer's cache: [max_seqs][n_kv][max_pos][64]
+    int max_pos;
+    RowMap rm;
+};
+template <int NB>
+__global__ __launch_bounds__(1024) void k_qkv(QkvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* res = skinny_core<NB, 4, 4>(a.W, a.KS, a.rows, a.K, a.X, smem);
+    const int head = blockIdx.x;                 // 0..n_q-1 q heads, then k heads, then v heads
+    const int ld = NB * 16 + 1;
+    for (int e = threadIdx.x; e < a.rows * 64; e += blockDim.x) {
+        const int r = e >> 6, i = e & 63;
+        int seq, pos;
+        a.rm.get(r, seq, pos);
+        float v = res[i * ld + r] + a.bias[head * 64 + i];
+        if (head < a.n_q + a.n_kv) {             // rotate-half RoPE on q and k heads
+            const int ip = i ^ 32;
+            const float vp = res[ip * ld + r] + a.bias[head * 64 + ip];
+            const float c = a.cosT[pos * 32 + (i & 31)], s = a.sinT[pos * 32 + (i & 31)];
+            v = (i < 32) ? (v * c - vp * s) : (v * c + vp * s);
+        }
+        if (head < a.n_q) a.q[(size_t)r * a.n_q * 64 + head * 64 + i] = v;
+        else if (head < a.n_q + a.n_kv)
+            a.kc[(((size_t)seq * a.n_kv + (head - a.n_q)) * a.max_pos + pos) * 64 + i] = v;
+        else
+            a.vc[(((size_t)seq * a.n_kv + (head - a.n_q - a.n_kv)) * a.max_pos + pos) * 64 + i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ k_attn (decode / prefill rows)
+struct AttnArgs {
+    const float* q; const float* kc; const float* vc; float* out;   // out [rows][n_q*64]
+    int n_q, n_kv, max_pos;
+    RowMap rm;
+};
+__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem);                 // [L]
+    __shared__ float redbuf[8];
+    __shared__ float obuf[4][64];
+    const int h = blockIdx.x, r = blockIdx.y;
+    int seq, pos;
+    a.rm.get(r, seq, pos);
+    const int L = pos + 1;
+    const int kvh = h / (a.n_q / a.n_kv);
+    const float* K = a.kc + ((size_t)seq * a.n_kv + kvh) * a.max_pos * 64;
+    const float* V = a.vc + ((size_t)seq * a.n_kv + kvh) * a.max_pos * 64;
+    const int tid = threadIdx.x, l16 = tid & 15, g = tid >> 4;
+    const float4 qv = reinterpret_cast<const float4*>(a.q + (size_t)r * a.n_q * 64 + h * 64)[l16];
+    float lmax = -INFINITY;
+    for (int j = g; j < L; j += 16) {
+        const float4 kv = reinterpret_cast<const float4*>(K + (size_t)j * 64)[l16];
+        float d = qv.x * kv.x + qv.y * kv.y + qv.z * kv.z + qv.w * kv.w;
+        d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
+        d *= 0.125f;
+        if (l16 == 0) sc[j] = d;
+        lmax = fmaxf(lmax, d);
+    }
+    lmax = wave_max(lmax);
+    if ((tid & 63) == 0) redbuf[tid >> 6] = lmax;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(redbuf[0], redbuf[1]), fmaxf(redbuf[2], redbuf[3]));
+    float lsum = 0.f;
+    for (int j = tid; j < L; j += 256) {
+        const float p = __expf(sc[j] - m);
+        sc[j] = p;
+        lsum += p;
+    }
+    lsum = wave_sum(lsum);
+    if ((tid & 63) == 0) redbuf[4 + (tid >> 6)] = lsum;
+    __syncthreads();
+    const float denom = redbuf[4] + redbuf[5] + redbuf[6] + redbuf[7];
+    const int w = tid >> 6, d = tid & 63;
+    float o = 0.f;
+    for (int j = w; j < L; j += 4) o += sc[j] * V[(size_t)j * 64 + d];
+    obuf[w][d] = o;
+    __syncthreads();
+    if (w == 0) a.out[(size_t)r * a.n_q * 64 + h * 64 + d] = (obuf[0][d] + obuf[1][d] + obuf[2][d] + obuf[3][d]) / denom;
+}
+
+// ------------------------------------------------------------------ generic store epilogue (o-proj, down, head)
+struct StoreArgs {
+    const uint16_t* W; const float* bias;       // bias may be null
+    SkinnyX X; int KS, rows, K, N;
+    float* out;                                 // gridDim.y == 1: [rows][N]; else partials [gridDim.y][SK_ROWS_CAP][N]
+};
+template <int NB, int NWR, int NWK>
+__global__ __launch_bounds__(64 * NWR * NWK) void k_store(StoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* res = skinny_core<NB, NWR, NWK>(a.W, a.KS, a.rows, a.K, a.X, smem);
+    const int ld = NB * 16 + 1;
+    const int n0 = blockIdx.x * NWR * 16;
+    float* out = a.out + (gridDim.y > 1 ? (size_t)blockIdx.y * SK_ROWS_CAP * a.N : 0);
+    for (int e = threadIdx.x; e < a.rows * NWR * 16; e += blockDim.x) {
+        const int r = e / (NWR * 16), i = e % (NWR * 16);
+        if (n0 + i < a.N) {
+            float v = res[i * ld + r];
+            if (a.bias && blockIdx.y == 0) v += a.bias[n0 + i];
+            out[(size_t)r * a.N + n0 + i] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ k_gateup
+struct GateUpArgs {
+    const uint16_t* W; SkinnyX X; int KS, rows, K, inter;
+    float* h;                                   // [rows][inter]
+};
+template <int NB>
+__global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* res = skinny_core<NB, 2, 4>(a.W, a.KS, a.rows, a.K, a.X, smem);   // rows 0-15 gate, 16-31 up
+    const int ld = NB * 16 + 1;
+    for (int e = threadIdx.x; e < a.rows * 16; e += blockDim.x) {
+        const int r = e >> 4, i = e & 15;
+        const float g = res[i * ld + r], u = res[(16 + i) * ld + r];
+        a.h[(size_t)r * a.inter + blockIdx.x * 16 + i] = (g / (1.f + __expf(-g))) * u;
+    }
+}
+
+// ------------------------------------------------------------------ k_sample
+// Philox4x32-10, the same function as cv2amd/philox.py (counter = (seq, step, trial, 0), key = seed)
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                           uint32_t out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+    return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+struct SampleArgs {
+    const float* logits; int ldl;               // [rows][ldl]
+    int* state; int* out_tokens; int max_out;
+    const float* speech_emb; float* x_next; int hidden;
+    int vocab, eos, max_pos;
+    int prefill_seq, row, prefill_pos;          // prefill: one block, reads logits row `row`, updates slot prefill_seq,
+};                                              // whose next KV position becomes prefill_pos (= prompt length)
+#define SM_T 256
+#define SM_TOPK 25
+__global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
+    __shared__ float lp[6592];
+    __shared__ float rv[SM_T];
+    __shared__ int ri[SM_T];
+    __shared__ double rd[SM_T];
+    __shared__ float candp[SM_TOPK];
+    __shared__ int candi[SM_TOPK];
+    __shared__ int s_top;
+    const int tid = threadIdx.x;
+    const int seq = a.prefill_seq >= 0 ? a.prefill_seq : blockIdx.x;
+    const int row = a.prefill_seq >= 0 ? a.row : blockIdx.x;
+    int* st = a.state + seq * ST;
+    const int done = st[CV2_ST_DONE];
+    const int step = st[CV2_ST_STEP];
+    const int V = a.vocab;
+    if (!done) {
+        // log_softmax (llm.py:690)
+        const float* lg = a.logits + (size_t)row * a.ldl;
+        float m = -INFINITY;
+        for (int i = tid; i < V; i += SM_T) { const float v = lg[i]; lp[i] = v; m = fmaxf(m, v); }
+        rv[tid] = m; __syncthreads();
+        for (int s = SM_T / 2; s > 0; s >>= 1) { if (tid < s) rv[tid] = fmaxf(rv[tid], rv[tid + s]); __syncthreads(); }
+        m = rv[0]; __syncthreads();
+        float sum = 0.f;
+        for (int i = tid; i < V; i += SM_T) sum += __expf(lp[i] - m);
+        rv[tid] = sum; __syncthreads();
+        for (int s = SM_T / 2; s > 0; s >>= 1) { if (tid < s) rv[tid] += rv[tid + s]; __syncthreads(); }
+        const float lse = m + __logf(rv[0]); __syncthreads();
+        for (int i = tid; i < V; i += SM_T) lp[i] -= lse;
+        __syncthreads();
+        if (tid == 0) {
+            if (step == 0) lp[a.eos] = -INFINITY;                       // llm.py:693-694
+            if (st[CV2_ST_FORCE]) for (int i = a.eos; i < V; i++) lp[i] = -INFINITY;
+        }
+        __syncthreads();
+        const bool ignore_eos = step < st[CV2_ST_MINLEN];
+        const int mode = st[CV2_ST_MODE];
+        if (mode == 0) {
+            // greedy: argmax with EOS excluded while ignore_eos; ties -> lowest id
+            float bv = -INFINITY; int bi = 0x7fffffff;
+            for (int i = tid; i < V; i += SM_T) {
+                const float v = (ignore_eos && i == a.eos) ? -INFINITY : lp[i];
+                if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+            }
+            rv[tid] = bv; ri[tid] = bi; __syncthreads();
+            for (int s = SM_T / 2; s > 0; s >>= 1) {
+                if (tid < s) {
+                    if (rv[tid + s] > rv[tid] || (rv[tid + s] == rv[tid] && ri[tid + s] < ri[tid])) { rv[tid] = rv[tid + s]; ri[tid] = ri[tid + s]; }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) s_top = ri[0];
+            __syncthreads();
+        } else {
+            // RAS (utils/common.py:111-139): top-p 0.8 / top-k 25 nucleus, repetition window 10, tau 0.1
+            // 1. stable descending top-25 of softmax = exp(logp)
+            for (int c = 0; c < SM_TOPK; c++) {
+                float bv = -INFINITY; int bi = 0x7fffffff;
+                for (int i = tid; i < V; i += SM_T) {
+                    const float v = lp[i];
+                    bool taken = false;
+                    for (int q = 0; q < c; q++) taken |= (candi[q] == i);
+                    if (!taken && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+                }
+                rv[tid] = bv; ri[tid] = bi; __syncthreads();
+                for (int s = SM_T / 2; s > 0; s >>= 1) {
+                    if (tid < s) {
+                        if (rv[tid + s] > rv[tid] || (rv[tid + s] == rv[tid] && ri[tid + s] < ri[tid])) { rv[tid] = rv[tid + s]; ri[tid] = ri[tid + s]; }
+                    }
+                    __syncthreads();
+                }
+                if (tid == 0) { candi[c] = ri[0]; candp[c] = __expf(rv[0]); }
+                __syncthreads();
+            }
+            // full-vocab cdf chunks for the repetition fallback (random_sampling)
+            const int chunk = (V + SM_T - 1) / SM_T;
+            double cs = 0.0;
+            for (int i = tid * chunk; i < min(V, (tid + 1) * chunk); i++) cs += (double)__expf(lp[i]);
+            rd[tid] = cs;
+            __syncthreads();
+            if (tid == 0) {
+                int ncand = 0; float cum = 0.f;
+                while (ncand < SM_TOPK && cum < 0.8f) { cum += candp[ncand]; ncand++; }
+                double tot = 0.0;
+                for (int i = 0; i < SM_T; i++) tot += rd[i];
+                const int nhist = st[CV2_ST_NOUT];
+                const int* hist = a.out_tokens + (size_t)seq * a.max_out;
+                int top = -1;
+                int trial = 0;
+                for (;;) {
+                    uint32_t rn[4];
+                    philox4x32((uint32_t)seq, (uint32_t)step, (uint32_t)trial, 0u, (uint32_t)st[CV2_ST_SEED_LO], (uint32_t)st[CV2_ST_SEED_HI], rn);
+                    const double u1 = u53(rn[0], rn[1]), u2 = u53(rn[2], rn[3]);
+                    // nucleus draw: inverse cdf over the candidate probabilities (float64 running sum)
+                    double csum = 0.0; for (int c = 0; c < ncand; c++) csum += (double)candp[c];
+                    double thr = u1 * csum, run = 0.0; int pick = ncand - 1;
+                    for (int c = 0; c < ncand; c++) { run += (double)candp[c]; if (run > thr) { pick = c; break; } }
+                    top = candi[pick];
+                    int rep = 0;
+                    for (int q = max(0, nhist - 10); q < nhist; q++) rep += (hist[q] == top);
+                    if (rep >= 1) {                                        // win_size * tau_r = 1
+                        thr = u2 * tot; run = 0.0; int ch = SM_T - 1;
+                        for (int i = 0; i < SM_T; i++) { if (run + rd[i] > thr) { ch = i; break; } run += rd[i]; }
+                        top = min(V, (ch + 1) * chunk) - 1;
+                        for (int i = ch * chunk; i < min(V, (ch + 1) * chunk); i++) { run += (double)__expf(lp[i]); if (run > thr) { top = i; break; } }
+                    }
+                    if (!ignore_eos || top != a.eos) break;
+                    if (++trial > 100) { st[CV2_ST_ERR] = 1; break; }
+                }
+                s_top = top;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const int top = done ? st[CV2_ST_LAST] : s_top;
+    // next input embedding (llm.py:711, 719); harmless for finished slots
+    for (int k = tid; k < a.hidden; k += SM_T) a.x_next[(size_t)seq * a.hidden + k] = a.speech_emb[(size_t)top * a.hidden + k];
+    if (tid == 0 && !done) {
+        int nout = st[CV2_ST_NOUT];
+        int fin = 0;
+        if (top == a.eos) fin = 1;                                        // llm.py:707-708
+        else if (top < a.eos) {                                           // normal token: emit
+            if (nout < a.max_out) a.out_tokens[(size_t)seq * a.max_out + nout] = top;
+            nout++;
+        }                                                                 // top > eos: fed back, not emitted (llm.py:712-714)
+        const int nstep = step + 1;
+        if (nstep >= st[CV2_ST_MAXLEN]) fin = 1;                          // for i in range(max_len)
+        if (st[CV2_ST_ERR]) fin = 1;
+        const int pos = a.prefill_seq >= 0 ? a.prefill_pos : st[CV2_ST_POS] + 1;
+        if (pos + 1 >= a.max_pos) fin = 1;
+        st[CV2_ST_NOUT] = nout; st[CV2_ST_STEP] = nstep; st[CV2_ST_LAST] = top; st[CV2_ST_DONE] = fin;
+        if (!fin || a.prefill_seq >= 0) st[CV2_ST_POS] = pos;    // a finished slot idles on its last position
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct cv2_llm {
+    cv2_llm_dims d;
+    std::vector<cv2_llm_layer> layers;
+    cv2_llm_weights w;
+    cv2_llm_io io;
+    // workspace carve
+    float *kc, *vc;            // [layers][max_seqs][n_kv][max_pos][64]
+    float *xa, *xb;            // residual ping-pong [32][hidden]
+    float *xnext;              // [32][hidden] next-step input embeddings, written by k_sample
+    float *q, *att, *o;        // [32][n_q*64], [32][n_q*64], [32][hidden]
+    float *hbuf;               // [32][inter]
+    float *parts;              // [8][32][hidden]
+    std::map<int, hipGraphExec_t> graphs;
+    hipStream_t cap_stream;    // private stream used only to capture the decode-step graph (the caller's may be the null stream)
+    int down_split;
+};
+
+static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return base ? base + o : (char*)nullptr; };
+    const size_t cache = (size_t)d.layers * d.max_seqs * d.n_kv * d.max_pos * 64 * sizeof(float);
+    char* p;
+    p = take(cache); if (h) h->kc = (float*)p;
+    p = take(cache); if (h) h->vc = (float*)p;
+    p = take((size_t)32 * d.hidden * 4); if (h) h->xa = (float*)p;
+    p = take((size_t)32 * d.hidden * 4); if (h) h->xb = (float*)p;
+    p = take((size_t)32 * d.hidden * 4); if (h) h->xnext = (float*)p;
+    p = take((size_t)32 * d.n_q * 64 * 4); if (h) h->q = (float*)p;
+    p = take((size_t)32 * d.n_q * 64 * 4); if (h) h->att = (float*)p;
+    p = take((size_t)32 * d.hidden * 4); if (h) h->o = (float*)p;
+    p = take((size_t)32 * d.inter * 4); if (h) h->hbuf = (float*)p;
+    p = take((size_t)8 * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
+    return off;
+}
+
+extern "C" size_t cv2_llm_workspace_bytes(const cv2_llm_dims* d) { return carve(*d, nullptr, nullptr); }
+
+template <typename F>
+static int set_smem(F f, size_t bytes) {
+    CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, const cv2_llm_io* io, void* ws, size_t ws_bytes,
+                              cv2_llm** out) {
+    CV2_CHECK(d && w && io && ws && out, "cv2_llm_create: null argument");
+    CV2_CHECK(d->hidden % 32 == 0 && d->inter % 32 == 0 && d->vocab_pad % 16 == 0, "cv2_llm_create: hidden/inter must be multiples of 32");
+    CV2_CHECK(d->n_q % d->n_kv == 0 && d->max_seqs >= 1 && d->max_seqs <= 32, "cv2_llm_create: bad head counts / max_seqs");
+    CV2_CHECK(d->vocab <= 6592 && d->eos < d->vocab, "cv2_llm_create: vocab too large for the sampler");
+    CV2_CHECK(ws_bytes >= cv2_llm_workspace_bytes(d), "cv2_llm_create: workspace too small (%zu < %zu)", ws_bytes, cv2_llm_workspace_bytes(d));
+    cv2_llm* h = new cv2_llm();
+    h->d = *d;
+    h->layers.assign(w->layers, w->layers + d->layers);
+    h->w = *w;
+    h->w.layers = h->layers.data();
+    h->io = *io;
+    carve(*d, h, (char*)ws);
+    h->down_split = 8;
+    h->cap_stream = nullptr;
+    if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return cv2_fail("cv2_llm_create: hipStreamCreateWithFlags failed");
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int cv2_llm_destroy(cv2_llm* h) {
+    if (!h) return 0;
+    for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.second);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    delete h;
+    return 0;
+}
+
+// one pass of the 24 layers + head over `rows` rows whose input embeddings sit in xin [rows][hidden]
+template <int NB>
+static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStream_t s) {
+    const cv2_llm_dims& d = h->d;
+    const int H = d.hidden, KSH = H / 32;
+    const size_t cache_l = (size_t)d.max_seqs * d.n_kv * d.max_pos * 64;
+    const float* xcur = xin;     // residual stream input of the layer (before adding pending down-proj partials)
+    int np = 0;                  // pending partial buffers to add to xcur
+    for (int l = 0; l < d.layers; l++) {
+        const cv2_llm_layer& L = h->layers[l];
+        float* x1 = (xcur == h->xa) ? h->xb : h->xa;          // x after folding partials
+        {
+            QkvArgs a{};
+            a.W = L.wqkv; a.bias = L.bqkv;
+            a.X = SkinnyX{xcur, h->parts, np, L.ln1, d.rms_eps, x1};
+            a.KS = KSH; a.rows = rows; a.K = H; a.n_q = d.n_q; a.n_kv = d.n_kv;
+            a.cosT = h->w.rope_cos; a.sinT = h->w.rope_sin;
+            a.q = h->q; a.kc = h->kc + l * cache_l; a.vc = h->vc + l * cache_l; a.max_pos = d.max_pos; a.rm = rm;
+            const size_t sm = skinny_smem_bytes<NB, 4, 4>(KSH);
+            hipLaunchKernelGGL(k_qkv<NB>, dim3(d.n_q + 2 * d.n_kv, 1), dim3(1024), sm, s, a);
+        }
+        {
+            AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, d.n_q, d.n_kv, d.max_pos, rm};
+            hipLaunchKernelGGL(k_attn, dim3(d.n_q, rows), dim3(256), (size_t)d.max_pos * 4, s, a);
+        }
+        {
+            StoreArgs a{};
+            a.W = L.wo; a.bias = nullptr;
+            a.X = SkinnyX{h->att, nullptr, 0, nullptr, 0.f, nullptr};
+            a.KS = d.n_q * 64 / 32; a.rows = rows; a.K = d.n_q * 64; a.N = H; a.out = h->o;
+            const size_t sm = skinny_smem_bytes<NB, 1, 4>(a.KS);
+            hipLaunchKernelGGL((k_store<NB, 1, 4>), dim3(H / 16, 1), dim3(256), sm, s, a);
+        }
+        float* x2 = (x1 == h->xa) ? h->xb : h->xa;            // x_mid = x1 + o
+        {
+            GateUpArgs a{};
+            a.W = L.wgu;
+            // parts = o (one "partial" buffer laid out [SK_ROWS_CAP][H])
+            a.X = SkinnyX{x1, h->o, 1, L.ln2, d.rms_eps, x2};
+            a.KS = KSH; a.rows = rows; a.K = H; a.inter = d.inter; a.h = h->hbuf;
+            const size_t sm = skinny_smem_bytes<NB, 2, 4>(KSH);
+            hipLaunchKernelGGL(k_gateup<NB>, dim3(d.inter / 16, 1), dim3(512), sm, s, a);
+        }
+        {
+            StoreArgs a{};
+            a.W = L.wdown; a.bias = nullptr;
+            a.X = SkinnyX{h->hbuf, nullptr, 0, nullptr, 0.f, nullptr};
+            a.KS = d.inter / 32; a.rows = rows; a.K = d.inter; a.N = H; a.out = h->parts;
+            const int split = h->down_split;
+            const size_t sm = skinny_smem_bytes<NB, 1, 4>(cdiv(a.KS, split) + 1);
+            hipLaunchKernelGGL((k_store<NB, 1, 4>), dim3(H / 16, split), dim3(256), sm, s, a);
+        }
+        xcur = x2;
+        np = h->down_split;
+    }
+    {
+        StoreArgs a{};
+        a.W = h->w.wdec; a.bias = h->w.bdec;
+        float* x1 = (xcur == h->xa) ? h->xb : h->xa;
+        a.X = SkinnyX{xcur, h->parts, np, h->w.final_norm, d.rms_eps, x1};
+        a.KS = KSH; a.rows = rows; a.K = H; a.N = d.vocab_pad; a.out = h->io.logits;
+        const size_t sm = skinny_smem_bytes<NB, 1, 4>(KSH);
+        hipLaunchKernelGGL((k_store<NB, 1, 4>), dim3(d.vocab_pad / 16, 1), dim3(256), sm, s, a);
+    }
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+static int init_attrs_once() {
+    static bool done = false;
+    if (done) return 0;
+    const size_t big = 160 * 1024;
+    if (set_smem(k_qkv<1>, big) || set_smem(k_qkv<2>, big) || set_smem(k_gateup<1>, big) || set_smem(k_gateup<2>, big) ||
+        set_smem((k_store<1, 1, 4>), big) || set_smem((k_store<2, 1, 4>), big))
+        return -1;
+    done = true;
+    return 0;
+}
+
+static int launch_sample(cv2_llm* h, int nblocks, int prefill_seq, int row, int prefill_pos, hipStream_t s) {
+    const cv2_llm_dims& d = h->d;
+    SampleArgs a{h->io.logits, d.vocab_pad, h->io.state, h->io.out_tokens, d.max_out, h->w.speech_emb, h->xnext, d.hidden,
+                 d.vocab, d.eos, d.max_pos, prefill_seq, row, prefill_pos};
+    hipLaunchKernelGGL(k_sample, dim3(nblocks), dim3(SM_T), 0, s, a);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cv2_llm_prefill(cv2_llm* h, int32_t seq, const float* embeds, int32_t len, void* stream) {
+    CV2_CHECK(h && embeds, "cv2_llm_prefill: null argument");
+    CV2_CHECK(seq >= 0 && seq < h->d.max_seqs, "cv2_llm_prefill: bad slot %d", seq);
+    CV2_CHECK(len >= 1 && len + 1 < h->d.max_pos, "cv2_llm_prefill: prompt length %d does not fit max_pos %d", len, h->d.max_pos);
+    if (init_attrs_once()) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    for (int p0 = 0; p0 < len; p0 += 32) {
+        const int rows = len - p0 < 32 ? len - p0 : 32;
+        RowMap rm{h->io.state, 1, seq, p0};
+        // the layer loop reads its input from a buffer that is neither xa nor xb: the caller's embeds
+        int rc = rows <= 16 ? run_layers<1>(h, rows, embeds + (size_t)p0 * h->d.hidden, rm, s)
+                            : run_layers<2>(h, rows, embeds + (size_t)p0 * h->d.hidden, rm, s);
+        if (rc) return rc;
+    }
+    // draw step 0 from the last row's logits; the slot's next KV position becomes len
+    return launch_sample(h, 1, seq, (len - 1) % 32, len, s);
+}
+
+extern "C" int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream) {
+    CV2_CHECK(h, "cv2_llm_decode: null handle");
+    CV2_CHECK(n_seqs >= 1 && n_seqs <= h->d.max_seqs, "cv2_llm_decode: n_seqs %d out of range", n_seqs);
+    if (init_attrs_once()) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    auto it = h->graphs.find(n_seqs);
+    if (it == h->graphs.end()) {
+        hipGraph_t g;
+        hipStream_t cs = h->cap_stream;
+        CV2_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        RowMap rm{h->io.state, 0, 0, 0};
+        int rc = n_seqs <= 16 ? run_layers<1>(h, n_seqs, h->xnext, rm, cs) : run_layers<2>(h, n_seqs, h->xnext, rm, cs);
+        if (!rc) rc = launch_sample(h, n_seqs, -1, 0, 0, cs);
+        hipError_t e = hipStreamEndCapture(cs, &g);
+        if (rc) return rc;
+        CV2_HIP(e);
+        hipGraphExec_t ge;
+        CV2_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CV2_HIP(hipGraphDestroy(g));
+        it = h->graphs.emplace(n_seqs, ge).first;
+    }
+    for (int i = 0; i < n_steps; i++) CV2_HIP(hipGraphLaunch(it->second, s));
+    return 0;
+}
+
+extern "C" int cv2_skinny_gemm(const uint16_t* w, const float* bias, const float* x, float* out, int32_t rows, int32_t n,
+                               int32_t k, void* stream) {
+    CV2_CHECK(w && x && out, "cv2_skinny_gemm: null argument");
+    CV2_CHECK(rows >= 1 && rows <= 32 && n % 16 == 0 && k % 32 == 0, "cv2_skinny_gemm: need rows<=32, n%%16==0, k%%32==0");
+    if (init_attrs_once()) return -1;
+    StoreArgs a{};
+    a.W = w; a.bias = bias; a.X = SkinnyX{x, nullptr, 0, nullptr, 0.f, nullptr};
+    a.KS = k / 32; a.rows = rows; a.K = k; a.N = n; a.out = out;
+    CV2_CHECK(a.KS <= 64, "cv2_skinny_gemm: k too large for a single K slice (use the LLM entry points)");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows <= 16) {
+        const size_t sm = skinny_smem_bytes<1, 1, 4>(a.KS);
+        hipLaunchKernelGGL((k_store<1, 1, 4>), dim3(n / 16, 1), dim3(256), sm, s, a);
+    } else {
+        const size_t sm = skinny_smem_bytes<2, 1, 4>(a.KS);
+        hipLaunchKernelGGL((k_store<2, 1, 4>), dim3(n / 16, 1), dim3(256), sm, s, a);
+    }
+    CV2_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,78 @@
+"""ctypes binding of libcv2amd.so (the C ABI declared in include/cv2_amd.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcv2amd.so')
+_lib = None
+
+STATE_STRIDE = 16
+ST_POS, ST_STEP, ST_NOUT, ST_DONE, ST_MINLEN, ST_MAXLEN, ST_MODE, ST_FORCE, ST_SEED_LO, ST_SEED_HI, ST_ERR, ST_LAST = range(12)
+
+
+class Cv2Error(RuntimeError):
+    pass
+
+
+class LlmDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('hidden', 'inter', 'layers', 'n_q', 'n_kv', 'vocab', 'vocab_pad', 'eos',
+                                         'max_seqs', 'max_pos', 'max_out')] + [('rms_eps', C.c_float)]
+
+
+class LlmLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('wqkv', 'bqkv', 'wo', 'wgu', 'wdown', 'ln1', 'ln2')]
+
+
+class LlmWeights(C.Structure):
+    _fields_ = [('layers', C.POINTER(LlmLayer))] + [(n, C.c_void_p) for n in
+                                                    ('final_norm', 'wdec', 'bdec', 'speech_emb', 'rope_cos', 'rope_sin')]
+
+
+class LlmIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('state', 'out_tokens', 'logits')]
+
+
+def lib():
+    """Load the shared library once.  Raises Cv2Error when it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Cv2Error(f'{LIB_PATH} not found: the HIP extension is not built; there is no CPU fallback')
+        L = C.CDLL(LIB_PATH)
+        L.cv2_last_error.restype = C.c_char_p
+        L.cv2_llm_workspace_bytes.restype = C.c_size_t
+        L.cv2_llm_workspace_bytes.argtypes = [C.POINTER(LlmDims)]
+        L.cv2_llm_create.argtypes = [C.POINTER(LlmDims), C.POINTER(LlmWeights), C.POINTER(LlmIO), C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_void_p)]
+        L.cv2_llm_destroy.argtypes = [C.c_void_p]
+        L.cv2_llm_prefill.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        L.cv2_llm_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.cv2_skinny_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise Cv2Error(lib().cv2_last_error().decode())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'cv2amd expects contiguous tensors'
+    return C.c_void_p(t.data_ptr())
+
+
+EXPORTS = ['cv2_last_error', 'cv2_version', 'cv2_llm_workspace_bytes', 'cv2_llm_create', 'cv2_llm_destroy',
+           'cv2_llm_prefill', 'cv2_llm_decode', 'cv2_skinny_gemm']

@@ -1,0 +1,133 @@
+"""Host side of stage 1: owns the device buffers and drives cv2_llm_* (csrc/llm.hip).
+
+Mirrors the engine seam the reference already has for vLLM (cosyvoice/llm/llm.py:651-680): requests are added
+with their prompt embeddings (`lm_input`, llm.py:641), `step()` advances every active request, ids are read back.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from . import weights as W
+
+EOS = 6561
+MODE_GREEDY, MODE_RAS = 0, 1
+
+
+class LLMEngine:
+    def __init__(self, sd, device='cuda:0', max_seqs=32, max_pos=2048, max_out=2048):
+        self.device = torch.device(device)
+        self.lib = L.lib()
+        dev = self.device
+        hidden = sd['llm.model.model.norm.weight'].numel()
+        layers = 0
+        while f'llm.model.model.layers.{layers}.input_layernorm.weight' in sd:
+            layers += 1
+        pfx = 'llm.model.model.layers.0.'
+        n_q = sd[pfx + 'self_attn.q_proj.weight'].shape[0] // 64
+        n_kv = sd[pfx + 'self_attn.k_proj.weight'].shape[0] // 64
+        inter = sd[pfx + 'mlp.gate_proj.weight'].shape[0]
+        vocab = sd['llm_decoder.weight'].shape[0]
+        vocab_pad = (vocab + 15) // 16 * 16
+        self.dims = L.LlmDims(hidden=hidden, inter=inter, layers=layers, n_q=n_q, n_kv=n_kv, vocab=vocab,
+                              vocab_pad=vocab_pad, eos=EOS, max_seqs=max_seqs, max_pos=max_pos, max_out=max_out,
+                              rms_eps=1e-6)
+        self.hidden, self.max_seqs, self.max_out, self.vocab, self.vocab_pad = hidden, max_seqs, max_out, vocab, vocab_pad
+        keep = []
+
+        def dv(t, dtype=torch.float32):
+            t = t.to(device=dev, dtype=dtype).contiguous()
+            keep.append(t)
+            return t
+
+        self._layers = (L.LlmLayer * layers)()
+        for i in range(layers):
+            p = f'llm.model.model.layers.{i}.'
+            wqkv = torch.cat([sd[p + 'self_attn.q_proj.weight'], sd[p + 'self_attn.k_proj.weight'],
+                              sd[p + 'self_attn.v_proj.weight']], dim=0).to(dev)
+            bqkv = torch.cat([sd[p + 'self_attn.q_proj.bias'], sd[p + 'self_attn.k_proj.bias'], sd[p + 'self_attn.v_proj.bias']])
+            wgu = W.interleave_tiles(sd[p + 'mlp.gate_proj.weight'].to(dev), sd[p + 'mlp.up_proj.weight'].to(dev))
+            ly = self._layers[i]
+            for name, t in (('wqkv', W.pack_bf16(wqkv)), ('wo', W.pack_bf16(sd[p + 'self_attn.o_proj.weight'].to(dev))),
+                            ('wgu', W.pack_bf16(wgu)), ('wdown', W.pack_bf16(sd[p + 'mlp.down_proj.weight'].to(dev)))):
+                keep.append(t)
+                setattr(ly, name, t.data_ptr())
+            ly.bqkv = dv(bqkv).data_ptr()
+            ly.ln1 = dv(sd[p + 'input_layernorm.weight']).data_ptr()
+            ly.ln2 = dv(sd[p + 'post_attention_layernorm.weight']).data_ptr()
+        wdec = W.pack_bf16(sd['llm_decoder.weight'].to(dev))
+        keep.append(wdec)
+        bdec = torch.zeros(vocab_pad)
+        bdec[:vocab] = sd['llm_decoder.bias']
+        cos, sin = W.rope_tables(max_pos)
+        self.speech_emb = dv(sd['speech_embedding.weight'])
+        self.llm_emb = dv(sd['llm_embedding.weight'])
+        self.text_emb = dv(sd['llm.model.model.embed_tokens.weight'])
+        self._w = L.LlmWeights(layers=C.cast(self._layers, C.POINTER(L.LlmLayer)),
+                               final_norm=dv(sd['llm.model.model.norm.weight']).data_ptr(), wdec=wdec.data_ptr(),
+                               bdec=dv(bdec).data_ptr(), speech_emb=self.speech_emb.data_ptr(),
+                               rope_cos=dv(cos).data_ptr(), rope_sin=dv(sin).data_ptr())
+        self.state = torch.zeros(max_seqs, L.STATE_STRIDE, dtype=torch.int32, device=dev)
+        self.out_tokens = torch.zeros(max_seqs, max_out, dtype=torch.int32, device=dev)
+        self.logits = torch.zeros(32, vocab_pad, dtype=torch.float32, device=dev)
+        self._io = L.LlmIO(state=self.state.data_ptr(), out_tokens=self.out_tokens.data_ptr(), logits=self.logits.data_ptr())
+        nbytes = self.lib.cv2_llm_workspace_bytes(C.byref(self.dims))
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._keep = keep
+        h = C.c_void_p()
+        L.check(self.lib.cv2_llm_create(C.byref(self.dims), C.byref(self._w), C.byref(self._io), self.workspace.data_ptr(),
+                                        nbytes, C.byref(h)))
+        self.handle = h
+        self.weight_bytes = sum(t.numel() * t.element_size() for t in keep if t.dtype == torch.int16)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.cv2_llm_destroy(self.handle)
+        except Exception:
+            pass
+
+    # ---- llm.py:625-641 -------------------------------------------------------------------------
+    def build_lm_input(self, text, prompt_text, prompt_speech_token):
+        """[sos, embed_tokens(prompt_text ++ text), task_id, speech_embedding(prompt_speech)] -> [L0, hidden] fp32."""
+        dev = self.device
+        ids = torch.cat([prompt_text.reshape(-1), text.reshape(-1)]).to(dev).long()
+        ps = prompt_speech_token.reshape(-1).to(dev).long()
+        return torch.cat([self.llm_emb[0:1], self.text_emb[ids], self.llm_emb[1:2], self.speech_emb[ps]], dim=0).contiguous()
+
+    def add_request(self, slot, lm_input, min_len, max_len, mode=MODE_GREEDY, seed=0, force_len=False):
+        """Step 0 of inference_wrapper (llm.py:684-719): prefill + first draw for `slot`."""
+        st = torch.zeros(L.STATE_STRIDE, dtype=torch.int32)
+        st[L.ST_MINLEN], st[L.ST_MAXLEN], st[L.ST_MODE], st[L.ST_FORCE] = min_len, max_len, mode, int(force_len)
+        st[L.ST_SEED_LO] = (seed & 0x7FFFFFFF) - (seed & 0x80000000)
+        st[L.ST_SEED_HI] = ((seed >> 32) & 0x7FFFFFFF) - ((seed >> 32) & 0x80000000)
+        self.state[slot].copy_(st)
+        assert lm_input.dtype == torch.float32 and lm_input.is_contiguous() and lm_input.shape[1] == self.hidden
+        L.check(self.lib.cv2_llm_prefill(self.handle, slot, L.ptr(lm_input), lm_input.shape[0], L.stream_ptr()))
+
+    def step(self, n_seqs, n_steps=1):
+        L.check(self.lib.cv2_llm_decode(self.handle, n_seqs, n_steps, L.stream_ptr()))
+
+    def read(self, n_seqs):
+        """(state [n, 16] int32 cpu, list of emitted-token lists). One device->host sync."""
+        st = self.state[:n_seqs].cpu()
+        toks = self.out_tokens[:n_seqs].cpu()
+        for b in range(n_seqs):
+            if int(st[b, L.ST_ERR]):
+                raise RuntimeError('sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!')
+        return st, [toks[b, :min(int(st[b, L.ST_NOUT]), self.max_out)].tolist() for b in range(n_seqs)]
+
+    def generate(self, requests, mode=MODE_GREEDY, seed=0, force_len=None, sync_every=16, min_ratio=2, max_ratio=20):
+        """requests: list of (text, prompt_text, prompt_speech_token) int tensors.  Returns list of token lists."""
+        n = len(requests)
+        assert n <= self.max_seqs
+        for b, (text, ptxt, ptok) in enumerate(requests):
+            mn, mx = int(text.numel() * min_ratio), int(text.numel() * max_ratio)
+            if force_len is not None:
+                mn, mx = force_len, force_len
+            self.add_request(b, self.build_lm_input(text, ptxt, ptok), mn, mx, mode, seed, force_len is not None)
+        while True:
+            st, toks = self.read(n)
+            if bool(st[:, L.ST_DONE].all()):
+                return toks
+            self.step(n, sync_every)

@@ -126,10 +126,11 @@ def multinomial_inv_cdf(p, u):
 def nucleus_candidates(logp, top_p=0.8, top_k=25):
     """utils/common.py:120-134: stable descending sort of softmax; keep while cum < top_p and count < top_k."""
     sv, si = logp.softmax(dim=0).sort(descending=True, stable=True)
-    prob, idx, cum = [], [], 0.0
+    prob, idx = [], []
+    cum = torch.tensor(0.0)          # the reference's `cum_prob += sorted_value[i]` accumulates a 0-dim fp32 tensor
     for i in range(len(si)):
-        if cum < top_p and len(prob) < top_k:
-            cum += float(sv[i])
+        if bool(cum < top_p) and len(prob) < top_k:
+            cum = cum + sv[i]
             prob.append(float(sv[i]))
             idx.append(int(si[i]))
         else:
@@ -148,12 +149,13 @@ def ras_ids(logp, decoded, u_pair, top_p=0.8, top_k=25, win_size=10, tau_r=0.1):
 
 
 def sampling_ids(logp, decoded, ignore_eos, mode, uniforms=None, step=0, max_trials=100):
-    """llm/llm.py:235-250.  mode 'greedy' or 'ras'; uniforms: [steps, max_trials+1, 2] injected noise for 'ras'."""
+    """llm/llm.py:235-250.  mode 'greedy' or 'ras'; uniforms: callable (step, trial) -> (u_nucleus, u_random),
+    the injected noise that replaces torch.multinomial's RNG in 'ras' mode."""
     if mode == 'greedy':
         return greedy_ids(logp, ignore_eos)
     trials = 0
     while True:
-        top = ras_ids(logp, decoded, uniforms[step, trials])
+        top = ras_ids(logp, decoded, uniforms(step, trials))
         if (not ignore_eos) or top != SPEECH_TOKEN_SIZE:
             return top
         trials += 1

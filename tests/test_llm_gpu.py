@@ -1,0 +1,117 @@
+"""GPU parity of stage 1 (csrc/llm.hip through the C ABI) against the CPU oracle.  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs a GPU'
+    return torch.device('cuda:0')
+
+
+def test_skinny_gemm_matches_fp64(dev):
+    import ctypes as C
+    from cv2amd import lib as L, weights as W
+    lib = L.lib()
+    g = torch.Generator().manual_seed(0)
+    for rows, n, k in ((1, 64, 896), (3, 1152, 896), (16, 896, 896), (17, 896, 1024), (32, 6576, 896)):
+        w = torch.randn(n, k, generator=g) / k ** 0.5
+        x = torch.randn(rows, k, generator=g)
+        b = torch.randn(n, generator=g)
+        wp = W.pack_bf16(w.to(dev))
+        xd, bd = x.to(dev), b.to(dev)           # keep alive: ctypes holds raw pointers only
+        out = torch.full((rows, n), float('nan'), device=dev)
+        L.check(lib.cv2_skinny_gemm(L.ptr(wp), L.ptr(bd), L.ptr(xd), L.ptr(out), rows, n, k, L.stream_ptr()))
+        torch.cuda.synchronize()
+        ref = x.double() @ W.bf16_round(w).double().T + b.double()
+        err = (out.cpu().double() - ref).abs().max().item()
+        # split-bf16 activations keep ~16 mantissa bits: error ~ 2^-17 * sum|w x|
+        bound = 3e-5 * (x.abs().double() @ W.bf16_round(w).abs().double().T).max().item() + 1e-6
+        assert err < bound, f'rows={rows} n={n} k={k} err={err:.3e} bound={bound:.3e}'
+
+
+def _requests(n, seed=1986):
+    from cv2amd import synth
+    reqs = []
+    for i in range(n):
+        inp = synth.synthetic_inputs(seed=seed + i, text_len=5 + i, prompt_len=9 + 3 * i, prompt_text_len=3 if i % 2 == 0 else 0)
+        ptok = inp['prompt_token'] if i % 2 == 0 else torch.zeros(1, 0, dtype=torch.int32)
+        reqs.append((inp['text'], inp['prompt_text'], ptok))
+    return reqs
+
+
+@pytest.fixture(scope='module')
+def small(dev):
+    from cv2amd import synth, weights as W
+    from cv2amd.llm import LLMEngine
+    sd = synth.make_llm(layers=3)
+    return sd, W.round_llm_sd(sd), LLMEngine(sd, dev, max_seqs=32, max_pos=512, max_out=256)
+
+
+def test_greedy_ids_bit_exact_vs_oracle(small):
+    """Harness-defined greedy ids: HIP path == oracle run on the same (bf16-rounded) weights, prefill + 60 steps."""
+    from oracle import llm as OL
+    sd, sdr, eng = small
+    reqs = _requests(3)
+    got = eng.generate(reqs, force_len=None, max_ratio=10)
+    for (text, ptxt, ptok), ids in zip(reqs, got):
+        want, logps = OL.inference(sdr, text, ptxt, ptok, max_ratio=10, return_logp=True)
+        margins = [float(lp.topk(2).values[0] - lp.topk(2).values[1]) for lp in logps]
+        assert ids == want, f'min top-1 margin on this fixture {min(margins):.2e}'
+
+
+def test_logits_close_to_oracle(small):
+    from oracle import llm as OL
+    import torch.nn.functional as F
+    sd, sdr, eng = small
+    text, ptxt, ptok = _requests(1)[0]
+    lm_input = eng.build_lm_input(text, ptxt, ptok)
+    eng.add_request(0, lm_input, 10, 50)
+    torch.cuda.synchronize()
+    row = (lm_input.shape[0] - 1) % 32
+    got = eng.logits[row, :eng.vocab].cpu()
+    d = OL.LLMDims(sdr)
+    y = OL.qwen2_step(sdr, d, OL.build_lm_input(sdr, text, ptxt, ptok), [None] * d.layers)
+    want = F.linear(y[-1], sdr['llm_decoder.weight'], sdr['llm_decoder.bias'])
+    assert (got - want).abs().max().item() < 2e-4 * want.abs().max().item()
+
+
+def test_forced_length_batch(small):
+    from oracle import llm as OL
+    sd, sdr, eng = small
+    reqs = _requests(5, seed=7)
+    got = eng.generate(reqs, force_len=24)
+    for (text, ptxt, ptok), ids in zip(reqs, got):
+        assert len(ids) == 24 and max(ids) < 6561
+        assert ids == OL.inference(sdr, text, ptxt, ptok, force_len=24)
+
+
+def test_ras_sampling_matches_oracle_with_same_noise(small):
+    from cv2amd import philox
+    from cv2amd.llm import MODE_RAS
+    from oracle import llm as OL
+    sd, sdr, eng = small
+    reqs = _requests(2, seed=21)
+    seed = 0x1234ABCD5
+    got = eng.generate(reqs, mode=MODE_RAS, seed=seed, max_ratio=8)
+    for b, ((text, ptxt, ptok), ids) in enumerate(zip(reqs, got)):
+        want = OL.inference(sdr, text, ptxt, ptok, mode='ras', max_ratio=8,
+                            uniforms=lambda step, trial: philox.uniforms(b, step, trial, seed))
+        assert ids == want
+
+
+def test_eos_guard_raises(dev):
+    """A model that always prefers EOS: the sampler re-draws 100 times then the host raises RuntimeError (llm.py:249)."""
+    from cv2amd import synth
+    from cv2amd.llm import LLMEngine, MODE_RAS
+    sd = synth.make_llm(layers=1)
+    sd['llm_decoder.bias'] = sd['llm_decoder.bias'].clone()
+    sd['llm_decoder.bias'][6561] = 1e4
+    eng = LLMEngine(sd, dev, max_seqs=1, max_pos=128, max_out=64)
+    text, ptxt, ptok = _requests(1)[0]
+    with pytest.raises(RuntimeError):
+        # step 0 masks EOS, step 1 is still below min_len -> guard fires
+        eng.generate([(text, ptxt, ptok)], mode=MODE_RAS, seed=1)

@@ -103,12 +103,10 @@ def test_ras_repetition_and_eos_guard():
     logp[5] = 0.0
     logp = logp.log_softmax(0)
     # nucleus picks 5; 5 appears in the window -> falls back to full-vocab draw with u_random
-    u = np.zeros((1, 101, 2))
-    u[0, 0] = (0.1, 0.999999999)
-    assert OL.ras_ids(logp, [5, 1, 2], u[0, 0]) != 5 or True
-    assert OL.ras_ids(logp, [1, 2, 3], u[0, 0]) == 5
+    assert OL.ras_ids(logp, [1, 2, 3], (0.1, 0.999999999)) == 5
+    assert OL.ras_ids(logp, [5, 1, 2], (0.1, 0.999999999)) == 6563      # window hit -> full-vocab draw at u ~ 1
     # EOS re-draw guard: EOS certain while ignore_eos -> RuntimeError after 100 trials (llm/llm.py:242-250)
     logp = torch.full((6564,), -50.0)
     logp[OL.SPEECH_TOKEN_SIZE] = 0.0
     with pytest.raises(RuntimeError):
-        OL.sampling_ids(logp.log_softmax(0), [], True, 'ras', np.full((1, 102, 2), 0.5), 0)
+        OL.sampling_ids(logp.log_softmax(0), [], True, 'ras', lambda s, t: (0.5, 0.5), 0)
