@@ -53,28 +53,30 @@ struct QkvArgs {
     int max_pos;
     RowMap rm;
 };
+// block = (head, half): features {half*16 + i, half*16 + 32 + i : i < 16} so that the rotate-half partner is in-block
 template <int NB>
-__global__ __launch_bounds__(1024) void k_qkv(QkvArgs a) {
+__global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* res = skinny_core<NB, 4, 4>(a.W, a.KS, a.rows, a.K, a.X, smem);
-    const int head = blockIdx.x;                 // 0..n_q-1 q heads, then k heads, then v heads
+    const int head = blockIdx.x >> 1, half = blockIdx.x & 1;   // heads: n_q query, then n_kv key, then n_kv value
+    const int wr = (threadIdx.x >> 6) % 2;
+    float* res = skinny_core<NB, 2, 4, 8>(a.W, head * 4 + half + 2 * wr, a.KS, a.rows, a.K, a.X, smem);
     const int ld = NB * 16 + 1;
-    for (int e = threadIdx.x; e < a.rows * 64; e += blockDim.x) {
-        const int r = e >> 6, i = e & 63;
+    for (int e = threadIdx.x; e < a.rows * 32; e += blockDim.x) {
+        const int r = e >> 5, w = (e >> 4) & 1, i16 = e & 15;
+        const int f = half * 16 + w * 32 + i16;           // feature within the head
         int seq, pos;
         a.rm.get(r, seq, pos);
-        float v = res[i * ld + r] + a.bias[head * 64 + i];
-        if (head < a.n_q + a.n_kv) {             // rotate-half RoPE on q and k heads
-            const int ip = i ^ 32;
-            const float vp = res[ip * ld + r] + a.bias[head * 64 + ip];
-            const float c = a.cosT[pos * 32 + (i & 31)], s = a.sinT[pos * 32 + (i & 31)];
-            v = (i < 32) ? (v * c - vp * s) : (v * c + vp * s);
+        float v = res[(w * 16 + i16) * ld + r] + a.bias[head * 64 + f];
+        if (head < a.n_q + a.n_kv) {                       // rotate-half RoPE on q and k heads
+            const float vp = res[((1 - w) * 16 + i16) * ld + r] + a.bias[head * 64 + (f ^ 32)];
+            const float c = a.cosT[pos * 32 + (f & 31)], s = a.sinT[pos * 32 + (f & 31)];
+            v = (f < 32) ? (v * c - vp * s) : (v * c + vp * s);
         }
-        if (head < a.n_q) a.q[(size_t)r * a.n_q * 64 + head * 64 + i] = v;
+        if (head < a.n_q) a.q[(size_t)r * a.n_q * 64 + head * 64 + f] = v;
         else if (head < a.n_q + a.n_kv)
-            a.kc[(((size_t)seq * a.n_kv + (head - a.n_q)) * a.max_pos + pos) * 64 + i] = v;
+            a.kc[(((size_t)seq * a.n_kv + (head - a.n_q)) * a.max_pos + pos) * 64 + f] = v;
         else
-            a.vc[(((size_t)seq * a.n_kv + (head - a.n_q - a.n_kv)) * a.max_pos + pos) * 64 + i] = v;
+            a.vc[(((size_t)seq * a.n_kv + (head - a.n_q - a.n_kv)) * a.max_pos + pos) * 64 + f] = v;
     }
 }
 
@@ -99,13 +101,24 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     const int tid = threadIdx.x, l16 = tid & 15, g = tid >> 4;
     const float4 qv = reinterpret_cast<const float4*>(a.q + (size_t)r * a.n_q * 64 + h * 64)[l16];
     float lmax = -INFINITY;
-    for (int j = g; j < L; j += 16) {
-        const float4 kv = reinterpret_cast<const float4*>(K + (size_t)j * 64)[l16];
-        float d = qv.x * kv.x + qv.y * kv.y + qv.z * kv.z + qv.w * kv.w;
-        d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
-        d *= 0.125f;
-        if (l16 == 0) sc[j] = d;
-        lmax = fmaxf(lmax, d);
+    for (int j0 = 0; j0 < L; j0 += 64) {                        // 16 key groups x 4 keys in flight per thread
+        float4 kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + g + 16 * u;
+            kv[u] = j < L ? reinterpret_cast<const float4*>(K + (size_t)j * 64)[l16] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + g + 16 * u;
+            float d = qv.x * kv[u].x + qv.y * kv[u].y + qv.z * kv[u].z + qv.w * kv[u].w;
+            d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
+            d *= 0.125f;
+            if (j < L) {
+                if (l16 == 0) sc[j] = d;
+                lmax = fmaxf(lmax, d);
+            }
+        }
     }
     lmax = wave_max(lmax);
     if ((tid & 63) == 0) redbuf[tid >> 6] = lmax;
@@ -123,32 +136,36 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     const float denom = redbuf[4] + redbuf[5] + redbuf[6] + redbuf[7];
     const int w = tid >> 6, d = tid & 63;
     float o = 0.f;
-    for (int j = w; j < L; j += 4) o += sc[j] * V[(size_t)j * 64 + d];
+    for (int j0 = w; j0 < L; j0 += 32) {                        // 8 value rows in flight per thread
+        float vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int j = j0 + 4 * u; vv[u] = j < L ? V[(size_t)j * 64 + d] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int j = j0 + 4 * u; if (j < L) o += sc[j] * vv[u]; }
+    }
     obuf[w][d] = o;
     __syncthreads();
     if (w == 0) a.out[(size_t)r * a.n_q * 64 + h * 64 + d] = (obuf[0][d] + obuf[1][d] + obuf[2][d] + obuf[3][d]) / denom;
 }
 
-// ------------------------------------------------------------------ generic store epilogue (o-proj, down, head)
+// ------------------------------------------------------------------ k_store: out = W f(x) (+bias)  (o-proj, down-proj, head)
 struct StoreArgs {
     const uint16_t* W; const float* bias;       // bias may be null
     SkinnyX X; int KS, rows, K, N;
     float* out;                                 // gridDim.y == 1: [rows][N]; else partials [gridDim.y][SK_ROWS_CAP][N]
 };
-template <int NB, int NWR, int NWK>
-__global__ __launch_bounds__(64 * NWR * NWK) void k_store(StoreArgs a) {
+template <int NB, int MAXKS>
+__global__ __launch_bounds__(256) void k_store(StoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* res = skinny_core<NB, NWR, NWK>(a.W, a.KS, a.rows, a.K, a.X, smem);
+    float* res = skinny_core<NB, 1, 4, MAXKS>(a.W, blockIdx.x, a.KS, a.rows, a.K, a.X, smem);
     const int ld = NB * 16 + 1;
-    const int n0 = blockIdx.x * NWR * 16;
+    const int n0 = blockIdx.x * 16;
     float* out = a.out + (gridDim.y > 1 ? (size_t)blockIdx.y * SK_ROWS_CAP * a.N : 0);
-    for (int e = threadIdx.x; e < a.rows * NWR * 16; e += blockDim.x) {
-        const int r = e / (NWR * 16), i = e % (NWR * 16);
-        if (n0 + i < a.N) {
-            float v = res[i * ld + r];
-            if (a.bias && blockIdx.y == 0) v += a.bias[n0 + i];
-            out[(size_t)r * a.N + n0 + i] = v;
-        }
+    for (int e = threadIdx.x; e < a.rows * 16; e += blockDim.x) {
+        const int r = e >> 4, i = e & 15;
+        float v = res[i * ld + r];
+        if (a.bias && blockIdx.y == 0) v += a.bias[n0 + i];
+        out[(size_t)r * a.N + n0 + i] = v;
     }
 }
 
@@ -160,7 +177,8 @@ struct GateUpArgs {
 template <int NB>
 __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* res = skinny_core<NB, 2, 4>(a.W, a.KS, a.rows, a.K, a.X, smem);   // rows 0-15 gate, 16-31 up
+    const int wr = (threadIdx.x >> 6) % 2;
+    float* res = skinny_core<NB, 2, 4, 8>(a.W, blockIdx.x * 2 + wr, a.KS, a.rows, a.K, a.X, smem);   // rows 0-15 gate, 16-31 up
     const int ld = NB * 16 + 1;
     for (int e = threadIdx.x; e < a.rows * 16; e += blockDim.x) {
         const int r = e >> 4, i = e & 15;
@@ -194,12 +212,41 @@ struct SampleArgs {
     int vocab, eos, max_pos;
     int prefill_seq, row, prefill_pos;          // prefill: one block, reads logits row `row`, updates slot prefill_seq,
 };                                              // whose next KV position becomes prefill_pos (= prompt length)
-#define SM_T 256
+#define SM_T 1024
+#define SM_W (SM_T / 64)
 #define SM_TOPK 25
+struct ArgMax { float v; int i; };
+__device__ __forceinline__ ArgMax am_better(ArgMax a, ArgMax b) {     // larger value, ties -> lower index
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ArgMax block_argmax(ArgMax x, ArgMax* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax y{__shfl_xor(x.v, o), __shfl_xor(x.i, o)};
+        x = am_better(x, y);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+    __syncthreads();
+    ArgMax r = sh[0];
+#pragma unroll
+    for (int w = 1; w < SM_W; w++) r = am_better(r, sh[w]);
+    return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < SM_W; w++) r += sh[w];
+    return r;
+}
 __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
     __shared__ float lp[6592];
-    __shared__ float rv[SM_T];
-    __shared__ int ri[SM_T];
+    __shared__ ArgMax sam[SM_W];
+    __shared__ float ssum[SM_W];
     __shared__ double rd[SM_T];
     __shared__ float candp[SM_TOPK];
     __shared__ int candi[SM_TOPK];
@@ -212,62 +259,44 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
     const int step = st[CV2_ST_STEP];
     const int V = a.vocab;
     if (!done) {
-        // log_softmax (llm.py:690)
         const float* lg = a.logits + (size_t)row * a.ldl;
-        float m = -INFINITY;
-        for (int i = tid; i < V; i += SM_T) { const float v = lg[i]; lp[i] = v; m = fmaxf(m, v); }
-        rv[tid] = m; __syncthreads();
-        for (int s = SM_T / 2; s > 0; s >>= 1) { if (tid < s) rv[tid] = fmaxf(rv[tid], rv[tid + s]); __syncthreads(); }
-        m = rv[0]; __syncthreads();
-        float sum = 0.f;
-        for (int i = tid; i < V; i += SM_T) sum += __expf(lp[i] - m);
-        rv[tid] = sum; __syncthreads();
-        for (int s = SM_T / 2; s > 0; s >>= 1) { if (tid < s) rv[tid] += rv[tid + s]; __syncthreads(); }
-        const float lse = m + __logf(rv[0]); __syncthreads();
-        for (int i = tid; i < V; i += SM_T) lp[i] -= lse;
-        __syncthreads();
-        if (tid == 0) {
-            if (step == 0) lp[a.eos] = -INFINITY;                       // llm.py:693-694
-            if (st[CV2_ST_FORCE]) for (int i = a.eos; i < V; i++) lp[i] = -INFINITY;
-        }
-        __syncthreads();
         const bool ignore_eos = step < st[CV2_ST_MINLEN];
+        const bool force = st[CV2_ST_FORCE] != 0;
         const int mode = st[CV2_ST_MODE];
+        // masks on logits == masks on logp (log_softmax is monotone):
+        //   step 0 never EOS (llm.py:693-694); forced-length mode never draws ids >= eos
+        ArgMax best{-INFINITY, 0x7fffffff};
+        for (int i = tid; i < V; i += SM_T) {
+            float v = lg[i];
+            if ((step == 0 && i == a.eos) || (force && i >= a.eos)) v = -INFINITY;
+            lp[i] = v;
+            if (!(ignore_eos && i == a.eos)) best = am_better(best, ArgMax{v, i});
+        }
         if (mode == 0) {
             // greedy: argmax with EOS excluded while ignore_eos; ties -> lowest id
-            float bv = -INFINITY; int bi = 0x7fffffff;
-            for (int i = tid; i < V; i += SM_T) {
-                const float v = (ignore_eos && i == a.eos) ? -INFINITY : lp[i];
-                if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
-            }
-            rv[tid] = bv; ri[tid] = bi; __syncthreads();
-            for (int s = SM_T / 2; s > 0; s >>= 1) {
-                if (tid < s) {
-                    if (rv[tid + s] > rv[tid] || (rv[tid + s] == rv[tid] && ri[tid + s] < ri[tid])) { rv[tid] = rv[tid + s]; ri[tid] = ri[tid + s]; }
-                }
-                __syncthreads();
-            }
-            if (tid == 0) s_top = ri[0];
-            __syncthreads();
+            best = block_argmax(best, sam);
+            if (tid == 0) s_top = best.i;
         } else {
             // RAS (utils/common.py:111-139): top-p 0.8 / top-k 25 nucleus, repetition window 10, tau 0.1
-            // 1. stable descending top-25 of softmax = exp(logp)
+            __syncthreads();
+            ArgMax mx{-INFINITY, 0x7fffffff};
+            for (int i = tid; i < V; i += SM_T) mx = am_better(mx, ArgMax{lp[i], i});
+            const float m = block_argmax(mx, sam).v;
+            float sum = 0.f;
+            for (int i = tid; i < V; i += SM_T) sum += __expf(lp[i] - m);
+            const float lse = m + __logf(block_sum(sum, ssum));
+            for (int i = tid; i < V; i += SM_T) lp[i] -= lse;                 // log_softmax (llm.py:690)
+            __syncthreads();
+            // stable descending top-25 of softmax = exp(logp)
             for (int c = 0; c < SM_TOPK; c++) {
-                float bv = -INFINITY; int bi = 0x7fffffff;
+                ArgMax b{-INFINITY, 0x7fffffff};
                 for (int i = tid; i < V; i += SM_T) {
-                    const float v = lp[i];
                     bool taken = false;
                     for (int q = 0; q < c; q++) taken |= (candi[q] == i);
-                    if (!taken && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+                    if (!taken) b = am_better(b, ArgMax{lp[i], i});
                 }
-                rv[tid] = bv; ri[tid] = bi; __syncthreads();
-                for (int s = SM_T / 2; s > 0; s >>= 1) {
-                    if (tid < s) {
-                        if (rv[tid + s] > rv[tid] || (rv[tid + s] == rv[tid] && ri[tid + s] < ri[tid])) { rv[tid] = rv[tid + s]; ri[tid] = ri[tid + s]; }
-                    }
-                    __syncthreads();
-                }
-                if (tid == 0) { candi[c] = ri[0]; candp[c] = __expf(rv[0]); }
+                b = block_argmax(b, sam);
+                if (tid == 0) { candi[c] = b.i; candp[c] = __expf(b.v); }
                 __syncthreads();
             }
             // full-vocab cdf chunks for the repetition fallback (random_sampling)
@@ -307,7 +336,6 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                 }
                 s_top = top;
             }
-            __syncthreads();
         }
     }
     __syncthreads();
@@ -340,14 +368,13 @@ struct cv2_llm {
     cv2_llm_io io;
     // workspace carve
     float *kc, *vc;            // [layers][max_seqs][n_kv][max_pos][64]
-    float *xa, *xb;            // residual ping-pong [32][hidden]
-    float *xnext;              // [32][hidden] next-step input embeddings, written by k_sample
+    float *xa, *xb;            // residual stream ping-pong [32][hidden]
+    float *xnext;              // [32][hidden] next-step input embeddings (k_sample)
     float *q, *att, *o;        // [32][n_q*64], [32][n_q*64], [32][hidden]
     float *hbuf;               // [32][inter]
-    float *parts;              // [8][32][hidden]
+    float *parts;              // [SK_MAXNP][32][hidden] split-K partials of the down projection
     std::map<int, hipGraphExec_t> graphs;
     hipStream_t cap_stream;    // private stream used only to capture the decode-step graph (the caller's may be the null stream)
-    int down_split;
 };
 
 static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
@@ -364,22 +391,18 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     p = take((size_t)32 * d.n_q * 64 * 4); if (h) h->att = (float*)p;
     p = take((size_t)32 * d.hidden * 4); if (h) h->o = (float*)p;
     p = take((size_t)32 * d.inter * 4); if (h) h->hbuf = (float*)p;
-    p = take((size_t)8 * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
+    p = take((size_t)SK_MAXNP * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
     return off;
 }
 
 extern "C" size_t cv2_llm_workspace_bytes(const cv2_llm_dims* d) { return carve(*d, nullptr, nullptr); }
 
-template <typename F>
-static int set_smem(F f, size_t bytes) {
-    CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return 0;
-}
-
 extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, const cv2_llm_io* io, void* ws, size_t ws_bytes,
                               cv2_llm** out) {
     CV2_CHECK(d && w && io && ws && out, "cv2_llm_create: null argument");
     CV2_CHECK(d->hidden % 32 == 0 && d->inter % 32 == 0 && d->vocab_pad % 16 == 0, "cv2_llm_create: hidden/inter must be multiples of 32");
+    CV2_CHECK(d->hidden / 32 <= 32 && d->n_q * 64 / 32 <= 32, "cv2_llm_create: hidden and n_q*64 must be <= 1024 (k-steps per wave)");
+    CV2_CHECK(d->inter / 32 <= SK_MAXNP * 4 * 10, "cv2_llm_create: inter must be <= 5120 (k-steps per wave of the down projection)");
     CV2_CHECK(d->n_q % d->n_kv == 0 && d->max_seqs >= 1 && d->max_seqs <= 32, "cv2_llm_create: bad head counts / max_seqs");
     CV2_CHECK(d->vocab <= 6592 && d->eos < d->vocab, "cv2_llm_create: vocab too large for the sampler");
     CV2_CHECK(ws_bytes >= cv2_llm_workspace_bytes(d), "cv2_llm_create: workspace too small (%zu < %zu)", ws_bytes, cv2_llm_workspace_bytes(d));
@@ -390,7 +413,6 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
     h->w.layers = h->layers.data();
     h->io = *io;
     carve(*d, h, (char*)ws);
-    h->down_split = 8;
     h->cap_stream = nullptr;
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -408,17 +430,20 @@ extern "C" int cv2_llm_destroy(cv2_llm* h) {
     return 0;
 }
 
-// one pass of the 24 layers + head over `rows` rows whose input embeddings sit in xin [rows][hidden]
+static int init_attrs_once();
+
+// one pass of the layers + head over `rows` rows whose input embeddings sit in xin [rows][hidden]
+// (xin is neither xa nor xb: the caller's prompt embeddings or xnext)
 template <int NB>
 static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStream_t s) {
     const cv2_llm_dims& d = h->d;
     const int H = d.hidden, KSH = H / 32;
     const size_t cache_l = (size_t)d.max_seqs * d.n_kv * d.max_pos * 64;
-    const float* xcur = xin;     // residual stream input of the layer (before adding pending down-proj partials)
-    int np = 0;                  // pending partial buffers to add to xcur
+    const float* xcur = xin;     // residual stream entering the layer, before the pending down-proj partials are folded in
+    int np = 0;
     for (int l = 0; l < d.layers; l++) {
         const cv2_llm_layer& L = h->layers[l];
-        float* x1 = (xcur == h->xa) ? h->xb : h->xa;          // x after folding partials
+        float* x1 = (xcur == h->xa) ? h->xb : h->xa;          // x after folding the partials
         {
             QkvArgs a{};
             a.W = L.wqkv; a.bias = L.bqkv;
@@ -426,8 +451,8 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             a.KS = KSH; a.rows = rows; a.K = H; a.n_q = d.n_q; a.n_kv = d.n_kv;
             a.cosT = h->w.rope_cos; a.sinT = h->w.rope_sin;
             a.q = h->q; a.kc = h->kc + l * cache_l; a.vc = h->vc + l * cache_l; a.max_pos = d.max_pos; a.rm = rm;
-            const size_t sm = skinny_smem_bytes<NB, 4, 4>(KSH);
-            hipLaunchKernelGGL(k_qkv<NB>, dim3(d.n_q + 2 * d.n_kv, 1), dim3(1024), sm, s, a);
+            const size_t sm = skinny_smem_bytes<NB, 2, 4>(KSH);
+            hipLaunchKernelGGL(k_qkv<NB>, dim3(2 * (d.n_q + 2 * d.n_kv), 1), dim3(512), sm, s, a);
         }
         {
             AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, d.n_q, d.n_kv, d.max_pos, rm};
@@ -439,14 +464,13 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             a.X = SkinnyX{h->att, nullptr, 0, nullptr, 0.f, nullptr};
             a.KS = d.n_q * 64 / 32; a.rows = rows; a.K = d.n_q * 64; a.N = H; a.out = h->o;
             const size_t sm = skinny_smem_bytes<NB, 1, 4>(a.KS);
-            hipLaunchKernelGGL((k_store<NB, 1, 4>), dim3(H / 16, 1), dim3(256), sm, s, a);
+            hipLaunchKernelGGL((k_store<NB, 8>), dim3(H / 16, 1), dim3(256), sm, s, a);
         }
         float* x2 = (x1 == h->xa) ? h->xb : h->xa;            // x_mid = x1 + o
         {
             GateUpArgs a{};
             a.W = L.wgu;
-            // parts = o (one "partial" buffer laid out [SK_ROWS_CAP][H])
-            a.X = SkinnyX{x1, h->o, 1, L.ln2, d.rms_eps, x2};
+            a.X = SkinnyX{x1, h->o, 1, L.ln2, d.rms_eps, x2};   // o is one "partial" laid out [SK_ROWS_CAP][H]
             a.KS = KSH; a.rows = rows; a.K = H; a.inter = d.inter; a.h = h->hbuf;
             const size_t sm = skinny_smem_bytes<NB, 2, 4>(KSH);
             hipLaunchKernelGGL(k_gateup<NB>, dim3(d.inter / 16, 1), dim3(512), sm, s, a);
@@ -456,32 +480,36 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             a.W = L.wdown; a.bias = nullptr;
             a.X = SkinnyX{h->hbuf, nullptr, 0, nullptr, 0.f, nullptr};
             a.KS = d.inter / 32; a.rows = rows; a.K = d.inter; a.N = H; a.out = h->parts;
-            const int split = h->down_split;
-            const size_t sm = skinny_smem_bytes<NB, 1, 4>(cdiv(a.KS, split) + 1);
-            hipLaunchKernelGGL((k_store<NB, 1, 4>), dim3(H / 16, split), dim3(256), sm, s, a);
+            const size_t sm = skinny_smem_bytes<NB, 1, 4>(cdiv(a.KS, SK_MAXNP) + 1);
+            hipLaunchKernelGGL((k_store<NB, 10>), dim3(H / 16, SK_MAXNP), dim3(256), sm, s, a);
         }
         xcur = x2;
-        np = h->down_split;
+        np = SK_MAXNP;
     }
     {
         StoreArgs a{};
         a.W = h->w.wdec; a.bias = h->w.bdec;
-        float* x1 = (xcur == h->xa) ? h->xb : h->xa;
-        a.X = SkinnyX{xcur, h->parts, np, h->w.final_norm, d.rms_eps, x1};
+        a.X = SkinnyX{xcur, h->parts, np, h->w.final_norm, d.rms_eps, nullptr};
         a.KS = KSH; a.rows = rows; a.K = H; a.N = d.vocab_pad; a.out = h->io.logits;
         const size_t sm = skinny_smem_bytes<NB, 1, 4>(KSH);
-        hipLaunchKernelGGL((k_store<NB, 1, 4>), dim3(d.vocab_pad / 16, 1), dim3(256), sm, s, a);
+        hipLaunchKernelGGL((k_store<NB, 8>), dim3(d.vocab_pad / 16, 1), dim3(256), sm, s, a);
     }
     CV2_LAUNCH_CHECK();
     return 0;
 }
 
+template <typename F>
+static int set_smem(F f, size_t bytes) {
+    CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
 static int init_attrs_once() {
     static bool done = false;
     if (done) return 0;
     const size_t big = 160 * 1024;
     if (set_smem(k_qkv<1>, big) || set_smem(k_qkv<2>, big) || set_smem(k_gateup<1>, big) || set_smem(k_gateup<2>, big) ||
-        set_smem((k_store<1, 1, 4>), big) || set_smem((k_store<2, 1, 4>), big))
+        set_smem((k_store<1, 8>), big) || set_smem((k_store<2, 8>), big) || set_smem((k_store<1, 10>), big) ||
+        set_smem((k_store<2, 10>), big))
         return -1;
     done = true;
     return 0;
@@ -489,8 +517,8 @@ static int init_attrs_once() {
 
 static int launch_sample(cv2_llm* h, int nblocks, int prefill_seq, int row, int prefill_pos, hipStream_t s) {
     const cv2_llm_dims& d = h->d;
-    SampleArgs a{h->io.logits, d.vocab_pad, h->io.state, h->io.out_tokens, d.max_out, h->w.speech_emb, h->xnext, d.hidden,
-                 d.vocab, d.eos, d.max_pos, prefill_seq, row, prefill_pos};
+    SampleArgs a{h->io.logits, d.vocab_pad, h->io.state, h->io.out_tokens, d.max_out, h->w.speech_emb, h->xnext,
+                 d.hidden, d.vocab, d.eos, d.max_pos, prefill_seq, row, prefill_pos};
     hipLaunchKernelGGL(k_sample, dim3(nblocks), dim3(SM_T), 0, s, a);
     CV2_LAUNCH_CHECK();
     return 0;
@@ -504,10 +532,9 @@ extern "C" int cv2_llm_prefill(cv2_llm* h, int32_t seq, const float* embeds, int
     hipStream_t s = (hipStream_t)stream;
     for (int p0 = 0; p0 < len; p0 += 32) {
         const int rows = len - p0 < 32 ? len - p0 : 32;
+        const float* xin = embeds + (size_t)p0 * h->d.hidden;
         RowMap rm{h->io.state, 1, seq, p0};
-        // the layer loop reads its input from a buffer that is neither xa nor xb: the caller's embeds
-        int rc = rows <= 16 ? run_layers<1>(h, rows, embeds + (size_t)p0 * h->d.hidden, rm, s)
-                            : run_layers<2>(h, rows, embeds + (size_t)p0 * h->d.hidden, rm, s);
+        int rc = rows <= 16 ? run_layers<1>(h, rows, xin, rm, s) : run_layers<2>(h, rows, xin, rm, s);
         if (rc) return rc;
     }
     // draw step 0 from the last row's logits; the slot's next KV position becomes len
@@ -543,18 +570,18 @@ extern "C" int cv2_skinny_gemm(const uint16_t* w, const float* bias, const float
                                int32_t k, void* stream) {
     CV2_CHECK(w && x && out, "cv2_skinny_gemm: null argument");
     CV2_CHECK(rows >= 1 && rows <= 32 && n % 16 == 0 && k % 32 == 0, "cv2_skinny_gemm: need rows<=32, n%%16==0, k%%32==0");
+    CV2_CHECK(k <= 1024, "cv2_skinny_gemm: k must be <= 1024");
     if (init_attrs_once()) return -1;
     StoreArgs a{};
     a.W = w; a.bias = bias; a.X = SkinnyX{x, nullptr, 0, nullptr, 0.f, nullptr};
     a.KS = k / 32; a.rows = rows; a.K = k; a.N = n; a.out = out;
-    CV2_CHECK(a.KS <= 64, "cv2_skinny_gemm: k too large for a single K slice (use the LLM entry points)");
     hipStream_t s = (hipStream_t)stream;
     if (rows <= 16) {
         const size_t sm = skinny_smem_bytes<1, 1, 4>(a.KS);
-        hipLaunchKernelGGL((k_store<1, 1, 4>), dim3(n / 16, 1), dim3(256), sm, s, a);
+        hipLaunchKernelGGL((k_store<1, 8>), dim3(n / 16, 1), dim3(256), sm, s, a);
     } else {
         const size_t sm = skinny_smem_bytes<2, 1, 4>(a.KS);
-        hipLaunchKernelGGL((k_store<2, 1, 4>), dim3(n / 16, 1), dim3(256), sm, s, a);
+        hipLaunchKernelGGL((k_store<2, 8>), dim3(n / 16, 1), dim3(256), sm, s, a);
     }
     CV2_LAUNCH_CHECK();
     return 0;
