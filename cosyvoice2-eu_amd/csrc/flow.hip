@@ -1,0 +1,949 @@
+// Stage 2 on MI355X: speech tokens -> mel (replaces cosyvoice/flow/flow.py:235-283 and everything under it).
+//
+// Data layout in HBM ("packed ragged rows"): every activation is TIME-MAJOR, one row per frame, channels contiguous.
+// The sequences of a call (utterances; for the estimator also their classifier-free-guidance twins) are packed
+// one after another; sequence s owns rows [start_s, start_s + len_s), start_s is a multiple of 128 and at least 8
+// zero rows follow every sequence.  Buffers that feed convolutions carry 128 zero guard rows in front.  With this
+// layout a causal Conv1d(k) is a GEMM whose A operand is the same buffer read at row offset -(k-1) with
+// K = k*C (the tap window of a row is contiguous memory), and the zero rows are the causal padding.  Every
+// epilogue re-zeroes the rows beyond a sequence (the reference's `* mask`), so the invariant holds end to end.
+//
+// Kernels (roofline that bounds each):
+//   k_gemm (gemm.h)        MFMA bf16   every Linear / Conv1d of the encoder and the estimator, fused epilogues
+//   k_attn_est             MFMA bf16   estimator self-attention, flash style (no T x T matrix in HBM)
+//   k_relsoftmax           HBM         conformer rel-pos softmax over explicit score matrices (encoder only, ~2 % of FLOPs)
+//   k_layernorm, k_pack, k_euler, ...  HBM   small row-wise kernels
+#include "gemm.h"
+#include "skinny_launch.h"
+#include "../../include/cv2_amd.h"
+#include <algorithm>
+#include <map>
+#include <math.h>
+#include <vector>
+
+#define GUARD 128
+
+// =========================================================================== GEMM launch
+template <int BM, int BN, int WM, int WN>
+static int gemm_go(const GemmArgs& a, int batch, bool packed, hipStream_t s) {
+    constexpr size_t sm = gemm_smem_bytes<BM, BN>();
+    dim3 grid(a.N / BN, a.M / BM, batch), block(WM * WN * 64);
+    if (packed) {
+        static bool once = false;
+        if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true>), grid, block, sm, s, a);
+    } else {
+        static bool once = false;
+        if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false>), grid, block, sm, s, a);
+    }
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+// cfg 0: 128x128; cfg 1: 64x256 (whole rows of N == 256); cfg 2: 128x64
+static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, hipStream_t s) {
+    CV2_CHECK(a.K % 64 == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of 64", a.K);
+    CV2_CHECK(a.M % 128 == 0 && a.M > 0, "gemm: M=%d must be a positive multiple of 128", a.M);
+    if (cfg == 0) { CV2_CHECK(a.N % 128 == 0, "gemm cfg0: N=%d %% 128", a.N); return gemm_go<128, 128, 2, 2>(a, batch, packed, s); }
+    if (cfg == 1) {
+        CV2_CHECK(a.N % 256 == 0, "gemm cfg1: N=%d %% 256", a.N);
+        CV2_CHECK((!a.ln1_g && !a.ln2_g) || a.N == 256, "gemm cfg1: LayerNorm epilogue needs N == 256");
+        return gemm_go<64, 256, 1, 4>(a, batch, packed, s);
+    }
+    CV2_CHECK(a.N % 64 == 0, "gemm cfg2: N=%d %% 64", a.N);
+    return gemm_go<128, 64, 2, 2>(a, batch, packed, s);
+}
+
+static GemmArgs gemm_args(const uint16_t* A, long lda, long a_off, const uint16_t* W, int M, int N, int K) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.a_row_off = a_off; a.W = W; a.M = M; a.N = N; a.K = K; a.M_valid = M;
+    a.out_scale = 1.f; a.n_store = N; a.ln2_scale = 1.f; a.act_slope = 0.01f;
+    return a;
+}
+
+extern "C" int cv2_gemm_bf16(const uint16_t* a, int64_t lda, const uint16_t* w, const float* bias, float* out, int64_t ldo,
+                             int32_t m, int32_t n, int32_t k, void* stream) {
+    CV2_CHECK(a && w && out, "cv2_gemm_bf16: null argument");
+    GemmArgs g = gemm_args(a, lda, 0, w, m, n, k);
+    g.bias = bias; g.out_f32 = out; g.ldo = ldo;
+    return gemm_launch_cfg(g, n % 256 == 0 && n <= 256 ? 1 : 0, 1, true, (hipStream_t)stream);
+}
+
+// =========================================================================== small kernels
+struct LnArgs {
+    const float* x; long ldx; int C;
+    const float* g; const float* b; float eps; float scale;
+    SeqTable seq; int rows;
+    float* out_f32; long ldo; uint16_t* out_bf16; long ldo16;
+};
+// one wave per row; C in {256, 512}
+template <int PER>
+__global__ __launch_bounds__(256) void k_layernorm(LnArgs a) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.rows) return;
+    const int s = a.seq.tile_seq[row >> 6];
+    const bool valid = s >= 0 && row - a.seq.seq_start[s] < a.seq.seq_len[s];
+    constexpr int per = PER;                        // 4 or 8 consecutive channels per lane
+    float v[PER];
+    const float* xr = a.x + (size_t)row * a.ldx + lane * per;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < per; i += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(xr + i);
+        v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
+        sum += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    const float mean = wave_sum(sum) / a.C;
+    float sq = 0.f;
+    for (int i = 0; i < per; i++) { v[i] -= mean; sq += v[i] * v[i]; }
+    const float rstd = rsqrtf(wave_sum(sq) / a.C + a.eps);
+    for (int i = 0; i < per; i++) {
+        const int c = lane * per + i;
+        v[i] = valid ? (v[i] * rstd * a.g[c] + a.b[c]) * a.scale : 0.f;
+    }
+    if (a.out_f32) for (int i = 0; i < per; i += 4)
+        *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)row * a.ldo + lane * per + i) = (f32x4){v[i], v[i + 1], v[i + 2], v[i + 3]};
+    if (a.out_bf16) for (int i = 0; i < per; i += 4)
+        *reinterpret_cast<uint2*>(a.out_bf16 + (size_t)row * a.ldo16 + lane * per + i) = make_uint2(pack_bf16x2(v[i], v[i + 1]), pack_bf16x2(v[i + 2], v[i + 3]));
+}
+
+// token ids -> embedding rows (flow.py:252-256): bf16 [rows][512]; ids clamped at 0; rows beyond the sequence -> 0
+struct EmbedPtrArgs { const int* const* tokens; const float* table; SeqTable seq; int rows; uint16_t* out; };
+__global__ __launch_bounds__(256) void k_embed_tokens_ptr(EmbedPtrArgs a) {
+    const int row = blockIdx.x * 2 + (threadIdx.x >> 7), c = (threadIdx.x & 127) * 4;
+    if (row >= a.rows) return;
+    const int s = a.seq.tile_seq[row >> 6];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s >= 0) {
+        const int t = row - a.seq.seq_start[s];
+        if (t < a.seq.seq_len[s]) {
+            int id = a.tokens[s][t];
+            id = id < 0 ? 0 : id;
+            v = *reinterpret_cast<const f32x4*>(a.table + (size_t)id * 512 + c);
+        }
+    }
+    *reinterpret_cast<uint2*>(a.out + (size_t)row * 512 + c) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+// 3 look-ahead context rows (fp32 [3][512]) -> bf16 rows
+__global__ __launch_bounds__(256) void k_ctx_rows(const float* ctx, uint16_t* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 3 * 512) out[i] = f2bf(ctx[i]);
+}
+
+// fp32 [rows][512] -> bf16 (plain cast with mask), used for externally supplied encoder inputs
+struct CastArgs { const float* x; uint16_t* out; SeqTable seq; int rows; int C; const int* src_row_off; };
+__global__ __launch_bounds__(256) void k_cast_rows(CastArgs a) {
+    const int per_row = a.C / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int row = idx / per_row, c = (idx % per_row) * 4;
+    if (row >= a.rows) return;
+    const int s = a.seq.tile_seq[row >> 6];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s >= 0) {
+        const int t = row - a.seq.seq_start[s];
+        if (t < a.seq.seq_len[s]) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)a.src_row_off[s] + t) * a.C + c);
+    }
+    *reinterpret_cast<uint2*>(a.out + (size_t)row * a.C + c) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+
+// Upsample1D nearest x2 (upsample_encoder.py:55-57): token-rate fp32 rows -> mel-rate bf16 rows of the new layout
+struct RepeatArgs { const float* x; SeqTable seq_in; SeqTable seq_out; int rows_out; uint16_t* out; };
+__global__ __launch_bounds__(256) void k_repeat2(RepeatArgs a) {
+    const int row = blockIdx.x * 2 + (threadIdx.x >> 7), c = (threadIdx.x & 127) * 4;
+    if (row >= a.rows_out) return;
+    const int s = a.seq_out.tile_seq[row >> 6];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s >= 0) {
+        const int t = row - a.seq_out.seq_start[s];
+        if (t < a.seq_out.seq_len[s]) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)a.seq_in.seq_start[s] + (t >> 1)) * 512 + c);
+    }
+    *reinterpret_cast<uint2*>(a.out + (size_t)row * 512 + c) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+
+// EspnetRelPositionalEncoding (embedding.py:226-302): rows r = 0 .. 2T-2 hold position T-1-r; even cols sin, odd cos.
+__global__ __launch_bounds__(256) void k_pos_emb(uint16_t* out, int T, int rows_pad) {
+    const int r = blockIdx.x, i2 = threadIdx.x;              // 256 (sin, cos) pairs
+    float sv = 0.f, cv = 0.f;
+    if (r < 2 * T - 1) {
+        const float pos = (float)(T - 1 - r);
+        const float div = expf((float)(2 * i2) * (-(logf(10000.0f) / 512.f)));
+        sv = sinf(pos * div); cv = cosf(pos * div);
+    }
+    if (r < rows_pad) *reinterpret_cast<uint32_t*>(out + (size_t)r * 512 + 2 * i2) = pack_bf16x2(sv, cv);
+}
+
+// softmax over (ac[i][j] + bd[i][T-1-i+j]) / 8 with the chunk mask (attention.py:225-247 rel_shift, :297-330)
+struct RelSmArgs { const float* ac; const float* bd; uint16_t* probs; int T, Tp, P, chunk; };
+__global__ __launch_bounds__(256) void k_relsoftmax(RelSmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem);
+    __shared__ float red[8];
+    const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    uint16_t* pr = a.probs + ((size_t)h * a.Tp + i) * a.Tp;
+    if (i >= a.T) { for (int j = tid; j < a.Tp; j += 256) pr[j] = 0; return; }
+    const int kmax = a.chunk > 0 ? min(a.T, (i / a.chunk + 1) * a.chunk) : a.T;
+    const float* acr = a.ac + ((size_t)h * a.Tp + i) * a.Tp;
+    const float* bdr = a.bd + ((size_t)h * a.Tp + i) * a.P + (a.T - 1 - i);
+    float mx = -INFINITY;
+    for (int j = tid; j < kmax; j += 256) { const float v = (acr[j] + bdr[j]) * 0.125f; sc[j] = v; mx = fmaxf(mx, v); }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < kmax; j += 256) { const float p = __expf(sc[j] - mx); sc[j] = p; sum += p; }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    for (int j = tid; j < a.Tp; j += 256) pr[j] = j < kmax ? f2bf(sc[j] * inv) : (uint16_t)0;
+}
+
+// F.normalize(embedding) -> Linear 192 -> 80 (flow.py:248-249), fp32; one block per utterance
+struct SpkArgs { const float* const* emb; const float* w; const float* b; float* out; };
+__global__ __launch_bounds__(128) void k_spk(SpkArgs a) {
+    __shared__ float e[192];
+    __shared__ float red[2];
+    const float* x = a.emb[blockIdx.x];
+    float sq = 0.f;
+    for (int i = threadIdx.x; i < 192; i += 128) { e[i] = x[i]; sq += x[i] * x[i]; }
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    const float inv = 1.f / fmaxf(sqrtf(red[0] + red[1]), 1e-12f);
+    if (threadIdx.x < 80) {
+        float acc = 0.f;
+        for (int i = 0; i < 192; i++) acc += a.w[threadIdx.x * 192 + i] * (e[i] * inv);
+        a.out[blockIdx.x * 80 + threadIdx.x] = acc + a.b[threadIdx.x];
+    }
+}
+
+// ---- estimator input pack / Euler update (flow_matching.py:94-121) --------------------------------------------
+// Estimator rows: cond twins occupy rows [0, RU) in the encoder's mel-rate layout, uncond twins rows [RU, 2RU).
+struct PackArgs {
+    float* x;                    // [RU][80] state
+    const float* mu;             // [RU][80]
+    const float* spk;            // [U][80]
+    const float* const* prompt;  // [U] -> fp32 [n_prompt][80]
+    const int* n_prompt;         // [U]
+    const float* noise;          // [15000][80]; != null on the first step: x = noise[t]
+    const float* v;              // [2RU][80] estimator output of the previous step (null on the first)
+    float dt, cfg;
+    SeqTable seq;                // estimator table (2U sequences)
+    int RU, U;
+    uint16_t* a0;                // [2RU][320]
+};
+__global__ __launch_bounds__(256) void k_euler_pack(PackArgs a) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int row = idx / 20, c = (idx % 20) * 4;            // 80 channels = 20 float4
+    if (row >= a.RU) return;
+    const int s = a.seq.tile_seq[row >> 6];
+    f32x4 x = {0.f, 0.f, 0.f, 0.f}, mu = x, sp = x, cd = x;
+    bool valid = false;
+    if (s >= 0) {
+        const int t = row - a.seq.seq_start[s];
+        valid = t < a.seq.seq_len[s];
+        if (valid) {
+            if (a.noise) x = *reinterpret_cast<const f32x4*>(a.noise + (size_t)t * 80 + c);
+            else {
+                x = *reinterpret_cast<const f32x4*>(a.x + (size_t)row * 80 + c);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(a.v + (size_t)row * 80 + c);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(a.v + (size_t)(row + a.RU) * 80 + c);
+                x = x + a.dt * ((1.0f + a.cfg) * v0 - a.cfg * v1);
+            }
+            mu = *reinterpret_cast<const f32x4*>(a.mu + (size_t)row * 80 + c);
+            sp = *reinterpret_cast<const f32x4*>(a.spk + (size_t)s * 80 + c);
+            if (t < a.n_prompt[s]) cd = *reinterpret_cast<const f32x4*>(a.prompt[s] + (size_t)t * 80 + c);
+        }
+    }
+    *reinterpret_cast<f32x4*>(a.x + (size_t)row * 80 + c) = x;
+    const uint2 xb = make_uint2(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]));
+    uint16_t* r0 = a.a0 + (size_t)row * 320 + c;
+    uint16_t* r1 = a.a0 + (size_t)(row + a.RU) * 320 + c;
+    *reinterpret_cast<uint2*>(r0) = xb;
+    *reinterpret_cast<uint2*>(r0 + 80) = make_uint2(pack_bf16x2(mu[0], mu[1]), pack_bf16x2(mu[2], mu[3]));
+    *reinterpret_cast<uint2*>(r0 + 160) = make_uint2(pack_bf16x2(sp[0], sp[1]), pack_bf16x2(sp[2], sp[3]));
+    *reinterpret_cast<uint2*>(r0 + 240) = make_uint2(pack_bf16x2(cd[0], cd[1]), pack_bf16x2(cd[2], cd[3]));
+    *reinterpret_cast<uint2*>(r1) = xb;
+    *reinterpret_cast<uint2*>(r1 + 80) = make_uint2(0u, 0u);
+    *reinterpret_cast<uint2*>(r1 + 160) = make_uint2(0u, 0u);
+    *reinterpret_cast<uint2*>(r1 + 240) = make_uint2(0u, 0u);
+}
+
+// final state -> mel_out[u][80][mel_len2] (flow.py:281): drop the prompt frames, channel-major
+struct MelOutArgs { const float* x; float* const* out; const int* n_prompt; SeqTable seq; };
+__global__ __launch_bounds__(256) void k_mel_out(MelOutArgs a) {
+    const int s = blockIdx.y;
+    const int len = a.seq.seq_len[s], p = a.n_prompt[s], start = a.seq.seq_start[s];
+    const int n2 = len - p;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)n2 * 80) return;
+    const int c = idx / n2, t = idx % n2;
+    a.out[s][(size_t)c * n2 + t] = a.x[(size_t)(start + p + t) * 80 + c];
+}
+
+// TensorRT-seam pack / unpack (flow_matching.py:125-150): channel-major (2,80,T) tensors <-> packed rows
+struct SeamPackArgs { const float* x; const float* mu; const float* spks; const float* cond; int T; int row1; uint16_t* a0; int rows; };
+__global__ __launch_bounds__(256) void k_seam_pack(SeamPackArgs a) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int row = idx / 320, c = idx % 320;
+    if (row >= a.rows) return;
+    const int b = row >= a.row1 ? 1 : 0, t = row - b * a.row1;
+    float v = 0.f;
+    if (t < a.T) {
+        const int g = c / 80, ch = c % 80;
+        const size_t o = ((size_t)b * 80 + ch) * a.T + t;
+        v = g == 0 ? a.x[o] : g == 1 ? a.mu[o] : g == 2 ? a.spks[b * 80 + ch] : a.cond[o];
+    }
+    a.a0[(size_t)row * 320 + c] = f2bf(v);
+}
+__global__ __launch_bounds__(256) void k_seam_unpack(const float* v, float* x, int T, int row1) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 2L * 80 * T) return;
+    const int t = idx % T, ch = (idx / T) % 80, b = idx / (80L * T);
+    x[idx] = v[(size_t)(b * row1 + t) * 80 + ch];
+}
+
+// sinusoidal time embedding (matcha decoder.py:14-29): [n][320] fp32, scale 1000
+__global__ void k_sinus(const float* t, float* out, int n) {
+    const int i = blockIdx.x, j = threadIdx.x;          // 160 threads
+    if (i >= n || j >= 160) return;
+    const float e = expf((float)j * -(logf(10000.0f) / 159.f));
+    const float arg = 1000.f * t[i] * e;
+    out[i * 320 + j] = sinf(arg);
+    out[i * 320 + 160 + j] = cosf(arg);
+}
+__global__ void k_act_inplace(float* x, int n, int act) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = act_apply(x[i], act, 0.f);
+}
+
+// =========================================================================== estimator attention (flash style)
+// grid (q tiles of 64 rows, 8 heads); 4 waves x 16 query rows.  S^T = K Q^T so a lane owns one query column and
+// 4 keys per 16-key tile; P feeds the PV MFMA from the same registers (the k-slot order of the second product is
+// chosen to match), V^T comes pre-transposed from the QKV GEMM epilogue.
+struct AttnEstArgs {
+    const uint16_t* qk;   // [R][1024]: q cols [0,512), k cols [512,1024)
+    const uint16_t* vt;   // [512][R]
+    uint16_t* out;        // [R][512]
+    SeqTable seq; int chunk; long R;
+};
+#define AK_LD 72    // K tile row stride (bf16 elements): 64 + 8
+#define AV_LD 68    // V^T tile row stride: 64 + 4
+__global__ __launch_bounds__(256) void k_attn_est(AttnEstArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[2][64 * AK_LD];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[2][64 * AV_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.x * 64, h = blockIdx.y;
+    const int q16 = lane & 15, g = lane >> 4;
+    const int s = a.seq.tile_seq[m0 >> 6];
+    uint16_t* orow = a.out + (size_t)(m0 + 16 * w + q16) * 512 + h * 64 + 4 * g;
+    if (s < 0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) *reinterpret_cast<uint2*>(orow + 16 * dt) = make_uint2(0u, 0u);
+        return;
+    }
+    const int start = a.seq.seq_start[s], len = a.seq.seq_len[s];
+    const int t0 = m0 - start;
+    const int tq = t0 + 16 * w + q16;                                  // this lane's query frame
+    const int kmax_q = a.chunk > 0 ? min(len, (tq / a.chunk + 1) * a.chunk) : len;
+    const int kmax_blk = a.chunk > 0 ? min(len, ((t0 + 63) / a.chunk + 1) * a.chunk) : len;
+    const int ntiles = (kmax_blk + 63) / 64;
+
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(a.qk + (size_t)(m0 + 16 * w + q16) * 1024 + h * 64 + ks * 32 + g * 8);
+
+    // staging: thread -> 2 K chunks (row kr, 16-B chunk kc) and 2 V^T chunks
+    const int kr = tid >> 3, kc = tid & 7;                             // rows kr, kr + 32
+    uint4 kreg[2], vreg[2];
+    auto gload = [&](int kt) {
+        const long krow = (long)start + kt * 64;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            kreg[u] = *reinterpret_cast<const uint4*>(a.qk + (size_t)(krow + kr + 32 * u) * 1024 + 512 + h * 64 + kc * 8);
+            vreg[u] = *reinterpret_cast<const uint4*>(a.vt + (size_t)(h * 64 + kr + 32 * u) * a.R + krow + kc * 8);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            *reinterpret_cast<uint4*>(&Ks[buf][(kr + 32 * u) * AK_LD + kc * 8]) = kreg[u];
+            uint2* vd = reinterpret_cast<uint2*>(&Vs[buf][(kr + 32 * u) * AV_LD + kc * 8]);
+            vd[0] = make_uint2(vreg[u].x, vreg[u].y);
+            vd[1] = make_uint2(vreg[u].z, vreg[u].w);
+        }
+    };
+
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lrun = 0.f;
+
+    gload(0);
+    for (int kt = 0; kt < ntiles; kt++) {
+        const int buf = kt & 1;
+        lstore(buf);
+        __syncthreads();
+        if (kt + 1 < ntiles) gload(kt + 1);
+        // S^T: 4 key tiles x (d = 64 in two k-steps)
+        f32x4 sacc[4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+            sacc[k4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[buf][(16 * k4 + q16) * AK_LD + ks * 32 + g * 8]);
+                sacc[k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[k4], 0, 0, 0);
+            }
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = kt * 64 + 16 * k4 + 4 * g + r;
+                const float v = key < kmax_q ? sacc[k4][r] * 0.125f : -INFINITY;
+                sacc[k4][r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float mnew = fmaxf(mrun, mloc);
+        const float msafe = mnew == -INFINITY ? 0.f : mnew;
+        const float alpha = __expf(mrun - msafe);                     // mrun = -inf -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const float p = __expf(sacc[k4][r] - msafe); sacc[k4][r] = p; psum += p; }
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) o[dt] *= alpha;
+        // O^T += V^T P^T ; k slots of key-pair tile kp: j < 4 -> key 32kp + 4g + j, j >= 4 -> key 32kp + 16 + 4g + (j - 4)
+#pragma unroll
+        for (int kp = 0; kp < 2; kp++) {
+            typedef __attribute__((ext_vector_type(8))) float f32x8;
+            const f32x8 pv = {sacc[2 * kp][0], sacc[2 * kp][1], sacc[2 * kp][2], sacc[2 * kp][3],
+                              sacc[2 * kp + 1][0], sacc[2 * kp + 1][1], sacc[2 * kp + 1][2], sacc[2 * kp + 1][3]};
+            const bf16x8 pf = __builtin_convertvector(pv, bf16x8);
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                const uint16_t* vrow = &Vs[buf][(16 * dt + q16) * AV_LD + 32 * kp + 4 * g];
+                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+                const uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    lrun += __shfl_xor(lrun, 16);
+    lrun += __shfl_xor(lrun, 32);
+    const float inv = (tq < len && lrun > 0.f) ? 1.f / lrun : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)
+        *reinterpret_cast<uint2*>(orow + 16 * dt) = make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+}
+
+// =========================================================================== host side
+struct Layout {
+    int S = 0, rows = 0;
+    std::vector<int> start, len, ext;          // ext = padded extent in rows (multiple of 128)
+    int* d_tile_seq = nullptr; int* d_start = nullptr; int* d_len = nullptr;   // device copies (workspace slices)
+    SeqTable tab() const { return SeqTable{d_tile_seq, d_start, d_len}; }
+};
+static int pad_rows(int len) { return (len + 8 + 127) / 128 * 128; }
+
+struct cv2_flow {
+    cv2_flow_dims d;
+    cv2_flow_weights w;
+    hipStream_t stream0;
+    // workspace
+    char* ws; size_t ws_bytes;
+    int R;                       // row capacity
+    int TPmax, Pmax;
+    float* temb_tab;             // [n_timesteps][14][256]
+    float* t_steps_dev;          // [n_timesteps]
+    float* tmp_t;                // [32][1024] x 3 scratch for the time MLP
+    std::vector<float> t_host, dt_host;
+    // row buffers
+    uint16_t *a0, *hb, *xa, *xbuf, *cat, *lnb, *qk, *vt, *att, *ff;      // bf16
+    float *xf, *rf, *vf, *xs, *mu, *spk, *tmpf;                           // fp32
+    float *ac, *bd; uint16_t* probs; uint16_t *pos, *posp;
+    // encoder buffers (C = 512)
+    uint16_t *e_a, *e_b, *e_ln, *e_qkv, *e_vt, *e_att, *e_ff; float *e_x, *e_tmp;
+    int* itab;                   // int tables region
+    void* ptab;                  // pointer tables region
+    std::vector<char> host_stage;
+};
+
+struct Carver {
+    char* base; size_t off = 0;
+    template <typename T> T* take(size_t n) {
+        size_t o = off; off += (n * sizeof(T) + 255) & ~(size_t)255;
+        return base ? reinterpret_cast<T*>(base + o) : nullptr;
+    }
+};
+
+static size_t flow_carve(const cv2_flow_dims& d, cv2_flow* h, char* base) {
+    Carver c{base};
+    const size_t R = (size_t)d.max_rows, RG = R + GUARD + 8;
+    const int TP = pad_rows(d.max_len), P = (2 * d.max_len - 1 + 127) / 128 * 128;
+    cv2_flow tmp_{};
+    cv2_flow& f = h ? *h : tmp_;
+    f.R = (int)R; f.TPmax = TP; f.Pmax = P;
+    f.temb_tab = c.take<float>((size_t)32 * 14 * 256);
+    f.t_steps_dev = c.take<float>(32);
+    f.tmp_t = c.take<float>((size_t)3 * 32 * 1024);
+    f.a0 = c.take<uint16_t>(RG * 320); f.hb = c.take<uint16_t>(RG * 256); f.xa = c.take<uint16_t>(RG * 256);
+    f.xbuf = c.take<uint16_t>(RG * 256); f.cat = c.take<uint16_t>(RG * 512); f.lnb = c.take<uint16_t>(RG * 256);
+    f.qk = c.take<uint16_t>(RG * 1024); f.vt = c.take<uint16_t>((size_t)(512 + 64) * RG); f.att = c.take<uint16_t>(RG * 512);
+    f.ff = c.take<uint16_t>(RG * 1024);
+    f.xf = c.take<float>(R * 256); f.rf = c.take<float>(R * 256); f.vf = c.take<float>(R * 80); f.xs = c.take<float>(R * 80);
+    f.mu = c.take<float>(R * 80); f.spk = c.take<float>((size_t)d.max_seqs * 80); f.tmpf = c.take<float>(R * 512);
+    f.ac = c.take<float>((size_t)8 * TP * TP); f.bd = c.take<float>((size_t)8 * TP * P); f.probs = c.take<uint16_t>((size_t)8 * TP * TP);
+    f.pos = c.take<uint16_t>((size_t)P * 512); f.posp = c.take<uint16_t>((size_t)P * 512);
+    f.e_a = c.take<uint16_t>(RG * 512); f.e_b = c.take<uint16_t>(RG * 512); f.e_ln = c.take<uint16_t>(RG * 512);
+    f.e_qkv = c.take<uint16_t>(RG * 1536); f.e_vt = c.take<uint16_t>((size_t)(512 + 64) * RG); f.e_att = c.take<uint16_t>(RG * 512);
+    f.e_ff = c.take<uint16_t>(RG * 2048); f.e_x = c.take<float>(R * 512); f.e_tmp = c.take<float>(R * 512);
+    f.itab = c.take<int>((size_t)6 * (R / 64 + 4 * d.max_seqs + 64));
+    f.ptab = c.take<void*>((size_t)8 * d.max_seqs + 64);
+    return c.off;
+}
+
+extern "C" size_t cv2_flow_workspace_bytes(const cv2_flow_dims* d) { return flow_carve(*d, nullptr, nullptr); }
+
+// guard-offset views: bf16 row buffers are addressed from their first real row
+#define GB(p, C) ((p) + (size_t)GUARD * (C))
+
+static int upload_layout(cv2_flow* h, Layout& L, int slot, hipStream_t s) {
+    // slot selects a disjoint slice of the int-table region
+    const int per = h->R / 64 + 4 * h->d.max_seqs + 64;
+    int* base = h->itab + (size_t)slot * per;
+    std::vector<int> host(L.rows / 64 + 2 * L.S);
+    for (int i = 0; i < L.rows / 64; i++) host[i] = -1;
+    for (int q = 0; q < L.S; q++) {
+        for (int r = L.start[q]; r < L.start[q] + L.ext[q]; r += 64) host[r / 64] = q;
+        host[L.rows / 64 + q] = L.start[q];
+        host[L.rows / 64 + L.S + q] = L.len[q];
+    }
+    CV2_CHECK((int)host.size() <= per, "flow: layout table overflow");
+    CV2_HIP(hipMemcpyAsync(base, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    CV2_HIP(hipStreamSynchronize(s));            // host vector goes out of scope
+    L.d_tile_seq = base; L.d_start = base + L.rows / 64; L.d_len = L.d_start + L.S;
+    return 0;
+}
+
+static Layout make_layout(const std::vector<int>& lens) {
+    Layout L;
+    L.S = (int)lens.size();
+    int r = 0;
+    for (int l : lens) { L.start.push_back(r); L.len.push_back(l); L.ext.push_back(pad_rows(l)); r += pad_rows(l); }
+    L.rows = r;
+    return L;
+}
+
+static int time_tables(cv2_flow* h, const float* t_dev, int n, float* tab_out, hipStream_t s) {
+    // temb = Linear2(SiLU(Linear1(sinus(t)))) ; per resnet: Linear(Mish(temb))  (decoder.py:420-421, matcha decoder.py:58)
+    float* e0 = h->tmp_t; float* e1 = e0 + 32 * 1024; float* e2 = e1 + 32 * 1024;
+    hipLaunchKernelGGL(k_sinus, dim3(n), dim3(160), 0, s, t_dev, e0, n);
+    if (skinny_gemm_launch(h->w.time1.w, h->w.time1.b, e0, e1, n, 1024, 320, s)) return -1;
+    hipLaunchKernelGGL(k_act_inplace, dim3((n * 1024 + 255) / 256), dim3(256), 0, s, e1, n * 1024, ACT_SILU);
+    if (skinny_gemm_launch(h->w.time2.w, h->w.time2.b, e1, e2, n, 1024, 1024, s)) return -1;
+    hipLaunchKernelGGL(k_act_inplace, dim3((n * 1024 + 255) / 256), dim3(256), 0, s, e2, n * 1024, ACT_MISH);
+    // 14 resnets: down, mid 0..11, up ; output [n][14][256] -> skinny writes [n][256] with row stride 256, so go via e0
+    for (int r = 0; r < 14; r++) {
+        const cv2_resnet& rn = r == 0 ? h->w.down.rn : r == 13 ? h->w.up_blk.rn : h->w.mid[r - 1].rn;
+        if (skinny_gemm_launch(rn.mlp.w, rn.mlp.b, e2, e0, n, 256, 1024, s)) return -1;
+        CV2_HIP(hipMemcpy2DAsync(tab_out + r * 256, (size_t)14 * 256 * 4, e0, 256 * 4, 256 * 4, n, hipMemcpyDeviceToDevice, s));
+    }
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cv2_flow_create(const cv2_flow_dims* d, const cv2_flow_weights* w, void* ws, size_t ws_bytes, void* stream, cv2_flow** out) {
+    CV2_CHECK(d && w && ws && out, "cv2_flow_create: null argument");
+    CV2_CHECK(d->max_rows % 128 == 0 && d->max_rows >= 256, "cv2_flow_create: max_rows must be a multiple of 128");
+    CV2_CHECK(d->n_timesteps >= 1 && d->n_timesteps <= 31, "cv2_flow_create: n_timesteps out of range");
+    CV2_CHECK(ws_bytes >= cv2_flow_workspace_bytes(d), "cv2_flow_create: workspace too small");
+    cv2_flow* h = new cv2_flow();
+    h->d = *d; h->w = *w; h->ws = (char*)ws; h->ws_bytes = ws_bytes;
+    flow_carve(*d, h, (char*)ws);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, cv2_flow_workspace_bytes(d), s) != hipSuccess) { delete h; return cv2_fail("cv2_flow_create: memset failed"); }
+    // t schedule exactly as solve_euler walks it (flow_matching.py:91-121): t_span = 1 - cos(linspace(0,1,n+1) * pi/2) in fp32
+    const int n = d->n_timesteps;
+    std::vector<float> span(n + 1);
+    for (int i = 0; i <= n; i++) {
+        // torch.linspace (fp32): start + i*step for the first half, end - (n-i)*step for the second
+        const float step = 1.0f / (float)n;
+        const float lin = i < (n + 1) / 2 ? 0.0f + step * (float)i : 1.0f - step * (float)(n - i);
+        span[i] = 1.0f - cosf(lin * 0.5f * 3.14159265358979323846f);
+    }
+    h->t_host.resize(n); h->dt_host.resize(n);
+    float t = span[0], dt = span[1] - span[0];
+    for (int st = 1; st <= n; st++) {
+        h->t_host[st - 1] = t; h->dt_host[st - 1] = dt;
+        t = t + dt;
+        if (st < n) dt = span[st + 1] - t;
+    }
+    if (hipMemcpyAsync(h->t_steps_dev, h->t_host.data(), n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) { delete h; return cv2_fail("cv2_flow_create: upload failed"); }
+    if (time_tables(h, h->t_steps_dev, n, h->temb_tab, s)) { delete h; return -1; }
+    *out = h;
+    return 0;
+}
+extern "C" int cv2_flow_destroy(cv2_flow* h) { delete h; return 0; }
+
+// ------------------------------------------------------------------ estimator core
+struct EstCtx { cv2_flow* h; const Layout* L; const float* temb; int chunk; hipStream_t s; };
+
+static int est_gemm(EstCtx& c, GemmArgs a, int cfg) {
+    a.seq = c.L->tab(); a.mask = 1;
+    return gemm_launch_cfg(a, cfg, 1, true, c.s);
+}
+
+// resnet: A = bf16 input (guard-offset pointer) with C_in channels; leaves x (fp32, xf) and LN'd bf16 (lnb) for the first tblock
+static int est_resnet(EstCtx& c, const cv2_resnet& rn, int ridx, const uint16_t* A, int cin, const cv2_ln& next_ln) {
+    cv2_flow* h = c.h; const int M = c.L->rows;
+    {   // res_conv 1x1
+        GemmArgs a = gemm_args(A, cin, 0, rn.res.w, M, 256, cin);
+        a.bias = rn.res.b; a.out_f32 = h->rf; a.ldo = 256;
+        if (est_gemm(c, a, 1)) return -1;
+    }
+    {   // block1: conv k3 -> LN -> Mish -> + time embedding
+        GemmArgs a = gemm_args(A, cin, -2, rn.conv1.w, M, 256, 3 * cin);
+        a.bias = rn.conv1.b; a.ln1_g = rn.ln1.g; a.ln1_b = rn.ln1.b; a.ln1_eps = 1e-5f; a.act = ACT_MISH;
+        a.rowadd = c.temb + ridx * 256; a.rowadd_ld = 0;
+        a.out_bf16 = GB(h->hb, 256); a.ldo16 = 256;
+        if (est_gemm(c, a, 1)) return -1;
+    }
+    {   // block2 + residual; second LN = norm1 of the first transformer block
+        GemmArgs a = gemm_args(GB(h->hb, 256), 256, -2, rn.conv2.w, M, 256, 768);
+        a.bias = rn.conv2.b; a.ln1_g = rn.ln2.g; a.ln1_b = rn.ln2.b; a.ln1_eps = 1e-5f; a.act = ACT_MISH;
+        a.res = h->rf; a.ldres = 256; a.out_f32 = h->xf; a.ldo = 256;
+        a.ln2_g = next_ln.g; a.ln2_b = next_ln.b; a.ln2_eps = 1e-5f; a.out_ln2 = GB(h->lnb, 256); a.ldo_ln2 = 256;
+        if (est_gemm(c, a, 1)) return -1;
+    }
+    return 0;
+}
+
+// transformer block; next_ln == null: last of its group -> bf16 copy of x goes to (xout, ldx)
+static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, uint16_t* xout, long ldx) {
+    cv2_flow* h = c.h; const int M = c.L->rows;
+    {
+        GemmArgs a = gemm_args(GB(h->lnb, 256), 256, 0, tb.qkv.w, M, 1536, 256);
+        a.out_bf16 = GB(h->qk, 1024); a.ldo16 = 1024; a.n_store = 1024;
+        a.vt = h->vt + GUARD; a.vt_ld = h->R + GUARD + 8; a.vt_n0 = 1024;
+        if (est_gemm(c, a, 0)) return -1;
+    }
+    {
+        AttnEstArgs a{GB(h->qk, 1024), h->vt + GUARD, GB(h->att, 512), c.L->tab(), c.chunk, (long)(h->R + GUARD + 8)};
+        hipLaunchKernelGGL(k_attn_est, dim3(M / 64, 8), dim3(256), 0, c.s, a);
+    }
+    {
+        GemmArgs a = gemm_args(GB(h->att, 512), 512, 0, tb.out.w, M, 256, 512);
+        a.bias = tb.out.b; a.res = h->xf; a.ldres = 256; a.out_f32 = h->xf; a.ldo = 256;
+        a.ln2_g = tb.norm3.g; a.ln2_b = tb.norm3.b; a.ln2_eps = 1e-5f; a.out_ln2 = GB(h->lnb, 256); a.ldo_ln2 = 256;
+        if (est_gemm(c, a, 1)) return -1;
+    }
+    {
+        GemmArgs a = gemm_args(GB(h->lnb, 256), 256, 0, tb.ff1.w, M, 1024, 256);
+        a.bias = tb.ff1.b; a.act = ACT_GELU; a.out_bf16 = GB(h->ff, 1024); a.ldo16 = 1024;
+        if (est_gemm(c, a, 0)) return -1;
+    }
+    {
+        GemmArgs a = gemm_args(GB(h->ff, 1024), 1024, 0, tb.ff2.w, M, 256, 1024);
+        a.bias = tb.ff2.b; a.res = h->xf; a.ldres = 256;
+        if (next_ln) {
+            a.out_f32 = h->xf; a.ldo = 256;
+            a.ln2_g = next_ln->g; a.ln2_b = next_ln->b; a.ln2_eps = 1e-5f; a.out_ln2 = GB(h->lnb, 256); a.ldo_ln2 = 256;
+        } else {
+            a.out_bf16 = xout; a.ldo16 = ldx;
+        }
+        if (est_gemm(c, a, 1)) return -1;
+    }
+    return 0;
+}
+
+static int est_block(EstCtx& c, const cv2_unet_block& b, int ridx, const uint16_t* A, int cin, uint16_t* xout, long ldx) {
+    if (est_resnet(c, b.rn, ridx, A, cin, b.tb[0].norm1)) return -1;
+    for (int j = 0; j < 4; j++)
+        if (est_tblock(c, b.tb[j], j < 3 ? &b.tb[j + 1].norm1 : nullptr, xout, ldx)) return -1;
+    return 0;
+}
+
+// a0 (bf16 [rows][320]) -> vf (fp32 [rows][80])      CausalConditionalDecoder.forward, decoder.py:405-494
+static int estimator_core(EstCtx& c) {
+    cv2_flow* h = c.h; const int M = c.L->rows;
+    const cv2_flow_weights& w = h->w;
+    if (est_block(c, w.down, 0, GB(h->a0, 320), 320, GB(h->xa, 256), 256)) return -1;
+    // skip connection: xa -> cat[:, 256:512]
+    CV2_HIP(hipMemcpy2DAsync(GB(h->cat, 512) + 256, 512 * 2, GB(h->xa, 256), 256 * 2, 256 * 2, M, hipMemcpyDeviceToDevice, c.s));
+    {   // downsample tail: CausalConv1d(256,256,3)
+        GemmArgs a = gemm_args(GB(h->xa, 256), 256, -2, w.down.tail.w, M, 256, 768);
+        a.bias = w.down.tail.b; a.out_bf16 = GB(h->xbuf, 256); a.ldo16 = 256;
+        if (est_gemm(c, a, 1)) return -1;
+    }
+    for (int i = 0; i < 12; i++) {
+        const uint16_t* A = i == 0 ? GB(h->xbuf, 256) : GB(h->xa, 256);
+        uint16_t* xo = i == 11 ? GB(h->cat, 512) : GB(h->xa, 256);
+        if (est_block(c, w.mid[i], 1 + i, A, 256, xo, i == 11 ? 512 : 256)) return -1;
+    }
+    if (est_block(c, w.up_blk, 13, GB(h->cat, 512), 512, GB(h->xa, 256), 256)) return -1;
+    {   // upsample tail
+        GemmArgs a = gemm_args(GB(h->xa, 256), 256, -2, w.up_blk.tail.w, M, 256, 768);
+        a.bias = w.up_blk.tail.b; a.out_bf16 = GB(h->xbuf, 256); a.ldo16 = 256;
+        if (est_gemm(c, a, 1)) return -1;
+    }
+    {   // final_block: conv -> LN -> Mish
+        GemmArgs a = gemm_args(GB(h->xbuf, 256), 256, -2, w.final_conv.w, M, 256, 768);
+        a.bias = w.final_conv.b; a.ln1_g = w.final_ln.g; a.ln1_b = w.final_ln.b; a.ln1_eps = 1e-5f; a.act = ACT_MISH;
+        a.out_bf16 = GB(h->hb, 256); a.ldo16 = 256;
+        if (est_gemm(c, a, 1)) return -1;
+    }
+    {   // final_proj 256 -> 80 (weights padded to 128 rows)
+        GemmArgs a = gemm_args(GB(h->hb, 256), 256, 0, w.final_proj.w, M, 128, 256);
+        a.bias = w.final_proj.b; a.out_f32 = h->vf; a.ldo = 80; a.n_store = 80;
+        if (est_gemm(c, a, 0)) return -1;
+    }
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cv2_flow_estimator(cv2_flow* h, float* x, const float* mask, const float* mu, const float* t, const float* spks,
+                                  const float* cond, int32_t T, int32_t streaming, void* stream) {
+    CV2_CHECK(h && x && mu && t && spks && cond, "cv2_flow_estimator: null argument");
+    (void)mask;   // the reference always passes an all-ones mask of length T (flow.py:272); lengths come from T
+    hipStream_t s = (hipStream_t)stream;
+    Layout L = make_layout({T, T});
+    CV2_CHECK(L.rows <= h->R, "cv2_flow_estimator: T=%d exceeds the workspace (rows %d > %d)", T, L.rows, h->R);
+    if (upload_layout(h, L, 0, s)) return -1;
+    // time embedding for this t (both rows carry the same t, flow_matching.py:108)
+    float* tab = h->temb_tab + (size_t)31 * 14 * 256;
+    if (time_tables(h, t, 1, tab, s)) return -1;
+    SeamPackArgs p{x, mu, spks, cond, T, L.start[1], GB(h->a0, 320), L.rows};
+    hipLaunchKernelGGL(k_seam_pack, dim3(((long)L.rows * 320 + 255) / 256), dim3(256), 0, s, p);
+    EstCtx c{h, &L, tab, streaming ? 50 : 0, s};
+    if (estimator_core(c)) return -1;
+    hipLaunchKernelGGL(k_seam_unpack, dim3((2L * 80 * T + 255) / 256), dim3(256), 0, s, (const float*)h->vf, x, (int)T, L.start[1]);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ encoder
+struct EncCtx { cv2_flow* h; const Layout* L; int chunk; hipStream_t s; };
+
+static int enc_gemm(EncCtx& c, GemmArgs a, int cfg) {
+    a.seq = c.L->tab(); a.mask = 1;
+    return gemm_launch_cfg(a, cfg, 1, true, c.s);
+}
+static int enc_ln(EncCtx& c, const float* x, const cv2_ln& ln, float eps, float scale, float* of, uint16_t* ob) {
+    LnArgs a{x, 512, 512, ln.g, ln.b, eps, scale, c.L->tab(), c.L->rows, of, 512, ob, 512};
+    hipLaunchKernelGGL(k_layernorm<8>, dim3((c.L->rows + 3) / 4), dim3(256), 0, c.s, a);
+    return 0;
+}
+
+// one ConformerEncoderLayer over x (fp32 e_x, in place)      encoder_layer.py:160-236, attention.py:249-330
+static int conformer_layer(EncCtx& c, const cv2_conformer& cl) {
+    cv2_flow* h = c.h; const int M = c.L->rows; const long RG = h->R + GUARD + 8;
+    enc_ln(c, h->e_x, cl.norm_mha, 1e-12f, 1.f, nullptr, GB(h->e_ln, 512));
+    {
+        GemmArgs a = gemm_args(GB(h->e_ln, 512), 512, 0, cl.qkv.w, M, 2048, 512);
+        a.bias = cl.qkv.b; a.out_bf16 = GB(h->e_qkv, 1536); a.ldo16 = 1536; a.n_store = 1536;
+        a.vt = h->e_vt + GUARD; a.vt_ld = RG; a.vt_n0 = 1536;
+        if (enc_gemm(c, a, 0)) return -1;
+    }
+    int pos_T = -1;
+    for (int q = 0; q < c.L->S; q++) {
+        const int T = c.L->len[q], r0 = c.L->start[q], Tp = pad_rows(T), P = (2 * T - 1 + 127) / 128 * 128;
+        if (T != pos_T) {       // linear_pos(pos_emb(T)) for this layer
+            hipLaunchKernelGGL(k_pos_emb, dim3(P), dim3(256), 0, c.s, h->pos, T, P);
+            GemmArgs a = gemm_args(h->pos, 512, 0, cl.pos.w, P, 512, 512);
+            a.out_bf16 = h->posp; a.ldo16 = 512;
+            if (gemm_launch_cfg(a, 0, 1, true, c.s)) return -1;
+            pos_T = T;
+        }
+        const uint16_t* qkv = GB(h->e_qkv, 1536) + (size_t)r0 * 1536;
+        {   // ac[h] = (q + u) k^T
+            GemmArgs a = gemm_args(qkv, 1536, 0, qkv + 1024, Tp, Tp, 64);
+            a.a_bstride = 64; a.ldw = 1536; a.w_bstride = 64;
+            a.out_f32 = h->ac; a.ldo = Tp; a.o_bstride = (long)Tp * Tp;
+            if (gemm_launch_cfg(a, 0, 8, false, c.s)) return -1;
+        }
+        {   // bd[h] = (q + v) p^T
+            GemmArgs a = gemm_args(qkv + 512, 1536, 0, h->posp, Tp, P, 64);
+            a.a_bstride = 64; a.ldw = 512; a.w_bstride = 64;
+            a.out_f32 = h->bd; a.ldo = P; a.o_bstride = (long)Tp * P;
+            if (gemm_launch_cfg(a, 0, 8, false, c.s)) return -1;
+        }
+        {
+            RelSmArgs a{h->ac, h->bd, h->probs, T, Tp, P, c.chunk};
+            hipLaunchKernelGGL(k_relsoftmax, dim3(Tp, 8), dim3(256), (size_t)Tp * 4, c.s, a);
+        }
+        {   // att[:, h*64:(h+1)*64] = probs[h] V[h]
+            GemmArgs a = gemm_args(h->probs, Tp, 0, h->e_vt + GUARD + r0, Tp, 64, Tp);
+            a.a_bstride = (long)Tp * Tp; a.ldw = RG; a.w_bstride = 64 * RG;
+            a.out_bf16 = GB(h->e_att, 512) + (size_t)r0 * 512; a.ldo16 = 512; a.o16_bstride = 64;
+            if (gemm_launch_cfg(a, 2, 8, false, c.s)) return -1;
+        }
+    }
+    {
+        GemmArgs a = gemm_args(GB(h->e_att, 512), 512, 0, cl.out.w, M, 512, 512);
+        a.bias = cl.out.b; a.res = h->e_x; a.ldres = 512; a.out_f32 = h->e_x; a.ldo = 512;
+        if (enc_gemm(c, a, 0)) return -1;
+    }
+    enc_ln(c, h->e_x, cl.norm_ff, 1e-12f, 1.f, nullptr, GB(h->e_ln, 512));
+    {
+        GemmArgs a = gemm_args(GB(h->e_ln, 512), 512, 0, cl.w1.w, M, 2048, 512);
+        a.bias = cl.w1.b; a.act = ACT_SILU; a.out_bf16 = GB(h->e_ff, 2048); a.ldo16 = 2048;
+        if (enc_gemm(c, a, 0)) return -1;
+    }
+    {
+        GemmArgs a = gemm_args(GB(h->e_ff, 2048), 2048, 0, cl.w2.w, M, 512, 2048);
+        a.bias = cl.w2.b; a.res = h->e_x; a.ldres = 512; a.out_f32 = h->e_x; a.ldo = 512;
+        if (enc_gemm(c, a, 0)) return -1;
+    }
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+// Token-rate bf16 input rows (e_a; with look-ahead context rows when LA.len = T + 3) -> mel-rate rows:
+//   final fp32 [rows2][512] after after_norm (out_f32, may be null) and/or bf16 (e_ln) for encoder_proj.
+// LA = layout with the embed-stage lengths, LT = token-rate layout (T), L2 = mel-rate layout (2T); same starts for LA/LT.
+static int encoder_core(cv2_flow* h, Layout& LA, Layout& LT, Layout& L2, int streaming, float* out_f32, hipStream_t s) {
+    const cv2_flow_weights& w = h->w;
+    const float SQ = sqrtf(512.f);
+    EncCtx ca{h, &LA, streaming ? 25 : 0, s}, ct{h, &LT, streaming ? 25 : 0, s}, c2{h, &L2, streaming ? 50 : 0, s};
+    const int M = LT.rows;
+    {   // embed: Linear -> LayerNorm(1e-5) -> * sqrt(512)     subsampling.py:69-113, embedding.py:268
+        GemmArgs a = gemm_args(GB(h->e_a, 512), 512, 0, w.embed.w, M, 512, 512);
+        a.bias = w.embed.b; a.out_f32 = h->e_tmp; a.ldo = 512;
+        if (enc_gemm(ca, a, 0)) return -1;
+        enc_ln(ca, h->e_tmp, w.embed_ln, 1e-5f, SQ, h->e_x, GB(h->e_b, 512));
+    }
+    {   // pre_lookahead: conv k4 over [t, t+3] -> leaky_relu -> causal conv k3 -> + x      upsample_encoder.py:82-102
+        GemmArgs a = gemm_args(GB(h->e_b, 512), 512, 0, w.pre1.w, M, 512, 2048);
+        a.bias = w.pre1.b; a.act = ACT_LRELU; a.act_slope = 0.01f; a.out_bf16 = GB(h->e_a, 512); a.ldo16 = 512;
+        if (enc_gemm(ct, a, 0)) return -1;
+        GemmArgs b = gemm_args(GB(h->e_a, 512), 512, -2, w.pre2.w, M, 512, 1536);
+        b.bias = w.pre2.b; b.res = h->e_x; b.ldres = 512; b.out_f32 = h->e_x; b.ldo = 512;
+        if (enc_gemm(ct, b, 0)) return -1;
+    }
+    for (int i = 0; i < 6; i++) if (conformer_layer(ct, w.enc[i])) return -1;
+    {   // Upsample1D: nearest x2, left pad 4, conv k5   upsample_encoder.py:37-63 ; then up_embed
+        RepeatArgs r{h->e_x, LT.tab(), L2.tab(), L2.rows, GB(h->e_a, 512)};
+        hipLaunchKernelGGL(k_repeat2, dim3((L2.rows + 1) / 2), dim3(256), 0, s, r);
+        GemmArgs a = gemm_args(GB(h->e_a, 512), 512, -4, w.up_conv.w, L2.rows, 512, 2560);
+        a.bias = w.up_conv.b; a.out_bf16 = GB(h->e_b, 512); a.ldo16 = 512;
+        if (enc_gemm(c2, a, 0)) return -1;
+        GemmArgs b = gemm_args(GB(h->e_b, 512), 512, 0, w.up_embed.w, L2.rows, 512, 512);
+        b.bias = w.up_embed.b; b.out_f32 = h->e_tmp; b.ldo = 512;
+        if (enc_gemm(c2, b, 0)) return -1;
+        enc_ln(c2, h->e_tmp, w.up_embed_ln, 1e-5f, SQ, h->e_x, nullptr);
+    }
+    for (int i = 0; i < 4; i++) if (conformer_layer(c2, w.up[i])) return -1;
+    enc_ln(c2, h->e_x, w.after_norm, 1e-5f, 1.f, out_f32, GB(h->e_ln, 512));
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+static int check_rows(cv2_flow* h, const Layout& L, const char* who) {
+    CV2_CHECK(L.rows <= h->R, "%s: %d packed rows exceed the workspace capacity %d", who, L.rows, h->R);
+    for (int l : L.len) CV2_CHECK(l >= 1 && l <= h->d.max_len + 3, "%s: sequence length %d out of range (max %d)", who, l, h->d.max_len);
+    CV2_CHECK(L.S <= h->d.max_seqs, "%s: too many sequences", who);
+    return 0;
+}
+
+extern "C" int cv2_flow_encoder(cv2_flow* h, const float* xs, int32_t T, const float* context, int32_t streaming, float* out, void* stream) {
+    CV2_CHECK(h && xs && out && T >= 1, "cv2_flow_encoder: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    Layout LT = make_layout({T}), L2 = make_layout({2 * T});
+    Layout LA = LT;                                   // same rows; the 3 context rows sit in the zero tail of the sequence
+    if (context) LA.len[0] += 3;
+    if (check_rows(h, L2, "cv2_flow_encoder")) return -1;
+    if (upload_layout(h, LA, 0, s) || upload_layout(h, LT, 1, s) || upload_layout(h, L2, 2, s)) return -1;
+    // fp32 rows -> bf16 e_a (context rows appended)
+    int zero = 0;
+    int* off = h->itab + (size_t)4 * (h->R / 64 + 4 * h->d.max_seqs + 64);
+    CV2_HIP(hipMemcpyAsync(off, &zero, sizeof(int), hipMemcpyHostToDevice, s));
+    CV2_HIP(hipStreamSynchronize(s));
+    CastArgs ca{xs, GB(h->e_a, 512), LT.tab(), LT.rows, 512, off};
+    hipLaunchKernelGGL(k_cast_rows, dim3(((long)LT.rows * 128 + 255) / 256), dim3(256), 0, s, ca);
+    if (context) hipLaunchKernelGGL(k_ctx_rows, dim3(6), dim3(256), 0, s, context, GB(h->e_a, 512) + (size_t)T * 512);
+    if (encoder_core(h, LA, LT, L2, streaming, h->e_tmp, s)) return -1;
+    CV2_HIP(hipMemcpyAsync(out, h->e_tmp, (size_t)2 * T * 512 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+extern "C" int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t U, int32_t streaming, int32_t finalize, void* stream) {
+    CV2_CHECK(h && utts && U >= 1, "cv2_flow_inference: bad argument");
+    CV2_CHECK(2 * U <= h->d.max_seqs, "cv2_flow_inference: %d utterances exceed max_seqs/2", U);
+    hipStream_t s = (hipStream_t)stream;
+    const int la = finalize ? 0 : 3;                      // pre_lookahead_len (flow.py:260-263)
+    std::vector<int> lensT, lens2, lensE;
+    for (int u = 0; u < U; u++) {
+        const int T = utts[u].n_tok - la;
+        CV2_CHECK(T >= 1, "cv2_flow_inference: utterance %d has no tokens", u);
+        CV2_CHECK(utts[u].n_prompt_feat >= 0 && utts[u].n_prompt_feat <= 2 * T, "cv2_flow_inference: prompt_feat longer than the mel (%d > %d)", utts[u].n_prompt_feat, 2 * T);
+        lensT.push_back(T); lens2.push_back(2 * T);
+    }
+    Layout LT = make_layout(lensT), L2 = make_layout(lens2);
+    Layout LA = LT;                                   // embed-stage lengths include the look-ahead rows (zero tail of each sequence)
+    for (int u = 0; u < U; u++) LA.len[u] += la;
+    lensE = lens2; lensE.insert(lensE.end(), lens2.begin(), lens2.end());
+    Layout LE = make_layout(lensE);
+    if (check_rows(h, LE, "cv2_flow_inference")) return -1;
+    const int RU = L2.rows;
+    if (upload_layout(h, LA, 0, s) || upload_layout(h, LT, 1, s) || upload_layout(h, L2, 2, s) || upload_layout(h, LE, 3, s)) return -1;
+    // pointer / int tables
+    {
+        std::vector<const void*> ptrs(4 * U);
+        std::vector<int> ints(U);
+        for (int u = 0; u < U; u++) {
+            ptrs[u] = utts[u].embedding; ptrs[U + u] = utts[u].prompt_feat; ptrs[2 * U + u] = utts[u].mel_out; ptrs[3 * U + u] = utts[u].tokens;
+            ints[u] = utts[u].n_prompt_feat;
+        }
+        CV2_HIP(hipMemcpyAsync(h->ptab, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, s));
+        int* ibase = h->itab + (size_t)4 * (h->R / 64 + 4 * h->d.max_seqs + 64);
+        CV2_HIP(hipMemcpyAsync(ibase, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        CV2_HIP(hipStreamSynchronize(s));
+        const void* const* dp = (const void* const*)h->ptab;
+        // speaker projection
+        SpkArgs sp{(const float* const*)dp, h->w.spk_w, h->w.spk_b, h->spk};
+        hipLaunchKernelGGL(k_spk, dim3(U), dim3(128), 0, s, sp);
+        // token embedding rows
+        EmbedPtrArgs ea{(const int* const*)(dp + 3 * U), h->w.input_embedding, LA.tab(), LA.rows, GB(h->e_a, 512)};
+        hipLaunchKernelGGL(k_embed_tokens_ptr, dim3((LA.rows + 1) / 2), dim3(256), 0, s, ea);
+        if (encoder_core(h, LA, LT, L2, streaming, nullptr, s)) return -1;
+        {   // encoder_proj 512 -> 80 -> mu
+            GemmArgs a = gemm_args(GB(h->e_ln, 512), 512, 0, h->w.enc_proj.w, L2.rows, 128, 512);
+            a.bias = h->w.enc_proj.b; a.out_f32 = h->mu; a.ldo = 80; a.n_store = 80; a.seq = L2.tab(); a.mask = 1;
+            if (gemm_launch_cfg(a, 0, 1, true, s)) return -1;
+        }
+        // Euler loop (flow_matching.py:91-121)
+        EstCtx c{h, &LE, nullptr, streaming ? 50 : 0, s};
+        for (int st = 0; st < h->d.n_timesteps; st++) {
+            PackArgs p{h->xs, h->mu, h->spk, (const float* const*)(dp + U), ibase, st == 0 ? h->w.rand_noise : nullptr,
+                       st == 0 ? nullptr : h->vf, st == 0 ? 0.f : h->dt_host[st - 1], h->d.cfg_rate, L2.tab(), RU, U, GB(h->a0, 320)};
+            hipLaunchKernelGGL(k_euler_pack, dim3(((long)RU * 20 + 255) / 256), dim3(256), 0, s, p);
+            c.temb = h->temb_tab + (size_t)st * 14 * 256;
+            if (estimator_core(c)) return -1;
+        }
+        {   // last update without a following pack: reuse k_euler_pack (a0 is scratch now)
+            const int st = h->d.n_timesteps;
+            PackArgs p{h->xs, h->mu, h->spk, (const float* const*)(dp + U), ibase, nullptr, h->vf, h->dt_host[st - 1], h->d.cfg_rate,
+                       L2.tab(), RU, U, GB(h->a0, 320)};
+            hipLaunchKernelGGL(k_euler_pack, dim3(((long)RU * 20 + 255) / 256), dim3(256), 0, s, p);
+        }
+        int maxn2 = 1;
+        for (int u = 0; u < U; u++) maxn2 = std::max(maxn2, lens2[u] - utts[u].n_prompt_feat);
+        MelOutArgs mo{h->xs, (float* const*)(dp + 2 * U), ibase, L2.tab()};
+        hipLaunchKernelGGL(k_mel_out, dim3(((long)maxn2 * 80 + 255) / 256, U), dim3(256), 0, s, mo);
+    }
+    CV2_LAUNCH_CHECK();
+    return 0;
+}

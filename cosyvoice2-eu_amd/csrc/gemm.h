@@ -1,0 +1,257 @@
+// bf16 MFMA GEMM with an LDS-staged row epilogue: the MFMA workhorse of stage 2 (flow).
+//
+//   out[m][n] = epilogue( sum_k A[m + a_row_off][k] * W[n][k] )          A bf16 row-major, W bf16
+//
+// Roofline: MFMA (bf16 16x16x32, fp32 accumulate).  Tile BM x BN x 64; both operand tiles are staged by LDS-DMA
+// (global_load_lds, 16 B per lane) into two LDS stages as 16-row x 32-k sub-tiles of 1 KiB in MFMA operand order:
+//   * activations (row-major, any leading dimension; a causal Conv1d over time-major rows is this GEMM with
+//     lda = C and K = taps*C, the tap window being contiguous memory) are gathered with a per-lane SOURCE address
+//     and the st_16x32 XOR swizzle (conflict-free ds_read_b128 fragment reads);
+//   * weights are pre-packed in HBM in exactly that order (include/cv2_amd.h), so a stage is a linear stream.
+// The prefetch of K-step k+1 stays in flight across the barrier (counted vmcnt + raw s_barrier).
+// Orientation: the MFMA "A" operand is the weight fragment, "B" the activation fragment, so a lane ends with 4
+// consecutive output features of one row; the accumulator tile is then staged through LDS (re-using the operand
+// stages) and finished row-wise: bias, LayerNorm over the row, activation, per-sequence vector add, sequence
+// mask, fp32 residual, fp32 / bf16 stores, a second LayerNorm for the next GEMM's operand, or a transposed
+// bf16 store (V^T for attention).  Rows live in the packed ragged layout described in flow.hip.
+#pragma once
+#include "common.h"
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_MISH = 3, ACT_LRELU = 4 };
+
+struct SeqTable {
+    const int* tile_seq;    // [rows / 64]: sequence id of every 64-row tile, -1 = padding tile
+    const int* seq_start;   // [S] first row (multiple of 128)
+    const int* seq_len;     // [S] valid rows
+};
+
+struct GemmArgs {
+    const uint16_t* A; long lda; long a_row_off; long a_bstride;   // bf16 activations; row m reads A[(m + a_row_off) * lda ..]
+    const uint16_t* W; long ldw; long w_bstride;                    // packed (WPACKED) or row-major [N][ldw]
+    int M, N, K;                                                    // M % BM == 0 (padded rows), K % 64 == 0
+    SeqTable seq;                                                   // tile_seq == null: every row m < M_valid is valid
+    int M_valid;
+    // epilogue, in this order
+    const float* bias;                                              // [N]
+    const float* ln1_g; const float* ln1_b; float ln1_eps;          // LayerNorm over the row (BN == N)
+    int act; float act_slope;
+    const float* rowadd; int rowadd_ld;                             // + rowadd[seq][n]
+    const float* res; long ldres;                                   // + res[m][n] (fp32)
+    int mask;                                                       // rows beyond their sequence -> 0
+    float out_scale;                                                // * out_scale (applied to acc before bias when != 1)
+    float* out_f32; long ldo; long o_bstride;
+    uint16_t* out_bf16; long ldo16; long o16_bstride;
+    const float* ln2_g; const float* ln2_b; float ln2_eps; float ln2_scale; uint16_t* out_ln2; long ldo_ln2;
+    uint16_t* vt; long vt_ld; int vt_n0;                            // features n >= vt_n0: vt[(n - vt_n0) * vt_ld + m]
+    int n_store;                                                    // only features n < n_store are written (N padded up)
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    switch (act) {
+        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_MISH: {                                   // x * tanh(softplus(x)), softplus threshold 20 as torch
+            const float sp = v > 20.f ? v : log1pf(__expf(v));
+            return v * tanhf(sp);
+        }
+        case ACT_LRELU: return v > 0.f ? v : v * slope;
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const bf16x2 h = __builtin_convertvector((f32x2){a, b}, bf16x2);
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+// LDS byte offset of (row, 16-B chunk) inside a 16 x 32 bf16 sub-tile, st_16x32 swizzle
+__device__ __forceinline__ int subtile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 3) << 1)) << 4); }
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int BM, int BN, int WM, int WN, bool WPACKED>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
+    constexpr int NW = WM * WN, NT_ = NW * 64;
+    constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
+    constexpr int NA = BM / 16 * 2, NB = BN / 16 * 2, NP = NA + NB;          // 1 KiB pieces per stage
+    constexpr int STAGE = NP * 1024;
+    constexpr int LDC = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const uint16_t* A = a.A + (size_t)blockIdx.z * a.a_bstride;
+    const uint16_t* W = a.W + (size_t)blockIdx.z * a.w_bstride;
+    const int KS = a.K / 32;                                                  // 32-wide k blocks in the packed W
+    const int nk = a.K / 64;
+
+    // per-lane source coordinates of an LDS-DMA piece (lane writes LDS byte lane*16 of the sub-tile)
+    const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 5) << 1);
+
+    auto issue = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < NP / NW; i++) {
+            const int p = wave + i * NW;                 // NA % NW == 0: the A / W decision is per i, not per wave
+            const void* src;
+            if (i < NA / NW) {
+                const int sub = p >> 1, ks = p & 1;
+                src = A + ((long)(m0 + sub * 16 + srow) + a.a_row_off) * a.lda + kt * 64 + ks * 32 + schunk * 8;
+            } else {
+                const int q = p - NA, sub = q >> 1, ks = q & 1;
+                if (WPACKED)
+                    src = W + (((size_t)(n0 / 16 + sub) * KS + kt * 2 + ks) * 64 + lane) * 8;
+                else
+                    src = W + (long)(n0 + sub * 16 + srow) * a.ldw + kt * 64 + ks * 32 + schunk * 8;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
+        }
+    };
+    static_assert(NA % NW == 0 && NB % NW == 0, "A and W pieces must each divide evenly over the waves");
+    constexpr int PER_WAVE = (NP + NW - 1) / NW;       // NP % NW == 0 for every instantiated config
+    static_assert(NP % NW == 0, "pieces must divide evenly over the waves");
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int i = 0; i < MT; i++) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int a_off = subtile_off(lane & 15, lane >> 4);
+    const int w_off = WPACKED ? lane * 16 : a_off;
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            issue(kt + 1, buf ^ 1);
+            if (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (PER_WAVE == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (PER_WAVE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (PER_WAVE == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                    // stage kt has landed for every wave
+        const char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 af[MT], wf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+                af[i] = *reinterpret_cast<const bf16x8*>(base + ((wm * MT + i) * 2 + ks) * 1024 + a_off);
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+                wf[j] = *reinterpret_cast<const bf16x8*>(base + (NA + (wn * NT + j) * 2 + ks) * 1024 + w_off);
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // everyone is done reading this stage
+    }
+
+    // ---- accumulators -> LDS C tile [BM][LDC] ----
+    float* C = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const int m = wm * TM + i * 16 + (lane & 15);
+            const int n = wn * TN + j * 16 + 4 * (lane >> 4);
+            *reinterpret_cast<f32x4*>(&C[m * LDC + n]) = acc[j][i] * a.out_scale;
+        }
+    __syncthreads();
+
+    float* out_f32 = a.out_f32 ? a.out_f32 + (size_t)blockIdx.z * a.o_bstride : nullptr;
+    uint16_t* out_bf16 = a.out_bf16 ? a.out_bf16 + (size_t)blockIdx.z * a.o16_bstride : nullptr;
+
+    if (a.vt && n0 >= a.vt_n0) {
+        // transposed bf16 store: 8 consecutive rows of one feature = 16 B
+        for (int it = tid; it < BN * (BM / 8); it += NT_) {
+            const int n = it % BN, rg = it / BN;
+            const int mrow = m0 + rg * 8;
+            int s = 0, start = 0, len = a.M_valid;
+            if (a.seq.tile_seq) { s = a.seq.tile_seq[mrow >> 6]; if (s >= 0) { start = a.seq.seq_start[s]; len = a.seq.seq_len[s]; } }
+            const float b = a.bias ? a.bias[n0 + n] : 0.f;
+            uint32_t pk[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v0 = C[(rg * 8 + 2 * r) * LDC + n] + b, v1 = C[(rg * 8 + 2 * r + 1) * LDC + n] + b;
+                if (a.mask) {
+                    if (s < 0 || mrow + 2 * r - start >= len) v0 = 0.f;
+                    if (s < 0 || mrow + 2 * r + 1 - start >= len) v1 = 0.f;
+                }
+                pk[r] = pack_bf16x2(v0, v1);
+            }
+            *reinterpret_cast<uint4*>(a.vt + (size_t)(n0 + n - a.vt_n0) * a.vt_ld + mrow) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+        return;
+    }
+
+    // ---- row-wise epilogue: LPR lanes per row, 4 consecutive features per lane ----
+    constexpr int LPR = BN / 4, RPI = NT_ / LPR;        // lanes per row, rows per iteration of the block
+    static_assert(LPR <= 64, "BN <= 256");
+    const int rsub = tid / LPR, cl = tid % LPR;
+    const int n = n0 + cl * 4;
+    for (int r0 = 0; r0 < BM; r0 += RPI) {
+        const int ml = r0 + rsub, m = m0 + ml;
+        int s = 0; bool valid = m < a.M_valid;
+        if (a.seq.tile_seq) {
+            s = a.seq.tile_seq[m >> 6];
+            valid = s >= 0 && (m - a.seq.seq_start[s]) < a.seq.seq_len[s];
+            if (s < 0) s = 0;
+        }
+        f32x4 v = *reinterpret_cast<const f32x4*>(&C[ml * LDC + cl * 4]);
+        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (a.ln1_g) {
+            const float mean = group_sum<LPR>(v[0] + v[1] + v[2] + v[3]) * (1.f / BN);
+            const f32x4 d = v - mean;
+            const float var = group_sum<LPR>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / BN);
+            const float rstd = rsqrtf(var + a.ln1_eps);
+            v = d * rstd * *reinterpret_cast<const f32x4*>(a.ln1_g + n) + *reinterpret_cast<const f32x4*>(a.ln1_b + n);
+        }
+        if (a.act != ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = act_apply(v[e], a.act, a.act_slope);
+        }
+        if (a.rowadd) v += *reinterpret_cast<const f32x4*>(a.rowadd + (size_t)s * a.rowadd_ld + n);
+        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + (size_t)m * a.ldres + n);
+        if (a.mask && !valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool wr = n < a.n_store;
+        if (out_f32 && wr) *reinterpret_cast<f32x4*>(out_f32 + (size_t)m * a.ldo + n) = v;
+        if (out_bf16 && wr)
+            *reinterpret_cast<uint2*>(out_bf16 + (size_t)m * a.ldo16 + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        if (a.ln2_g) {
+            const float mean = group_sum<LPR>(v[0] + v[1] + v[2] + v[3]) * (1.f / BN);
+            const f32x4 d = v - mean;
+            const float var = group_sum<LPR>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / BN);
+            const float rstd = rsqrtf(var + a.ln2_eps);
+            f32x4 y = (d * rstd * *reinterpret_cast<const f32x4*>(a.ln2_g + n) + *reinterpret_cast<const f32x4*>(a.ln2_b + n)) * a.ln2_scale;
+            if (a.mask && !valid) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<uint2*>(a.out_ln2 + (size_t)m * a.ldo_ln2 + n) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+        }
+    }
+}
+
+template <int BM, int BN>
+constexpr size_t gemm_smem_bytes() {
+    constexpr size_t stages = 2 * (size_t)((BM + BN) / 16 * 2) * 1024;
+    constexpr size_t ctile = (size_t)BM * (BN + 4) * 4;
+    return stages > ctile ? stages : ctile;
+}
+

@@ -12,6 +12,7 @@
 // All are HBM-bound weight streams (skinny.h); the per-step algorithmic traffic is the bf16 weights once
 // (727.6 MB at the real dims) plus the KV read.
 #include "skinny.h"
+#include "skinny_launch.h"
 #include "../../include/cv2_amd.h"
 #include <map>
 #include <stdarg.h>
@@ -566,16 +567,14 @@ extern "C" int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void*
     return 0;
 }
 
-extern "C" int cv2_skinny_gemm(const uint16_t* w, const float* bias, const float* x, float* out, int32_t rows, int32_t n,
-                               int32_t k, void* stream) {
-    CV2_CHECK(w && x && out, "cv2_skinny_gemm: null argument");
-    CV2_CHECK(rows >= 1 && rows <= 32 && n % 16 == 0 && k % 32 == 0, "cv2_skinny_gemm: need rows<=32, n%%16==0, k%%32==0");
-    CV2_CHECK(k <= 1024, "cv2_skinny_gemm: k must be <= 1024");
+int skinny_gemm_launch(const uint16_t* w, const float* bias, const float* x, float* out, int rows, int n, int k, hipStream_t s) {
+    CV2_CHECK(w && x && out, "skinny_gemm: null argument");
+    CV2_CHECK(rows >= 1 && rows <= 32 && n % 16 == 0 && k % 32 == 0, "skinny_gemm: need rows<=32, n%%16==0, k%%32==0");
+    CV2_CHECK(k <= 1024, "skinny_gemm: k must be <= 1024");
     if (init_attrs_once()) return -1;
     StoreArgs a{};
     a.W = w; a.bias = bias; a.X = SkinnyX{x, nullptr, 0, nullptr, 0.f, nullptr};
     a.KS = k / 32; a.rows = rows; a.K = k; a.N = n; a.out = out;
-    hipStream_t s = (hipStream_t)stream;
     if (rows <= 16) {
         const size_t sm = skinny_smem_bytes<1, 1, 4>(a.KS);
         hipLaunchKernelGGL((k_store<1, 8>), dim3(n / 16, 1), dim3(256), sm, s, a);
@@ -585,4 +584,9 @@ extern "C" int cv2_skinny_gemm(const uint16_t* w, const float* bias, const float
     }
     CV2_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cv2_skinny_gemm(const uint16_t* w, const float* bias, const float* x, float* out, int32_t rows, int32_t n,
+                               int32_t k, void* stream) {
+    return skinny_gemm_launch(w, bias, x, out, rows, n, k, (hipStream_t)stream);
 }

@@ -111,6 +111,115 @@ int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream);
 int cv2_skinny_gemm(const uint16_t* w_packed, const float* bias, const float* x, float* out, int32_t rows,
                     int32_t n, int32_t k, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Generic bf16 MFMA GEMM (exported for unit tests): out[m][n] = sum_k A[m][k] W[n][k] (+bias[n]).
+ * A row-major bf16 [M][lda] (M % 128 == 0, K % 64 == 0), W packed (above), out fp32 [M][ldo], N % 128 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int cv2_gemm_bf16(const uint16_t* a, int64_t lda, const uint16_t* w_packed, const float* bias, float* out, int64_t ldo,
+                  int32_t m, int32_t n, int32_t k, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage 2 — token -> mel (replaces CausalMaskedDiffWithXvec.inference, cosyvoice/flow/flow.py:235-283, and
+ * everything below it: UpsampleConformerEncoder.forward transformer/upsample_encoder.py:243-306,
+ * CausalConditionalCFM.forward / solve_euler flow/flow_matching.py:200-225,71-123,
+ * CausalConditionalDecoder.forward flow/decoder.py:405-494).
+ *
+ * Linear / Conv1d weights are bf16 in the packed layout above; a Conv1d weight [C_out][C_in][k] is packed as the
+ * [C_out][k*C_in] matrix with column index tap*C_in + c_in (time-major activations make the tap window contiguous).
+ * Biases, LayerNorm parameters, embeddings stay fp32.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cv2_flow cv2_flow;
+
+typedef struct { const uint16_t* w; const float* b; } cv2_lin;      /* packed bf16 weight, fp32 bias (may be NULL) */
+typedef struct { const float* g; const float* b; } cv2_ln;
+
+typedef struct {            /* ConformerEncoderLayer (transformer/encoder_layer.py:160-236) */
+    cv2_ln norm_mha, norm_ff;
+    cv2_lin qkv;            /* rows [Wq; Wq; Wk; Wv] (2048 x 512), bias [bq + pos_bias_u; bq + pos_bias_v; bk; bv] */
+    cv2_lin pos;            /* linear_pos 512 -> 512, no bias */
+    cv2_lin out;            /* linear_out */
+    cv2_lin w1, w2;         /* feed_forward 512 -> 2048 -> 512 */
+} cv2_conformer;
+
+typedef struct {            /* matcha BasicTransformerBlock (matcha/models/components/transformer.py:243-316) */
+    cv2_ln norm1, norm3;
+    cv2_lin qkv;            /* rows [to_q; to_k; to_v] (1536 x 256), no bias */
+    cv2_lin out;            /* to_out.0 512 -> 256 */
+    cv2_lin ff1, ff2;       /* 256 -> 1024 (GELU) -> 256 */
+} cv2_tblock;
+
+typedef struct {            /* CausalResnetBlock1D (flow/decoder.py:65-85, matcha decoder.py:46-61) */
+    cv2_lin conv1;          /* [256][3*C_in] */
+    cv2_ln ln1;
+    cv2_lin mlp;            /* Linear 1024 -> 256 applied to Mish(time embedding) */
+    cv2_lin conv2;          /* [256][3*256] */
+    cv2_ln ln2;
+    cv2_lin res;            /* res_conv 1x1: [256][C_in] */
+} cv2_resnet;
+
+typedef struct {
+    cv2_resnet rn;
+    cv2_tblock tb[4];
+    cv2_lin tail;           /* down/up CausalConv1d(256,256,3); w == NULL for mid blocks */
+} cv2_unet_block;
+
+typedef struct {
+    const float* input_embedding;   /* [6561][512] */
+    const float* spk_w;             /* spk_embed_affine_layer.weight [80][192] fp32 */
+    const float* spk_b;             /* [80] */
+    cv2_lin embed; cv2_ln embed_ln;             /* encoder.embed.out.{0,1} */
+    cv2_lin pre1, pre2;                         /* pre_lookahead conv1 [512][4*512], conv2 [512][3*512] */
+    cv2_conformer enc[6];
+    cv2_lin up_conv;                            /* encoder.up_layer.conv [512][5*512] */
+    cv2_lin up_embed; cv2_ln up_embed_ln;
+    cv2_conformer up[4];
+    cv2_ln after_norm;
+    cv2_lin enc_proj;                           /* encoder_proj 512 -> 80, rows padded to 128 */
+    cv2_lin time1, time2;                       /* time_mlp linear_1 (320 -> 1024), linear_2 (1024 -> 1024) */
+    cv2_unet_block down, mid[12], up_blk;
+    cv2_lin final_conv; cv2_ln final_ln;        /* final_block */
+    cv2_lin final_proj;                         /* 256 -> 80, rows padded to 128 */
+    const float* rand_noise;                    /* [15000][80] fp32: flow_matching.py:197-198 noise, time-major */
+} cv2_flow_weights;
+
+typedef struct {
+    int32_t max_rows;       /* capacity: packed mel-rate rows (sum over sequences of the padded lengths) */
+    int32_t max_seqs;       /* sequences per call incl. the CFG twins (2 x utterances) */
+    int32_t max_len;        /* longest single sequence in mel frames */
+    int32_t n_timesteps;    /* Euler steps (10) */
+    float cfg_rate;         /* inference_cfg_rate (0.7) */
+} cv2_flow_dims;
+
+size_t cv2_flow_workspace_bytes(const cv2_flow_dims* d);
+int cv2_flow_create(const cv2_flow_dims* d, const cv2_flow_weights* w, void* workspace, size_t workspace_bytes,
+                    void* stream, cv2_flow** out);
+int cv2_flow_destroy(cv2_flow* h);
+
+/* One batch of utterances through flow.inference (flow.py:235-283).  For utterance u (all pointers DEVICE):
+ *   tokens[u]       int32 [n_tok[u]]     prompt tokens followed by generated tokens (flow.py:252)
+ *   prompt_feat[u]  fp32  [n_prompt_feat[u]][80]   prompt mel, time-major (the reference's prompt_feat[0])
+ *   embedding[u]    fp32  [192]
+ *   mel_out[u]      fp32  [80][mel_len2[u]] channel-major like the reference's return value,
+ *                   mel_len2 = 2 * (n_tok - 3 * !finalize) - n_prompt_feat
+ * streaming: chunk-causal attention masks (static chunk 25 tokens / 50 frames); finalize == 0: the last 3 tokens are
+ * look-ahead context (flow.py:260-263). */
+typedef struct {
+    const int32_t* tokens; int32_t n_tok;
+    const float* prompt_feat; int32_t n_prompt_feat;
+    const float* embedding;
+    float* mel_out;
+} cv2_flow_utt;
+int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t n_utts, int32_t streaming, int32_t finalize, void* stream);
+
+/* The estimator alone behind the reference's TensorRT seam (flow_matching.py:125-150): six contiguous device
+ * tensors x(2,80,T) mask(2,1,T) mu(2,80,T) t(2,) spks(2,80) cond(2,80,T), result written in place into x. */
+int cv2_flow_estimator(cv2_flow* h, float* x, const float* mask, const float* mu, const float* t, const float* spks,
+                       const float* cond, int32_t T, int32_t streaming, void* stream);
+/* The encoder alone (UpsampleConformerEncoder.forward): xs fp32 [T][512] embedded tokens (+ optional context [3][512]),
+ * out fp32 [2T][512]. */
+int cv2_flow_encoder(cv2_flow* h, const float* xs, int32_t T, const float* context, int32_t streaming, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
