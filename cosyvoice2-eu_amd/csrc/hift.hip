@@ -1,0 +1,435 @@
+// Stage 3 on MI355X: HiFT vocoder, mel -> waveform (replaces cosyvoice/hifigan/generator.py:570-582 and below:
+// decode :520-552, _stft/_istft :504-518, ResBlock :94-101, SineGen2 :256-339, SourceModuleHnNSF2 :375-389,
+// ConvRNNF0Predictor f0_predictor.py:55-58, Snake transformer/activation.py:73-84).
+//
+// Layout: every activation is fp32, TIME-MAJOR [L][C].  All arithmetic is fp32 (the reference computes this stage in
+// fp32 and the waveform is exp()/sin() of the last conv, so bf16 products would not hold a tight tolerance).
+//
+// k_conv: Conv1d as an LDS line-buffered implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, bit-exact
+// fp32 FMA chains at the vector-FMA peak rate, leaving the VALU to the activation and address work):
+//   * block = 128 output frames x 64 output channels, 4 waves of 32 frames each;
+//   * per 64-input-channel chunk the block loads the frames [t0 - pad, t0 + 128 + (k-1)*dil - pad) ONCE into an LDS
+//     line buffer, applying the pre-activation (Snake / leaky-ReLU) and the zero padding while loading, and every tap
+//     then reads its shifted window from LDS (row stride 65 floats: conflict-free ds_read_b32 across frames);
+//   * weights are pre-packed per (tap, channel pair, 32-channel output tile) in MFMA B-operand order, one coalesced
+//     256 B read per MFMA straight from L2 (they are shared by every block);
+//   * epilogue: bias, residual, ELU, and the MRF accumulate modes (sum / (sum + v) / 3) so the three ResBlocks of a
+//     stage and the source branch never take an extra pass over HBM.
+// ConvTranspose1d(stride u) is the same kernel with u*C_out output channels over 3 input taps (polyphase), whose
+// [frame][phase][channel] output IS the time-major upsampled signal.
+// Roofline: fp32 MFMA (157 TFLOP/s); HBM traffic per conv is one read + one write of the activation.
+#include "common.h"
+#include "../../include/cv2_amd.h"
+#include <math.h>
+#include <vector>
+
+enum { PRE_NONE = 0, PRE_SNAKE = 1, PRE_LRELU = 2 };
+enum { POST_NONE = 0, POST_ELU = 1 };
+enum { ACC_STORE = 0, ACC_ADD = 1, ACC_ADD_DIV3 = 2 };
+
+struct ConvArgs {
+    const float* x; int L_in, Cin;          // input frames, channels (row stride Cin)
+    const float* wp; const float* bias;     // packed weights [taps][CinP/2][CoutP/32][64], bias [CoutP]
+    int CinP, CoutP, Cout_store;            // padded sizes (CinP % 64 == 0, CoutP % 64 == 0)
+    int taps, dil, pad_left;
+    int pre; const float* alpha; float slope;
+    int L_out;
+    float* out; int ldo; long out_off;      // out[(t) * ldo + out_off + co]
+    const float* res; int ldres;
+    int post, acc;
+};
+
+#define CV_BT 128
+#define CV_CK 64
+#define CV_LD 65
+
+__device__ __forceinline__ float pre_apply(float v, int pre, float al, float slope) {
+    if (pre == PRE_SNAKE) { const float s = sinf(v * al); return v + (1.0f / (al + 1e-9f)) * (s * s); }
+    if (pre == PRE_LRELU) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);                     // [rows][CV_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * CV_BT, co0 = blockIdx.y * 64;
+    const int span = (a.taps - 1) * a.dil;
+    const int rows = CV_BT + span;
+    const int ntile = a.CoutP / 32;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const int li = lane & 31, lk = lane >> 5;
+    for (int c0 = 0; c0 < a.CinP; c0 += CV_CK) {
+        __syncthreads();
+        // line buffer: frames t0 - pad_left + r, channels c0 .. c0+63 ; 16 lanes x float4 per frame
+        for (int it = tid; it < rows * 16; it += 256) {
+            const int r = it >> 4, c4 = (it & 15) * 4;
+            const int t = t0 - a.pad_left + r, c = c0 + c4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (t >= 0 && t < a.L_in) {
+                const float* src = a.x + (size_t)t * a.Cin + c;
+                if (c + 3 < a.Cin) { const f32x4 q = *reinterpret_cast<const f32x4*>(src); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
+                else for (int e = 0; e < 4; e++) if (c + e < a.Cin) v[e] = src[e];
+                if (a.pre != PRE_NONE)
+                    for (int e = 0; e < 4; e++)
+                        if (c + e < a.Cin) v[e] = pre_apply(v[e], a.pre, a.pre == PRE_SNAKE ? a.alpha[c + e] : 0.f, a.slope);
+            }
+            float* d = xs + r * CV_LD + c4;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+        __syncthreads();
+        for (int tap = 0; tap < a.taps; tap++) {
+            const float* xr = xs + (wave * 32 + li + tap * a.dil) * CV_LD + lk;
+            const float* wb = a.wp + (((size_t)tap * (a.CinP / 2) + c0 / 2) * ntile + co0 / 32) * 64 + lane;
+#pragma unroll 8
+            for (int kk = 0; kk < CV_CK / 2; kk++) {
+                const float av = xr[2 * kk];
+                const float b0 = wb[(size_t)kk * ntile * 64];
+                const float b1 = wb[(size_t)kk * ntile * 64 + 64];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: lane holds channel co (li) of tile 0 / 1 and 16 frames
+#pragma unroll
+    for (int tile = 0; tile < 2; tile++) {
+        const int co = co0 + tile * 32 + li;
+        if (co >= a.Cout_store) continue;
+        const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int t = t0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (t >= a.L_out) continue;
+            float v = (tile == 0 ? acc0[r] : acc1[r]) + b;
+            if (a.res) v += a.res[(size_t)t * a.ldres + co];
+            if (a.post == POST_ELU) v = v > 0.f ? v : expm1f(v);
+            float* o = a.out + (size_t)t * a.ldo + a.out_off + co;
+            if (a.acc == ACC_ADD) v = *o + v;
+            else if (a.acc == ACC_ADD_DIV3) v = (*o + v) / 3.0f;
+            *o = v;
+        }
+    }
+}
+
+// source_downs: Conv1d(18 -> C, k, stride, pad) over s_stft [F][18] (generator.py:468-479); tiny, direct
+struct SdArgs { const float* x; int F; const float* w; const float* b; int C, k, stride, pad; float* out; int L_out; };
+__global__ __launch_bounds__(256) void k_source_down(SdArgs a) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)a.L_out * a.C) return;
+    const int t = idx / a.C, co = idx % a.C;
+    float acc = 0.f;
+    for (int j = 0; j < a.k; j++) {
+        const int f = t * a.stride - a.pad + j;
+        if (f < 0 || f >= a.F) continue;
+        const float* xr = a.x + (size_t)f * 18;
+        const float* wr = a.w + ((size_t)co * a.k + j) * 18;         // packed [C][k][18]
+#pragma unroll
+        for (int c = 0; c < 18; c++) acc += wr[c] * xr[c];
+    }
+    a.out[(size_t)t * a.C + co] = acc + a.b[co];
+}
+
+// mel [80][T] channel-major -> [T][80]
+__global__ void k_mel_tm(const float* mel, float* out, int T) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * 80) return;
+    const int t = idx / 80, c = idx % 80;
+    out[idx] = mel[(size_t)c * T + t];
+}
+
+// f0 = |Linear(512 -> 1)| (f0_predictor.py:57-58): one wave per frame
+__global__ __launch_bounds__(256) void k_f0_head(const float* x, const float* w, const float* b, float* f0, int T) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;
+    float acc = 0.f;
+    for (int c = lane; c < 512; c += 64) acc += x[(size_t)t * 512 + c] * w[c];
+    acc = wave_sum(acc);
+    if (lane == 0) f0[t] = fabsf(acc + b[0]);
+}
+
+// SineGen2._f02sine (generator.py:263-285), first half: per harmonic the frame-rate phase.
+//   rad_h[i] = (f0[i] * h / 24000) % 1     (the 1/480 linear down-interpolation of the nearest-upsampled signal returns
+//   exactly the frame value: both taps, samples 480 i + 239 and + 240, lie inside frame i, so rand_ini at sample 0 never matters)
+//   phase = cumsum(rad) (float64 accumulate like torch's CPU cumsum) -> fp32 -> * 2 pi -> * 480
+__global__ void k_phase(const float* f0, float* phase, int T) {
+    const int h = threadIdx.x;            // 9 threads
+    if (h >= 9) return;
+    double acc = 0.0;
+    const float hm = (float)(h + 1);
+    for (int i = 0; i < T; i++) {
+        const float fn = __fmul_rn(f0[i], hm);
+        const float q = __fdiv_rn(fn, 24000.0f);
+        const float rad = fmodf(q, 1.0f);
+        acc += (double)rad;
+        const float c = (float)acc;
+        phase[i * 9 + h] = __fmul_rn(__fmul_rn(c, 6.283185307179586f), 480.0f);
+    }
+}
+
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const uint32_t n0 = mulhi32(0xCD9E8D57u, c2) ^ c1 ^ k0, n1 = 0xCD9E8D57u * c2;
+        const uint32_t n2 = mulhi32(0xD2511F53u, c0) ^ c3 ^ k1, n3 = 0xD2511F53u * c0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// second half + SourceModuleHnNSF2.forward (generator.py:375-389): per sample
+//   phase up-interpolation x480 (linear, align_corners=False, the exact fp32 expression order of torch's CPU kernel:
+//   src = fma(1/480, n + 0.5, -0.5), w1 = src - floor, out = fma(1 - w1, p0, w1 * p1)), sin, * 0.1, uv gate,
+//   + noise_amp * N(0,1), tanh(Linear 9 -> 1).  noise == null: N(0,1) from Philox (seed, sample, harmonic).
+struct SrcArgs {
+    const float* f0; const float* phase; int T;
+    const float* noise;                  // [480 T][9] or null
+    uint32_t seed_lo, seed_hi;
+    const float* lw; const float* lb;    // m_source.l_linear
+    const float* cache; int n_cache;     // cache_source overwrite (generator.py:579-580)
+    float* s;                            // [480 T]
+};
+__global__ __launch_bounds__(256) void k_source(SrcArgs a) {
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const long Ls = (long)a.T * 480;
+    if (n >= Ls) return;
+    if (n < a.n_cache) { a.s[n] = a.cache[n]; return; }
+    float src = __fmaf_rn(1.0f / 480.0f, __fadd_rn((float)n, 0.5f), -0.5f);
+    src = fmaxf(src, 0.f);
+    const int i0 = (int)src, i1 = min(i0 + 1, a.T - 1);
+    const float w1 = __fsub_rn(src, (float)i0), w0 = __fsub_rn(1.0f, w1);
+    const float f0 = a.f0[n / 480];
+    const float uv = f0 > 10.f ? 1.f : 0.f;
+    const float namp = __fadd_rn(__fmul_rn(uv, 0.003f), __fdiv_rn(__fmul_rn(__fsub_rn(1.f, uv), 0.1f), 3.0f));
+    float acc = 0.f;
+    float z[9];
+    if (a.noise) {
+#pragma unroll
+        for (int h = 0; h < 9; h++) z[h] = a.noise[n * 9 + h];
+    } else {
+        uint32_t r[4];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {          // 3 x (2 Box-Muller pairs) -> 12 normals, 9 used
+            philox4((uint32_t)n, (uint32_t)(n >> 32), (uint32_t)q, 0x48694654u, a.seed_lo, a.seed_hi, r);
+            const float u0 = ((r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = (r[1] >> 8) * (1.0f / 16777216.0f);
+            const float u2 = ((r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = (r[3] >> 8) * (1.0f / 16777216.0f);
+            const float ra = sqrtf(-2.f * logf(u0)), rb = sqrtf(-2.f * logf(u2));
+            const float n0 = ra * cosf(6.283185307f * u1), n1 = ra * sinf(6.283185307f * u1), n2 = rb * cosf(6.283185307f * u3);
+            z[3 * q] = n0; z[3 * q + 1] = n1; z[3 * q + 2] = n2;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 9; h++) {
+        const float p0 = a.phase[i0 * 9 + h], p1 = a.phase[i1 * 9 + h];
+        const float ph = __fmaf_rn(w0, p0, __fmul_rn(w1, p1));
+        const float sw = __fadd_rn(__fmul_rn(__fmul_rn(sinf(ph), 0.1f), uv), __fmul_rn(namp, z[h]));
+        acc += a.lw[h] * sw;
+    }
+    a.s[n] = tanhf(acc + a.lb[0]);
+}
+
+// STFT n_fft 16 / hop 4 / periodic hann / center reflect (generator.py:504-510): s [L] -> [L/4 + 1][18] (9 real, 9 imag)
+__global__ __launch_bounds__(256) void k_stft(const float* s, int L, float* out, int F) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)F * 9) return;
+    const int f = idx / 9, k = idx % 9;
+    float re = 0.f, im = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        int p = f * 4 - 8 + j;
+        p = p < 0 ? -p : (p >= L ? 2 * (L - 1) - p : p);
+        const float w = 0.5f - 0.5f * cospif((float)j / 8.0f);
+        const float v = s[p] * w;
+        const int ph = (k * j) & 15;
+        re += v * cospif((float)ph / 8.0f);
+        im -= v * sinpif((float)ph / 8.0f);
+    }
+    out[(size_t)f * 18 + k] = re;
+    out[(size_t)f * 18 + 9 + k] = im;
+}
+
+// conv_post output [F][18] -> magnitude / phase (generator.py:546-548) -> inverse rFFT(16) * window: frames [F][16]
+__global__ __launch_bounds__(256) void k_istft_frames(const float* x, int F, float* fr) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)F * 16) return;
+    const int f = idx / 16, n = idx % 16;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const float mag = fminf(expf(x[(size_t)f * 18 + k]), 100.f);
+        const float ph = sinf(x[(size_t)f * 18 + 9 + k]);
+        const float re = mag * cosf(ph), im = mag * sinf(ph);
+        const int a = (k * n) & 15;
+        const float c = cospif((float)a / 8.0f), sn = sinpif((float)a / 8.0f);
+        if (k == 0 || k == 8) acc += re * c;                      // imaginary parts of DC / Nyquist are ignored by irfft
+        else acc += 2.f * (re * c - im * sn);
+    }
+    const float w = 0.5f - 0.5f * cospif((float)n / 8.0f);
+    fr[idx] = acc * (1.0f / 16.0f) * w;
+}
+// overlap-add / window envelope, trim n_fft/2, clamp (generator.py:517-518, :551)
+__global__ __launch_bounds__(256) void k_istft_ola(const float* fr, int F, float* wav, int L, float limit) {
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= L) return;
+    const long p = n + 8;                                          // position in the un-trimmed signal
+    float acc = 0.f, env = 0.f;
+    for (int f = (int)(p / 4); f >= 0 && f * 4 + 16 > p; f--) {
+        if (f >= F) continue;
+        const int j = (int)(p - f * 4);
+        const float w = 0.5f - 0.5f * cospif((float)j / 8.0f);
+        acc += fr[(size_t)f * 16 + j];
+        env += w * w;
+    }
+    const float v = acc / env;
+    wav[n] = fminf(fmaxf(v, -limit), limit);
+}
+// ReflectionPad1d((1, 0)) after the last upsample (generator.py:529-530): row 0 := row 2 of the shifted signal
+__global__ void k_reflect_row0(float* x, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) x[c] = x[2 * C + c];
+}
+
+// =========================================================================== host
+struct cv2_hift {
+    cv2_hift_dims d;
+    cv2_hift_weights w;
+    // workspace
+    float *melT, *f0a, *f0b, *f0, *phase, *s, *sstft, *xpre, *x, *xt, *ra, *sum, *sd, *post, *frames;
+};
+
+struct HCarver {
+    char* base; size_t off = 0;
+    float* take(size_t n) { size_t o = off; off += (n * 4 + 255) & ~(size_t)255; return base ? reinterpret_cast<float*>(base + o) : nullptr; }
+};
+static size_t hift_carve(const cv2_hift_dims& d, cv2_hift* h, char* base) {
+    HCarver c{base};
+    const size_t T = d.max_frames, L3 = 120 * T + 1;
+    cv2_hift tmp_{};
+    cv2_hift& f = h ? *h : tmp_;
+    f.melT = c.take(T * 80); f.f0a = c.take(T * 512); f.f0b = c.take(T * 512); f.f0 = c.take(T); f.phase = c.take(T * 9);
+    f.s = c.take(480 * T); f.sstft = c.take(L3 * 18); f.xpre = c.take(T * 512);
+    const size_t big = L3 * 64 + 64;                                 // every stage is C * L = 7680 T (+ the reflect row)
+    f.x = c.take(big); f.xt = c.take(big); f.ra = c.take(big); f.sum = c.take(big); f.sd = c.take(big);
+    f.post = c.take(L3 * 18); f.frames = c.take(L3 * 16);
+    return c.off;
+}
+extern "C" size_t cv2_hift_workspace_bytes(const cv2_hift_dims* d) { return hift_carve(*d, nullptr, nullptr); }
+
+extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w, void* ws, size_t ws_bytes, cv2_hift** out) {
+    CV2_CHECK(d && w && ws && out, "cv2_hift_create: null argument");
+    CV2_CHECK(d->max_frames >= 4, "cv2_hift_create: max_frames too small");
+    CV2_CHECK(ws_bytes >= cv2_hift_workspace_bytes(d), "cv2_hift_create: workspace too small");
+    cv2_hift* h = new cv2_hift();
+    h->d = *d; h->w = *w;
+    hift_carve(*d, h, (char*)ws);
+    static bool once = false;
+    if (!once) {
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once = true;
+    }
+    *out = h;
+    return 0;
+}
+extern "C" int cv2_hift_destroy(cv2_hift* h) { delete h; return 0; }
+// test hook: device pointers of intermediate buffers (0 melT, 1 f0, 2 s_stft, 3 conv_pre out, 4 x (last stage out), 5 conv_post out)
+extern "C" const float* cv2_hift_debug_buffer(cv2_hift* h, int32_t which) {
+    switch (which) { case 0: return h->melT; case 1: return h->f0; case 2: return h->sstft; case 3: return h->xpre; case 4: return h->sum; case 5: return h->post; default: return nullptr; }
+}
+
+static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out, int ldo, long out_off, int L_out, int pre,
+                       const float* alpha, float slope, const float* res, int ldres, int post, int acc, hipStream_t s) {
+    ConvArgs a{};
+    a.x = x; a.L_in = L_in; a.Cin = cw.cin; a.wp = cw.w; a.bias = cw.b; a.CinP = cw.cin_pad; a.CoutP = cw.cout_pad;
+    a.Cout_store = cw.cout; a.taps = cw.taps; a.dil = cw.dil; a.pad_left = cw.pad_left; a.pre = pre; a.alpha = alpha; a.slope = slope;
+    a.L_out = L_out; a.out = out; a.ldo = ldo; a.out_off = out_off; a.res = res; a.ldres = ldres; a.post = post; a.acc = acc;
+    CV2_CHECK(cw.cin_pad % 64 == 0 && cw.cout_pad % 64 == 0 && cw.w, "hift conv: bad packed weight (cin_pad %d cout_pad %d)", cw.cin_pad, cw.cout_pad);
+    const size_t sm = (size_t)(CV_BT + (cw.taps - 1) * cw.dil) * CV_LD * 4;
+    hipLaunchKernelGGL(k_conv, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64), dim3(256), sm, s, a);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+// ResBlock.forward (generator.py:94-101); x read-only, result accumulated into `dst` with mode `acc`
+static int resblock(cv2_hift* h, const cv2_resblock& rb, const float* x, int L, int C, float* dst, int acc, hipStream_t s) {
+    for (int i = 0; i < 3; i++) {
+        const float* in = i == 0 ? x : h->ra;
+        if (conv_launch(rb.c1[i], in, L, h->xt, C, 0, L, PRE_SNAKE, rb.a1[i], 0.f, nullptr, 0, POST_NONE, ACC_STORE, s)) return -1;
+        float* o = i == 2 ? dst : h->ra;
+        if (conv_launch(rb.c2[i], h->xt, L, o, C, 0, L, PRE_SNAKE, rb.a2[i], 0.f, in, C, POST_NONE, i == 2 ? acc : ACC_STORE, s)) return -1;
+    }
+    return 0;
+}
+
+extern "C" int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, const float* cache_source, int32_t n_cache,
+                                  const float* noise, uint64_t seed, float* wav, float* source, void* stream) {
+    CV2_CHECK(h && mel && wav && source, "cv2_hift_inference: null argument");
+    CV2_CHECK(T >= 2 && T <= h->d.max_frames, "cv2_hift_inference: T=%d out of range (max %d)", T, h->d.max_frames);
+    CV2_CHECK(n_cache >= 0 && n_cache <= 480 * T && (n_cache == 0 || cache_source), "cv2_hift_inference: bad cache_source");
+    hipStream_t s = (hipStream_t)stream;
+    const cv2_hift_weights& w = h->w;
+    const int Ls = 480 * T, F = Ls / 4 + 1;
+    hipLaunchKernelGGL(k_mel_tm, dim3((T * 80 + 255) / 256), dim3(256), 0, s, mel, h->melT, (int)T);
+    // f0 predictor: 5 x (conv k3 + ELU), Linear, abs
+    {
+        const float* in = h->melT; float* bufs[2] = {h->f0a, h->f0b};
+        for (int i = 0; i < 5; i++) {
+            if (conv_launch(w.f0_conv[i], in, T, bufs[i & 1], 512, 0, T, PRE_NONE, nullptr, 0.f, nullptr, 0, POST_ELU, ACC_STORE, s)) return -1;
+            in = bufs[i & 1];
+        }
+        hipLaunchKernelGGL(k_f0_head, dim3((T + 3) / 4), dim3(256), 0, s, in, w.f0_w, w.f0_b, h->f0, (int)T);
+    }
+    // source
+    hipLaunchKernelGGL(k_phase, dim3(1), dim3(64), 0, s, (const float*)h->f0, h->phase, (int)T);
+    {
+        SrcArgs a{h->f0, h->phase, T, noise, (uint32_t)seed, (uint32_t)(seed >> 32), w.src_w, w.src_b, cache_source, n_cache, source};
+        hipLaunchKernelGGL(k_source, dim3((Ls + 255) / 256), dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(k_stft, dim3(((long)F * 9 + 255) / 256), dim3(256), 0, s, (const float*)source, Ls, h->sstft, F);
+    // decode
+    if (conv_launch(w.conv_pre, h->melT, T, h->xpre, 512, 0, T, PRE_NONE, nullptr, 0.f, nullptr, 0, POST_NONE, ACC_STORE, s)) return -1;
+    const int ups_u[3] = {8, 5, 3}, chans[4] = {512, 256, 128, 64};
+    const int sd_k[3] = {30, 6, 1}, sd_s[3] = {15, 3, 1}, sd_p[3] = {7, 1, 0};
+    const float* xin = h->xpre;
+    int Lin = T;
+    for (int i = 0; i < 3; i++) {
+        const int C = chans[i + 1], u = ups_u[i];
+        int L = Lin * u;
+        // leaky_relu(0.1) -> ConvTranspose1d as a polyphase conv: output [Lin][u*C] == [L][C]
+        const long shift = i == 2 ? C : 0;                                            // reflect pad: frame t lands on row t+1
+        if (conv_launch(w.ups[i], xin, Lin, h->x, u * C, shift, Lin, PRE_LRELU, nullptr, 0.1f, nullptr, 0, POST_NONE, ACC_STORE, s)) return -1;
+        if (i == 2) { hipLaunchKernelGGL(k_reflect_row0, dim3(1), dim3(256), 0, s, h->x, C); L += 1; }
+        // source branch: source_down -> source_resblock, added into x
+        {
+            CV2_CHECK((F + 2 * sd_p[i] - sd_k[i]) / sd_s[i] + 1 == L, "hift: source_down length %d != %d", (F + 2 * sd_p[i] - sd_k[i]) / sd_s[i] + 1, L);
+            SdArgs a{h->sstft, F, w.sd_w[i], w.sd_b[i], C, sd_k[i], sd_s[i], sd_p[i], h->sd, L};
+            hipLaunchKernelGGL(k_source_down, dim3(((long)L * C + 255) / 256), dim3(256), 0, s, a);
+            if (resblock(h, w.src_rb[i], h->sd, L, C, h->x, ACC_ADD, s)) return -1;
+        }
+        // MRF: mean of 3 ResBlocks
+        for (int j = 0; j < 3; j++)
+            if (resblock(h, w.rb[i * 3 + j], h->x, L, C, h->sum, j == 0 ? ACC_STORE : j == 1 ? ACC_ADD : ACC_ADD_DIV3, s)) return -1;
+        // next stage input = MRF output (the next upsample reads `sum` and writes `x`: never in place)
+        xin = h->sum; Lin = L;
+    }
+    // leaky_relu(0.01) -> conv_post -> exp / sin -> iSTFT -> clamp
+    if (conv_launch(w.conv_post, xin, Lin, h->post, 18, 0, Lin, PRE_LRELU, nullptr, 0.01f, nullptr, 0, POST_NONE, ACC_STORE, s)) return -1;
+    hipLaunchKernelGGL(k_istft_frames, dim3(((long)F * 16 + 255) / 256), dim3(256), 0, s, (const float*)h->post, F, h->frames);
+    hipLaunchKernelGGL(k_istft_ola, dim3((Ls + 255) / 256), dim3(256), 0, s, (const float*)h->frames, F, wav, Ls, 0.99f);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void k_fade(float* x, const float* old_tail, const float* win, int w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < w) x[i] = x[i] * win[i] + old_tail[i] * win[w + i];
+}
+extern "C" int cv2_fade_in_out(float* fade_in, const float* old_tail, const float* window, int32_t w, void* stream) {
+    CV2_CHECK(fade_in && old_tail && window && w > 0, "cv2_fade_in_out: bad argument");
+    hipLaunchKernelGGL(k_fade, dim3((w + 255) / 256), dim3(256), 0, (hipStream_t)stream, fade_in, old_tail, window, (int)w);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,166 @@
+"""Host side of stage 3 (HiFT vocoder): folds weight-norm, packs a `hift.pt` state dict into the fp32 MFMA layout of
+include/cv2_amd.h and drives cv2_hift_inference (csrc/hift.hip).
+
+Mirrors `HiFTGenerator.inference(speech_feat, cache_source)` (cosyvoice/hifigan/generator.py:570-582): returns
+`(wav [1, 480 T], source [1, 1, 480 T])`.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+class Conv(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('b', C.c_void_p)] + [(n, C.c_int32) for n in
+                                                          ('cin', 'cout', 'cin_pad', 'cout_pad', 'taps', 'dil', 'pad_left')]
+
+
+class ResBlock(C.Structure):
+    _fields_ = [('c1', Conv * 3), ('c2', Conv * 3), ('a1', C.c_void_p * 3), ('a2', C.c_void_p * 3)]
+
+
+class HiftWeights(C.Structure):
+    _fields_ = [('f0_conv', Conv * 5), ('f0_w', C.c_void_p), ('f0_b', C.c_void_p), ('src_w', C.c_void_p), ('src_b', C.c_void_p),
+                ('conv_pre', Conv), ('ups', Conv * 3), ('sd_w', C.c_void_p * 3), ('sd_b', C.c_void_p * 3),
+                ('src_rb', ResBlock * 3), ('rb', ResBlock * 9), ('conv_post', Conv)]
+
+
+class HiftDims(C.Structure):
+    _fields_ = [('max_frames', C.c_int32)]
+
+
+def _bind(lib):
+    if getattr(lib, '_hift_bound', False):
+        return
+    lib.cv2_hift_workspace_bytes.restype = C.c_size_t
+    lib.cv2_hift_workspace_bytes.argtypes = [C.POINTER(HiftDims)]
+    lib.cv2_hift_create.argtypes = [C.POINTER(HiftDims), C.POINTER(HiftWeights), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.cv2_hift_destroy.argtypes = [C.c_void_p]
+    lib.cv2_hift_inference.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.cv2_fade_in_out.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib._hift_bound = True
+
+
+def weight_norm(sd, name):
+    """w = g * v / ||v|| over all dims but 0 (torch.nn.utils.parametrizations.weight_norm); plain weights pass through."""
+    if name + '.weight' in sd:
+        return sd[name + '.weight'].float()
+    g = sd[name + '.parametrizations.weight.original0'].float()
+    v = sd[name + '.parametrizations.weight.original1'].float()
+    return torch._weight_norm(v, g, 0)
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def pack_conv_f32(w):
+    """[C_out][C_in][k] fp32 -> [k][cin_pad/2][cout_pad/32][64]: lane = (c_in & 1) * 32 + (c_out & 31)."""
+    co, ci, k = w.shape
+    cip, cop = _pad64(ci), _pad64(co)
+    wp = w.new_zeros(k, cip, cop)
+    wp[:, :ci, :co] = w.permute(2, 1, 0)
+    return wp.view(k, cip // 2, 2, cop // 32, 32).permute(0, 1, 3, 2, 4).contiguous().reshape(-1), cip, cop
+
+
+def polyphase(wt, u, pad):
+    """ConvTranspose1d weight [C_in][C_out][k] -> equivalent Conv1d weight [u*C_out][C_in][3] over input taps q-1, q, q+1."""
+    ci, co, k = wt.shape
+    w = wt.new_zeros(u * co, ci, 3)
+    for r in range(u):
+        for j in range(3):
+            kk = r + pad + u * (1 - j)
+            if 0 <= kk < k:
+                w[r * co:(r + 1) * co, :, j] = wt[:, :, kk].t()
+    return w
+
+
+class HiftEngine:
+    def __init__(self, sd, device='cuda:0', max_frames=2048):
+        sd = {k[len('generator.'):] if k.startswith('generator.') else k: v for k, v in sd.items()}     # cli/model.py:88
+        self.device = dev = torch.device(device)
+        self.lib = L.lib()
+        _bind(self.lib)
+        self._keep = keep = []
+
+        def f32(t):
+            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def conv(w, bias, dil, pad_left):
+            co, ci, k = w.shape
+            wp, cip, cop = pack_conv_f32(w.float())
+            b = torch.zeros(cop)
+            b[:co] = bias.float()
+            return Conv(f32(wp), f32(b), ci, co, cip, cop, k, dil, pad_left)
+
+        def resblock(p, k, dils=(1, 3, 5)):
+            rb = ResBlock()
+            for i, d in enumerate(dils):
+                rb.c1[i] = conv(weight_norm(sd, f'{p}.convs1.{i}'), sd[f'{p}.convs1.{i}.bias'], d, (k * d - d) // 2)
+                rb.c2[i] = conv(weight_norm(sd, f'{p}.convs2.{i}'), sd[f'{p}.convs2.{i}.bias'], 1, (k - 1) // 2)
+                rb.a1[i] = f32(sd[f'{p}.activations1.{i}.alpha'])
+                rb.a2[i] = f32(sd[f'{p}.activations2.{i}.alpha'])
+            return rb
+
+        w = HiftWeights()
+        for n, i in enumerate((0, 2, 4, 6, 8)):
+            w.f0_conv[n] = conv(weight_norm(sd, f'f0_predictor.condnet.{i}'), sd[f'f0_predictor.condnet.{i}.bias'], 1, 1)
+        w.f0_w, w.f0_b = f32(sd['f0_predictor.classifier.weight'].reshape(-1)), f32(sd['f0_predictor.classifier.bias'])
+        w.src_w, w.src_b = f32(sd['m_source.l_linear.weight'].reshape(-1)), f32(sd['m_source.l_linear.bias'])
+        w.conv_pre = conv(weight_norm(sd, 'conv_pre'), sd['conv_pre.bias'], 1, 3)
+        for i, (u, k) in enumerate(((8, 16), (5, 11), (3, 7))):
+            wt = weight_norm(sd, f'ups.{i}')
+            b = sd[f'ups.{i}.bias'].float()
+            w.ups[i] = conv(polyphase(wt, u, (k - u) // 2), b.repeat(u), 1, 1)
+            w.sd_w[i] = f32(sd[f'source_downs.{i}.weight'].float().permute(0, 2, 1))
+            w.sd_b[i] = f32(sd[f'source_downs.{i}.bias'])
+            w.src_rb[i] = resblock(f'source_resblocks.{i}', (7, 7, 11)[i])
+            for j, k2 in enumerate((3, 7, 11)):
+                w.rb[i * 3 + j] = resblock(f'resblocks.{i * 3 + j}', k2)
+        w.conv_post = conv(weight_norm(sd, 'conv_post'), sd['conv_post.bias'], 1, 3)
+        self._w = w
+        self.dims = HiftDims(max_frames=max_frames)
+        self.max_frames = max_frames
+        nbytes = self.lib.cv2_hift_workspace_bytes(C.byref(self.dims))
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        h = C.c_void_p()
+        L.check(self.lib.cv2_hift_create(C.byref(self.dims), C.byref(w), self.workspace.data_ptr(), nbytes, C.byref(h)))
+        self.handle = h
+        self.seed = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.cv2_hift_destroy(self.handle)
+        except Exception:
+            pass
+
+    def inference(self, speech_feat, cache_source=None, noise=None, seed=None):
+        """speech_feat [1,80,T] fp32 device; cache_source [1,1,k]; noise [1,480T,9] injects the N(0,1) draws
+        (parity tests), otherwise they come from the device Philox stream (seed advances per call)."""
+        assert speech_feat.shape[0] == 1 and speech_feat.shape[1] == 80
+        dev = self.device
+        mel = speech_feat.to(dev, torch.float32).contiguous()
+        T = mel.shape[2]
+        wav = torch.empty(1, 480 * T, dtype=torch.float32, device=dev)
+        src = torch.empty(1, 1, 480 * T, dtype=torch.float32, device=dev)
+        cs = None
+        if cache_source is not None and cache_source.numel() > 0:
+            cs = cache_source.to(dev, torch.float32).contiguous()
+        nz = noise.to(dev, torch.float32).contiguous() if noise is not None else None
+        if seed is None:
+            self.seed += 1
+            seed = self.seed
+        L.check(self.lib.cv2_hift_inference(self.handle, L.ptr(mel), T, L.ptr(cs), cs.numel() if cs is not None else 0,
+                                            L.ptr(nz), C.c_uint64(seed), L.ptr(wav), L.ptr(src), L.stream_ptr()))
+        return wav, src
+
+    def fade_in_out(self, fade_in, fade_out_tail, window):
+        """utils/common.py:142-150, on the device and in place: fade_in [1,n], fade_out_tail [1,w], window [2w]."""
+        w = window.numel() // 2
+        L.check(self.lib.cv2_fade_in_out(L.ptr(fade_in), L.ptr(fade_out_tail), L.ptr(window), w, L.stream_ptr()))
+        return fade_in

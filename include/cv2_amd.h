@@ -220,6 +220,53 @@ int cv2_flow_estimator(cv2_flow* h, float* x, const float* mask, const float* mu
  * out fp32 [2T][512]. */
 int cv2_flow_encoder(cv2_flow* h, const float* xs, int32_t T, const float* context, int32_t streaming, float* out, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage 3 — HiFT vocoder (replaces HiFTGenerator.inference, cosyvoice/hifigan/generator.py:570-582, and decode :520-552,
+ * _stft/_istft :504-518, ResBlock :94-101, SourceModuleHnNSF2 :375-389, SineGen2 :256-339, ConvRNNF0Predictor
+ * f0_predictor.py:55-58).  All fp32.
+ *
+ * Conv weights (weight-norm already folded, w = g v / ||v||) are fp32 in the MFMA 32x32x2 B-operand order
+ * [tap][c_in/2][c_out/32][64 lanes], lane = (c_in & 1) * 32 + (c_out & 31), both channel counts zero-padded to 64.
+ * A ConvTranspose1d(stride u, kernel k, padding p) is stored as its polyphase Conv1d with u*C_out output channels
+ * (index r*C_out + c_out) over 3 taps: W'[r*C_out + c_out][c_in][j] = W[c_in][c_out][r + p + u (1 - j)] where that
+ * index lies in [0, k), else 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cv2_hift cv2_hift;
+typedef struct {
+    const float* w; const float* b;     /* packed weight, bias [cout_pad] */
+    int32_t cin, cout, cin_pad, cout_pad, taps, dil, pad_left;
+} cv2_conv;
+typedef struct {                          /* ResBlock: convs1 (dilated), convs2, Snake alphas */
+    cv2_conv c1[3], c2[3];
+    const float* a1[3]; const float* a2[3];
+} cv2_resblock;
+typedef struct {
+    cv2_conv f0_conv[5];                  /* f0_predictor.condnet.{0,2,4,6,8} */
+    const float* f0_w; const float* f0_b; /* f0_predictor.classifier [512], [1] */
+    const float* src_w; const float* src_b; /* m_source.l_linear [9], [1] */
+    cv2_conv conv_pre;
+    cv2_conv ups[3];
+    const float* sd_w[3]; const float* sd_b[3];  /* source_downs weights re-ordered [C][k][18] */
+    cv2_resblock src_rb[3];
+    cv2_resblock rb[9];
+    cv2_conv conv_post;
+} cv2_hift_weights;
+typedef struct { int32_t max_frames; } cv2_hift_dims;   /* longest mel in frames */
+
+size_t cv2_hift_workspace_bytes(const cv2_hift_dims* d);
+int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w, void* workspace, size_t workspace_bytes, cv2_hift** out);
+int cv2_hift_destroy(cv2_hift* h);
+/* mel fp32 [80][T] (channel-major, the reference's speech_feat[0]); cache_source fp32 [n_cache] or NULL;
+ * noise: fp32 [480 T][9] standard normals injected in place of the reference's randn_like (generator.py:334), or NULL
+ * to draw them on the device from Philox(seed); wav fp32 [480 T]; source fp32 [480 T]. */
+int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, const float* cache_source, int32_t n_cache,
+                       const float* noise, uint64_t seed, float* wav, float* source, void* stream);
+
+/* fade_in_out (cosyvoice/utils/common.py:142-150): new[:w] = new[:w] * win[:w] + old[-w:] * win[w:], in place on `fade_in`;
+ * win fp32 [2w] (np.hamming(2w)), old_tail points at the last w samples of the previous chunk. */
+int cv2_fade_in_out(float* fade_in, const float* old_tail, const float* window, int32_t w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
