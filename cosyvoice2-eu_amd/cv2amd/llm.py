@@ -131,3 +131,18 @@ class LLMEngine:
             if bool(st[:, L.ST_DONE].all()):
                 return toks
             self.step(n, sync_every)
+
+    def generate_fixed(self, requests, n_tokens, mode=MODE_RAS, seed=0):
+        """Synthetic-weights mode: exactly n_tokens per request, EOS never drawn, no host sync inside the
+        decode loop.  Returns (list of token lists, (start, end) torch events bracketing the n_tokens-1 decode steps)."""
+        n = len(requests)
+        assert n <= self.max_seqs and n_tokens <= self.max_out
+        for b, (text, ptxt, ptok) in enumerate(requests):
+            self.add_request(b, self.build_lm_input(text, ptxt, ptok), n_tokens, n_tokens, mode, seed, True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.step(n, n_tokens - 1)
+        e1.record()
+        st, toks = self.read(n)
+        assert bool(st[:, L.ST_DONE].all()) and all(len(t) == n_tokens for t in toks)
+        return toks, (e0, e1)
