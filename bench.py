@@ -45,6 +45,19 @@ def flow_flops(T):
     return (0.2644e9 * T + 229376.0 * T * T) * 10 + 80e9 * (T / 1010.0)
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if any, else the affinity mask (a GPU box exposes 256 logical CPUs but
+    grants ~16 to one GPU's container; oversubscribing torch threads makes the baseline meaningless)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(n_threads):
     """CPU fp32 oracle on a bounded sample, extrapolated linearly to the full C2 utterance."""
     import torch
@@ -211,7 +224,7 @@ def main():
                        'hift_fp32_mfma': {'achieved': round(hift_tf, 2), 'peak': FP32_MFMA_PEAK, 'unit': 'TFLOP/s', 'frac': round(hift_tf / FP32_MFMA_PEAK, 4)}},
         }
         if not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(os.cpu_count() or 1)
+            out['cpu_baseline'] = cpu_baseline(host_cores())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

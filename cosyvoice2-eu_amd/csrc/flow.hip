@@ -49,6 +49,8 @@ static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, h
     if (cfg == 1) {
         CV2_CHECK(a.N % 256 == 0, "gemm cfg1: N=%d %% 256", a.N);
         CV2_CHECK((!a.ln1_g && !a.ln2_g) || a.N == 256, "gemm cfg1: LayerNorm epilogue needs N == 256");
+        // few rows (one utterance): 32-row tiles double the blocks that share the latency-bound K loop and the row epilogue
+        if ((long)(a.M / 64) * (a.N / 256) * batch < 200) return gemm_go<32, 256, 1, 4>(a, batch, packed, s);
         return gemm_go<64, 256, 1, 4>(a, batch, packed, s);
     }
     CV2_CHECK(a.N % 64 == 0, "gemm cfg2: N=%d %% 64", a.N);

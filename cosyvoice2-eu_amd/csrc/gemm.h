@@ -50,9 +50,10 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
         case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
         case ACT_SILU: return v / (1.f + __expf(-v));
-        case ACT_MISH: {                                   // x * tanh(softplus(x)), softplus threshold 20 as torch
-            const float sp = v > 20.f ? v : log1pf(__expf(v));
-            return v * tanhf(sp);
+        case ACT_MISH: {                                   // x * tanh(softplus(x)); tanh(log(1 + e^x)) = n / (n + 2), n = e^x (e^x + 2)
+            const float e = __expf(fminf(v, 20.f));        // torch's softplus switches to the identity above 20: the ratio is 1 there
+            const float nn = e * (e + 2.f);
+            return v * __fdividef(nn, nn + 2.f);
         }
         case ACT_LRELU: return v > 0.f ? v : v * slope;
         default: return v;
@@ -129,6 +130,31 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     const int w_off = WPACKED ? lane * 16 : a_off;
 
     issue(0, 0);
+    // epilogue operands that do not depend on the row: fetched now, consumed after the K loop
+    constexpr int LPR = BN / 4, RPI = NT_ / LPR, NIT = BM / RPI;   // lanes per row, rows per epilogue iteration, iterations
+    static_assert(LPR <= 64, "BN <= 256");
+    const int rsub = tid / LPR, cl = tid % LPR;
+    const int n = n0 + cl * 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 ep_bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : z4;
+    const f32x4 ep_g1 = a.ln1_g ? *reinterpret_cast<const f32x4*>(a.ln1_g + n) : z4;
+    const f32x4 ep_b1 = a.ln1_g ? *reinterpret_cast<const f32x4*>(a.ln1_b + n) : z4;
+    const f32x4 ep_g2 = a.ln2_g ? *reinterpret_cast<const f32x4*>(a.ln2_g + n) : z4;
+    const f32x4 ep_b2 = a.ln2_g ? *reinterpret_cast<const f32x4*>(a.ln2_b + n) : z4;
+    constexpr int NTL = (BM + 63) / 64;                            // 64-row sequence tiles touched by this block
+    int ep_start[NTL], ep_len[NTL];
+    f32x4 ep_radd[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; t++) {
+        int sq = 0;
+        ep_start[t] = 0; ep_len[t] = a.M_valid;
+        if (a.seq.tile_seq) {
+            sq = a.seq.tile_seq[(m0 >> 6) + t];
+            if (sq >= 0) { ep_start[t] = a.seq.seq_start[sq]; ep_len[t] = a.seq.seq_len[sq]; }
+            else { ep_len[t] = 0; sq = 0; }
+        }
+        ep_radd[t] = a.rowadd ? *reinterpret_cast<const f32x4*>(a.rowadd + (size_t)sq * a.rowadd_ld + n) : z4;
+    }
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
         if (kt + 1 < nk) {
@@ -139,6 +165,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
             else if (PER_WAVE == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else if (PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if (PER_WAVE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (PER_WAVE == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
             else if (PER_WAVE == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
@@ -175,6 +202,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
             const int n = wn * TN + j * 16 + 4 * (lane >> 4);
             *reinterpret_cast<f32x4*>(&C[m * LDC + n]) = acc[j][i] * a.out_scale;
         }
+    const bool use_res = a.res && !(a.vt && n0 >= a.vt_n0);
+    f32x4 res_next = z4;
+    if (use_res) res_next = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m0 + rsub) * a.ldres + n);
     __syncthreads();
 
     float* out_f32 = a.out_f32 ? a.out_f32 + (size_t)blockIdx.z * a.o_bstride : nullptr;
@@ -204,33 +234,31 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     }
 
     // ---- row-wise epilogue: LPR lanes per row, 4 consecutive features per lane ----
-    constexpr int LPR = BN / 4, RPI = NT_ / LPR;        // lanes per row, rows per iteration of the block
-    static_assert(LPR <= 64, "BN <= 256");
-    const int rsub = tid / LPR, cl = tid % LPR;
-    const int n = n0 + cl * 4;
-    for (int r0 = 0; r0 < BM; r0 += RPI) {
-        const int ml = r0 + rsub, m = m0 + ml;
-        int s = 0; bool valid = m < a.M_valid;
-        if (a.seq.tile_seq) {
-            s = a.seq.tile_seq[m >> 6];
-            valid = s >= 0 && (m - a.seq.seq_start[s]) < a.seq.seq_len[s];
-            if (s < 0) s = 0;
-        }
+    // Everything that does not depend on the row (this lane's 4 columns of bias / LayerNorm parameters, the sequence
+    // records of the block's 64-row tiles) was loaded into registers BEFORE the K loop (ep_* below), and the residual rows
+    // are fetched in one batch, so the loop itself only touches LDS and issues stores.
+#pragma unroll 1
+    for (int it = 0; it < NIT; it++) {
+        const int ml = it * RPI + rsub, m = m0 + ml;
+        const f32x4 res_cur = res_next;                  // residual row fetched one iteration ahead
+        if (use_res && it + 1 < NIT) res_next = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m + RPI) * a.ldres + n);
+        const int tl = BM > 64 ? (ml >> 6) : 0;
+        const bool valid = tl == 0 ? (m - ep_start[0]) < ep_len[0] : (m - ep_start[BM > 64 ? 1 : 0]) < ep_len[BM > 64 ? 1 : 0];
         f32x4 v = *reinterpret_cast<const f32x4*>(&C[ml * LDC + cl * 4]);
-        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+        v += ep_bias;
         if (a.ln1_g) {
             const float mean = group_sum<LPR>(v[0] + v[1] + v[2] + v[3]) * (1.f / BN);
             const f32x4 d = v - mean;
             const float var = group_sum<LPR>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / BN);
             const float rstd = rsqrtf(var + a.ln1_eps);
-            v = d * rstd * *reinterpret_cast<const f32x4*>(a.ln1_g + n) + *reinterpret_cast<const f32x4*>(a.ln1_b + n);
+            v = d * rstd * ep_g1 + ep_b1;
         }
         if (a.act != ACT_NONE) {
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = act_apply(v[e], a.act, a.act_slope);
         }
-        if (a.rowadd) v += *reinterpret_cast<const f32x4*>(a.rowadd + (size_t)s * a.rowadd_ld + n);
-        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + (size_t)m * a.ldres + n);
+        if (a.rowadd) v += tl == 0 ? ep_radd[0] : ep_radd[BM > 64 ? 1 : 0];
+        if (use_res) v += res_cur;
         if (a.mask && !valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
         const bool wr = n < a.n_store;
         if (out_f32 && wr) *reinterpret_cast<f32x4*>(out_f32 + (size_t)m * a.ldo + n) = v;
@@ -241,7 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
             const f32x4 d = v - mean;
             const float var = group_sum<LPR>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / BN);
             const float rstd = rsqrtf(var + a.ln2_eps);
-            f32x4 y = (d * rstd * *reinterpret_cast<const f32x4*>(a.ln2_g + n) + *reinterpret_cast<const f32x4*>(a.ln2_b + n)) * a.ln2_scale;
+            f32x4 y = (d * rstd * ep_g2 + ep_b2) * a.ln2_scale;
             if (a.mask && !valid) y = (f32x4){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<uint2*>(a.out_ln2 + (size_t)m * a.ldo_ln2 + n) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
         }

@@ -81,72 +81,100 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ k_attn (decode / prefill rows)
+// ------------------------------------------------------------------ k_attn (decode / prefill rows), split over keys
+// Flash-decoding: block = (kv head, key split, row).  The block stages its K and V key range (fp32) in LDS once and
+// serves every query head of the GQA group from it, then leaves UNNORMALISED partial outputs and (max, sum) per head;
+// the O-projection kernel combines the splits while it loads its operand (skinny.h, att_ns), so attention costs one
+// launch and no extra pass.  Grid is fixed (graph capture): splits beyond the current length flag themselves empty.
 struct AttnArgs {
-    const float* q; const float* kc; const float* vc; float* out;   // out [rows][n_q*64]
-    int n_q, n_kv, max_pos;
+    const float* q; const float* kc; const float* vc;
+    float* part_o;            // [nsplit][SK_ROWS_CAP][n_q*64]
+    float* part_ml;           // [nsplit][SK_ROWS_CAP][n_q][2]
+    int* part_cnt;            // [SK_ROWS_CAP] number of non-empty splits of the row
+    int n_q, n_kv, max_pos, nsplit, keys_per_split;
     RowMap rm;
 };
+#define AT_KB 64
+// No LDS staging of K or V: thread (key, quarter) keeps its 16 dims of one key row in registers for the scores of all
+// heads of the group, thread (dim, head pair) keeps the V column of the tile in registers; one round of global loads.
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sc = reinterpret_cast<float*>(smem);                 // [L]
-    __shared__ float redbuf[8];
-    __shared__ float obuf[4][64];
-    const int h = blockIdx.x, r = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) float qs[8 * 64];
+    __shared__ __attribute__((aligned(16))) float ps[8 * AT_KB];
+    __shared__ float run_m[8], run_l[8], tile_scale[8];
+    const int rep = a.n_q / a.n_kv;                               // <= 8
+    const int g = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit, r = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int seq, pos;
     a.rm.get(r, seq, pos);
     const int L = pos + 1;
-    const int kvh = h / (a.n_q / a.n_kv);
-    const float* K = a.kc + ((size_t)seq * a.n_kv + kvh) * a.max_pos * 64;
-    const float* V = a.vc + ((size_t)seq * a.n_kv + kvh) * a.max_pos * 64;
-    const int tid = threadIdx.x, l16 = tid & 15, g = tid >> 4;
-    const float4 qv = reinterpret_cast<const float4*>(a.q + (size_t)r * a.n_q * 64 + h * 64)[l16];
-    float lmax = -INFINITY;
-    for (int j0 = 0; j0 < L; j0 += 64) {                        // 16 key groups x 4 keys in flight per thread
-        float4 kv[4];
+    const int j_lo = sp * a.keys_per_split, j_hi = min(L, j_lo + a.keys_per_split);
+    if (blockIdx.x == 0 && tid == 0) a.part_cnt[r] = (L + a.keys_per_split - 1) / a.keys_per_split;
+    float* ml = a.part_ml + (((size_t)sp * SK_ROWS_CAP + r) * a.n_q + g * rep) * 2;
+    if (j_lo >= j_hi) return;                                     // empty split: the consumer stops at part_cnt
+    const float* K = a.kc + ((size_t)seq * a.n_kv + g) * a.max_pos * 64;
+    const float* V = a.vc + ((size_t)seq * a.n_kv + g) * a.max_pos * 64;
+    for (int i = tid; i < rep * 64; i += 256) qs[i] = a.q[(size_t)r * a.n_q * 64 + g * rep * 64 + i];
+    if (tid < 8) { run_m[tid] = -INFINITY; run_l[tid] = 0.f; }
+    const int d = tid & 63, hq = tid >> 6;                        // PV: thread = (dim, head pair {hq, hq + 4})
+    const int key_t = tid >> 2, qd = tid & 3;                     // scores: thread = (key, 16-dim quarter)
+    float o0 = 0.f, o1 = 0.f;
+    for (int j0 = j_lo; j0 < j_hi; j0 += AT_KB) {
+        const int n = min(AT_KB, j_hi - j0);
+        f32x4 kk[4];
+        float vv[AT_KB];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = j0 + g + 16 * u;
-            kv[u] = j < L ? reinterpret_cast<const float4*>(K + (size_t)j * 64)[l16] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < 4; i++)
+            kk[i] = key_t < n ? *reinterpret_cast<const f32x4*>(K + (size_t)(j0 + key_t) * 64 + qd * 16 + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < AT_KB; k++) vv[k] = k < n ? V[(size_t)(j0 + k) * 64 + d] : 0.f;
+        __syncthreads();                                          // qs ready; previous tile's ps consumed
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            if (h < rep) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[h * 64 + qd * 16 + 4 * i]);
+                    acc += kk[i][0] * qv[0] + kk[i][1] * qv[1] + kk[i][2] * qv[2] + kk[i][3] * qv[3];
+                }
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                if (qd == 0) ps[h * AT_KB + key_t] = key_t < n ? acc * 0.125f : -INFINITY;
+            }
         }
+        __syncthreads();
+        for (int h = w; h < rep; h += 4) {                       // per head: tile max / exp / sum, merged into the running pair
+            const float s0 = ps[h * AT_KB + lane];
+            const float mt = wave_max(s0);
+            const float mo = run_m[h], mn = fmaxf(mo, mt);
+            const float p0 = __expf(s0 - mn);
+            ps[h * AT_KB + lane] = p0;
+            const float lt = wave_sum(p0);
+            if (lane == 0) {
+                tile_scale[h] = __expf(mo - mn);                   // 0 on the first tile (mo = -inf)
+                run_l[h] = run_l[h] * tile_scale[h] + lt;
+                run_m[h] = mn;
+            }
+        }
+        __syncthreads();
+        {
+            const int h0 = hq, h1 = hq + 4 < rep ? hq + 4 : hq;
+            o0 *= tile_scale[h0];
+            o1 *= tile_scale[h1];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = j0 + g + 16 * u;
-            float d = qv.x * kv[u].x + qv.y * kv[u].y + qv.z * kv[u].z + qv.w * kv[u].w;
-            d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
-            d *= 0.125f;
-            if (j < L) {
-                if (l16 == 0) sc[j] = d;
-                lmax = fmaxf(lmax, d);
+            for (int k4 = 0; k4 < AT_KB / 4; k4++) {
+                const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[h0 * AT_KB + 4 * k4]);
+                const f32x4 pb = *reinterpret_cast<const f32x4*>(&ps[h1 * AT_KB + 4 * k4]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { o0 += pa[e] * vv[4 * k4 + e]; o1 += pb[e] * vv[4 * k4 + e]; }
             }
         }
     }
-    lmax = wave_max(lmax);
-    if ((tid & 63) == 0) redbuf[tid >> 6] = lmax;
+    float* po = a.part_o + ((size_t)sp * SK_ROWS_CAP + r) * a.n_q * 64 + (size_t)g * rep * 64;
+    if (hq < rep) po[hq * 64 + d] = o0;
+    if (hq + 4 < rep) po[(hq + 4) * 64 + d] = o1;
     __syncthreads();
-    const float m = fmaxf(fmaxf(redbuf[0], redbuf[1]), fmaxf(redbuf[2], redbuf[3]));
-    float lsum = 0.f;
-    for (int j = tid; j < L; j += 256) {
-        const float p = __expf(sc[j] - m);
-        sc[j] = p;
-        lsum += p;
-    }
-    lsum = wave_sum(lsum);
-    if ((tid & 63) == 0) redbuf[4 + (tid >> 6)] = lsum;
-    __syncthreads();
-    const float denom = redbuf[4] + redbuf[5] + redbuf[6] + redbuf[7];
-    const int w = tid >> 6, d = tid & 63;
-    float o = 0.f;
-    for (int j0 = w; j0 < L; j0 += 32) {                        // 8 value rows in flight per thread
-        float vv[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const int j = j0 + 4 * u; vv[u] = j < L ? V[(size_t)j * 64 + d] : 0.f; }
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const int j = j0 + 4 * u; if (j < L) o += sc[j] * vv[u]; }
-    }
-    obuf[w][d] = o;
-    __syncthreads();
-    if (w == 0) a.out[(size_t)r * a.n_q * 64 + h * 64 + d] = (obuf[0][d] + obuf[1][d] + obuf[2][d] + obuf[3][d]) / denom;
+    if (tid < rep) { ml[tid * 2] = run_m[tid]; ml[tid * 2 + 1] = run_l[tid]; }
 }
 
 // ------------------------------------------------------------------ k_store: out = W f(x) (+bias)  (o-proj, down-proj, head)
@@ -155,10 +183,10 @@ struct StoreArgs {
     SkinnyX X; int KS, rows, K, N;
     float* out;                                 // gridDim.y == 1: [rows][N]; else partials [gridDim.y][SK_ROWS_CAP][N]
 };
-template <int NB, int MAXKS>
+template <int NB, int MAXKS, bool ATT = false>
 __global__ __launch_bounds__(256) void k_store(StoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* res = skinny_core<NB, 1, 4, MAXKS>(a.W, blockIdx.x, a.KS, a.rows, a.K, a.X, smem);
+    float* res = skinny_core<NB, 1, 4, MAXKS, ATT>(a.W, blockIdx.x, a.KS, a.rows, a.K, a.X, smem);
     const int ld = NB * 16 + 1;
     const int n0 = blockIdx.x * 16;
     float* out = a.out + (gridDim.y > 1 ? (size_t)blockIdx.y * SK_ROWS_CAP * a.N : 0);
@@ -244,6 +272,11 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     for (int w = 0; w < SM_W; w++) r += sh[w];
     return r;
 }
+__device__ __forceinline__ double shfl_up_f64(double v, int o) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __shfl_up((int)b, o), hi = __shfl_up((int)(b >> 32), o);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
     __shared__ float lp[6592];
     __shared__ ArgMax sam[SM_W];
@@ -251,7 +284,10 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
     __shared__ double rd[SM_T];
     __shared__ float candp[SM_TOPK];
     __shared__ int candi[SM_TOPK];
-    __shared__ int s_top;
+    __shared__ int s_top, s_need, s_done, s_ncand;
+    __shared__ float wl_v[SM_W * SM_TOPK];
+    __shared__ int wl_i[SM_W * SM_TOPK];
+    __shared__ double s_u2;
     const int tid = threadIdx.x;
     const int seq = a.prefill_seq >= 0 ? a.prefill_seq : blockIdx.x;
     const int row = a.prefill_seq >= 0 ? a.row : blockIdx.x;
@@ -280,62 +316,129 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
         } else {
             // RAS (utils/common.py:111-139): top-p 0.8 / top-k 25 nucleus, repetition window 10, tau 0.1
             __syncthreads();
+            constexpr int NE = (6592 + SM_T - 1) / SM_T;                      // elements per thread (strided: tid + e * SM_T)
+            float lv[NE];
             ArgMax mx{-INFINITY, 0x7fffffff};
-            for (int i = tid; i < V; i += SM_T) mx = am_better(mx, ArgMax{lp[i], i});
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const int i = tid + e * SM_T;
+                lv[e] = i < V ? lp[i] : -INFINITY;
+                mx = am_better(mx, ArgMax{lv[e], i < V ? i : 0x7fffffff});
+            }
             const float m = block_argmax(mx, sam).v;
             float sum = 0.f;
-            for (int i = tid; i < V; i += SM_T) sum += __expf(lp[i] - m);
+#pragma unroll
+            for (int e = 0; e < NE; e++) if (tid + e * SM_T < V) sum += __expf(lv[e] - m);
             const float lse = m + __logf(block_sum(sum, ssum));
-            for (int i = tid; i < V; i += SM_T) lp[i] -= lse;                 // log_softmax (llm.py:690)
-            __syncthreads();
-            // stable descending top-25 of softmax = exp(logp)
-            for (int c = 0; c < SM_TOPK; c++) {
-                ArgMax b{-INFINITY, 0x7fffffff};
-                for (int i = tid; i < V; i += SM_T) {
-                    bool taken = false;
-                    for (int q = 0; q < c; q++) taken |= (candi[q] == i);
-                    if (!taken) b = am_better(b, ArgMax{lp[i], i});
+#pragma unroll
+            for (int e = 0; e < NE; e++) {                                    // log_softmax (llm.py:690)
+                lv[e] -= lse;
+                if (tid + e * SM_T < V) lp[tid + e * SM_T] = lv[e];
+            }
+            // nucleus candidates (common.py:120-134) = head of the stable descending order.  Two stages, one block barrier:
+            // every wave extracts the top 25 of its own 1/16 of the vocabulary with shuffles only, wave 0 merges the 16 sorted lists.
+            {
+                unsigned taken = 0;
+                const int lane = tid & 63, w = tid >> 6;
+                for (int c = 0; c < SM_TOPK; c++) {
+                    ArgMax bq{-INFINITY, 0x7fffffff};
+#pragma unroll
+                    for (int e = 0; e < NE; e++)
+                        if (!((taken >> e) & 1u) && tid + e * SM_T < V) bq = am_better(bq, ArgMax{lv[e], tid + e * SM_T});
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) bq = am_better(bq, ArgMax{__shfl_xor(bq.v, o), __shfl_xor(bq.i, o)});
+                    if (bq.i != 0x7fffffff && (bq.i & (SM_T - 1)) == tid) taken |= 1u << (bq.i / SM_T);
+                    if (lane == 0) { wl_v[w * SM_TOPK + c] = bq.v; wl_i[w * SM_TOPK + c] = bq.i; }
                 }
-                b = block_argmax(b, sam);
-                if (tid == 0) { candi[c] = b.i; candp[c] = __expf(b.v); }
+                __syncthreads();
+                if (w == 0) {
+                    int ptr = 0;
+                    ArgMax head = lane < SM_W ? ArgMax{wl_v[lane * SM_TOPK], wl_i[lane * SM_TOPK]} : ArgMax{-INFINITY, 0x7fffffff};
+                    for (int c = 0; c < SM_TOPK; c++) {
+                        ArgMax bq = head;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) bq = am_better(bq, ArgMax{__shfl_xor(bq.v, o), __shfl_xor(bq.i, o)});
+                        if (lane == 0) { candi[c] = bq.i; candp[c] = __expf(bq.v); }
+                        if (lane < SM_W && head.i == bq.i && bq.i != 0x7fffffff) {
+                            ptr++;
+                            head = ptr < SM_TOPK ? ArgMax{wl_v[lane * SM_TOPK + ptr], wl_i[lane * SM_TOPK + ptr]} : ArgMax{-INFINITY, 0x7fffffff};
+                        }
+                    }
+                    if (lane == 0) {
+                        int nc = 0; float cum = 0.f;
+                        while (nc < SM_TOPK && cum < 0.8f) { cum += candp[nc]; nc++; }
+                        s_ncand = nc;
+                    }
+                }
                 __syncthreads();
             }
-            // full-vocab cdf chunks for the repetition fallback (random_sampling)
+            const int ncand = s_ncand;
+            const int nhist = st[CV2_ST_NOUT];
+            const int* hist = a.out_tokens + (size_t)seq * a.max_out;
             const int chunk = (V + SM_T - 1) / SM_T;
-            double cs = 0.0;
-            for (int i = tid * chunk; i < min(V, (tid + 1) * chunk); i++) cs += (double)__expf(lp[i]);
-            rd[tid] = cs;
-            __syncthreads();
-            if (tid == 0) {
-                int ncand = 0; float cum = 0.f;
-                while (ncand < SM_TOPK && cum < 0.8f) { cum += candp[ncand]; ncand++; }
-                double tot = 0.0;
-                for (int i = 0; i < SM_T; i++) tot += rd[i];
-                const int nhist = st[CV2_ST_NOUT];
-                const int* hist = a.out_tokens + (size_t)seq * a.max_out;
-                int top = -1;
-                int trial = 0;
-                for (;;) {
+            bool rd_ready = false;
+            int trial = 0;
+            for (;;) {
+                if (tid == 0) {
                     uint32_t rn[4];
                     philox4x32((uint32_t)seq, (uint32_t)step, (uint32_t)trial, 0u, (uint32_t)st[CV2_ST_SEED_LO], (uint32_t)st[CV2_ST_SEED_HI], rn);
-                    const double u1 = u53(rn[0], rn[1]), u2 = u53(rn[2], rn[3]);
+                    const double u1 = u53(rn[0], rn[1]);
+                    s_u2 = u53(rn[2], rn[3]);
                     // nucleus draw: inverse cdf over the candidate probabilities (float64 running sum)
                     double csum = 0.0; for (int c = 0; c < ncand; c++) csum += (double)candp[c];
-                    double thr = u1 * csum, run = 0.0; int pick = ncand - 1;
+                    const double thr = u1 * csum; double run = 0.0; int pick = ncand - 1;
                     for (int c = 0; c < ncand; c++) { run += (double)candp[c]; if (run > thr) { pick = c; break; } }
-                    top = candi[pick];
+                    const int top = candi[pick];
                     int rep = 0;
                     for (int q = max(0, nhist - 10); q < nhist; q++) rep += (hist[q] == top);
-                    if (rep >= 1) {                                        // win_size * tau_r = 1
-                        thr = u2 * tot; run = 0.0; int ch = SM_T - 1;
-                        for (int i = 0; i < SM_T; i++) { if (run + rd[i] > thr) { ch = i; break; } run += rd[i]; }
-                        top = min(V, (ch + 1) * chunk) - 1;
-                        for (int i = ch * chunk; i < min(V, (ch + 1) * chunk); i++) { run += (double)__expf(lp[i]); if (run > thr) { top = i; break; } }
+                    s_top = top;
+                    s_need = rep >= 1;                                         // win_size * tau_r = 1 -> random_sampling over the full vocabulary
+                    s_done = 0;
+                    if (!s_need) {
+                        if (!ignore_eos || top != a.eos) s_done = 1;
+                        else if (trial + 1 > 100) { st[CV2_ST_ERR] = 1; s_done = 1; }
                     }
-                    if (!ignore_eos || top != a.eos) break;
-                    if (++trial > 100) { st[CV2_ST_ERR] = 1; break; }
                 }
-                s_top = top;
+                __syncthreads();
+                if (s_need) {
+                    if (!rd_ready) {                                           // full-vocab cdf, chunked: thread t owns ids [t*chunk, (t+1)*chunk)
+                        double cs = 0.0;
+                        for (int i = tid * chunk; i < min(V, (tid + 1) * chunk); i++) cs += (double)__expf(lp[i]);
+                        rd[tid] = cs;
+                        rd_ready = true;
+                        __syncthreads();
+                    }
+                    if (tid < 64) {
+                        double mine = 0.0;
+                        for (int j = 0; j < SM_T / 64; j++) mine += rd[tid * (SM_T / 64) + j];
+                        double incl = mine;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) { const double up = shfl_up_f64(incl, o); if (tid >= o) incl += up; }
+                        const double tot = __builtin_bit_cast(double, ((long long)__shfl((int)(__builtin_bit_cast(long long, incl) >> 32), 63) << 32) |
+                                                                         (unsigned int)__shfl((int)__builtin_bit_cast(long long, incl), 63));
+                        const double thr = s_u2 * tot;
+                        const unsigned long long crossed = __ballot(incl > thr);
+                        const int owner = crossed ? __ffsll((long long)crossed) - 1 : 63;
+                        if (tid == owner) {
+                            double run = incl - mine;
+                            int ch = (owner + 1) * (SM_T / 64) - 1;
+                            for (int j = 0; j < SM_T / 64; j++) {
+                                const int c = owner * (SM_T / 64) + j;
+                                if (run + rd[c] > thr) { ch = c; break; }
+                                run += rd[c];
+                            }
+                            int top = min(V, (ch + 1) * chunk) - 1;
+                            for (int i = ch * chunk; i < min(V, (ch + 1) * chunk); i++) { run += (double)__expf(lp[i]); if (run > thr) { top = i; break; } }
+                            s_top = top;
+                            if (!ignore_eos || top != a.eos) s_done = 1;
+                            else if (trial + 1 > 100) { st[CV2_ST_ERR] = 1; s_done = 1; }
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (s_done) break;
+                trial++;
+                __syncthreads();
             }
         }
     }
@@ -371,7 +474,10 @@ struct cv2_llm {
     float *kc, *vc;            // [layers][max_seqs][n_kv][max_pos][64]
     float *xa, *xb;            // residual stream ping-pong [32][hidden]
     float *xnext;              // [32][hidden] next-step input embeddings (k_sample)
-    float *q, *att, *o;        // [32][n_q*64], [32][n_q*64], [32][hidden]
+    float *q, *att, *o;        // [32][n_q*64], attention partials [nsplit][32][n_q*64], [32][hidden]
+    float *att_ml;             // [nsplit][32][n_q][2]
+    int *att_cnt;              // [32] non-empty splits per row
+    int nsplit, keys_per_split;
     float *hbuf;               // [32][inter]
     float *parts;              // [SK_MAXNP][32][hidden] split-K partials of the down projection
     std::map<int, hipGraphExec_t> graphs;
@@ -389,7 +495,9 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     p = take((size_t)32 * d.hidden * 4); if (h) h->xb = (float*)p;
     p = take((size_t)32 * d.hidden * 4); if (h) h->xnext = (float*)p;
     p = take((size_t)32 * d.n_q * 64 * 4); if (h) h->q = (float*)p;
-    p = take((size_t)32 * d.n_q * 64 * 4); if (h) h->att = (float*)p;
+    p = take((size_t)SK_MAXSPLIT * 32 * d.n_q * 64 * 4); if (h) h->att = (float*)p;
+    p = take((size_t)SK_MAXSPLIT * 32 * d.n_q * 2 * 4); if (h) h->att_ml = (float*)p;
+    p = take(32 * 4); if (h) h->att_cnt = (int*)p;
     p = take((size_t)32 * d.hidden * 4); if (h) h->o = (float*)p;
     p = take((size_t)32 * d.inter * 4); if (h) h->hbuf = (float*)p;
     p = take((size_t)SK_MAXNP * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
@@ -404,7 +512,7 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
     CV2_CHECK(d->hidden % 32 == 0 && d->inter % 32 == 0 && d->vocab_pad % 16 == 0, "cv2_llm_create: hidden/inter must be multiples of 32");
     CV2_CHECK(d->hidden / 32 <= 32 && d->n_q * 64 / 32 <= 32, "cv2_llm_create: hidden and n_q*64 must be <= 1024 (k-steps per wave)");
     CV2_CHECK(d->inter / 32 <= SK_MAXNP * 4 * 10, "cv2_llm_create: inter must be <= 5120 (k-steps per wave of the down projection)");
-    CV2_CHECK(d->n_q % d->n_kv == 0 && d->max_seqs >= 1 && d->max_seqs <= 32, "cv2_llm_create: bad head counts / max_seqs");
+    CV2_CHECK(d->n_q % d->n_kv == 0 && d->n_q / d->n_kv <= 8 && d->max_seqs >= 1 && d->max_seqs <= 32, "cv2_llm_create: bad head counts / max_seqs");
     CV2_CHECK(d->vocab <= 6592 && d->eos < d->vocab, "cv2_llm_create: vocab too large for the sampler");
     CV2_CHECK(ws_bytes >= cv2_llm_workspace_bytes(d), "cv2_llm_create: workspace too small (%zu < %zu)", ws_bytes, cv2_llm_workspace_bytes(d));
     cv2_llm* h = new cv2_llm();
@@ -414,6 +522,9 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
     h->w.layers = h->layers.data();
     h->io = *io;
     carve(*d, h, (char*)ws);
+    h->keys_per_split = AT_KB;
+    while ((d->max_pos + h->keys_per_split - 1) / h->keys_per_split > SK_MAXSPLIT) h->keys_per_split *= 2;
+    h->nsplit = (d->max_pos + h->keys_per_split - 1) / h->keys_per_split;
     h->cap_stream = nullptr;
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -456,16 +567,16 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             hipLaunchKernelGGL(k_qkv<NB>, dim3(2 * (d.n_q + 2 * d.n_kv), 1), dim3(512), sm, s, a);
         }
         {
-            AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, d.n_q, d.n_kv, d.max_pos, rm};
-            hipLaunchKernelGGL(k_attn, dim3(d.n_q, rows), dim3(256), (size_t)d.max_pos * 4, s, a);
+            AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm};
+            hipLaunchKernelGGL(k_attn, dim3(d.n_kv * h->nsplit, rows), dim3(256), 0, s, a);
         }
         {
             StoreArgs a{};
             a.W = L.wo; a.bias = nullptr;
-            a.X = SkinnyX{h->att, nullptr, 0, nullptr, 0.f, nullptr};
+            a.X = SkinnyX{nullptr, h->att, 0, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt};
             a.KS = d.n_q * 64 / 32; a.rows = rows; a.K = d.n_q * 64; a.N = H; a.out = h->o;
             const size_t sm = skinny_smem_bytes<NB, 1, 4>(a.KS);
-            hipLaunchKernelGGL((k_store<NB, 8>), dim3(H / 16, 1), dim3(256), sm, s, a);
+            hipLaunchKernelGGL((k_store<NB, 8, true>), dim3(H / 16, 1), dim3(256), sm, s, a);
         }
         float* x2 = (x1 == h->xa) ? h->xb : h->xa;            // x_mid = x1 + o
         {
@@ -509,7 +620,7 @@ static int init_attrs_once() {
     if (done) return 0;
     const size_t big = 160 * 1024;
     if (set_smem(k_qkv<1>, big) || set_smem(k_qkv<2>, big) || set_smem(k_gateup<1>, big) || set_smem(k_gateup<2>, big) ||
-        set_smem((k_store<1, 8>), big) || set_smem((k_store<2, 8>), big) || set_smem((k_store<1, 10>), big) ||
+        set_smem((k_store<1, 8>), big) || set_smem((k_store<2, 8>), big) || set_smem((k_store<1, 8, true>), big) || set_smem((k_store<2, 8, true>), big) || set_smem((k_store<1, 10>), big) ||
         set_smem((k_store<2, 10>), big))
         return -1;
     done = true;

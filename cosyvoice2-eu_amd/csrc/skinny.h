@@ -18,6 +18,8 @@
 
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 
+#define SK_MAXSPLIT 16    // key splits of the decode attention a consumer can combine
+
 struct SkinnyX {
     const float* base;    // [rows][K]
     const float* parts;   // [np][SK_ROWS_CAP][K] partial sums added to base in index order (may be null)
@@ -25,6 +27,10 @@ struct SkinnyX {
     const float* norm_w;  // RMSNorm weight [K] or null (requires gridDim.y == 1)
     float eps;
     float* x_out;         // optional [rows][K]: receives base + sum(parts) (pre-norm); written by blockIdx.x == 0
+    // split-key attention combine (flash-decoding): x[r][k] = sum_s w_s o_s[r][k] / sum_s w_s l_s, w_s = exp(m_s - max m),
+    // o_s = parts[s][r][k] unnormalised, (m_s, l_s) = att_ml[((s * SK_ROWS_CAP + r) * (K / 64) + k / 64) * 2 + {0, 1}]
+    const float* att_ml;
+    const int* att_cnt;   // != null selects this mode (base / np unused): [SK_ROWS_CAP] non-empty splits per row
 };
 
 __device__ __forceinline__ void split8(const f32x8 v, bf16x8& hi, bf16x8& lo) {
@@ -33,7 +39,36 @@ __device__ __forceinline__ void split8(const f32x8 v, bf16x8& hi, bf16x8& lo) {
     lo = __builtin_convertvector(v - back, bf16x8);
 }
 
+template <bool ATT>
 __device__ __forceinline__ f32x8 sk_load_x(const SkinnyX& X, int r, int K, int k) {
+    if (ATT) {
+        const int nq = K >> 6, hd = k >> 6;
+        const int ns = X.att_cnt[r];
+        float mv[SK_MAXSPLIT], lv[SK_MAXSPLIT];
+        f32x8 ov[SK_MAXSPLIT];
+        float M = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < SK_MAXSPLIT; s++) {                  // all loads in flight together
+            if (s < ns) {
+                const float* ml = X.att_ml + (((size_t)s * SK_ROWS_CAP + r) * nq + hd) * 2;
+                mv[s] = ml[0]; lv[s] = ml[1];
+                ov[s] = *reinterpret_cast<const f32x8*>(X.parts + ((size_t)s * SK_ROWS_CAP + r) * K + k);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SK_MAXSPLIT; s++) if (s < ns) M = fmaxf(M, mv[s]);
+        f32x8 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float den = 0.f;
+#pragma unroll
+        for (int s = 0; s < SK_MAXSPLIT; s++) {
+            if (s < ns) {
+                const float w = __expf(mv[s] - M);
+                den += w * lv[s];
+                acc += w * ov[s];
+            }
+        }
+        return acc * (1.f / den);
+    }
     f32x8 v = *reinterpret_cast<const f32x8*>(X.base + (size_t)r * K + k);
     if (X.np > 0) {
         f32x8 p[SK_MAXNP];
@@ -54,7 +89,7 @@ __device__ __host__ constexpr int sk_xstage_bytes(int nks) { return nks * NB * 2
 
 // Leaves the reduced tile in LDS: res[NWR*16 features][NB*16+1 rows]; returns its address.
 // `tile` = this wave's 16-feature row tile of W.
-template <int NB, int NWR, int NWK, int MAXKS>
+template <int NB, int NWR, int NWK, int MAXKS, bool ATT = false>
 __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, int tile, int KS, int rows, int K,
                                                const SkinnyX& X, char* smem) {
     const int tid = threadIdx.x;
@@ -85,12 +120,12 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     f32x8 v0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (tid < nitems) {
         const int r = tid / k8n, k8 = tid - r * k8n;
-        v0 = sk_load_x(X, r, K, ks0 * 32 + k8 * 8);
+        v0 = sk_load_x<ATT>(X, r, K, ks0 * 32 + k8 * 8);
     }
     if (X.norm_w) {
         for (int it = tid; it < nitems; it += nthreads) {
             f32x8 v = v0;
-            if (it != tid) { const int r = it / k8n, k8 = it - r * k8n; v = sk_load_x(X, r, K, ks0 * 32 + k8 * 8); }
+            if (it != tid) { const int r = it / k8n, k8 = it - r * k8n; v = sk_load_x<ATT>(X, r, K, ks0 * 32 + k8 * 8); }
             isq[it] = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
         }
         __syncthreads();
@@ -106,7 +141,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         const int r = it / k8n, k8 = it - r * k8n;
         const int k = ks0 * 32 + k8 * 8;
         f32x8 v = v0;
-        if (it != tid) v = sk_load_x(X, r, K, k);
+        if (it != tid) v = sk_load_x<ATT>(X, r, K, k);
         if (X.x_out && blockIdx.x == 0) *reinterpret_cast<f32x8*>(X.x_out + (size_t)r * K + k) = v;
         if (X.norm_w) v = *reinterpret_cast<const f32x8*>(X.norm_w + k) * (v * rstd[r]);
         bf16x8 hi, lo;
