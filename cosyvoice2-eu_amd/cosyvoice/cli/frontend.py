@@ -1,0 +1,142 @@
+"""Prompt / text frontend (cosyvoice/cli/frontend.py of the reference).  OUT OF THE HOT PATH ("next #1"):
+it runs once per prompt on third-party models (Qwen tokenizer, whisper log-mel -> speech_tokenizer_v2.onnx,
+kaldi fbank -> campplus.onnx).  This module keeps the interface the API layer calls and delegates to those packages
+when they are installed; `PrecomputedFrontEnd` serves pre-extracted prompts (the reference's own `spk2info` mechanism,
+cli/cosyvoice.py:70-76) and is what the tests and the benchmark use.
+"""
+import os
+
+import torch
+
+
+class FrontEndUnavailable(RuntimeError):
+    pass
+
+
+def _mel_24k(speech_24k):
+    """matcha.utils.audio.mel_spectrogram with the cosyvoice2.yaml feat_extractor settings (n_fft 1920, hop 480, win 1920,
+    80 mels, fmin 0, fmax 8000, center False; matcha/utils/audio.py:45-82): reflect-pad (n_fft-hop)/2, hann STFT, slaney mel
+    filterbank, log(clamp(.., 1e-5))."""
+    import numpy as np
+    n_fft, hop, n_mels, sr, fmax = 1920, 480, 80, 24000, 8000
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        mel = f / (200.0 / 3)
+        lin = f >= 1000.0
+        return np.where(lin, 15.0 + np.log(np.maximum(f, 1e-9) / 1000.0) / (np.log(6.4) / 27.0), mel)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), m * (200.0 / 3))
+
+    fftfreqs = np.linspace(0, sr / 2, n_fft // 2 + 1)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(0.0), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    fb = np.maximum(0, np.minimum(lower, upper)) * (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    fb = torch.from_numpy(fb.astype(np.float32))
+    y = torch.nn.functional.pad(speech_24k.unsqueeze(1), ((n_fft - hop) // 2, (n_fft - hop) // 2), mode='reflect').squeeze(1)
+    spec = torch.view_as_real(torch.stft(y, n_fft, hop_length=hop, win_length=n_fft, window=torch.hann_window(n_fft), center=False,
+                                         pad_mode='reflect', normalized=False, onesided=True, return_complex=True))
+    spec = torch.sqrt(spec.pow(2).sum(-1) + 1e-9)
+    return torch.log(torch.clamp(torch.matmul(fb, spec), min=1e-5))
+
+
+class PrecomputedFrontEnd:
+    """Frontend over pre-extracted prompts: spk2info[id] holds the dict frontend_zero_shot would build (prompt_text tokens,
+    speech tokens, prompt mel, embeddings).  Text -> ids goes through `tokenize` (any callable str -> list[int])."""
+
+    def __init__(self, tokenize, spk2info=None):
+        self.tokenize = tokenize
+        self.spk2info = dict(spk2info or {})
+
+    def text_normalize(self, text, split=True, text_frontend=True):
+        # text_frontend=False path of frontend.py:436-437: no normalisation, no splitting
+        return [text] if split else text
+
+    def _extract_text_token(self, text):
+        ids = self.tokenize(text)
+        t = torch.tensor([ids], dtype=torch.int32)
+        return t, torch.tensor([t.shape[1]], dtype=torch.int32)
+
+    def frontend_zero_shot(self, tts_text, prompt_text, prompt_speech_16k, resample_rate, zero_shot_spk_id):
+        if zero_shot_spk_id == '':
+            raise FrontEndUnavailable('prompt feature extraction needs onnxruntime + whisper + the model_dir ONNX files; '
+                                      'use add_zero_shot_spk() with pre-extracted features or install them')
+        model_input = dict(self.spk2info[zero_shot_spk_id])
+        model_input['text'], model_input['text_len'] = self._extract_text_token(tts_text)
+        return model_input
+
+    def frontend_cross_lingual(self, tts_text, prompt_speech_16k, resample_rate, zero_shot_spk_id):
+        model_input = self.frontend_zero_shot(tts_text, '', prompt_speech_16k, resample_rate, zero_shot_spk_id)
+        for k in ('prompt_text', 'prompt_text_len', 'llm_prompt_speech_token', 'llm_prompt_speech_token_len'):
+            model_input.pop(k, None)              # frontend.py:517-521: the LLM sees the text only
+        return model_input
+
+
+class CosyVoiceFrontEnd(PrecomputedFrontEnd):
+    """The reference's frontend on its own third-party stack (frontend.py:38-127).  Raises FrontEndUnavailable at construction
+    when that stack (onnxruntime, whisper, transformers tokenizer files) is not installed."""
+
+    def __init__(self, model_dir, allowed_special='all'):
+        try:
+            import onnxruntime
+            import whisper
+            from transformers import AutoTokenizer
+        except ImportError as e:
+            raise FrontEndUnavailable('CosyVoiceFrontEnd needs onnxruntime, openai-whisper and transformers: {}'.format(e))
+        self._whisper = whisper
+        tok_dir = os.path.join(model_dir, 'CosyVoice-BlankEN')
+        self._tok = AutoTokenizer.from_pretrained(tok_dir)
+        special = {'eos_token': '<|endoftext|>', 'pad_token': '<|endoftext|>',
+                   'additional_special_tokens': ['<|im_start|>', '<|im_end|>', '<|endofprompt|>', '[breath]', '<strong>', '</strong>', '[noise]',
+                                                 '[laughter]', '[cough]', '[clucking]', '[accent]', '[quick_breath]', '<laughter>', '</laughter>',
+                                                 '[hissing]', '[sigh]', '[vocalized-noise]', '[lipsmack]', '[mn]']}
+        self._tok.add_special_tokens(special)                                   # tokenizer/tokenizer.py:244-265
+        super().__init__(lambda t: self._tok([t], return_tensors='pt')['input_ids'][0].tolist())
+        opt = onnxruntime.SessionOptions()
+        opt.graph_optimization_level = onnxruntime.GraphOptimizationLevel.ORT_ENABLE_ALL
+        opt.intra_op_num_threads = 1
+        self.campplus_session = onnxruntime.InferenceSession(os.path.join(model_dir, 'campplus.onnx'), sess_options=opt, providers=['CPUExecutionProvider'])
+        self.speech_tokenizer_session = onnxruntime.InferenceSession(os.path.join(model_dir, 'speech_tokenizer_v2.onnx'), sess_options=opt,
+                                                                     providers=['CPUExecutionProvider'])
+        spk = os.path.join(model_dir, 'spk2info.pt')
+        if os.path.exists(spk):
+            self.spk2info = torch.load(spk, map_location='cpu')
+
+    def _extract_speech_token(self, speech):                                    # frontend.py:262-274
+        assert speech.shape[1] / 16000 <= 30, 'do not support extract speech token for audio longer than 30s'
+        feat = self._whisper.log_mel_spectrogram(speech, n_mels=128)
+        ort_in = self.speech_tokenizer_session.get_inputs()
+        tok = self.speech_tokenizer_session.run(None, {ort_in[0].name: feat.detach().cpu().numpy(),
+                                                       ort_in[1].name: __import__('numpy').array([feat.shape[2]], dtype='int32')})[0].flatten().tolist()
+        t = torch.tensor([tok], dtype=torch.int32)
+        return t, torch.tensor([t.shape[1]], dtype=torch.int32)
+
+    def _extract_spk_embedding(self, speech):                                   # frontend.py:276-283
+        import torchaudio.compliance.kaldi as kaldi
+        feat = kaldi.fbank(speech, num_mel_bins=80, dither=0, sample_frequency=16000)
+        feat = feat - feat.mean(dim=0, keepdim=True)
+        emb = self.campplus_session.run(None, {self.campplus_session.get_inputs()[0].name: feat.unsqueeze(0).cpu().numpy()})[0].flatten().tolist()
+        return torch.tensor([emb])
+
+    def frontend_zero_shot(self, tts_text, prompt_text, prompt_speech_16k, resample_rate, zero_shot_spk_id):
+        if zero_shot_spk_id != '':
+            return super().frontend_zero_shot(tts_text, prompt_text, prompt_speech_16k, resample_rate, zero_shot_spk_id)
+        import torchaudio
+        text, text_len = self._extract_text_token(tts_text)
+        ptext, ptext_len = self._extract_text_token(prompt_text)
+        rs = torchaudio.transforms.Resample(orig_freq=16000, new_freq=resample_rate)(prompt_speech_16k)
+        feat = _mel_24k(rs).squeeze(0).transpose(0, 1).unsqueeze(0)
+        tok, tok_len = self._extract_speech_token(prompt_speech_16k)
+        n = min(int(feat.shape[1] / 2), tok.shape[1])                            # frontend.py:498-502: force feat = 2 x token
+        feat, tok = feat[:, :2 * n], tok[:, :n]
+        emb = self._extract_spk_embedding(prompt_speech_16k)
+        return {'text': text, 'text_len': text_len, 'prompt_text': ptext, 'prompt_text_len': ptext_len,
+                'llm_prompt_speech_token': tok, 'llm_prompt_speech_token_len': torch.tensor([n], dtype=torch.int32),
+                'flow_prompt_speech_token': tok, 'flow_prompt_speech_token_len': torch.tensor([n], dtype=torch.int32),
+                'prompt_speech_feat': feat, 'prompt_speech_feat_len': torch.tensor([2 * n], dtype=torch.int32),
+                'llm_embedding': emb, 'flow_embedding': emb}

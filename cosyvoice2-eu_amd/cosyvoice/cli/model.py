@@ -1,0 +1,199 @@
+"""`CosyVoice2Model` — the synthesis scheduler (replaces cosyvoice/cli/model.py:255-401 of the reference).
+
+Same contract: `tts(**model_input, stream, speed)` is a generator of `{'tts_speech': float32 CPU tensor [1, n]}`;
+per-call state lives in uuid-keyed dicts (`tts_speech_token_dict`, `llm_end_dict`, `hift_cache_dict`) created under
+`self.lock` and released when the generator finishes (model.py:342-345, 395-398); `token2wav` slices / caches / cross-fades
+exactly as model.py:300-334.
+
+What is different, by design:
+  * no LLM thread and no 100 ms polling loop: the LLM decode runs on its own HIP stream (the reference's `llm_context`
+    side stream, model.py:278) in bursts of exactly the tokens the next chunk needs, and the next burst is enqueued BEFORE
+    the current chunk's flow + HiFT are launched on the main stream, so the two overlap on the device while the host
+    never sleeps; first-chunk latency is the work itself, not a poll quantum;
+  * tokens stay on the device between the LLM and the flow (the reference round-trips a Python list, model.py:385);
+  * the cross-fade runs on the device (the reference's fade_in_out moves both tensors to the CPU, utils/common.py:144);
+  * one model object serialises concurrent tts() calls (the evaluation harness calls it from 8 threads,
+    evaluation/cosyvoice_synthesizer.py:219,260): a call holds `self.run_lock` from its first to its last device op.
+"""
+import threading
+import uuid
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from cv2amd.flow import FlowEngine
+from cv2amd.hift import HiftEngine
+from cv2amd.llm import LLMEngine, MODE_RAS, MODE_GREEDY
+from cv2amd import lib as L
+
+
+class CosyVoice2Model:
+    def __init__(self, llm_sd=None, flow_sd=None, hift_sd=None, fp16=False, device=None, max_text=512, max_prompt_tokens=750,
+                 max_new_tokens=3000, sampling='ras', seed=0):
+        if not torch.cuda.is_available():
+            raise L.Cv2Error('CosyVoice2Model (MI355X build) needs a GPU: the hot path has no CPU fallback')
+        self.device = torch.device(device or 'cuda')
+        self.fp16 = fp16                       # accepted for signature compatibility; the HIP path fixes its own dtypes
+        self.token_hop_len = 25                # must match the training static_chunk_size (model.py:271)
+        self.mel_cache_len = 8
+        self.source_cache_len = int(self.mel_cache_len * 480)
+        self.speech_window = np.hamming(2 * self.source_cache_len)
+        self.lock = threading.Lock()           # guards the per-uuid dicts, as in the reference
+        self.run_lock = threading.Lock()       # serialises device work of concurrent tts() calls (held from first to last device op)
+        self.tts_speech_token_dict = {}
+        self.llm_end_dict = {}
+        self.hift_cache_dict = {}
+        self.llm_stream = torch.cuda.Stream(self.device)
+        self.sampling_mode = MODE_RAS if sampling == 'ras' else MODE_GREEDY
+        self.seed = seed
+        self._limits = (max_text, max_prompt_tokens, max_new_tokens)
+        self.llm = self.flow = self.hift = None
+        self._noise_hook = None                # tests: callable(T) -> [1, 480 T, 9] N(0,1) injected in place of the device Philox draws
+        self._trace = None                     # tests: list receiving (flow mel, token_offset, finalize, noise) per token2wav call
+        if llm_sd is not None:
+            self.load_state_dicts(llm_sd, flow_sd, hift_sd)
+
+    # ---- model.py:67-90 ---------------------------------------------------------------------------------------
+    def load(self, llm_model, flow_model, hift_model):
+        llm_sd = torch.load(llm_model, map_location='cpu')
+        flow_sd = torch.load(flow_model, map_location='cpu')
+        hift_sd = {k.replace('generator.', ''): v for k, v in torch.load(hift_model, map_location='cpu').items()}
+        for sd in (llm_sd, flow_sd):
+            for k in ('epoch', 'step'):                      # training checkpoints carry these (train_utils.py:214)
+                sd.pop(k, None)
+        self.load_state_dicts(llm_sd, flow_sd, hift_sd)
+
+    def load_state_dicts(self, llm_sd, flow_sd, hift_sd):
+        max_text, max_prompt, max_new = self._limits
+        self.llm = LLMEngine(llm_sd, self.device, max_seqs=1, max_pos=max_text + max_prompt + max_new + 8, max_out=max_new)
+        self.flow = FlowEngine(flow_sd, self.device, max_utts=1, max_len=2 * (max_prompt + max_new))
+        self.hift = HiftEngine(hift_sd, self.device, max_frames=2 * max_new + self.mel_cache_len)
+        self._window_dev = torch.from_numpy(self.speech_window).float().to(self.device)
+
+    def load_jit(self, *a, **k):
+        raise NotImplementedError('load_jit: TorchScript flow encoder is an NVIDIA-path accelerator of the reference; not used on MI355X')
+
+    def load_trt(self, *a, **k):
+        raise NotImplementedError('load_trt: the TensorRT estimator seam is replaced by cv2_flow_estimator')
+
+    def load_vllm(self, *a, **k):
+        raise NotImplementedError('load_vllm: the vLLM seam is replaced by cv2_llm_*')
+
+    # ---- model.py:300-334 -------------------------------------------------------------------------------------
+    def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False, speed=1.0):
+        tts_mel, _ = self.flow.inference(token=token, token_len=None, prompt_token=prompt_token, prompt_token_len=None,
+                                         prompt_feat=prompt_feat, prompt_feat_len=None, embedding=embedding, streaming=stream,
+                                         finalize=finalize)
+        flow_mel = tts_mel
+        tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio:]
+        cache = self.hift_cache_dict[uuid]
+        if cache is not None:
+            tts_mel = torch.concat([cache['mel'], tts_mel], dim=2)
+            hift_cache_source = cache['source']
+        else:
+            hift_cache_source = None
+        noise = None
+        if self._noise_hook is not None:
+            n_frames = int(tts_mel.shape[2] / speed) if (finalize and speed != 1.0) else tts_mel.shape[2]
+            noise = self._noise_hook(n_frames)
+        if self._trace is not None:
+            self._trace.append((flow_mel.cpu(), token_offset, finalize, noise))
+        if finalize is False:
+            tts_speech, tts_source = self.hift.inference(speech_feat=tts_mel.contiguous(), cache_source=hift_cache_source, noise=noise)
+            if cache is not None:
+                self.hift.fade_in_out(tts_speech, cache['speech'], self._window_dev)
+            self.hift_cache_dict[uuid] = {'mel': tts_mel[:, :, -self.mel_cache_len:].clone(),
+                                          'source': tts_source[:, :, -self.source_cache_len:].clone(),
+                                          'speech': tts_speech[:, -self.source_cache_len:].clone()}
+            tts_speech = tts_speech[:, :-self.source_cache_len]
+        else:
+            if speed != 1.0:
+                assert cache is None, 'speed change only support non-stream inference mode'
+                tts_mel = F.interpolate(tts_mel, size=int(tts_mel.shape[2] / speed), mode='linear')
+            tts_speech, tts_source = self.hift.inference(speech_feat=tts_mel.contiguous(), cache_source=hift_cache_source, noise=noise)
+            if cache is not None:
+                self.hift.fade_in_out(tts_speech, cache['speech'], self._window_dev)
+        return tts_speech
+
+    # ---- llm side: llm_job (model.py:118-139) as bursts on the LLM stream -------------------------------------------
+    def _llm_start(self, text, prompt_text, llm_prompt_speech_token):
+        min_len, max_len = int(text.shape[1] * 2), int(text.shape[1] * 20)       # llm.py:643-644 (target text only)
+        with torch.cuda.stream(self.llm_stream):
+            x = self.llm.build_lm_input(text, prompt_text, llm_prompt_speech_token)
+            self.seed += 1
+            self.llm.add_request(0, x, min_len, max_len, self.sampling_mode, self.seed)
+
+    def _llm_advance(self, n_steps):
+        with torch.cuda.stream(self.llm_stream):
+            self.llm.step(1, n_steps)
+
+    def _llm_poll(self, this_uuid):
+        """Wait for the enqueued LLM work, publish the tokens so far (the reference's thread appends to the same list)."""
+        self.llm_stream.synchronize()
+        st, toks = self.llm.read(1)
+        self.tts_speech_token_dict[this_uuid] = toks[0]
+        self.llm_end_dict[this_uuid] = bool(st[0, L.ST_DONE])
+        return toks[0]
+
+    # ---- model.py:336-401 -------------------------------------------------------------------------------------
+    def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192), llm_embedding=torch.zeros(0, 192),
+            prompt_text=torch.zeros(1, 0, dtype=torch.int32),
+            llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
+            flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
+            prompt_speech_feat=torch.zeros(1, 0, 80), source_speech_token=torch.zeros(1, 0, dtype=torch.int32), stream=False, speed=1.0, **kwargs):
+        if source_speech_token.shape[1] != 0:
+            raise NotImplementedError('voice conversion (vc_job, model.py:141-143) is outside the zero-shot hot path')
+        if isinstance(text, torch.Tensor) is False:
+            raise NotImplementedError('generator text input (inference_bistream, llm.py:721-834) is not supported yet')
+        this_uuid = str(uuid.uuid1())
+        with self.lock:
+            self.tts_speech_token_dict[this_uuid], self.llm_end_dict[this_uuid] = [], False
+            self.hift_cache_dict[this_uuid] = None
+        dev = self.device
+        fpt = flow_prompt_speech_token.to(dev)
+        feat = prompt_speech_feat.to(dev)
+        femb = flow_embedding.to(dev)
+        if not self.run_lock.acquire(timeout=3600):
+            raise RuntimeError('CosyVoice2Model.tts: another synthesis call held the model for more than an hour')
+        try:
+            self._llm_start(text.to(dev), prompt_text.to(dev), llm_prompt_speech_token.to(dev))
+            la = self.flow.pre_lookahead_len
+            if stream is True:
+                token_offset = 0
+                prompt_token_pad = int(np.ceil(fpt.shape[1] / self.token_hop_len) * self.token_hop_len - fpt.shape[1])
+                need = self.token_hop_len + prompt_token_pad + la           # tokens the first chunk needs (model.py:353-357)
+                self._llm_advance(need - 1)                                    # the prefill already drew token 0
+                while True:
+                    toks = self._llm_poll(this_uuid)
+                    this_token_hop_len = self.token_hop_len + prompt_token_pad if token_offset == 0 else self.token_hop_len
+                    ended = self.llm_end_dict[this_uuid]
+                    if len(toks) - token_offset >= this_token_hop_len + la:
+                        if not ended:                                          # next burst overlaps this chunk's flow + HiFT
+                            self._llm_advance(self.token_hop_len)
+                        this_tok = torch.tensor(toks[:token_offset + this_token_hop_len + la], dtype=torch.int32).unsqueeze(0)
+                        speech = self.token2wav(this_tok, fpt, feat, femb, token_offset, this_uuid, stream=stream, finalize=False)
+                        token_offset += this_token_hop_len
+                        yield {'tts_speech': speech.cpu()}
+                        continue
+                    if ended:
+                        break
+                    self._llm_advance(this_token_hop_len + la - (len(toks) - token_offset))   # fill tokens skipped (ids > eos)
+                this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid], dtype=torch.int32).unsqueeze(0)
+                speech = self.token2wav(this_tok, fpt, feat, femb, token_offset, this_uuid, finalize=True)
+                yield {'tts_speech': speech.cpu()}
+            else:
+                while True:
+                    self._llm_advance(64)
+                    toks = self._llm_poll(this_uuid)
+                    if self.llm_end_dict[this_uuid]:
+                        break
+                this_tok = torch.tensor(toks, dtype=torch.int32).unsqueeze(0)
+                speech = self.token2wav(this_tok, fpt, feat, femb, 0, this_uuid, finalize=True, speed=speed)
+                yield {'tts_speech': speech.cpu()}
+        finally:
+            self.run_lock.release()
+            with self.lock:
+                self.tts_speech_token_dict.pop(this_uuid, None)
+                self.llm_end_dict.pop(this_uuid, None)
+                self.hift_cache_dict.pop(this_uuid, None)

@@ -197,7 +197,7 @@ class FlowEngine:
         outs, keep = [], []
         la = 0 if finalize else self.pre_lookahead_len
         for i, u in enumerate(utts):
-            tok = torch.cat([u['prompt_token'].reshape(-1), u['token'].reshape(-1)]).to(device=dev, dtype=torch.int32).contiguous()
+            tok = torch.cat([u['prompt_token'].reshape(-1).to(dev), u['token'].reshape(-1).to(dev)]).to(dtype=torch.int32).contiguous()
             pf = u['prompt_feat'].reshape(-1, 80).to(device=dev, dtype=torch.float32).contiguous()
             emb = u['embedding'].reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
             n2 = 2 * (tok.numel() - la) - pf.shape[0]

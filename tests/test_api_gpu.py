@@ -1,0 +1,121 @@
+"""GPU tests of the drop-in API layer and the synthesis scheduler (cosyvoice/cli/model.py of this build) against the
+reference's scheduling logic restated on the CPU oracle.  Run with -m gpu on an MI355X."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TEXT_IDS = {'bonjour': [11, 22, 33, 44, 55, 66, 77, 88], 'guten tag': [9, 8, 7, 6, 5, 4, 3, 2, 1, 10, 20, 30]}
+
+
+@pytest.fixture(scope='module')
+def cv():
+    assert torch.cuda.is_available(), 'needs a GPU'
+    from cv2amd import synth
+    from cosyvoice.cli.cosyvoice import CosyVoice2
+    from cosyvoice.cli.frontend import PrecomputedFrontEnd
+    inp = synth.synthetic_inputs(prompt_len=37, prompt_text_len=4)
+    spk = {'prompt_text': inp['prompt_text'], 'prompt_text_len': torch.tensor([4]), 'llm_prompt_speech_token': inp['prompt_token'],
+           'llm_prompt_speech_token_len': torch.tensor([37]), 'flow_prompt_speech_token': inp['prompt_token'],
+           'flow_prompt_speech_token_len': torch.tensor([37]), 'prompt_speech_feat': inp['prompt_feat'],
+           'prompt_speech_feat_len': torch.tensor([74]), 'llm_embedding': inp['embedding'], 'flow_embedding': inp['embedding']}
+    fe = PrecomputedFrontEnd(lambda t: TEXT_IDS[t], {'fr': spk})
+    m = CosyVoice2('unused', final=True, frontend=fe, state_dicts=(synth.make_llm(layers=2), synth.make_flow(), synth.make_hift()))
+    m.model.sampling_mode = 0            # harness-defined greedy: deterministic tokens
+    return m
+
+
+def test_non_stream_yield_contract(cv):
+    outs = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr', stream=False))
+    assert len(outs) == 1
+    wav = outs[0]['tts_speech']
+    assert wav.dtype == torch.float32 and wav.device.type == 'cpu' and wav.dim() == 2 and wav.shape[0] == 1
+    assert wav.shape[1] % 960 == 0 and wav.shape[1] >= 960 * 16        # min_len = 2 x 8 text tokens, 2 mel frames x 480 samples per token
+    assert torch.isfinite(wav).all() and wav.abs().max() <= 0.99
+    assert cv.model.tts_speech_token_dict == {} and cv.model.hift_cache_dict == {}      # per-call state released (model.py:395-398)
+
+
+def test_cross_lingual_drops_llm_prompt(cv):
+    a = list(cv.inference_cross_lingual('bonjour', None, zero_shot_spk_id='fr'))[0]['tts_speech']
+    b = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr'))[0]['tts_speech']
+    assert a.shape[1] > 0 and (a.shape != b.shape or not torch.equal(a, b))
+
+
+def test_streaming_scheduler_matches_reference_logic(cv):
+    """Chunking / caches / cross-fade of model.py:300-381 restated on the CPU oracle, fed with the SAME flow mels and the same
+    injected noise the device run used: waveform chunks must agree to 1e-3; the flow mels themselves are checked against the
+    oracle flow (bf16 tolerance) in test_flow_gpu.py."""
+    from cv2amd import synth
+    from oracle import hift as OH
+    mdl = cv.model
+    gen = torch.Generator().manual_seed(5)
+    noises = []
+
+    def hook(T):
+        nz = torch.randn(1, 480 * T, 9, generator=gen)
+        noises.append(nz)
+        return nz
+    mdl._noise_hook, mdl._trace = hook, []
+    try:
+        chunks = [o['tts_speech'] for o in cv.inference_zero_shot('guten tag', 'salut', None, zero_shot_spk_id='fr', stream=True)]
+        trace = mdl._trace
+    finally:
+        mdl._noise_hook, mdl._trace = None, None
+    assert len(chunks) >= 2 and len(chunks) == len(trace)
+    P, hop, la = 37, 25, 3
+    pad = int(np.ceil(P / hop) * hop - P)
+    offs = [t[1] for t in trace]
+    assert offs[0] == 0 and offs[1] == hop + pad and all(b - a == hop for a, b in zip(offs[1:-1], offs[2:]))
+    assert [t[2] for t in trace] == [False] * (len(trace) - 1) + [True]
+    # CPU restatement of token2wav's tail (model.py:311-334)
+    hsd = synth.make_hift()
+    win = torch.from_numpy(np.hamming(2 * 3840)).float()
+    cache, ref_chunks = None, []
+    ri = torch.zeros(1, 9)
+    for (mel, off, fin, nz) in trace:
+        mel = mel[:, :, off * 2:]
+        if cache is not None:
+            mel = torch.cat([cache['mel'], mel], dim=2)
+            cs = cache['source']
+        else:
+            cs = torch.zeros(1, 1, 0)
+        speech, src = OH.inference(hsd, mel, cs, ri, nz)
+        if cache is not None:
+            speech[..., :3840] = speech[..., :3840] * win[:3840] + cache['speech'][..., -3840:] * win[3840:]
+        if not fin:
+            cache = {'mel': mel[:, :, -8:], 'source': src[:, :, -3840:], 'speech': speech[:, -3840:]}
+            speech = speech[:, :-3840]
+        ref_chunks.append(speech)
+    for i, (a, b) in enumerate(zip(chunks, ref_chunks)):
+        assert a.shape == b.shape, f'chunk {i}: {a.shape} vs {b.shape}'
+        assert (a - b).abs().max().item() < 1e-3, f'chunk {i}: max abs err {(a - b).abs().max().item():.3e}'
+    total = sum(c.shape[1] for c in chunks)
+    n_tok = trace[-1][0].shape[2] // 2
+    assert total == 960 * n_tok
+
+
+def test_concurrent_calls_are_serialised(cv):
+    """The evaluation harness calls one model from several threads (evaluation/cosyvoice_synthesizer.py:219,260)."""
+    ref = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr'))[0]['tts_speech']
+    res, errs = [None] * 3, []
+
+    def work(i):
+        try:
+            res[i] = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr'))[0]['tts_speech']
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    [t.start() for t in ths]
+    [t.join(300) for t in ths]
+    assert not errs
+    for r in res:
+        assert r.shape == ref.shape       # greedy tokens are deterministic; HiFT noise differs per call (device Philox)
+
+
+def test_speed_changes_length(cv):
+    a = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr', speed=1.0))[0]['tts_speech']
+    b = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr', speed=2.0))[0]['tts_speech']
+    assert abs(b.shape[1] - a.shape[1] // 2) <= 480

