@@ -122,7 +122,7 @@ class CosyVoice2Model:
         with torch.cuda.stream(self.llm_stream):
             x = self.llm.build_lm_input(text, prompt_text, llm_prompt_speech_token)
             self.seed += 1
-            self.llm.add_request(0, x, min_len, max_len, self.sampling_mode, self.seed)
+            self.llm.add_requests([0], [x], [(min_len, max_len)], self.sampling_mode, self.seed)
 
     def _llm_advance(self, n_steps):
         with torch.cuda.stream(self.llm_stream):

@@ -13,7 +13,7 @@
 //   k_attn_est             MFMA bf16   estimator self-attention, flash style (no T x T matrix in HBM)
 //   k_relsoftmax           HBM         conformer rel-pos softmax over explicit score matrices (encoder only, ~2 % of FLOPs)
 //   k_layernorm, k_pack, k_euler, ...  HBM   small row-wise kernels
-#include "gemm.h"
+#include "gemm_launch.h"
 #include "skinny_launch.h"
 #include "../../include/cv2_amd.h"
 #include <algorithm>
@@ -22,47 +22,6 @@
 #include <vector>
 
 #define GUARD 128
-
-// =========================================================================== GEMM launch
-template <int BM, int BN, int WM, int WN>
-static int gemm_go(const GemmArgs& a, int batch, bool packed, hipStream_t s) {
-    constexpr size_t sm = gemm_smem_bytes<BM, BN>();
-    dim3 grid(a.N / BN, a.M / BM, batch), block(WM * WN * 64);
-    if (packed) {
-        static bool once = false;
-        if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true>), grid, block, sm, s, a);
-    } else {
-        static bool once = false;
-        if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false>), grid, block, sm, s, a);
-    }
-    CV2_LAUNCH_CHECK();
-    return 0;
-}
-
-// cfg 0: 128x128; cfg 1: 64x256 (whole rows of N == 256); cfg 2: 128x64
-static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, hipStream_t s) {
-    CV2_CHECK(a.K % 64 == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of 64", a.K);
-    CV2_CHECK(a.M % 128 == 0 && a.M > 0, "gemm: M=%d must be a positive multiple of 128", a.M);
-    if (cfg == 0) { CV2_CHECK(a.N % 128 == 0, "gemm cfg0: N=%d %% 128", a.N); return gemm_go<128, 128, 2, 2>(a, batch, packed, s); }
-    if (cfg == 1) {
-        CV2_CHECK(a.N % 256 == 0, "gemm cfg1: N=%d %% 256", a.N);
-        CV2_CHECK((!a.ln1_g && !a.ln2_g) || a.N == 256, "gemm cfg1: LayerNorm epilogue needs N == 256");
-        // few rows (one utterance): 32-row tiles double the blocks that share the latency-bound K loop and the row epilogue
-        if ((long)(a.M / 64) * (a.N / 256) * batch < 200) return gemm_go<32, 256, 1, 4>(a, batch, packed, s);
-        return gemm_go<64, 256, 1, 4>(a, batch, packed, s);
-    }
-    CV2_CHECK(a.N % 64 == 0, "gemm cfg2: N=%d %% 64", a.N);
-    return gemm_go<128, 64, 2, 2>(a, batch, packed, s);
-}
-
-static GemmArgs gemm_args(const uint16_t* A, long lda, long a_off, const uint16_t* W, int M, int N, int K) {
-    GemmArgs a{};
-    a.A = A; a.lda = lda; a.a_row_off = a_off; a.W = W; a.M = M; a.N = N; a.K = K; a.M_valid = M;
-    a.out_scale = 1.f; a.n_store = N; a.ln2_scale = 1.f; a.act_slope = 0.01f;
-    return a;
-}
 
 extern "C" int cv2_gemm_bf16(const uint16_t* a, int64_t lda, const uint16_t* w, const float* bias, float* out, int64_t ldo,
                              int32_t m, int32_t n, int32_t k, void* stream) {

@@ -27,6 +27,7 @@ struct SeqTable {
 
 struct GemmArgs {
     const uint16_t* A; long lda; long a_row_off; long a_bstride;   // bf16 activations; row m reads A[(m + a_row_off) * lda ..]
+    const uint16_t* A_lo;                                           // SPLITA kernels: low half of the operand split, same layout
     const uint16_t* W; long ldw; long w_bstride;                    // packed (WPACKED) or row-major [N][ldw]
     int M, N, K;                                                    // M % BM == 0 (padded rows), K % 64 == 0
     SeqTable seq;                                                   // tile_seq == null: every row m < M_valid is valid
@@ -77,11 +78,12 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool WPACKED>
+template <int BM, int BN, int WM, int WN, bool WPACKED, bool SPLITA = false>
 __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     constexpr int NW = WM * WN, NT_ = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
-    constexpr int NA = BM / 16 * 2, NB = BN / 16 * 2, NP = NA + NB;          // 1 KiB pieces per stage
+    // 1 KiB pieces per stage: A (hi) [, A lo: the operand split x = hi + lo keeps ~16 mantissa bits through two bf16 MFMAs], W
+    constexpr int NA = BM / 16 * 2, NAP = SPLITA ? 2 * NA : NA, NB = BN / 16 * 2, NP = NAP + NB;
     constexpr int STAGE = NP * 1024;
     constexpr int LDC = BN + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,11 +104,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
         for (int i = 0; i < NP / NW; i++) {
             const int p = wave + i * NW;                 // NA % NW == 0: the A / W decision is per i, not per wave
             const void* src;
-            if (i < NA / NW) {
-                const int sub = p >> 1, ks = p & 1;
-                src = A + ((long)(m0 + sub * 16 + srow) + a.a_row_off) * a.lda + kt * 64 + ks * 32 + schunk * 8;
+            if (i < NAP / NW) {
+                const int pp = SPLITA ? p % NA : p, sub = pp >> 1, ks = pp & 1;
+                const uint16_t* Ab = (SPLITA && p >= NA) ? a.A_lo : A;
+                src = Ab + ((long)(m0 + sub * 16 + srow) + a.a_row_off) * a.lda + kt * 64 + ks * 32 + schunk * 8;
             } else {
-                const int q = p - NA, sub = q >> 1, ks = q & 1;
+                const int q = p - NAP, sub = q >> 1, ks = q & 1;
                 if (WPACKED)
                     src = W + (((size_t)(n0 / 16 + sub) * KS + kt * 2 + ks) * 64 + lane) * 8;
                 else
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
                                              (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
         }
     };
-    static_assert(NA % NW == 0 && NB % NW == 0, "A and W pieces must each divide evenly over the waves");
+    static_assert(NAP % NW == 0 && NB % NW == 0, "A and W pieces must each divide evenly over the waves");
     constexpr int PER_WAVE = (NP + NW - 1) / NW;       // NP % NW == 0 for every instantiated config
     static_assert(NP % NW == 0, "pieces must divide evenly over the waves");
 
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
             else if (PER_WAVE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (PER_WAVE == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
             else if (PER_WAVE == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (PER_WAVE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -175,18 +179,22 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
         const char* base = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8 af[MT], wf[NT];
+            bf16x8 af[MT], al[SPLITA ? MT : 1], wf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; i++)
+            for (int i = 0; i < MT; i++) {
                 af[i] = *reinterpret_cast<const bf16x8*>(base + ((wm * MT + i) * 2 + ks) * 1024 + a_off);
+                if (SPLITA) al[i] = *reinterpret_cast<const bf16x8*>(base + (NA + (wm * MT + i) * 2 + ks) * 1024 + a_off);
+            }
 #pragma unroll
             for (int j = 0; j < NT; j++)
-                wf[j] = *reinterpret_cast<const bf16x8*>(base + (NA + (wn * NT + j) * 2 + ks) * 1024 + w_off);
+                wf[j] = *reinterpret_cast<const bf16x8*>(base + (NAP + (wn * NT + j) * 2 + ks) * 1024 + w_off);
 #pragma unroll
             for (int j = 0; j < NT; j++)
 #pragma unroll
-                for (int i = 0; i < MT; i++)
+                for (int i = 0; i < MT; i++) {
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                    if (SPLITA) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], al[i], acc[j][i], 0, 0, 0);
+                }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // everyone is done reading this stage
@@ -276,9 +284,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool SPLITA = false>
 constexpr size_t gemm_smem_bytes() {
-    constexpr size_t stages = 2 * (size_t)((BM + BN) / 16 * 2) * 1024;
+    constexpr size_t stages = 2 * (size_t)(((SPLITA ? 2 : 1) * BM + BN) / 16 * 2) * 1024;
     constexpr size_t ctile = (size_t)BM * (BN + 4) * 4;
     return stages > ctile ? stages : ctile;
 }

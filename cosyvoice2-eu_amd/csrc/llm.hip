@@ -13,6 +13,7 @@
 // (727.6 MB at the real dims) plus the KV read.
 #include "skinny.h"
 #include "skinny_launch.h"
+#include "gemm_launch.h"
 #include "../../include/cv2_amd.h"
 #include <map>
 #include <stdarg.h>
@@ -60,18 +61,33 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int head = blockIdx.x >> 1, half = blockIdx.x & 1;   // heads: n_q query, then n_kv key, then n_kv value
     const int wr = (threadIdx.x >> 6) % 2;
+    // epilogue operands of this thread's first element (position, bias, RoPE table entries): fetched now, so the dependent
+    // chain state -> pos -> cos/sin is hidden under the weight stream instead of trailing the GEMV
+    const bool rot = head < a.n_q + a.n_kv;
+    int seq0 = 0, pos0 = 0;
+    float pb0 = 0.f, pb1 = 0.f, pc0 = 1.f, ps0 = 0.f;
+    if (threadIdx.x < a.rows * 32) {
+        const int e = threadIdx.x, r = e >> 5, w = (e >> 4) & 1, i16 = e & 15, f = half * 16 + w * 32 + i16;
+        a.rm.get(r, seq0, pos0);
+        pb0 = a.bias[head * 64 + f];
+        if (rot) { pb1 = a.bias[head * 64 + (f ^ 32)]; pc0 = a.cosT[pos0 * 32 + (f & 31)]; ps0 = a.sinT[pos0 * 32 + (f & 31)]; }
+    }
     float* res = skinny_core<NB, 2, 4, 8>(a.W, head * 4 + half + 2 * wr, a.KS, a.rows, a.K, a.X, smem);
     const int ld = NB * 16 + 1;
     for (int e = threadIdx.x; e < a.rows * 32; e += blockDim.x) {
         const int r = e >> 5, w = (e >> 4) & 1, i16 = e & 15;
         const int f = half * 16 + w * 32 + i16;           // feature within the head
-        int seq, pos;
-        a.rm.get(r, seq, pos);
-        float v = res[(w * 16 + i16) * ld + r] + a.bias[head * 64 + f];
-        if (head < a.n_q + a.n_kv) {                       // rotate-half RoPE on q and k heads
-            const float vp = res[((1 - w) * 16 + i16) * ld + r] + a.bias[head * 64 + (f ^ 32)];
-            const float c = a.cosT[pos * 32 + (f & 31)], s = a.sinT[pos * 32 + (f & 31)];
-            v = (f < 32) ? (v * c - vp * s) : (v * c + vp * s);
+        int seq = seq0, pos = pos0;
+        float b0 = pb0, b1 = pb1, c = pc0, sn = ps0;
+        if (e != (int)threadIdx.x) {
+            a.rm.get(r, seq, pos);
+            b0 = a.bias[head * 64 + f];
+            if (rot) { b1 = a.bias[head * 64 + (f ^ 32)]; c = a.cosT[pos * 32 + (f & 31)]; sn = a.sinT[pos * 32 + (f & 31)]; }
+        }
+        float v = res[(w * 16 + i16) * ld + r] + b0;
+        if (rot) {                                         // rotate-half RoPE on q and k heads
+            const float vp = res[((1 - w) * 16 + i16) * ld + r] + b1;
+            v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);
         }
         if (head < a.n_q) a.q[(size_t)r * a.n_q * 64 + head * 64 + f] = v;
         else if (head < a.n_q + a.n_kv)
@@ -464,6 +480,176 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ batched prefill (rows of several prompts at once)
+// The prompt rows of all new requests are packed into one [M][hidden] matrix and go through the bf16 MFMA GEMM of gemm.h
+// with the operand split x = hi + lo (two MFMAs per tile, ~16 mantissa bits of x, the same arithmetic class as the skinny
+// decode kernels), so the weights are streamed once per prefill instead of once per 32 rows.
+__device__ __forceinline__ uint32_t pk2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+// RMSNorm + hi/lo split: x fp32 [M][H] -> bf16 planes; one wave per row; rows >= M_valid -> 0
+__global__ __launch_bounds__(256) void k_rms_split(const float* x, const float* g, float eps, uint16_t* hi, uint16_t* lo, int M_valid, int Mp, int H) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= Mp) return;
+    const int per = H / 64;                                   // 14 for hidden 896
+    float v[16];
+    float sq = 0.f;
+    for (int i = 0; i < per; i++) { v[i] = row < M_valid ? x[(size_t)row * H + lane * per + i] : 0.f; sq += v[i] * v[i]; }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+    for (int i = 0; i < per; i += 2) {
+        const int c = lane * per + i;
+        const float a0 = g[c] * (v[i] * rstd), a1 = g[c + 1] * (v[i + 1] * rstd);
+        const uint16_t h0 = f2bf(a0), h1 = f2bf(a1);
+        *reinterpret_cast<uint32_t*>(hi + (size_t)row * H + c) = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        *reinterpret_cast<uint32_t*>(lo + (size_t)row * H + c) = pk2(a0 - bf2f(h0), a1 - bf2f(h1));
+    }
+}
+
+// bias was added by the GEMM epilogue: RoPE on q / k, q -> qbuf, k / v -> cache at (slot, position) of the row
+struct RopeArgs {
+    const float* qkv; int ld; const int* row_seq; const int* row_pos; const float* cosT; const float* sinT;
+    float* q; float* kc; float* vc; int n_q, n_kv, max_pos, M;
+};
+__global__ __launch_bounds__(256) void k_rope_cache(RopeArgs a) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int nh = a.n_q + 2 * a.n_kv;
+    if (idx >= (long)a.M * nh * 32) return;
+    const int i = idx & 31, head = (idx >> 5) % nh, row = idx / (32L * nh);
+    const int seq = a.row_seq[row], pos = a.row_pos[row];
+    const float v0 = a.qkv[(size_t)row * a.ld + head * 64 + i], v1 = a.qkv[(size_t)row * a.ld + head * 64 + 32 + i];
+    float o0 = v0, o1 = v1;
+    if (head < a.n_q + a.n_kv) {
+        const float c = a.cosT[pos * 32 + i], sn = a.sinT[pos * 32 + i];
+        o0 = v0 * c - v1 * sn;
+        o1 = v1 * c + v0 * sn;
+    }
+    float* dst;
+    if (head < a.n_q) dst = a.q + (size_t)row * a.n_q * 64 + head * 64;
+    else if (head < a.n_q + a.n_kv) dst = a.kc + (((size_t)seq * a.n_kv + (head - a.n_q)) * a.max_pos + pos) * 64;
+    else dst = a.vc + (((size_t)seq * a.n_kv + (head - a.n_q - a.n_kv)) * a.max_pos + pos) * 64;
+    dst[i] = o0; dst[32 + i] = o1;
+}
+
+// causal attention of 16 prompt rows x one GQA group over the cache, fp32; output as hi/lo bf16 planes [M][n_q*64]
+struct PfAttnArgs {
+    const float* q; const float* kc; const float* vc; uint16_t* hi; uint16_t* lo;
+    const int* seq_row0; const int* seq_len; const int* seq_slot; const int* seq_pos0;
+    int n_q, n_kv, max_pos;
+};
+#define PF_KLD 68
+__global__ __launch_bounds__(256) void k_attn_prefill(PfAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rep = a.n_q / a.n_kv;                              // <= 8 ; pairs = 16 rows x rep heads <= 128
+    float* Ks = reinterpret_cast<float*>(smem);                  // [64][PF_KLD]
+    float* Vs = Ks + 64 * PF_KLD;                                // [64][64]
+    float* qs = Vs + 64 * 64;                                    // [128][64]
+    float* ss = qs + 128 * 64;                                   // [128][64]
+    float* m_run = ss + 128 * 64; float* l_run = m_run + 128; float* scl = l_run + 128;
+    const int qt = blockIdx.x, g = blockIdx.y, sq = blockIdx.z;
+    const int len = a.seq_len[sq];
+    if (qt * 16 >= len) return;
+    const int row0 = a.seq_row0[sq] + qt * 16, slot = a.seq_slot[sq], pos0 = a.seq_pos0[sq] + qt * 16;
+    const int nrow = min(16, len - qt * 16);
+    const int npair = 16 * rep, ppg = npair / 4;                 // pairs per thread group (4 groups of 64 threads)
+    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
+    const float* K = a.kc + ((size_t)slot * a.n_kv + g) * a.max_pos * 64;
+    const float* V = a.vc + ((size_t)slot * a.n_kv + g) * a.max_pos * 64;
+    for (int e = tid; e < npair * 64; e += 256) {
+        const int pr = e >> 6, d = e & 63, i = pr / rep, hh = pr % rep;
+        qs[e] = i < nrow ? a.q[(size_t)(row0 + i) * a.n_q * 64 + (g * rep + hh) * 64 + d] : 0.f;
+    }
+    if (tid < 128) { m_run[tid] = -INFINITY; l_run[tid] = 0.f; }
+    float o[32];
+#pragma unroll
+    for (int p = 0; p < 32; p++) o[p] = 0.f;
+    const int kend = pos0 + nrow;                                // keys 0 .. pos0 + nrow - 1 are visible to some row
+    for (int j0 = 0; j0 < kend; j0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = tid + 256 * u, key = idx >> 4, c4 = idx & 15;
+            const bool ok = j0 + key < kend;
+            *reinterpret_cast<f32x4*>(&Ks[key * PF_KLD + c4 * 4]) = ok ? *reinterpret_cast<const f32x4*>(K + (size_t)(j0 + key) * 64 + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&Vs[key * 64 + c4 * 4]) = ok ? *reinterpret_cast<const f32x4*>(V + (size_t)(j0 + key) * 64 + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        {   // scores: thread = (key, pair group)
+            f32x4 kr[16];
+#pragma unroll
+            for (int c4 = 0; c4 < 16; c4++) kr[c4] = *reinterpret_cast<const f32x4*>(&Ks[lane * PF_KLD + c4 * 4]);
+            for (int pp = 0; pp < ppg; pp++) {
+                const int pr = grp * ppg + pp, i = pr / rep;
+                float acc = 0.f;
+#pragma unroll
+                for (int c4 = 0; c4 < 16; c4++) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[pr * 64 + c4 * 4]);
+                    acc += kr[c4][0] * qv[0] + kr[c4][1] * qv[1] + kr[c4][2] * qv[2] + kr[c4][3] * qv[3];
+                }
+                const bool vis = i < nrow && (j0 + lane) <= (pos0 + i);
+                ss[pr * 64 + lane] = vis ? acc * 0.125f : -INFINITY;
+            }
+        }
+        __syncthreads();
+        for (int pp = 0; pp < ppg; pp++) {                       // wave grp owns its pair group: online softmax per pair
+            const int pr = grp * ppg + pp;
+            const float sv = ss[pr * 64 + lane];
+            const float mt = wave_max(sv);
+            const float mo = m_run[pr], mn = fmaxf(mo, mt);
+            const float pv = mn == -INFINITY ? 0.f : __expf(sv - mn);
+            ss[pr * 64 + lane] = pv;
+            const float lt = wave_sum(pv);
+            if (lane == 0) {
+                const float sc = mn == -INFINITY ? 1.f : __expf(mo - mn);
+                scl[pr] = sc; l_run[pr] = l_run[pr] * sc + lt; m_run[pr] = mn;
+            }
+        }
+        __syncthreads();
+        {   // PV: thread = (dim, pair group), V column in registers
+            float vv[64];
+#pragma unroll
+            for (int k = 0; k < 64; k++) vv[k] = Vs[k * 64 + lane];
+            for (int pp = 0; pp < ppg; pp++) {
+                const int pr = grp * ppg + pp;
+                float acc = o[pp] * scl[pr];
+#pragma unroll
+                for (int k4 = 0; k4 < 16; k4++) {
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(&ss[pr * 64 + 4 * k4]);
+                    acc += pv[0] * vv[4 * k4] + pv[1] * vv[4 * k4 + 1] + pv[2] * vv[4 * k4 + 2] + pv[3] * vv[4 * k4 + 3];
+                }
+                o[pp] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    for (int pp = 0; pp < ppg; pp++) {
+        const int pr = grp * ppg + pp, i = pr / rep, hh = pr % rep;
+        if (i >= nrow) continue;
+        const float l = l_run[pr];
+        const float v = l > 0.f ? o[pp] / l : 0.f;
+        const size_t off = (size_t)(row0 + i) * a.n_q * 64 + (g * rep + hh) * 64 + lane;
+        const uint16_t hb = f2bf(v);
+        a.hi[off] = hb; a.lo[off] = f2bf(v - bf2f(hb));
+    }
+}
+
+// gate / up (16-row tiles interleaved as packed for the decode kernels) -> SiLU(g) * u -> hi/lo planes [M][inter]
+__global__ __launch_bounds__(256) void k_swiglu_split(const float* gu, uint16_t* hi, uint16_t* lo, int M_valid, int Mp, int inter) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)Mp * inter) return;
+    const int c = idx % inter, row = idx / inter;
+    float v = 0.f;
+    if (row < M_valid) {
+        const int t = c >> 4, i = c & 15;
+        const float gt = gu[(size_t)row * 2 * inter + (2 * t) * 16 + i], up = gu[(size_t)row * 2 * inter + (2 * t + 1) * 16 + i];
+        v = (gt / (1.f + __expf(-gt))) * up;
+    }
+    const uint16_t hb = f2bf(v);
+    hi[idx] = hb; lo[idx] = f2bf(v - bf2f(hb));
+}
+__global__ void k_gather_rows(const float* x, const int* rows, float* out, int n, int H) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < n * H) out[idx] = x[(size_t)rows[idx / H] * H + idx % H];
+}
+
 // ------------------------------------------------------------------ host side
 struct cv2_llm {
     cv2_llm_dims d;
@@ -480,6 +666,11 @@ struct cv2_llm {
     int nsplit, keys_per_split;
     float *hbuf;               // [32][inter]
     float *parts;              // [SK_MAXNP][32][hidden] split-K partials of the down projection
+    // batched prefill buffers (rows = pf_rows, 0 = disabled)
+    int pf_rows;
+    float *pf_x, *pf_qkv, *pf_q, *pf_gu, *pf_last;
+    uint16_t *pf_hi, *pf_lo;
+    int* pf_int;               // row_seq[pf_rows], row_pos[pf_rows], seq tables 5 x 32
     std::map<int, hipGraphExec_t> graphs;
     hipStream_t cap_stream;    // private stream used only to capture the decode-step graph (the caller's may be the null stream)
 };
@@ -501,6 +692,19 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     p = take((size_t)32 * d.hidden * 4); if (h) h->o = (float*)p;
     p = take((size_t)32 * d.inter * 4); if (h) h->hbuf = (float*)p;
     p = take((size_t)SK_MAXNP * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
+    const size_t R = (size_t)(d.max_prefill_rows > 0 ? (d.max_prefill_rows + 127) / 128 * 128 : 0);
+    if (h) h->pf_rows = (int)R;
+    if (R) {
+        const size_t nqkv = (size_t)(d.n_q + 2 * d.n_kv) * 64;
+        p = take(R * d.hidden * 4); if (h) h->pf_x = (float*)p;
+        p = take(R * nqkv * 4); if (h) h->pf_qkv = (float*)p;
+        p = take(R * d.n_q * 64 * 4); if (h) h->pf_q = (float*)p;
+        p = take(R * 2 * d.inter * 4); if (h) h->pf_gu = (float*)p;
+        p = take((size_t)32 * d.hidden * 4); if (h) h->pf_last = (float*)p;
+        p = take(R * d.inter * 2); if (h) h->pf_hi = (uint16_t*)p;
+        p = take(R * d.inter * 2); if (h) h->pf_lo = (uint16_t*)p;
+        p = take((2 * R + 6 * 32) * 4); if (h) h->pf_int = (int*)p;
+    }
     return off;
 }
 
@@ -653,28 +857,135 @@ extern "C" int cv2_llm_prefill(cv2_llm* h, int32_t seq, const float* embeds, int
     return launch_sample(h, 1, seq, (len - 1) % 32, len, s);
 }
 
-extern "C" int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream) {
-    CV2_CHECK(h, "cv2_llm_decode: null handle");
-    CV2_CHECK(n_seqs >= 1 && n_seqs <= h->d.max_seqs, "cv2_llm_decode: n_seqs %d out of range", n_seqs);
+// Step 0 of inference_wrapper for several slots at once: embeds = the prompts' rows concatenated [sum(lens)][hidden] fp32
+extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int32_t* lens, const float* embeds, void* stream) {
+    CV2_CHECK(h && slots && lens && embeds && n >= 1 && n <= 32, "cv2_llm_prefill_batch: bad argument");
+    CV2_CHECK(h->pf_rows > 0, "cv2_llm_prefill_batch: created with max_prefill_rows == 0");
     if (init_attrs_once()) return -1;
+    static bool once = false;
+    if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_prefill), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    const cv2_llm_dims& d = h->d;
     hipStream_t s = (hipStream_t)stream;
-    auto it = h->graphs.find(n_seqs);
+    int M = 0, maxlen = 0;
+    for (int i = 0; i < n; i++) {
+        CV2_CHECK(slots[i] >= 0 && slots[i] < d.max_seqs, "cv2_llm_prefill_batch: bad slot %d", slots[i]);
+        CV2_CHECK(lens[i] >= 1 && lens[i] + 1 < d.max_pos, "cv2_llm_prefill_batch: prompt length %d does not fit max_pos %d", lens[i], d.max_pos);
+        M += lens[i]; maxlen = lens[i] > maxlen ? lens[i] : maxlen;
+    }
+    const int Mp = (M + 127) / 128 * 128;
+    CV2_CHECK(Mp <= h->pf_rows, "cv2_llm_prefill_batch: %d prompt rows exceed max_prefill_rows %d", M, h->pf_rows);
+    const int R = h->pf_rows;
+    std::vector<int> host(2 * R + 6 * 32, 0);
+    int* row_seq = host.data(); int* row_pos = row_seq + R;
+    int* row0 = row_pos + R; int* slen = row0 + 32; int* sslot = slen + 32; int* spos0 = sslot + 32; int* lastrow = spos0 + 32;
+    for (int i = 0, r = 0; i < n; i++) {
+        row0[i] = r; slen[i] = lens[i]; sslot[i] = slots[i]; spos0[i] = 0; lastrow[i] = r + lens[i] - 1;
+        for (int t = 0; t < lens[i]; t++, r++) { row_seq[r] = slots[i]; row_pos[r] = t; }
+    }
+    CV2_HIP(hipMemcpyAsync(h->pf_int, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    CV2_HIP(hipMemcpyAsync(h->pf_x, embeds, (size_t)M * d.hidden * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CV2_HIP(hipStreamSynchronize(s));
+    const int* d_row_seq = h->pf_int; const int* d_row_pos = d_row_seq + R;
+    const int* d_row0 = d_row_pos + R; const int* d_len = d_row0 + 32; const int* d_slot = d_len + 32; const int* d_pos0 = d_slot + 32; const int* d_last = d_pos0 + 32;
+    const int H = d.hidden, NQ = d.n_q * 64, NQKV = (d.n_q + 2 * d.n_kv) * 64, I = d.inter;
+    CV2_CHECK(H % 128 == 0 || H % 64 == 0, "prefill: hidden %% 64");
+    CV2_CHECK(NQKV % 128 == 0 && H % 128 == 0 && (2 * I) % 128 == 0 && NQ % 64 == 0 && I % 64 == 0, "cv2_llm_prefill_batch: dims must be multiples of 128 / 64 for the GEMM tiles");
+    const size_t cache_l = (size_t)d.max_seqs * d.n_kv * d.max_pos * 64;
+    const size_t pf_smem = (size_t)(64 * PF_KLD + 64 * 64 + 2 * 128 * 64 + 3 * 128) * 4;
+    for (int l = 0; l < d.layers; l++) {
+        const cv2_llm_layer& L = h->layers[l];
+        hipLaunchKernelGGL(k_rms_split, dim3(Mp / 4), dim3(256), 0, s, (const float*)h->pf_x, L.ln1, d.rms_eps, h->pf_hi, h->pf_lo, M, Mp, H);
+        {
+            GemmArgs g = gemm_args(h->pf_hi, H, 0, L.wqkv, Mp, NQKV, H);
+            g.A_lo = h->pf_lo; g.bias = L.bqkv; g.out_f32 = h->pf_qkv; g.ldo = NQKV;
+            if (gemm_launch_cfg(g, 4, 1, true, s)) return -1;
+        }
+        {
+            RopeArgs r{h->pf_qkv, NQKV, d_row_seq, d_row_pos, h->w.rope_cos, h->w.rope_sin, h->pf_q, h->kc + l * cache_l, h->vc + l * cache_l,
+                       d.n_q, d.n_kv, d.max_pos, M};
+            hipLaunchKernelGGL(k_rope_cache, dim3(((long)M * (d.n_q + 2 * d.n_kv) * 32 + 255) / 256), dim3(256), 0, s, r);
+        }
+        {
+            PfAttnArgs a{h->pf_q, h->kc + l * cache_l, h->vc + l * cache_l, h->pf_hi, h->pf_lo, d_row0, d_len, d_slot, d_pos0, d.n_q, d.n_kv, d.max_pos};
+            hipLaunchKernelGGL(k_attn_prefill, dim3((maxlen + 15) / 16, d.n_kv, n), dim3(256), pf_smem, s, a);
+        }
+        {
+            GemmArgs g = gemm_args(h->pf_hi, NQ, 0, L.wo, Mp, H, NQ);
+            g.A_lo = h->pf_lo; g.res = h->pf_x; g.ldres = H; g.out_f32 = h->pf_x; g.ldo = H;
+            if (gemm_launch_cfg(g, 4, 1, true, s)) return -1;
+        }
+        hipLaunchKernelGGL(k_rms_split, dim3(Mp / 4), dim3(256), 0, s, (const float*)h->pf_x, L.ln2, d.rms_eps, h->pf_hi, h->pf_lo, M, Mp, H);
+        {
+            GemmArgs g = gemm_args(h->pf_hi, H, 0, L.wgu, Mp, 2 * I, H);
+            g.A_lo = h->pf_lo; g.out_f32 = h->pf_gu; g.ldo = 2 * I;
+            if (gemm_launch_cfg(g, 4, 1, true, s)) return -1;
+        }
+        hipLaunchKernelGGL(k_swiglu_split, dim3(((long)Mp * I + 255) / 256), dim3(256), 0, s, (const float*)h->pf_gu, h->pf_hi, h->pf_lo, M, Mp, I);
+        {
+            GemmArgs g = gemm_args(h->pf_hi, I, 0, L.wdown, Mp, H, I);
+            g.A_lo = h->pf_lo; g.res = h->pf_x; g.ldres = H; g.out_f32 = h->pf_x; g.ldo = H;
+            if (gemm_launch_cfg(g, 4, 1, true, s)) return -1;
+        }
+    }
+    // last row of every prompt -> final norm -> llm_decoder -> first draw
+    hipLaunchKernelGGL(k_gather_rows, dim3((n * H + 255) / 256), dim3(256), 0, s, (const float*)h->pf_x, d_last, h->pf_last, n, H);
+    {
+        StoreArgs a{};
+        a.W = h->w.wdec; a.bias = h->w.bdec;
+        a.X = SkinnyX{h->pf_last, nullptr, 0, h->w.final_norm, d.rms_eps, nullptr};
+        a.KS = H / 32; a.rows = n; a.K = H; a.N = d.vocab_pad; a.out = h->io.logits;
+        if (n <= 16) { const size_t sm = skinny_smem_bytes<1, 1, 4>(a.KS); hipLaunchKernelGGL((k_store<1, 8>), dim3(d.vocab_pad / 16, 1), dim3(256), sm, s, a); }
+        else { const size_t sm = skinny_smem_bytes<2, 1, 4>(a.KS); hipLaunchKernelGGL((k_store<2, 8>), dim3(d.vocab_pad / 16, 1), dim3(256), sm, s, a); }
+    }
+    for (int i = 0; i < n; i++)
+        if (launch_sample(h, 1, slots[i], i, lens[i], s)) return -1;
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+// one captured graph holds `unroll` consecutive decode steps for n_seqs slots (key = n_seqs * 64 + unroll)
+static int get_graph(cv2_llm* h, int n_seqs, int unroll, hipGraphExec_t* out) {
+    const int key = n_seqs * 64 + unroll;
+    auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
         hipGraph_t g;
         hipStream_t cs = h->cap_stream;
         CV2_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         RowMap rm{h->io.state, 0, 0, 0};
-        int rc = n_seqs <= 16 ? run_layers<1>(h, n_seqs, h->xnext, rm, cs) : run_layers<2>(h, n_seqs, h->xnext, rm, cs);
-        if (!rc) rc = launch_sample(h, n_seqs, -1, 0, 0, cs);
+        int rc = 0;
+        for (int u = 0; u < unroll && !rc; u++) {
+            rc = n_seqs <= 16 ? run_layers<1>(h, n_seqs, h->xnext, rm, cs) : run_layers<2>(h, n_seqs, h->xnext, rm, cs);
+            if (!rc) rc = launch_sample(h, n_seqs, -1, 0, 0, cs);
+        }
         hipError_t e = hipStreamEndCapture(cs, &g);
         if (rc) return rc;
         CV2_HIP(e);
         hipGraphExec_t ge;
         CV2_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         CV2_HIP(hipGraphDestroy(g));
-        it = h->graphs.emplace(n_seqs, ge).first;
+        it = h->graphs.emplace(key, ge).first;
     }
-    for (int i = 0; i < n_steps; i++) CV2_HIP(hipGraphLaunch(it->second, s));
+    *out = it->second;
+    return 0;
+}
+
+extern "C" int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream) {
+    CV2_CHECK(h, "cv2_llm_decode: null handle");
+    CV2_CHECK(n_seqs >= 1 && n_seqs <= h->d.max_seqs, "cv2_llm_decode: n_seqs %d out of range", n_seqs);
+    if (init_attrs_once()) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    // graph replays cost ~8 us of host/queue gap each: 8 steps per replay where possible (finished slots idle inside a replay)
+    constexpr int UNROLL = 8;
+    hipGraphExec_t g8 = nullptr, g1 = nullptr;
+    int i = 0;
+    if (n_steps >= UNROLL) {
+        if (get_graph(h, n_seqs, UNROLL, &g8)) return -1;
+        for (; i + UNROLL <= n_steps; i += UNROLL) CV2_HIP(hipGraphLaunch(g8, s));
+    }
+    if (i < n_steps) {
+        if (get_graph(h, n_seqs, 1, &g1)) return -1;
+        for (; i < n_steps; i++) CV2_HIP(hipGraphLaunch(g1, s));
+    }
     return 0;
 }
 

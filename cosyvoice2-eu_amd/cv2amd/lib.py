@@ -19,7 +19,7 @@ class Cv2Error(RuntimeError):
 
 class LlmDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('hidden', 'inter', 'layers', 'n_q', 'n_kv', 'vocab', 'vocab_pad', 'eos',
-                                         'max_seqs', 'max_pos', 'max_out')] + [('rms_eps', C.c_float)]
+                                         'max_seqs', 'max_pos', 'max_out')] + [('rms_eps', C.c_float), ('max_prefill_rows', C.c_int32)]
 
 
 class LlmLayer(C.Structure):
@@ -50,6 +50,7 @@ def lib():
         L.cv2_llm_destroy.argtypes = [C.c_void_p]
         L.cv2_llm_prefill.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         L.cv2_llm_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.cv2_llm_prefill_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]
         L.cv2_skinny_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_void_p]
         _lib = L
@@ -75,7 +76,7 @@ def ptr(t):
 
 
 EXPORTS = ['cv2_last_error', 'cv2_version', 'cv2_llm_workspace_bytes', 'cv2_llm_create', 'cv2_llm_destroy',
-           'cv2_llm_prefill', 'cv2_llm_decode', 'cv2_skinny_gemm', 'cv2_gemm_bf16',
+           'cv2_llm_prefill', 'cv2_llm_prefill_batch', 'cv2_llm_decode', 'cv2_skinny_gemm', 'cv2_gemm_bf16',
            'cv2_flow_workspace_bytes', 'cv2_flow_create', 'cv2_flow_destroy', 'cv2_flow_inference', 'cv2_flow_estimator',
            'cv2_flow_encoder', 'cv2_hift_workspace_bytes', 'cv2_hift_create', 'cv2_hift_destroy', 'cv2_hift_inference',
            'cv2_fade_in_out']

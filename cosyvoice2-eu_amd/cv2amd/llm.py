@@ -15,7 +15,7 @@ MODE_GREEDY, MODE_RAS = 0, 1
 
 
 class LLMEngine:
-    def __init__(self, sd, device='cuda:0', max_seqs=32, max_pos=2048, max_out=2048):
+    def __init__(self, sd, device='cuda:0', max_seqs=32, max_pos=2048, max_out=2048, max_prefill_rows=None):
         self.device = torch.device(device)
         self.lib = L.lib()
         dev = self.device
@@ -31,7 +31,8 @@ class LLMEngine:
         vocab_pad = (vocab + 15) // 16 * 16
         self.dims = L.LlmDims(hidden=hidden, inter=inter, layers=layers, n_q=n_q, n_kv=n_kv, vocab=vocab,
                               vocab_pad=vocab_pad, eos=EOS, max_seqs=max_seqs, max_pos=max_pos, max_out=max_out,
-                              rms_eps=1e-6)
+                              rms_eps=1e-6,
+                              max_prefill_rows=(max_prefill_rows if max_prefill_rows is not None else min(max_seqs * 512, max_seqs * max_pos)))
         self.hidden, self.max_seqs, self.max_out, self.vocab, self.vocab_pad = hidden, max_seqs, max_out, vocab, vocab_pad
         keep = []
 
@@ -105,6 +106,23 @@ class LLMEngine:
         assert lm_input.dtype == torch.float32 and lm_input.is_contiguous() and lm_input.shape[1] == self.hidden
         L.check(self.lib.cv2_llm_prefill(self.handle, slot, L.ptr(lm_input), lm_input.shape[0], L.stream_ptr()))
 
+    def _init_state(self, slot, min_len, max_len, mode, seed, force_len):
+        st = torch.zeros(L.STATE_STRIDE, dtype=torch.int32)
+        st[L.ST_MINLEN], st[L.ST_MAXLEN], st[L.ST_MODE], st[L.ST_FORCE] = min_len, max_len, mode, int(force_len)
+        st[L.ST_SEED_LO] = (seed & 0x7FFFFFFF) - (seed & 0x80000000)
+        st[L.ST_SEED_HI] = ((seed >> 32) & 0x7FFFFFFF) - ((seed >> 32) & 0x80000000)
+        self.state[slot].copy_(st)
+
+    def add_requests(self, slots, lm_inputs, lens_minmax, mode=MODE_GREEDY, seed=0, force_len=False):
+        """Step 0 for several slots in one pass over the weights (cv2_llm_prefill_batch): lm_inputs = list of [L0, hidden] fp32."""
+        n = len(slots)
+        for slot, (mn, mx) in zip(slots, lens_minmax):
+            self._init_state(slot, mn, mx, mode, seed, force_len)
+        emb = torch.cat([x.reshape(-1, self.hidden) for x in lm_inputs], 0).to(torch.float32).contiguous()
+        sl = (C.c_int32 * n)(*slots)
+        ln = (C.c_int32 * n)(*[x.shape[0] for x in lm_inputs])
+        L.check(self.lib.cv2_llm_prefill_batch(self.handle, n, sl, ln, L.ptr(emb), L.stream_ptr()))
+
     def step(self, n_seqs, n_steps=1):
         L.check(self.lib.cv2_llm_decode(self.handle, n_seqs, n_steps, L.stream_ptr()))
 
@@ -117,15 +135,22 @@ class LLMEngine:
                 raise RuntimeError('sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!')
         return st, [toks[b, :min(int(st[b, L.ST_NOUT]), self.max_out)].tolist() for b in range(n_seqs)]
 
-    def generate(self, requests, mode=MODE_GREEDY, seed=0, force_len=None, sync_every=16, min_ratio=2, max_ratio=20):
+    def generate(self, requests, mode=MODE_GREEDY, seed=0, force_len=None, sync_every=16, min_ratio=2, max_ratio=20, batch_prefill=True):
         """requests: list of (text, prompt_text, prompt_speech_token) int tensors.  Returns list of token lists."""
         n = len(requests)
         assert n <= self.max_seqs
+        xs, mm = [], []
         for b, (text, ptxt, ptok) in enumerate(requests):
             mn, mx = int(text.numel() * min_ratio), int(text.numel() * max_ratio)
             if force_len is not None:
                 mn, mx = force_len, force_len
-            self.add_request(b, self.build_lm_input(text, ptxt, ptok), mn, mx, mode, seed, force_len is not None)
+            xs.append(self.build_lm_input(text, ptxt, ptok))
+            mm.append((mn, mx))
+        if batch_prefill and sum(x.shape[0] for x in xs) <= self.dims.max_prefill_rows:
+            self.add_requests(list(range(n)), xs, mm, mode, seed, force_len is not None)
+        else:
+            for b in range(n):
+                self.add_request(b, xs[b], mm[b][0], mm[b][1], mode, seed, force_len is not None)
         while True:
             st, toks = self.read(n)
             if bool(st[:, L.ST_DONE].all()):
@@ -137,8 +162,8 @@ class LLMEngine:
         decode loop.  Returns (list of token lists, (start, end) torch events bracketing the n_tokens-1 decode steps)."""
         n = len(requests)
         assert n <= self.max_seqs and n_tokens <= self.max_out
-        for b, (text, ptxt, ptok) in enumerate(requests):
-            self.add_request(b, self.build_lm_input(text, ptxt, ptok), n_tokens, n_tokens, mode, seed, True)
+        xs = [self.build_lm_input(text, ptxt, ptok) for (text, ptxt, ptok) in requests]
+        self.add_requests(list(range(n)), xs, [(n_tokens, n_tokens)] * n, mode, seed, True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         self.step(n, n_tokens - 1)

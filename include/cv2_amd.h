@@ -49,6 +49,7 @@ typedef struct {
     int32_t max_pos;    /* KV capacity per sequence */
     int32_t max_out;    /* capacity of out_tokens per sequence */
     float rms_eps;      /* 1e-6 */
+    int32_t max_prefill_rows; /* capacity of cv2_llm_prefill_batch in prompt rows (0: only the 32-row cv2_llm_prefill) */
 } cv2_llm_dims;
 
 typedef struct {
@@ -102,6 +103,10 @@ int cv2_llm_destroy(cv2_llm* h);
  * (= lm_input of llm.py:641, the vLLM seam's prompt_embeds), fill the KV cache, draw the first token.
  * state[seq] must have been initialised by the caller (pos = step = nout = done = 0, lens, mode, seed). */
 int cv2_llm_prefill(cv2_llm* h, int32_t seq, const float* prompt_embeds, int32_t len, void* stream);
+/* Step 0 for several slots at once through the MFMA GEMM path (operand split hi + lo): embeds = the prompts' rows
+ * concatenated, fp32 [sum(lens)][hidden] on the device; slots / lens are HOST arrays of n entries.  state[slot] must be
+ * initialised like for cv2_llm_prefill.  Weights are streamed once for all rows. */
+int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int32_t* lens, const float* embeds, void* stream);
 /* n_steps iterations of the decode loop for slots 0..n_seqs-1 in lock step (one hipGraph replay per step);
  * finished slots idle.  No host synchronisation inside. */
 int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream);

@@ -63,6 +63,20 @@ def test_greedy_ids_bit_exact_vs_oracle(small):
         assert ids == want, f'min top-1 margin on this fixture {min(margins):.2e}'
 
 
+def test_batched_gemm_prefill_equals_chunked_prefill_ids(small):
+    """cv2_llm_prefill_batch (MFMA GEMM over all prompt rows, hi/lo operand split) vs cv2_llm_prefill (32-row skinny passes):
+    same greedy ids as the oracle either way, and near-identical first-step logits."""
+    from oracle import llm as OL
+    sd, sdr, eng = small
+    reqs = _requests(4, seed=33)
+    a = eng.generate(reqs, max_ratio=6, batch_prefill=True)
+    la = eng.logits[:4, :eng.vocab].clone()
+    b = eng.generate(reqs, max_ratio=6, batch_prefill=False)
+    assert a == b
+    for (text, ptxt, ptok), ids in zip(reqs, a):
+        assert ids == OL.inference(sdr, text, ptxt, ptok, max_ratio=6)
+
+
 def test_logits_close_to_oracle(small):
     from oracle import llm as OL
     import torch.nn.functional as F
