@@ -56,7 +56,7 @@ struct QkvArgs {
     RowMap rm;
 };
 // block = (head, half): features {half*16 + i, half*16 + 32 + i : i < 16} so that the rotate-half partner is in-block
-template <int NB>
+template <int NB, bool PRE = false>
 __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int head = blockIdx.x >> 1, half = blockIdx.x & 1;   // heads: n_q query, then n_kv key, then n_kv value
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
         pb0 = a.bias[head * 64 + f];
         if (rot) { pb1 = a.bias[head * 64 + (f ^ 32)]; pc0 = a.cosT[pos0 * 32 + (f & 31)]; ps0 = a.sinT[pos0 * 32 + (f & 31)]; }
     }
-    float* res = skinny_core<NB, 2, 4, 8>(a.W, head * 4 + half + 2 * wr, a.KS, a.rows, a.K, a.X, smem);
+    float* res = skinny_core<NB, 2, 4, 8, false, PRE>(a.W, head * 4 + half + 2 * wr, a.KS, a.rows, a.K, a.X, smem);
     const int ld = NB * 16 + 1;
     for (int e = threadIdx.x; e < a.rows * 32; e += blockDim.x) {
         const int r = e >> 5, w = (e >> 4) & 1, i16 = e & 15;
@@ -193,16 +193,26 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     if (tid < rep) { ml[tid * 2] = run_m[tid]; ml[tid * 2 + 1] = run_l[tid]; }
 }
 
+// split combine as its own pass (used when many rows share a launch: inside the O-projection every block would redo it)
+struct CombArgs { const float* part_o; const float* part_ml; const int* part_cnt; float* out; int K; };
+__global__ __launch_bounds__(128) void k_attn_combine(CombArgs a) {
+    const int r = blockIdx.x, k = threadIdx.x * 8;
+    if (k >= a.K) return;
+    SkinnyX X{nullptr, a.part_o, 0, nullptr, 0.f, nullptr, a.part_ml, a.part_cnt};
+    const f32x8 v = sk_load_x<true>(X, r, a.K, k);
+    *reinterpret_cast<f32x8*>(a.out + (size_t)r * a.K + k) = v;
+}
+
 // ------------------------------------------------------------------ k_store: out = W f(x) (+bias)  (o-proj, down-proj, head)
 struct StoreArgs {
     const uint16_t* W; const float* bias;       // bias may be null
     SkinnyX X; int KS, rows, K, N;
     float* out;                                 // gridDim.y == 1: [rows][N]; else partials [gridDim.y][SK_ROWS_CAP][N]
 };
-template <int NB, int MAXKS, bool ATT = false>
+template <int NB, int MAXKS, bool ATT = false, bool PRE = false>
 __global__ __launch_bounds__(256) void k_store(StoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* res = skinny_core<NB, 1, 4, MAXKS, ATT>(a.W, blockIdx.x, a.KS, a.rows, a.K, a.X, smem);
+    float* res = skinny_core<NB, 1, 4, MAXKS, ATT, PRE>(a.W, blockIdx.x, a.KS, a.rows, a.K, a.X, smem);
     const int ld = NB * 16 + 1;
     const int n0 = blockIdx.x * 16;
     float* out = a.out + (gridDim.y > 1 ? (size_t)blockIdx.y * SK_ROWS_CAP * a.N : 0);
@@ -219,11 +229,11 @@ struct GateUpArgs {
     const uint16_t* W; SkinnyX X; int KS, rows, K, inter;
     float* h;                                   // [rows][inter]
 };
-template <int NB>
+template <int NB, bool PRE = false>
 __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wr = (threadIdx.x >> 6) % 2;
-    float* res = skinny_core<NB, 2, 4, 8>(a.W, blockIdx.x * 2 + wr, a.KS, a.rows, a.K, a.X, smem);   // rows 0-15 gate, 16-31 up
+    float* res = skinny_core<NB, 2, 4, 8, false, PRE>(a.W, blockIdx.x * 2 + wr, a.KS, a.rows, a.K, a.X, smem);   // rows 0-15 gate, 16-31 up
     const int ld = NB * 16 + 1;
     for (int e = threadIdx.x; e < a.rows * 16; e += blockDim.x) {
         const int r = e >> 4, i = e & 15;
@@ -663,6 +673,8 @@ struct cv2_llm {
     float *q, *att, *o;        // [32][n_q*64], attention partials [nsplit][32][n_q*64], [32][hidden]
     float *att_ml;             // [nsplit][32][n_q][2]
     int *att_cnt;              // [32] non-empty splits per row
+    float *attc;               // [32][n_q*64] combined attention output (many-row path)
+    uint16_t *xp;              // prepared operand planes [inter/32][2][hi, lo][512] (k_prep)
     int nsplit, keys_per_split;
     float *hbuf;               // [32][inter]
     float *parts;              // [SK_MAXNP][32][hidden] split-K partials of the down projection
@@ -689,6 +701,8 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     p = take((size_t)SK_MAXSPLIT * 32 * d.n_q * 64 * 4); if (h) h->att = (float*)p;
     p = take((size_t)SK_MAXSPLIT * 32 * d.n_q * 2 * 4); if (h) h->att_ml = (float*)p;
     p = take(32 * 4); if (h) h->att_cnt = (int*)p;
+    p = take((size_t)32 * d.n_q * 64 * 4); if (h) h->attc = (float*)p;
+    p = take((size_t)(d.inter / 32) * 2 * 2 * 1024); if (h) h->xp = (uint16_t*)p;
     p = take((size_t)32 * d.hidden * 4); if (h) h->o = (float*)p;
     p = take((size_t)32 * d.inter * 4); if (h) h->hbuf = (float*)p;
     p = take((size_t)SK_MAXNP * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
@@ -774,13 +788,22 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm};
             hipLaunchKernelGGL(k_attn, dim3(d.n_kv * h->nsplit, rows), dim3(256), 0, s, a);
         }
-        {
+        if (rows <= 4) {     // few rows: combine the key splits while loading the O-projection operand (saves a launch)
             StoreArgs a{};
             a.W = L.wo; a.bias = nullptr;
             a.X = SkinnyX{nullptr, h->att, 0, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt};
             a.KS = d.n_q * 64 / 32; a.rows = rows; a.K = d.n_q * 64; a.N = H; a.out = h->o;
             const size_t sm = skinny_smem_bytes<NB, 1, 4>(a.KS);
             hipLaunchKernelGGL((k_store<NB, 8, true>), dim3(H / 16, 1), dim3(256), sm, s, a);
+        } else {             // many rows: one combine pass, then a plain O-projection
+            CombArgs c{h->att, h->att_ml, h->att_cnt, h->attc, d.n_q * 64};
+            hipLaunchKernelGGL(k_attn_combine, dim3(rows), dim3(128), 0, s, c);
+            StoreArgs a{};
+            a.W = L.wo; a.bias = nullptr;
+            a.X = SkinnyX{h->attc, nullptr, 0, nullptr, 0.f, nullptr};
+            a.KS = d.n_q * 64 / 32; a.rows = rows; a.K = d.n_q * 64; a.N = H; a.out = h->o;
+            const size_t sm = skinny_smem_bytes<NB, 1, 4>(a.KS);
+            hipLaunchKernelGGL((k_store<NB, 8>), dim3(H / 16, 1), dim3(256), sm, s, a);
         }
         float* x2 = (x1 == h->xa) ? h->xb : h->xa;            // x_mid = x1 + o
         {
@@ -814,6 +837,69 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
     return 0;
 }
 
+// Many-row variant (17..32 rows: batched decode, 32-row prefill chunks): every operand is folded / normalised / split once
+// by k_prep and the weight-streaming kernels copy it, instead of every block redoing it for all rows.
+static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStream_t s) {
+    const cv2_llm_dims& d = h->d;
+    const int H = d.hidden, KSH = H / 32, NQ = d.n_q * 64;
+    const size_t cache_l = (size_t)d.max_seqs * d.n_kv * d.max_pos * 64;
+    const float* xcur = xin;
+    int np = 0;
+    auto prep = [&](const SkinnyX& X, int K, bool att) {
+        if (att) hipLaunchKernelGGL(k_prep<true>, dim3(rows), dim3(256), 0, s, X, K, h->xp);
+        else hipLaunchKernelGGL(k_prep<false>, dim3(rows), dim3(256), 0, s, X, K, h->xp);
+    };
+    SkinnyX pre{};
+    pre.pre = h->xp;
+    for (int l = 0; l < d.layers; l++) {
+        const cv2_llm_layer& L = h->layers[l];
+        float* x1 = (xcur == h->xa) ? h->xb : h->xa;
+        prep(SkinnyX{xcur, h->parts, np, L.ln1, d.rms_eps, x1}, H, false);
+        {
+            QkvArgs a{};
+            a.W = L.wqkv; a.bias = L.bqkv; a.X = pre;
+            a.KS = KSH; a.rows = rows; a.K = H; a.n_q = d.n_q; a.n_kv = d.n_kv;
+            a.cosT = h->w.rope_cos; a.sinT = h->w.rope_sin;
+            a.q = h->q; a.kc = h->kc + l * cache_l; a.vc = h->vc + l * cache_l; a.max_pos = d.max_pos; a.rm = rm;
+            { const size_t sm = skinny_smem_bytes<2, 2, 4>(KSH); hipLaunchKernelGGL((k_qkv<2, true>), dim3(2 * (d.n_q + 2 * d.n_kv), 1), dim3(512), sm, s, a); }
+        }
+        {
+            AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm};
+            hipLaunchKernelGGL(k_attn, dim3(d.n_kv * h->nsplit, rows), dim3(256), 0, s, a);
+        }
+        prep(SkinnyX{nullptr, h->att, 0, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt}, NQ, true);
+        {
+            StoreArgs a{};
+            a.W = L.wo; a.X = pre; a.KS = NQ / 32; a.rows = rows; a.K = NQ; a.N = H; a.out = h->o;
+            { const size_t sm = skinny_smem_bytes<2, 1, 4>(a.KS); hipLaunchKernelGGL((k_store<2, 8, false, true>), dim3(H / 16, 1), dim3(256), sm, s, a); }
+        }
+        float* x2 = (x1 == h->xa) ? h->xb : h->xa;
+        prep(SkinnyX{x1, h->o, 1, L.ln2, d.rms_eps, x2}, H, false);
+        {
+            GateUpArgs a{};
+            a.W = L.wgu; a.X = pre; a.KS = KSH; a.rows = rows; a.K = H; a.inter = d.inter; a.h = h->hbuf;
+            { const size_t sm = skinny_smem_bytes<2, 2, 4>(KSH); hipLaunchKernelGGL((k_gateup<2, true>), dim3(d.inter / 16, 1), dim3(512), sm, s, a); }
+        }
+        prep(SkinnyX{h->hbuf, nullptr, 0, nullptr, 0.f, nullptr}, d.inter, false);
+        {
+            StoreArgs a{};
+            a.W = L.wdown; a.X = pre; a.KS = d.inter / 32; a.rows = rows; a.K = d.inter; a.N = H; a.out = h->parts;
+            { const size_t sm = skinny_smem_bytes<2, 1, 4>(cdiv(a.KS, SK_MAXNP) + 1); hipLaunchKernelGGL((k_store<2, 10, false, true>), dim3(H / 16, SK_MAXNP), dim3(256), sm, s, a); }
+        }
+        xcur = x2;
+        np = SK_MAXNP;
+    }
+    prep(SkinnyX{xcur, h->parts, np, h->w.final_norm, d.rms_eps, nullptr}, H, false);
+    {
+        StoreArgs a{};
+        a.W = h->w.wdec; a.bias = h->w.bdec; a.X = pre;
+        a.KS = KSH; a.rows = rows; a.K = H; a.N = d.vocab_pad; a.out = h->io.logits;
+        { const size_t sm = skinny_smem_bytes<2, 1, 4>(KSH); hipLaunchKernelGGL((k_store<2, 8, false, true>), dim3(d.vocab_pad / 16, 1), dim3(256), sm, s, a); }
+    }
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename F>
 static int set_smem(F f, size_t bytes) {
     CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -825,7 +911,8 @@ static int init_attrs_once() {
     const size_t big = 160 * 1024;
     if (set_smem(k_qkv<1>, big) || set_smem(k_qkv<2>, big) || set_smem(k_gateup<1>, big) || set_smem(k_gateup<2>, big) ||
         set_smem((k_store<1, 8>), big) || set_smem((k_store<2, 8>), big) || set_smem((k_store<1, 8, true>), big) || set_smem((k_store<2, 8, true>), big) || set_smem((k_store<1, 10>), big) ||
-        set_smem((k_store<2, 10>), big))
+        set_smem((k_store<2, 10>), big) || set_smem((k_qkv<2, true>), big) || set_smem((k_gateup<2, true>), big) ||
+        set_smem((k_store<2, 8, false, true>), big) || set_smem((k_store<2, 10, false, true>), big))
         return -1;
     done = true;
     return 0;
@@ -850,7 +937,7 @@ extern "C" int cv2_llm_prefill(cv2_llm* h, int32_t seq, const float* embeds, int
         const int rows = len - p0 < 32 ? len - p0 : 32;
         const float* xin = embeds + (size_t)p0 * h->d.hidden;
         RowMap rm{h->io.state, 1, seq, p0};
-        int rc = rows <= 16 ? run_layers<1>(h, rows, xin, rm, s) : run_layers<2>(h, rows, xin, rm, s);
+        int rc = rows <= 16 ? run_layers<1>(h, rows, xin, rm, s) : run_layers_pre(h, rows, xin, rm, s);
         if (rc) return rc;
     }
     // draw step 0 from the last row's logits; the slot's next KV position becomes len
@@ -954,7 +1041,7 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, hipGraphExec_t* out) {
         RowMap rm{h->io.state, 0, 0, 0};
         int rc = 0;
         for (int u = 0; u < unroll && !rc; u++) {
-            rc = n_seqs <= 16 ? run_layers<1>(h, n_seqs, h->xnext, rm, cs) : run_layers<2>(h, n_seqs, h->xnext, rm, cs);
+            rc = n_seqs <= 16 ? run_layers<1>(h, n_seqs, h->xnext, rm, cs) : run_layers_pre(h, n_seqs, h->xnext, rm, cs);
             if (!rc) rc = launch_sample(h, n_seqs, -1, 0, 0, cs);
         }
         hipError_t e = hipStreamEndCapture(cs, &g);

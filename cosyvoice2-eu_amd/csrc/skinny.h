@@ -31,6 +31,9 @@ struct SkinnyX {
     // o_s = parts[s][r][k] unnormalised, (m_s, l_s) = att_ml[((s * SK_ROWS_CAP + r) * (K / 64) + k / 64) * 2 + {0, 1}]
     const float* att_ml;
     const int* att_cnt;   // != null selects this mode (base / np unused): [SK_ROWS_CAP] non-empty splits per row
+    // PRE kernels: the operand already folded / normalised / split by k_prep, in LDS B-operand order
+    // [K/32][NB=2][hi, lo][1 KiB]; the prologue is a straight copy of the block's K slice
+    const uint16_t* pre;
 };
 
 __device__ __forceinline__ void split8(const f32x8 v, bf16x8& hi, bf16x8& lo) {
@@ -89,7 +92,7 @@ __device__ __host__ constexpr int sk_xstage_bytes(int nks) { return nks * NB * 2
 
 // Leaves the reduced tile in LDS: res[NWR*16 features][NB*16+1 rows]; returns its address.
 // `tile` = this wave's 16-feature row tile of W.
-template <int NB, int NWR, int NWK, int MAXKS, bool ATT = false>
+template <int NB, int NWR, int NWK, int MAXKS, bool ATT = false, bool PRE = false>
 __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, int tile, int KS, int rows, int K,
                                                const SkinnyX& X, char* smem) {
     const int tid = threadIdx.x;
@@ -111,6 +114,13 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     for (int i = 0; i < MAXKS; i++)
         if (w0 + i < w1) abuf[i] = __builtin_nontemporal_load(wp + (size_t)i * 64);
 
+  if (PRE) {
+    // 2'. operand prepared once by k_prep: copy this block's K slice [ks0, ks1) of the hi / lo planes
+    const uint4* src = reinterpret_cast<const uint4*>(X.pre) + (size_t)ks0 * NB * 2 * 64;
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int i = tid; i < nks * NB * 2 * 64; i += nthreads) dst[i] = src[i];
+    __syncthreads();
+  } else {
     // 2. fold / normalise / split the block's x slice [ks0*32, ks1*32) into LDS (B-operand order)
     //    item = (row r, group of 8 columns); the first item of every thread stays in registers across the RMS barrier
     const int k8n = nks * 4;
@@ -152,6 +162,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         dst[64] = lo;
     }
     __syncthreads();
+  }
 
     // 3. MFMAs: A = weights (registers), B = x hi / lo (LDS)
     f32x4 acc[NB];
@@ -192,6 +203,37 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     }
     __syncthreads();
     return res;
+}
+
+// Operand preparation for many-row launches (rows > 16): fold + RMSNorm + hi/lo split ONCE per row instead of once per
+// block, written in the LDS B-operand order the PRE kernels copy.  One block per row; K % 8 == 0.
+template <bool ATT>
+__global__ __launch_bounds__(256) void k_prep(SkinnyX X, int K, uint16_t* pre) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int nitem = K / 8;
+    float sq = 0.f;
+    if (X.norm_w) {
+        for (int it = tid; it < nitem; it += 256) {
+            const f32x8 v = sk_load_x<ATT>(X, r, K, it * 8);
+            sq += ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+        }
+        sq = wave_sum(sq);
+        if ((tid & 63) == 0) red[tid >> 6] = sq;
+        __syncthreads();
+        sq = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + X.eps);
+    }
+    for (int it = tid; it < nitem; it += 256) {
+        f32x8 v = sk_load_x<ATT>(X, r, K, it * 8);
+        if (X.x_out) *reinterpret_cast<f32x8*>(X.x_out + (size_t)r * K + it * 8) = v;
+        if (X.norm_w) v = *reinterpret_cast<const f32x8*>(X.norm_w + it * 8) * (v * sq);
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        const int s = it >> 2, hq = it & 3, t = r >> 4;
+        bf16x8* dst = reinterpret_cast<bf16x8*>(pre + ((size_t)(s * 2 + t) * 2) * 512) + hq * 16 + (r & 15);
+        dst[0] = hi;
+        dst[64] = lo;
+    }
 }
 
 template <int NB, int NWR, int NWK>

@@ -103,6 +103,16 @@ def test_forced_length_batch(small):
         assert ids == OL.inference(sdr, text, ptxt, ptok, force_len=24)
 
 
+def test_many_row_decode_path(small):
+    """More than 16 sequences per step take the prepared-operand kernels (k_prep + PRE variants): ids still equal the oracle's."""
+    from oracle import llm as OL
+    sd, sdr, eng = small
+    reqs = _requests(19, seed=3)
+    got = eng.generate(reqs, force_len=8)
+    for (text, ptxt, ptok), ids in zip(reqs, got):
+        assert ids == OL.inference(sdr, text, ptxt, ptok, force_len=8)
+
+
 def test_ras_sampling_matches_oracle_with_same_noise(small):
     from cv2amd import philox
     from cv2amd.llm import MODE_RAS
