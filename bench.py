@@ -207,6 +207,11 @@ def main():
         Ts = [2 * (r['flow_prompt_speech_token'].numel() + n) for r, n in zip(reqs, ntoks)]
         flow_tf = sum(flow_flops(T) for T in Ts) * args.steps / (stage_ms['flow'] * 1e-3) / 1e12
         hift_tf = 30.6e9 * audio_per_step * args.steps / (stage_ms['hift'] * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, 'profiles', 'r1_pmc_decode.json')
+        if B == 1 and os.path.exists(pmc):          # PMC counters cannot be read from inside the bench: committed rocprofv3 --pmc measurement
+            pj = json.load(open(pmc))
+            traffic, traffic_src = pj['hbm_bytes_per_step'], 'profiles/r1_pmc_decode.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)'
         out = {
             'metric': 'audio-sec/sec, CosyVoice2-0.5B-EU zero-shot FR', 'value': round(value, 3), 'unit': 'audio-s/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
@@ -218,7 +223,7 @@ def main():
                        'audio_s_per_step_per_gpu': round(audio_per_step, 3)},
             'roofline': {'bound': 'hbm', 'kernel': 'LLM decode step = one hipGraph replay (24 x {k_qkv, k_attn, k_store(o), k_gateup, k_store(down)} + head + k_sample)',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': None, 'bytes_per_launch': int(step_bytes), 'avg_launch_us': round(step_ms * 1e3, 2)},
+                         'traffic': traffic, 'traffic_source': traffic_src, 'bytes_per_launch': int(step_bytes), 'avg_launch_us': round(step_ms * 1e3, 2)},
             'stages': {'ms_per_step': {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
                        'flow_mfma': {'achieved': round(flow_tf, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(flow_tf / MFMA_BF16_PEAK, 4)},
                        'hift_fp32_mfma': {'achieved': round(hift_tf, 2), 'peak': FP32_MFMA_PEAK, 'unit': 'TFLOP/s', 'frac': round(hift_tf / FP32_MFMA_PEAK, 4)}},
