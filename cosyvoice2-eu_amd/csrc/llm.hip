@@ -539,7 +539,8 @@ __global__ __launch_bounds__(256) void k_rope_cache(RopeArgs a) {
     dst[i] = o0; dst[32 + i] = o1;
 }
 
-// causal attention of 16 prompt rows x one GQA group over the cache, fp32; output as hi/lo bf16 planes [M][n_q*64]
+// causal attention of PF_ROWS prompt rows x one GQA group over the cache, fp32; output as hi/lo bf16 planes [M][n_q*64]
+#define PF_ROWS 4
 struct PfAttnArgs {
     const float* q; const float* kc; const float* vc; uint16_t* hi; uint16_t* lo;
     const int* seq_row0; const int* seq_len; const int* seq_slot; const int* seq_pos0;
@@ -548,7 +549,7 @@ struct PfAttnArgs {
 #define PF_KLD 68
 __global__ __launch_bounds__(256) void k_attn_prefill(PfAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int rep = a.n_q / a.n_kv;                              // <= 8 ; pairs = 16 rows x rep heads <= 128
+    const int rep = a.n_q / a.n_kv;                              // <= 8 ; pairs = PF_ROWS rows x rep heads <= 32
     float* Ks = reinterpret_cast<float*>(smem);                  // [64][PF_KLD]
     float* Vs = Ks + 64 * PF_KLD;                                // [64][64]
     float* qs = Vs + 64 * 64;                                    // [128][64]
@@ -556,10 +557,10 @@ __global__ __launch_bounds__(256) void k_attn_prefill(PfAttnArgs a) {
     float* m_run = ss + 128 * 64; float* l_run = m_run + 128; float* scl = l_run + 128;
     const int qt = blockIdx.x, g = blockIdx.y, sq = blockIdx.z;
     const int len = a.seq_len[sq];
-    if (qt * 16 >= len) return;
-    const int row0 = a.seq_row0[sq] + qt * 16, slot = a.seq_slot[sq], pos0 = a.seq_pos0[sq] + qt * 16;
-    const int nrow = min(16, len - qt * 16);
-    const int npair = 16 * rep, ppg = npair / 4;                 // pairs per thread group (4 groups of 64 threads)
+    if (qt * PF_ROWS >= len) return;
+    const int row0 = a.seq_row0[sq] + qt * PF_ROWS, slot = a.seq_slot[sq], pos0 = a.seq_pos0[sq] + qt * PF_ROWS;
+    const int nrow = min(PF_ROWS, len - qt * PF_ROWS);
+    const int npair = PF_ROWS * rep, ppg = npair / 4;                 // pairs per thread group (4 groups of 64 threads)
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
     const float* K = a.kc + ((size_t)slot * a.n_kv + g) * a.max_pos * 64;
     const float* V = a.vc + ((size_t)slot * a.n_kv + g) * a.max_pos * 64;
@@ -994,7 +995,7 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
         }
         {
             PfAttnArgs a{h->pf_q, h->kc + l * cache_l, h->vc + l * cache_l, h->pf_hi, h->pf_lo, d_row0, d_len, d_slot, d_pos0, d.n_q, d.n_kv, d.max_pos};
-            hipLaunchKernelGGL(k_attn_prefill, dim3((maxlen + 15) / 16, d.n_kv, n), dim3(256), pf_smem, s, a);
+            hipLaunchKernelGGL(k_attn_prefill, dim3((maxlen + PF_ROWS - 1) / PF_ROWS, d.n_kv, n), dim3(256), pf_smem, s, a);
         }
         {
             GemmArgs g = gemm_args(h->pf_hi, NQ, 0, L.wo, Mp, H, NQ);
