@@ -166,7 +166,7 @@ def main():
                      prompt_feat=r['prompt_speech_feat'], embedding=r['flow_embedding']) for r, t in zip(reqs, toks)]
         mels = syn.flow.inference_batch(utts, streaming=False, finalize=True)
         e[2].record()
-        wavs = [syn.hift.inference(m, None)[0] for m in mels]
+        wavs = [w for w, _ in syn.hift_pool.inference_many(mels)]
         e[3].record()
         if timed:
             torch.cuda.synchronize()

@@ -292,56 +292,70 @@ struct AttnEstArgs {
 };
 #define AK_LD 72    // K tile row stride (bf16 elements): 64 + 8
 #define AV_LD 68    // V^T tile row stride: 64 + 4
+// QS query sub-tiles of 16 rows per wave (block = 64*QS rows): K / V^T fragments read from LDS once serve QS MFMAs.
+template <int QS>
 __global__ __launch_bounds__(256) void k_attn_est(AttnEstArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t Ks[2][64 * AK_LD];
     __shared__ __attribute__((aligned(16))) uint16_t Vs[2][64 * AV_LD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int m0 = blockIdx.x * 64, h = blockIdx.y;
+    const int m0 = blockIdx.x * 64 * QS, h = blockIdx.y;
     const int q16 = lane & 15, g = lane >> 4;
-    const int s = a.seq.tile_seq[m0 >> 6];
-    uint16_t* orow = a.out + (size_t)(m0 + 16 * w + q16) * 512 + h * 64 + 4 * g;
+    const int s = a.seq.tile_seq[m0 >> 6];           // sequences start on 128-row boundaries: one sequence per block
+    uint16_t* orow[QS];
+#pragma unroll
+    for (int u = 0; u < QS; u++) orow[u] = a.out + (size_t)(m0 + 64 * u + 16 * w + q16) * 512 + h * 64 + 4 * g;
     if (s < 0) {
 #pragma unroll
-        for (int dt = 0; dt < 4; dt++) *reinterpret_cast<uint2*>(orow + 16 * dt) = make_uint2(0u, 0u);
+        for (int u = 0; u < QS; u++)
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) *reinterpret_cast<uint2*>(orow[u] + 16 * dt) = make_uint2(0u, 0u);
         return;
     }
     const int start = a.seq.seq_start[s], len = a.seq.seq_len[s];
     const int t0 = m0 - start;
-    const int tq = t0 + 16 * w + q16;                                  // this lane's query frame
-    const int kmax_q = a.chunk > 0 ? min(len, (tq / a.chunk + 1) * a.chunk) : len;
-    const int kmax_blk = a.chunk > 0 ? min(len, ((t0 + 63) / a.chunk + 1) * a.chunk) : len;
+    int tq[QS], kmax_q[QS];
+#pragma unroll
+    for (int u = 0; u < QS; u++) {
+        tq[u] = t0 + 64 * u + 16 * w + q16;                          // this lane's query frames
+        kmax_q[u] = a.chunk > 0 ? min(len, (tq[u] / a.chunk + 1) * a.chunk) : len;
+    }
+    const int kmax_blk = a.chunk > 0 ? min(len, ((t0 + 64 * QS - 1) / a.chunk + 1) * a.chunk) : len;
     const int ntiles = (kmax_blk + 63) / 64;
 
-    bf16x8 qf[2];
+    bf16x8 qf[QS][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++)
-        qf[ks] = *reinterpret_cast<const bf16x8*>(a.qk + (size_t)(m0 + 16 * w + q16) * 1024 + h * 64 + ks * 32 + g * 8);
+    for (int u = 0; u < QS; u++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+            qf[u][ks] = *reinterpret_cast<const bf16x8*>(a.qk + (size_t)(m0 + 64 * u + 16 * w + q16) * 1024 + h * 64 + ks * 32 + g * 8);
 
     // staging: thread -> 2 K chunks (row kr, 16-B chunk kc) and 2 V^T chunks
     const int kr = tid >> 3, kc = tid & 7;                             // rows kr, kr + 32
-    uint4 kreg[2], vreg[2];
+    uint4 kreg0, kreg1, vreg0, vreg1;
     auto gload = [&](int kt) {
         const long krow = (long)start + kt * 64;
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            kreg[u] = *reinterpret_cast<const uint4*>(a.qk + (size_t)(krow + kr + 32 * u) * 1024 + 512 + h * 64 + kc * 8);
-            vreg[u] = *reinterpret_cast<const uint4*>(a.vt + (size_t)(h * 64 + kr + 32 * u) * a.R + krow + kc * 8);
-        }
+        kreg0 = *reinterpret_cast<const uint4*>(a.qk + (size_t)(krow + kr) * 1024 + 512 + h * 64 + kc * 8);
+        kreg1 = *reinterpret_cast<const uint4*>(a.qk + (size_t)(krow + kr + 32) * 1024 + 512 + h * 64 + kc * 8);
+        vreg0 = *reinterpret_cast<const uint4*>(a.vt + (size_t)(h * 64 + kr) * a.R + krow + kc * 8);
+        vreg1 = *reinterpret_cast<const uint4*>(a.vt + (size_t)(h * 64 + kr + 32) * a.R + krow + kc * 8);
     };
     auto lstore = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            *reinterpret_cast<uint4*>(&Ks[buf][(kr + 32 * u) * AK_LD + kc * 8]) = kreg[u];
-            uint2* vd = reinterpret_cast<uint2*>(&Vs[buf][(kr + 32 * u) * AV_LD + kc * 8]);
-            vd[0] = make_uint2(vreg[u].x, vreg[u].y);
-            vd[1] = make_uint2(vreg[u].z, vreg[u].w);
-        }
+        *reinterpret_cast<uint4*>(&Ks[buf][kr * AK_LD + kc * 8]) = kreg0;
+        *reinterpret_cast<uint4*>(&Ks[buf][(kr + 32) * AK_LD + kc * 8]) = kreg1;
+        uint2* vd = reinterpret_cast<uint2*>(&Vs[buf][kr * AV_LD + kc * 8]);
+        vd[0] = make_uint2(vreg0.x, vreg0.y); vd[1] = make_uint2(vreg0.z, vreg0.w);
+        vd = reinterpret_cast<uint2*>(&Vs[buf][(kr + 32) * AV_LD + kc * 8]);
+        vd[0] = make_uint2(vreg1.x, vreg1.y); vd[1] = make_uint2(vreg1.z, vreg1.w);
     };
 
-    f32x4 o[4];
+    f32x4 o[QS][4];
+    float mrun[QS], lrun[QS];
 #pragma unroll
-    for (int dt = 0; dt < 4; dt++) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrun = -INFINITY, lrun = 0.f;
+    for (int u = 0; u < QS; u++) {
+        mrun[u] = -INFINITY; lrun[u] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) o[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     gload(0);
     for (int kt = 0; kt < ntiles; kt++) {
@@ -349,64 +363,77 @@ __global__ __launch_bounds__(256) void k_attn_est(AttnEstArgs a) {
         lstore(buf);
         __syncthreads();
         if (kt + 1 < ntiles) gload(kt + 1);
-        // S^T: 4 key tiles x (d = 64 in two k-steps)
-        f32x4 sacc[4];
+        // S^T: 4 key tiles x (d = 64 in two k-steps), K fragments shared by the QS query sub-tiles
+        f32x4 sacc[QS][4];
 #pragma unroll
         for (int k4 = 0; k4 < 4; k4++) {
-            sacc[k4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < QS; u++) sacc[u][k4] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[buf][(16 * k4 + q16) * AK_LD + ks * 32 + g * 8]);
-                sacc[k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[k4], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < QS; u++) sacc[u][k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][k4], 0, 0, 0);
             }
         }
-        float mloc = -INFINITY;
+        bf16x8 pf[QS][2];
 #pragma unroll
-        for (int k4 = 0; k4 < 4; k4++)
+        for (int u = 0; u < QS; u++) {
+            float mloc = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int key = kt * 64 + 16 * k4 + 4 * g + r;
-                const float v = key < kmax_q ? sacc[k4][r] * 0.125f : -INFINITY;
-                sacc[k4][r] = v;
-                mloc = fmaxf(mloc, v);
+            for (int k4 = 0; k4 < 4; k4++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int key = kt * 64 + 16 * k4 + 4 * g + r;
+                    const float v = key < kmax_q[u] ? sacc[u][k4][r] * 0.125f : -INFINITY;
+                    sacc[u][k4][r] = v;
+                    mloc = fmaxf(mloc, v);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float mnew = fmaxf(mrun[u], mloc);
+            const float msafe = mnew == -INFINITY ? 0.f : mnew;
+            const float alpha = __expf(mrun[u] - msafe);               // mrun = -inf -> 0
+            float psum = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; k4++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const float p = __expf(sacc[u][k4][r] - msafe); sacc[u][k4][r] = p; psum += p; }
+            lrun[u] = lrun[u] * alpha + psum;
+            mrun[u] = mnew;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) o[u][dt] *= alpha;
+#pragma unroll
+            for (int kp = 0; kp < 2; kp++) {
+                typedef __attribute__((ext_vector_type(8))) float f32x8;
+                const f32x8 pv = {sacc[u][2 * kp][0], sacc[u][2 * kp][1], sacc[u][2 * kp][2], sacc[u][2 * kp][3],
+                                  sacc[u][2 * kp + 1][0], sacc[u][2 * kp + 1][1], sacc[u][2 * kp + 1][2], sacc[u][2 * kp + 1][3]};
+                pf[u][kp] = __builtin_convertvector(pv, bf16x8);
             }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float mnew = fmaxf(mrun, mloc);
-        const float msafe = mnew == -INFINITY ? 0.f : mnew;
-        const float alpha = __expf(mrun - msafe);                     // mrun = -inf -> 0
-        float psum = 0.f;
-#pragma unroll
-        for (int k4 = 0; k4 < 4; k4++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) { const float p = __expf(sacc[k4][r] - msafe); sacc[k4][r] = p; psum += p; }
-        lrun = lrun * alpha + psum;
-        mrun = mnew;
-#pragma unroll
-        for (int dt = 0; dt < 4; dt++) o[dt] *= alpha;
+        }
         // O^T += V^T P^T ; k slots of key-pair tile kp: j < 4 -> key 32kp + 4g + j, j >= 4 -> key 32kp + 16 + 4g + (j - 4)
 #pragma unroll
-        for (int kp = 0; kp < 2; kp++) {
-            typedef __attribute__((ext_vector_type(8))) float f32x8;
-            const f32x8 pv = {sacc[2 * kp][0], sacc[2 * kp][1], sacc[2 * kp][2], sacc[2 * kp][3],
-                              sacc[2 * kp + 1][0], sacc[2 * kp + 1][1], sacc[2 * kp + 1][2], sacc[2 * kp + 1][3]};
-            const bf16x8 pf = __builtin_convertvector(pv, bf16x8);
+        for (int kp = 0; kp < 2; kp++)
 #pragma unroll
             for (int dt = 0; dt < 4; dt++) {
                 const uint16_t* vrow = &Vs[buf][(16 * dt + q16) * AV_LD + 32 * kp + 4 * g];
                 const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
                 const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
-                const uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
-            }
-        }
-    }
-    lrun += __shfl_xor(lrun, 16);
-    lrun += __shfl_xor(lrun, 32);
-    const float inv = (tq < len && lrun > 0.f) ? 1.f / lrun : 0.f;
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
-    for (int dt = 0; dt < 4; dt++)
-        *reinterpret_cast<uint2*>(orow + 16 * dt) = make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+                for (int u = 0; u < QS; u++) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][kp], o[u][dt], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < QS; u++) {
+        float l = lrun[u];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = (tq[u] < len && l > 0.f) ? 1.f / l : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+            *reinterpret_cast<uint2*>(orow[u] + 16 * dt) = make_uint2(pack_bf16x2(o[u][dt][0] * inv, o[u][dt][1] * inv), pack_bf16x2(o[u][dt][2] * inv, o[u][dt][3] * inv));
+    }
 }
 
 // =========================================================================== host side
@@ -603,7 +630,8 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
     }
     {
         AttnEstArgs a{GB(h->qk, 1024), h->vt + GUARD, GB(h->att, 512), c.L->tab(), c.chunk, (long)(h->R + GUARD + 8)};
-        hipLaunchKernelGGL(k_attn_est, dim3(M / 64, 8), dim3(256), 0, c.s, a);
+        if (M / 128 * 8 >= 512) hipLaunchKernelGGL(k_attn_est<2>, dim3(M / 128, 8), dim3(256), 0, c.s, a);   // enough blocks to fill the chip twice
+        else hipLaunchKernelGGL(k_attn_est<1>, dim3(M / 64, 8), dim3(256), 0, c.s, a);
     }
     {
         GemmArgs a = gemm_args(GB(h->att, 512), 512, 0, tb.out.w, M, 256, 512);

@@ -44,7 +44,8 @@ struct ConvArgs {
 #define CV_LD 65
 
 __device__ __forceinline__ float pre_apply(float v, int pre, float al, float slope) {
-    if (pre == PRE_SNAKE) { const float s = sinf(v * al); return v + (1.0f / (al + 1e-9f)) * (s * s); }
+    // v_sin_f32 (hardware range reduction, abs error ~1e-6 for the |x * alpha| < 100 seen here) instead of the ~40-instruction sinf
+    if (pre == PRE_SNAKE) { const float s = __sinf(v * al); return v + (1.0f / (al + 1e-9f)) * (s * s); }
     if (pre == PRE_LRELU) return v > 0.f ? v : v * slope;
     return v;
 }

@@ -78,7 +78,9 @@ def polyphase(wt, u, pad):
 
 
 class HiftEngine:
-    def __init__(self, sd, device='cuda:0', max_frames=2048):
+    def __init__(self, sd, device='cuda:0', max_frames=2048, share_weights_with=None):
+        """share_weights_with: another HiftEngine whose packed weights are reused (several engines = several workspaces, so
+        independent utterances can run on different HIP streams at once)."""
         sd = {k[len('generator.'):] if k.startswith('generator.') else k: v for k, v in sd.items()}     # cli/model.py:88
         self.device = dev = torch.device(device)
         self.lib = L.lib()
@@ -106,6 +108,23 @@ class HiftEngine:
                 rb.a2[i] = f32(sd[f'{p}.activations2.{i}.alpha'])
             return rb
 
+        if share_weights_with is not None:
+            w = share_weights_with._w
+            self._keep = share_weights_with._keep
+        else:
+            w = self._pack(sd, conv, resblock, f32)
+        self._w = w
+        self.dims = HiftDims(max_frames=max_frames)
+        self.max_frames = max_frames
+        nbytes = self.lib.cv2_hift_workspace_bytes(C.byref(self.dims))
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        h = C.c_void_p()
+        L.check(self.lib.cv2_hift_create(C.byref(self.dims), C.byref(w), self.workspace.data_ptr(), nbytes, C.byref(h)))
+        self.handle = h
+        self.seed = 0
+
+    @staticmethod
+    def _pack(sd, conv, resblock, f32):
         w = HiftWeights()
         for n, i in enumerate((0, 2, 4, 6, 8)):
             w.f0_conv[n] = conv(weight_norm(sd, f'f0_predictor.condnet.{i}'), sd[f'f0_predictor.condnet.{i}.bias'], 1, 1)
@@ -122,15 +141,7 @@ class HiftEngine:
             for j, k2 in enumerate((3, 7, 11)):
                 w.rb[i * 3 + j] = resblock(f'resblocks.{i * 3 + j}', k2)
         w.conv_post = conv(weight_norm(sd, 'conv_post'), sd['conv_post.bias'], 1, 3)
-        self._w = w
-        self.dims = HiftDims(max_frames=max_frames)
-        self.max_frames = max_frames
-        nbytes = self.lib.cv2_hift_workspace_bytes(C.byref(self.dims))
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        h = C.c_void_p()
-        L.check(self.lib.cv2_hift_create(C.byref(self.dims), C.byref(w), self.workspace.data_ptr(), nbytes, C.byref(h)))
-        self.handle = h
-        self.seed = 0
+        return w
 
     def __del__(self):
         try:
@@ -164,3 +175,32 @@ class HiftEngine:
         w = window.numel() // 2
         L.check(self.lib.cv2_fade_in_out(L.ptr(fade_in), L.ptr(fade_out_tail), L.ptr(window), w, L.stream_ptr()))
         return fade_in
+
+
+class HiftPool:
+    """Several HiftEngines (shared weights, own workspaces) on their own HIP streams: independent utterances of a batch run
+    concurrently, which fills the chip where a single utterance's early conv stages launch fewer blocks than there are CUs."""
+
+    def __init__(self, sd, device='cuda:0', max_frames=2048, n=4):
+        self.engines = [HiftEngine(sd, device, max_frames)]
+        for _ in range(1, n):
+            self.engines.append(HiftEngine(sd, device, max_frames, share_weights_with=self.engines[0]))
+        self.streams = [torch.cuda.Stream(device) for _ in self.engines]
+        self._seed = 0
+
+    def inference_many(self, mels):
+        """mels: list of [1,80,T] device tensors.  Returns list of (wav, source)."""
+        main = torch.cuda.current_stream()
+        outs = [None] * len(mels)
+        for st in self.streams:
+            st.wait_stream(main)
+        for i, mel in enumerate(mels):
+            k = i % len(self.engines)
+            self._seed += 1
+            with torch.cuda.stream(self.streams[k]):
+                outs[i] = self.engines[k].inference(mel, None, seed=self._seed)
+            for t in outs[i]:
+                t.record_stream(main)
+        for st in self.streams:
+            main.wait_stream(st)
+        return outs

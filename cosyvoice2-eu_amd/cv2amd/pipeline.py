@@ -8,7 +8,7 @@ the whole batch), the flow runs over the packed ragged batch, and HiFT runs per 
 import torch
 
 from .flow import FlowEngine
-from .hift import HiftEngine
+from .hift import HiftEngine, HiftPool
 from .llm import LLMEngine, MODE_GREEDY, MODE_RAS
 
 
@@ -22,7 +22,8 @@ class Synthesizer:
         self.llm = LLMEngine(llm_sd, device, max_seqs=max(1, max_batch), max_pos=max_pos, max_out=max_new_tokens)
         max_len = 2 * (max_prompt_tokens + max_new_tokens)
         self.flow = FlowEngine(flow_sd, device, max_utts=max_batch, max_len=max_len)
-        self.hift = HiftEngine(hift_sd, device, max_frames=2 * max_new_tokens)
+        self.hift_pool = HiftPool(hift_sd, device, max_frames=2 * max_new_tokens, n=1 if max_batch == 1 else 4)
+        self.hift = self.hift_pool.engines[0]
         self.max_batch = max_batch
 
     def tokens(self, reqs, mode=MODE_GREEDY, seed=0, force_len=None):
