@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void k_store(StoreArgs a) {
 struct GateUpArgs {
     const uint16_t* W; SkinnyX X; int KS, rows, K, inter;
     float* h;                                   // [rows][inter]
+    uint16_t* hpre;                             // PRE kernels: h written as prepared hi/lo planes for the down projection instead
 };
 template <int NB, bool PRE = false>
 __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
@@ -238,7 +239,16 @@ __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
     for (int e = threadIdx.x; e < a.rows * 16; e += blockDim.x) {
         const int r = e >> 4, i = e & 15;
         const float g = res[i * ld + r], u = res[(16 + i) * ld + r];
-        a.h[(size_t)r * a.inter + blockIdx.x * 16 + i] = (g / (1.f + __expf(-g))) * u;
+        const float hv = (g / (1.f + __expf(-g))) * u;
+        if (PRE && a.hpre) {                     // LDS B-operand order of skinny.h: [k-block][row tile][hi, lo][quarter][row][8]
+            const int c = blockIdx.x * 16 + i;
+            uint16_t* d = a.hpre + ((size_t)((c >> 5) * 2 + (r >> 4)) * 2) * 512 + (((c >> 3) & 3) * 16 + (r & 15)) * 8 + (c & 7);
+            const uint16_t hb = f2bf(hv);
+            d[0] = hb;
+            d[512] = f2bf(hv - bf2f(hb));
+        } else {
+            a.h[(size_t)r * a.inter + blockIdx.x * 16 + i] = hv;
+        }
     }
 }
 
@@ -675,7 +685,7 @@ struct cv2_llm {
     float *att_ml;             // [nsplit][32][n_q][2]
     int *att_cnt;              // [32] non-empty splits per row
     float *attc;               // [32][n_q*64] combined attention output (many-row path)
-    uint16_t *xp;              // prepared operand planes [inter/32][2][hi, lo][512] (k_prep)
+    uint16_t *xp, *xp_h;       // prepared operand planes [K/32][2][hi, lo][512]: k_prep output; SwiGLU output of k_gateup<2, true>
     int nsplit, keys_per_split;
     float *hbuf;               // [32][inter]
     float *parts;              // [SK_MAXNP][32][hidden] split-K partials of the down projection
@@ -704,6 +714,7 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     p = take(32 * 4); if (h) h->att_cnt = (int*)p;
     p = take((size_t)32 * d.n_q * 64 * 4); if (h) h->attc = (float*)p;
     p = take((size_t)(d.inter / 32) * 2 * 2 * 1024); if (h) h->xp = (uint16_t*)p;
+    p = take((size_t)(d.inter / 32) * 2 * 2 * 1024); if (h) h->xp_h = (uint16_t*)p;
     p = take((size_t)32 * d.hidden * 4); if (h) h->o = (float*)p;
     p = take((size_t)32 * d.inter * 4); if (h) h->hbuf = (float*)p;
     p = take((size_t)SK_MAXNP * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
@@ -878,13 +889,14 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
         prep(SkinnyX{x1, h->o, 1, L.ln2, d.rms_eps, x2}, H, false);
         {
             GateUpArgs a{};
-            a.W = L.wgu; a.X = pre; a.KS = KSH; a.rows = rows; a.K = H; a.inter = d.inter; a.h = h->hbuf;
+            a.W = L.wgu; a.X = pre; a.KS = KSH; a.rows = rows; a.K = H; a.inter = d.inter; a.h = h->hbuf; a.hpre = h->xp_h;
             { const size_t sm = skinny_smem_bytes<2, 2, 4>(KSH); hipLaunchKernelGGL((k_gateup<2, true>), dim3(d.inter / 16, 1), dim3(512), sm, s, a); }
         }
-        prep(SkinnyX{h->hbuf, nullptr, 0, nullptr, 0.f, nullptr}, d.inter, false);
         {
             StoreArgs a{};
-            a.W = L.wdown; a.X = pre; a.KS = d.inter / 32; a.rows = rows; a.K = d.inter; a.N = H; a.out = h->parts;
+            SkinnyX preh{};
+            preh.pre = h->xp_h;
+            a.W = L.wdown; a.X = preh; a.KS = d.inter / 32; a.rows = rows; a.K = d.inter; a.N = H; a.out = h->parts;
             { const size_t sm = skinny_smem_bytes<2, 1, 4>(cdiv(a.KS, SK_MAXNP) + 1); hipLaunchKernelGGL((k_store<2, 10, false, true>), dim3(H / 16, SK_MAXNP), dim3(256), sm, s, a); }
         }
         xcur = x2;

@@ -107,6 +107,14 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     const int w0 = ks0 + (nks * wk) / NWK;
     const int w1 = ks0 + (nks * (wk + 1)) / NWK;
 
+    // 0. (PRE) the operand prepared by k_prep goes global -> LDS by DMA, issued BEFORE the weight stream so that the two are in
+    //    flight together and no VGPR / ds_write work is spent on it: this block's K slice [ks0, ks1) of the hi / lo planes
+    if (PRE) {
+        const char* src = reinterpret_cast<const char*>(X.pre) + (size_t)ks0 * NB * 2 * 1024 + lane * 16;
+        for (int pc = wave; pc < nks * NB * 2; pc += NWR * NWK)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)pc * 1024),
+                                             (__attribute__((address_space(3))) void*)(smem + pc * 1024), 16, 0, 0);
+    }
     // 1. every weight fragment of this wave in flight
     const s16x8* wp = reinterpret_cast<const s16x8*>(W) + ((size_t)tile * KS + w0) * 64 + lane;
     s16x8 abuf[MAXKS];
@@ -115,10 +123,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         if (w0 + i < w1) abuf[i] = __builtin_nontemporal_load(wp + (size_t)i * 64);
 
   if (PRE) {
-    // 2'. operand prepared once by k_prep: copy this block's K slice [ks0, ks1) of the hi / lo planes
-    const uint4* src = reinterpret_cast<const uint4*>(X.pre) + (size_t)ks0 * NB * 2 * 64;
-    uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (int i = tid; i < nks * NB * 2 * 64; i += nthreads) dst[i] = src[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   } else {
     // 2. fold / normalise / split the block's x slice [ks0*32, ks1*32) into LDS (B-operand order)
