@@ -123,11 +123,19 @@ def main():
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the hot path has no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    dev = f'cuda:{local_rank}'
-    if world > 1:
+    # test hooks (one-GPU boxes): CV2_BENCH_DEVICE pins every rank to one GPU, CV2_BENCH_BACKEND=gloo replaces RCCL for the barriers
+    dev_index = int(os.environ.get('CV2_BENCH_DEVICE', local_rank))
+    backend = os.environ.get('CV2_BENCH_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    dev = f'cuda:{dev_index}'
+    if world > 1 or 'RANK' in os.environ:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(dev))
+        os.environ.setdefault('MASTER_PORT', '29531')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
+    use_dist = dist.is_initialized()
 
     from cv2amd import lib as L
     if not os.path.exists(L.LIB_PATH):
@@ -178,7 +186,8 @@ def main():
         return wavs
 
     def barrier():
-        if world > 1:
+        torch.cuda.synchronize()
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -190,8 +199,8 @@ def main():
         wavs = step(True, 1000 + i)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if use_dist:
+        t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert all(torch.isfinite(w).all() for w in wavs)
@@ -231,7 +240,7 @@ def main():
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(host_cores())
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
