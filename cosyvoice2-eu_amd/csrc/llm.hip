@@ -120,29 +120,46 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     const int rep = a.n_q / a.n_kv;                               // <= 8
     const int g = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit, r = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int d = tid & 63, hq = tid >> 6;                        // PV: thread = (dim, head pair {hq, hq + 4})
+    const int key_t = tid >> 2, qd = tid & 3;                     // scores: thread = (key, 16-dim quarter)
+    const int j_lo = sp * a.keys_per_split;
+    // The slot is known without touching memory (decode: slot = row), so the first tile's K / V / q loads are issued BEFORE the
+    // position is read from the state: state -> position is one L2 round trip, the loads a second one; issued this way they
+    // overlap.  Keys beyond the current length are masked once the position has arrived (the cache rows exist up to max_pos).
+    const int seq_s = a.rm.prefill ? a.rm.seq0 : r;
+    const float* K = a.kc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
+    const float* V = a.vc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
+    f32x4 kk[4];
+    float vv[AT_KB];
+    {
+        const int jk = min(j_lo + key_t, a.max_pos - 1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) kk[i] = *reinterpret_cast<const f32x4*>(K + (size_t)jk * 64 + qd * 16 + 4 * i);
+#pragma unroll
+        for (int k = 0; k < AT_KB; k++) vv[k] = V[(size_t)min(j_lo + k, a.max_pos - 1) * 64 + d];
+    }
+    for (int i = tid; i < rep * 64; i += 256) qs[i] = a.q[(size_t)r * a.n_q * 64 + g * rep * 64 + i];
     int seq, pos;
     a.rm.get(r, seq, pos);
     const int L = pos + 1;
-    const int j_lo = sp * a.keys_per_split, j_hi = min(L, j_lo + a.keys_per_split);
+    const int j_hi = min(L, j_lo + a.keys_per_split);
     if (blockIdx.x == 0 && tid == 0) a.part_cnt[r] = (L + a.keys_per_split - 1) / a.keys_per_split;
     float* ml = a.part_ml + (((size_t)sp * SK_ROWS_CAP + r) * a.n_q + g * rep) * 2;
     if (j_lo >= j_hi) return;                                     // empty split: the consumer stops at part_cnt
-    const float* K = a.kc + ((size_t)seq * a.n_kv + g) * a.max_pos * 64;
-    const float* V = a.vc + ((size_t)seq * a.n_kv + g) * a.max_pos * 64;
-    for (int i = tid; i < rep * 64; i += 256) qs[i] = a.q[(size_t)r * a.n_q * 64 + g * rep * 64 + i];
     if (tid < 8) { run_m[tid] = -INFINITY; run_l[tid] = 0.f; }
-    const int d = tid & 63, hq = tid >> 6;                        // PV: thread = (dim, head pair {hq, hq + 4})
-    const int key_t = tid >> 2, qd = tid & 3;                     // scores: thread = (key, 16-dim quarter)
     float o0 = 0.f, o1 = 0.f;
     for (int j0 = j_lo; j0 < j_hi; j0 += AT_KB) {
         const int n = min(AT_KB, j_hi - j0);
-        f32x4 kk[4];
-        float vv[AT_KB];
+        if (j0 != j_lo) {                                         // later tiles of a long split: plain bounded loads
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            kk[i] = key_t < n ? *reinterpret_cast<const f32x4*>(K + (size_t)(j0 + key_t) * 64 + qd * 16 + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; i++)
+                kk[i] = key_t < n ? *reinterpret_cast<const f32x4*>(K + (size_t)(j0 + key_t) * 64 + qd * 16 + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < AT_KB; k++) vv[k] = k < n ? V[(size_t)(j0 + k) * 64 + d] : 0.f;
+            for (int k = 0; k < AT_KB; k++) vv[k] = k < n ? V[(size_t)(j0 + k) * 64 + d] : 0.f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < AT_KB; k++) vv[k] = k < n ? vv[k] : 0.f;     // speculative rows beyond the length may hold anything
+        }
         __syncthreads();                                          // qs ready; previous tile's ps consumed
 #pragma unroll
         for (int h = 0; h < 8; h++) {
@@ -308,6 +325,25 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     for (int w = 0; w < SM_W; w++) r += sh[w];
     return r;
 }
+// order-preserving float -> uint key (larger float = larger key; every finite or -inf float maps to a key > 0) and back
+__device__ __forceinline__ unsigned fkey(float f) { const unsigned u = __builtin_bit_cast(unsigned, f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float fkey_inv(unsigned k) { return __builtin_bit_cast(float, (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+// wave-wide unsigned max through DPP: row_shr 1/2/4/8 leave each 16-lane row's max in its lane 15, row_bcast 15 / 31 carry it
+// across rows into lane 63 (invalid source lanes contribute the identity 0); the result is read back wave-uniform
+template <int CTRL, int RMASK>
+__device__ __forceinline__ unsigned dpp_umax(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, RMASK, 0xf, false);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = dpp_umax<0x111, 0xf>(v); v = dpp_umax<0x112, 0xf>(v); v = dpp_umax<0x114, 0xf>(v); v = dpp_umax<0x118, 0xf>(v);
+    v = dpp_umax<0x142, 0xa>(v); v = dpp_umax<0x143, 0xc>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned row0_umax(unsigned v) {       // max over lanes 0..15 only
+    v = dpp_umax<0x111, 0xf>(v); v = dpp_umax<0x112, 0xf>(v); v = dpp_umax<0x114, 0xf>(v); v = dpp_umax<0x118, 0xf>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
+}
 __device__ __forceinline__ double shfl_up_f64(double v, int o) {
     const long long b = __builtin_bit_cast(long long, v);
     const int lo = __shfl_up((int)b, o), hi = __shfl_up((int)(b >> 32), o);
@@ -321,7 +357,7 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
     __shared__ float candp[SM_TOPK];
     __shared__ int candi[SM_TOPK];
     __shared__ int s_top, s_need, s_done, s_ncand;
-    __shared__ float wl_v[SM_W * SM_TOPK];
+    __shared__ unsigned wl_v[SM_W * SM_TOPK];
     __shared__ int wl_i[SM_W * SM_TOPK];
     __shared__ double s_u2;
     const int tid = threadIdx.x;
@@ -371,33 +407,54 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                 lv[e] -= lse;
                 if (tid + e * SM_T < V) lp[tid + e * SM_T] = lv[e];
             }
-            // nucleus candidates (common.py:120-134) = head of the stable descending order.  Two stages, one block barrier:
-            // every wave extracts the top 25 of its own 1/16 of the vocabulary with shuffles only, wave 0 merges the 16 sorted lists.
+            if (mode == 2) { if (tid == 0) s_top = 0; goto sample_done; }       // diagnostic exit points (tools/dbg_sample.py): after log-softmax
+            // nucleus candidates (common.py:120-134) = head of the stable descending order (value desc, id asc).  Two stages, one
+            // block barrier: every wave extracts the top 25 of its own 1/16 of the vocabulary, wave 0 merges the 16 sorted lists.
+            // Cross-lane maxima go through DPP row operations (one VALU instruction per step) instead of LDS-routed shuffles.
             {
-                unsigned taken = 0;
                 const int lane = tid & 63, w = tid >> 6;
+                unsigned kk[NE]; int ki[NE];                                   // this lane's elements, sorted: key desc, id asc
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    const int i = tid + e * SM_T;
+                    kk[e] = i < V ? fkey(lv[e]) : 0u;                          // 0 = no element (every real key is > 0)
+                    ki[e] = i;
+                }
+#pragma unroll
+                for (int p = 0; p < NE - 1; p++)
+#pragma unroll
+                    for (int q = 0; q < NE - 1 - p; q++) {                     // ids increase with q: strict > keeps equal keys in id order
+                        const bool sw = kk[q + 1] > kk[q];
+                        const unsigned tk = sw ? kk[q] : kk[q + 1]; const int ti = sw ? ki[q] : ki[q + 1];
+                        kk[q] = sw ? kk[q + 1] : kk[q]; ki[q] = sw ? ki[q + 1] : ki[q];
+                        kk[q + 1] = tk; ki[q + 1] = ti;
+                    }
                 for (int c = 0; c < SM_TOPK; c++) {
-                    ArgMax bq{-INFINITY, 0x7fffffff};
+                    const unsigned M = wave_umax(kk[0]);
+                    const unsigned W = wave_umax((kk[0] == M && M != 0u) ? ~(unsigned)ki[0] : 0u);
+                    const int wi = (int)~W;
+                    if (lane == 0) { wl_v[w * SM_TOPK + c] = M; wl_i[w * SM_TOPK + c] = wi; }
+                    if (ki[0] == wi && kk[0] == M) {                           // the owner pops its head
 #pragma unroll
-                    for (int e = 0; e < NE; e++)
-                        if (!((taken >> e) & 1u) && tid + e * SM_T < V) bq = am_better(bq, ArgMax{lv[e], tid + e * SM_T});
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) bq = am_better(bq, ArgMax{__shfl_xor(bq.v, o), __shfl_xor(bq.i, o)});
-                    if (bq.i != 0x7fffffff && (bq.i & (SM_T - 1)) == tid) taken |= 1u << (bq.i / SM_T);
-                    if (lane == 0) { wl_v[w * SM_TOPK + c] = bq.v; wl_i[w * SM_TOPK + c] = bq.i; }
+                        for (int e = 0; e < NE - 1; e++) { kk[e] = kk[e + 1]; ki[e] = ki[e + 1]; }
+                        kk[NE - 1] = 0u;
+                    }
                 }
                 __syncthreads();
+                if (mode == 3) { if (tid == 0) s_top = 0; goto sample_done; }   // after the per-wave top-25
                 if (w == 0) {
                     int ptr = 0;
-                    ArgMax head = lane < SM_W ? ArgMax{wl_v[lane * SM_TOPK], wl_i[lane * SM_TOPK]} : ArgMax{-INFINITY, 0x7fffffff};
+                    unsigned hk = lane < SM_W ? wl_v[lane * SM_TOPK] : 0u;
+                    int hi = lane < SM_W ? wl_i[lane * SM_TOPK] : 0x7fffffff;
                     for (int c = 0; c < SM_TOPK; c++) {
-                        ArgMax bq = head;
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) bq = am_better(bq, ArgMax{__shfl_xor(bq.v, o), __shfl_xor(bq.i, o)});
-                        if (lane == 0) { candi[c] = bq.i; candp[c] = __expf(bq.v); }
-                        if (lane < SM_W && head.i == bq.i && bq.i != 0x7fffffff) {
+                        const unsigned M = row0_umax(hk);
+                        const unsigned W = row0_umax((hk == M && M != 0u) ? ~(unsigned)hi : 0u);
+                        const int wi = (int)~W;
+                        if (lane == 0) { candi[c] = wi; candp[c] = __expf(fkey_inv(M)); }
+                        if (lane < SM_W && hi == wi && hk == M) {
                             ptr++;
-                            head = ptr < SM_TOPK ? ArgMax{wl_v[lane * SM_TOPK + ptr], wl_i[lane * SM_TOPK + ptr]} : ArgMax{-INFINITY, 0x7fffffff};
+                            hk = ptr < SM_TOPK ? wl_v[lane * SM_TOPK + ptr] : 0u;
+                            hi = ptr < SM_TOPK ? wl_i[lane * SM_TOPK + ptr] : 0x7fffffff;
                         }
                     }
                     if (lane == 0) {
@@ -409,6 +466,7 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                 __syncthreads();
             }
             const int ncand = s_ncand;
+            if (mode == 4) { if (tid == 0) s_top = 0; goto sample_done; }       // after the 16-way merge
             const int nhist = st[CV2_ST_NOUT];
             const int* hist = a.out_tokens + (size_t)seq * a.max_out;
             const int chunk = (V + SM_T - 1) / SM_T;
@@ -478,6 +536,7 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
             }
         }
     }
+sample_done:
     __syncthreads();
     const int top = done ? st[CV2_ST_LAST] : s_top;
     // next input embedding (llm.py:711, 719); harmless for finished slots

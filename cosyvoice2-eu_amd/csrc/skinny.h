@@ -46,17 +46,17 @@ template <bool ATT>
 __device__ __forceinline__ f32x8 sk_load_x(const SkinnyX& X, int r, int K, int k) {
     if (ATT) {
         const int nq = K >> 6, hd = k >> 6;
-        const int ns = X.att_cnt[r];
         float mv[SK_MAXSPLIT], lv[SK_MAXSPLIT];
         f32x8 ov[SK_MAXSPLIT];
         float M = -INFINITY;
+        // every split slot is loaded unconditionally, together with the split count: nothing waits on the count before issuing
+        // (slots beyond it hold stale values and are only masked out below)
+        const int ns = X.att_cnt[r];
 #pragma unroll
-        for (int s = 0; s < SK_MAXSPLIT; s++) {                  // all loads in flight together
-            if (s < ns) {
-                const float* ml = X.att_ml + (((size_t)s * SK_ROWS_CAP + r) * nq + hd) * 2;
-                mv[s] = ml[0]; lv[s] = ml[1];
-                ov[s] = *reinterpret_cast<const f32x8*>(X.parts + ((size_t)s * SK_ROWS_CAP + r) * K + k);
-            }
+        for (int s = 0; s < SK_MAXSPLIT; s++) {
+            const float* ml = X.att_ml + (((size_t)s * SK_ROWS_CAP + r) * nq + hd) * 2;
+            mv[s] = ml[0]; lv[s] = ml[1];
+            ov[s] = *reinterpret_cast<const f32x8*>(X.parts + ((size_t)s * SK_ROWS_CAP + r) * K + k);
         }
 #pragma unroll
         for (int s = 0; s < SK_MAXSPLIT; s++) if (s < ns) M = fmaxf(M, mv[s]);
