@@ -292,18 +292,20 @@ struct AttnEstArgs {
 };
 #define AK_LD 72    // K tile row stride (bf16 elements): 64 + 8
 #define AV_LD 68    // V^T tile row stride: 64 + 4
-// QS query sub-tiles of 16 rows per wave (block = 64*QS rows): K / V^T fragments read from LDS once serve QS MFMAs.
-template <int QS>
-__global__ __launch_bounds__(256) void k_attn_est(AttnEstArgs a) {
+// QS query sub-tiles of 16 rows per wave, NW waves (block = 16*NW*QS rows): K / V^T fragments read from LDS once serve QS MFMAs;
+// NW = 2 doubles the block count for single-utterance calls, whose 64-row tiles would not even fill the chip once.
+template <int QS, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attn_est(AttnEstArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t Ks[2][64 * AK_LD];
     __shared__ __attribute__((aligned(16))) uint16_t Vs[2][64 * AV_LD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int m0 = blockIdx.x * 64 * QS, h = blockIdx.y;
+    constexpr int RB = 16 * NW;                                  // rows per query sub-tile group
+    const int m0 = blockIdx.x * RB * QS, h = blockIdx.y;
     const int q16 = lane & 15, g = lane >> 4;
     const int s = a.seq.tile_seq[m0 >> 6];           // sequences start on 128-row boundaries: one sequence per block
     uint16_t* orow[QS];
 #pragma unroll
-    for (int u = 0; u < QS; u++) orow[u] = a.out + (size_t)(m0 + 64 * u + 16 * w + q16) * 512 + h * 64 + 4 * g;
+    for (int u = 0; u < QS; u++) orow[u] = a.out + (size_t)(m0 + RB * u + 16 * w + q16) * 512 + h * 64 + 4 * g;
     if (s < 0) {
 #pragma unroll
         for (int u = 0; u < QS; u++)
@@ -316,10 +318,10 @@ __global__ __launch_bounds__(256) void k_attn_est(AttnEstArgs a) {
     int tq[QS], kmax_q[QS];
 #pragma unroll
     for (int u = 0; u < QS; u++) {
-        tq[u] = t0 + 64 * u + 16 * w + q16;                          // this lane's query frames
+        tq[u] = t0 + RB * u + 16 * w + q16;                          // this lane's query frames
         kmax_q[u] = a.chunk > 0 ? min(len, (tq[u] / a.chunk + 1) * a.chunk) : len;
     }
-    const int kmax_blk = a.chunk > 0 ? min(len, ((t0 + 64 * QS - 1) / a.chunk + 1) * a.chunk) : len;
+    const int kmax_blk = a.chunk > 0 ? min(len, ((t0 + RB * QS - 1) / a.chunk + 1) * a.chunk) : len;
     const int ntiles = (kmax_blk + 63) / 64;
 
     bf16x8 qf[QS][2];
@@ -327,26 +329,26 @@ __global__ __launch_bounds__(256) void k_attn_est(AttnEstArgs a) {
     for (int u = 0; u < QS; u++)
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
-            qf[u][ks] = *reinterpret_cast<const bf16x8*>(a.qk + (size_t)(m0 + 64 * u + 16 * w + q16) * 1024 + h * 64 + ks * 32 + g * 8);
+            qf[u][ks] = *reinterpret_cast<const bf16x8*>(a.qk + (size_t)(m0 + RB * u + 16 * w + q16) * 1024 + h * 64 + ks * 32 + g * 8);
 
-    // staging: thread -> 2 K chunks (row kr, 16-B chunk kc) and 2 V^T chunks
-    const int kr = tid >> 3, kc = tid & 7;                             // rows kr, kr + 32
-    uint4 kreg0, kreg1, vreg0, vreg1;
-    auto gload = [&](int kt) {
-        const long krow = (long)start + kt * 64;
-        kreg0 = *reinterpret_cast<const uint4*>(a.qk + (size_t)(krow + kr) * 1024 + 512 + h * 64 + kc * 8);
-        kreg1 = *reinterpret_cast<const uint4*>(a.qk + (size_t)(krow + kr + 32) * 1024 + 512 + h * 64 + kc * 8);
-        vreg0 = *reinterpret_cast<const uint4*>(a.vt + (size_t)(h * 64 + kr) * a.R + krow + kc * 8);
-        vreg1 = *reinterpret_cast<const uint4*>(a.vt + (size_t)(h * 64 + kr + 32) * a.R + krow + kc * 8);
-    };
-    auto lstore = [&](int buf) {
-        *reinterpret_cast<uint4*>(&Ks[buf][kr * AK_LD + kc * 8]) = kreg0;
-        *reinterpret_cast<uint4*>(&Ks[buf][(kr + 32) * AK_LD + kc * 8]) = kreg1;
-        uint2* vd = reinterpret_cast<uint2*>(&Vs[buf][kr * AV_LD + kc * 8]);
-        vd[0] = make_uint2(vreg0.x, vreg0.y); vd[1] = make_uint2(vreg0.z, vreg0.w);
-        vd = reinterpret_cast<uint2*>(&Vs[buf][(kr + 32) * AV_LD + kc * 8]);
-        vd[0] = make_uint2(vreg1.x, vreg1.y); vd[1] = make_uint2(vreg1.z, vreg1.w);
-    };
+    // staging: thread -> NCH K chunks (row, 16-B chunk) and NCH V^T chunks of the 64-key tile
+    constexpr int NCH = 512 / (64 * NW);
+    uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
+    kreg2 = kreg3 = vreg2 = vreg3 = make_uint4(0u, 0u, 0u, 0u);
+#define ATT_GLOAD1(C, KROW)                                                                                                  \
+    if (NCH > C) {                                                                                                           \
+        const int idx = tid + 64 * NW * C, kr = idx >> 3, kc = idx & 7;                                                       \
+        kreg##C = *reinterpret_cast<const uint4*>(a.qk + (size_t)((KROW) + kr) * 1024 + 512 + h * 64 + kc * 8);               \
+        vreg##C = *reinterpret_cast<const uint4*>(a.vt + (size_t)(h * 64 + kr) * a.R + (KROW) + kc * 8);                      \
+    }
+#define ATT_GLOAD(KT) { const long krow_ = (long)start + (KT) * 64; ATT_GLOAD1(0, krow_) ATT_GLOAD1(1, krow_) ATT_GLOAD1(2, krow_) ATT_GLOAD1(3, krow_) }
+#define ATT_LSTORE1(C, BUF)                                                                                                  \
+    if (NCH > C) {                                                                                                           \
+        const int idx = tid + 64 * NW * C, kr = idx >> 3, kc = idx & 7;                                                       \
+        *reinterpret_cast<uint4*>(&Ks[BUF][kr * AK_LD + kc * 8]) = kreg##C;                                                   \
+        uint2* vd = reinterpret_cast<uint2*>(&Vs[BUF][kr * AV_LD + kc * 8]);                                                  \
+        vd[0] = make_uint2(vreg##C.x, vreg##C.y); vd[1] = make_uint2(vreg##C.z, vreg##C.w);                                   \
+    }
 
     f32x4 o[QS][4];
     float mrun[QS], lrun[QS];
@@ -357,12 +359,12 @@ __global__ __launch_bounds__(256) void k_attn_est(AttnEstArgs a) {
         for (int dt = 0; dt < 4; dt++) o[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    gload(0);
+    ATT_GLOAD(0)
     for (int kt = 0; kt < ntiles; kt++) {
         const int buf = kt & 1;
-        lstore(buf);
+        ATT_LSTORE1(0, buf) ATT_LSTORE1(1, buf) ATT_LSTORE1(2, buf) ATT_LSTORE1(3, buf)
         __syncthreads();
-        if (kt + 1 < ntiles) gload(kt + 1);
+        if (kt + 1 < ntiles) ATT_GLOAD(kt + 1)
         // S^T: 4 key tiles x (d = 64 in two k-steps), K fragments shared by the QS query sub-tiles
         f32x4 sacc[QS][4];
 #pragma unroll
@@ -630,8 +632,9 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
     }
     {
         AttnEstArgs a{GB(h->qk, 1024), h->vt + GUARD, GB(h->att, 512), c.L->tab(), c.chunk, (long)(h->R + GUARD + 8)};
-        if (M / 128 * 8 >= 512) hipLaunchKernelGGL(k_attn_est<2>, dim3(M / 128, 8), dim3(256), 0, c.s, a);   // enough blocks to fill the chip twice
-        else hipLaunchKernelGGL(k_attn_est<1>, dim3(M / 64, 8), dim3(256), 0, c.s, a);
+        if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(M / 128, 8), dim3(256), 0, c.s, a);   // enough blocks to fill the chip twice
+        else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(M / 64, 8), dim3(256), 0, c.s, a);
+        else hipLaunchKernelGGL((k_attn_est<1, 2>), dim3(M / 32, 8), dim3(128), 0, c.s, a);
     }
     {
         GemmArgs a = gemm_args(GB(h->att, 512), 512, 0, tb.out.w, M, 256, 512);

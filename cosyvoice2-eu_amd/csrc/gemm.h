@@ -49,7 +49,13 @@ struct GemmArgs {
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
-        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        case ACT_GELU: {                                   // exact-erf GELU; erf by Abramowitz-Stegun 7.1.26 (|err| < 7e-7 in fp32, one exp + one rcp)
+            const float z = v * 0.70710678118654752f, az = fabsf(z);
+            const float t = __fdividef(1.f, 1.f + 0.3275911f * az);
+            const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+            const float e = 1.f - poly * __expf(-az * az);
+            return 0.5f * v * (1.f + copysignf(e, z));
+        }
         case ACT_SILU: return v / (1.f + __expf(-v));
         case ACT_MISH: {                                   // x * tanh(softplus(x)); tanh(log(1 + e^x)) = n / (n + 2), n = e^x (e^x + 2)
             const float e = __expf(fminf(v, 20.f));        // torch's softplus switches to the identity above 20: the ratio is 1 there
@@ -71,6 +77,27 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 // LDS byte offset of (row, 16-B chunk) inside a 16 x 32 bf16 sub-tile, st_16x32 swizzle
 __device__ __forceinline__ int subtile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 3) << 1)) << 4); }
 
+// s_waitcnt vmcnt(N) with a compile-time N (the immediate must be a literal)
+template <int N>
+__device__ __forceinline__ void vmcnt_wait() {
+    static_assert(N >= 0 && N <= 24, "add the literal below");
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // conservative for counts without a literal
+}
+
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -78,7 +105,7 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool WPACKED, bool SPLITA = false>
+template <int BM, int BN, int WM, int WN, bool WPACKED, bool SPLITA = false, int NSTAGE = 2>
 __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     constexpr int NW = WM * WN, NT_ = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
@@ -98,13 +125,17 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     // per-lane source coordinates of an LDS-DMA piece (lane writes LDS byte lane*16 of the sub-tile)
     const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 5) << 1);
 
+    // Pieces are dealt round-robin to the waves; every wave issues the same count PER_WAVE (the counted vmcnt below relies on
+    // it), a wave whose last slot falls beyond NP re-issues the last piece (same bytes to the same LDS address: harmless).
+    constexpr int PER_WAVE = (NP + NW - 1) / NW;
     auto issue = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < NP / NW; i++) {
-            const int p = wave + i * NW;                 // NA % NW == 0: the A / W decision is per i, not per wave
+        for (int i = 0; i < PER_WAVE; i++) {
+            int p = wave + i * NW;
+            if (NP % NW != 0) p = p < NP ? p : NP - 1;
             const void* src;
-            if (i < NAP / NW) {
+            if (p < NAP) {                                // wave-uniform
                 const int pp = SPLITA ? p % NA : p, sub = pp >> 1, ks = pp & 1;
                 const uint16_t* Ab = (SPLITA && p >= NA) ? a.A_lo : A;
                 src = Ab + ((long)(m0 + sub * 16 + srow) + a.a_row_off) * a.lda + kt * 64 + ks * 32 + schunk * 8;
@@ -119,9 +150,6 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
                                              (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
         }
     };
-    static_assert(NAP % NW == 0 && NB % NW == 0, "A and W pieces must each divide evenly over the waves");
-    constexpr int PER_WAVE = (NP + NW - 1) / NW;       // NP % NW == 0 for every instantiated config
-    static_assert(NP % NW == 0, "pieces must divide evenly over the waves");
 
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -158,23 +186,15 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
         }
         ep_radd[t] = a.rowadd ? *reinterpret_cast<const f32x4*>(a.rowadd + (size_t)sq * a.rowadd_ld + n) : z4;
     }
-    for (int kt = 0; kt < nk; kt++) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            issue(kt + 1, buf ^ 1);
-            if (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (PER_WAVE == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else if (PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (PER_WAVE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (PER_WAVE == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else if (PER_WAVE == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if (PER_WAVE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    if (NSTAGE == 3 && nk > 1) issue(1, 1);
+    for (int kt = 0, buf = 0; kt < nk; kt++, buf = (buf + 1 == NSTAGE ? 0 : buf + 1)) {
+        // keep NSTAGE - 1 K-steps in flight: wait only until stage kt has landed (counted vmcnt, loads retire in order)
+        const int ahead = NSTAGE - 1;
+        if (kt + ahead < nk) issue(kt + ahead, (buf + ahead) % NSTAGE);
+        const int inflight = (nk - 1 - kt) < ahead ? (nk - 1 - kt) : ahead;      // younger stages that may stay outstanding
+        if (inflight == 2) vmcnt_wait<2 * PER_WAVE>();
+        else if (inflight == 1) vmcnt_wait<PER_WAVE>();
+        else vmcnt_wait<0>();
         __builtin_amdgcn_s_barrier();                    // stage kt has landed for every wave
         const char* base = smem + buf * STAGE;
 #pragma unroll
@@ -284,9 +304,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     }
 }
 
-template <int BM, int BN, bool SPLITA = false>
+template <int BM, int BN, bool SPLITA = false, int NSTAGE = 2>
 constexpr size_t gemm_smem_bytes() {
-    constexpr size_t stages = 2 * (size_t)(((SPLITA ? 2 : 1) * BM + BN) / 16 * 2) * 1024;
+    constexpr size_t stages = NSTAGE * (size_t)(((SPLITA ? 2 : 1) * BM + BN) / 16 * 2) * 1024;
     constexpr size_t ctile = (size_t)BM * (BN + 4) * 4;
     return stages > ctile ? stages : ctile;
 }

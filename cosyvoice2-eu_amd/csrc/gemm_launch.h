@@ -2,14 +2,14 @@
 #pragma once
 #include "gemm.h"
 
-template <int BM, int BN, int WM, int WN, bool SPLITA = false>
+template <int BM, int BN, int WM, int WN, bool SPLITA = false, int NSTAGE = 2>
 static int gemm_go(const GemmArgs& a, int batch, bool packed, hipStream_t s) {
-    constexpr size_t sm = gemm_smem_bytes<BM, BN, SPLITA>();
+    constexpr size_t sm = gemm_smem_bytes<BM, BN, SPLITA, NSTAGE>();
     dim3 grid(a.N / BN, a.M / BM, batch), block(WM * WN * 64);
     if (packed) {
         static bool once = false;
-        if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, true, SPLITA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true, SPLITA>), grid, block, sm, s, a);
+        if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, true, SPLITA, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true, SPLITA, NSTAGE>), grid, block, sm, s, a);
     } else if (!SPLITA) {
         static bool once = false;
         if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
@@ -25,20 +25,20 @@ static int gemm_go(const GemmArgs& a, int batch, bool packed, hipStream_t s) {
 static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, hipStream_t s) {
     CV2_CHECK(a.K % 64 == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of 64", a.K);
     CV2_CHECK(a.M % 128 == 0 && a.M > 0, "gemm: M=%d must be a positive multiple of 128", a.M);
-    if (cfg == 0) { CV2_CHECK(a.N % 128 == 0, "gemm cfg0: N=%d %% 128", a.N); return gemm_go<128, 128, 2, 2>(a, batch, packed, s); }
+    if (cfg == 0) { CV2_CHECK(a.N % 128 == 0, "gemm cfg0: N=%d %% 128", a.N); return gemm_go<128, 128, 2, 4>(a, batch, packed, s); }
     if (cfg == 1) {
         CV2_CHECK(a.N % 256 == 0, "gemm cfg1: N=%d %% 256", a.N);
         CV2_CHECK((!a.ln1_g && !a.ln2_g) || a.N == 256, "gemm cfg1: LayerNorm epilogue needs N == 256");
         // few rows (one utterance): 32-row tiles double the blocks that share the latency-bound K loop and the row epilogue
-        if ((long)(a.M / 64) * (a.N / 256) * batch < 200) return gemm_go<32, 256, 1, 4>(a, batch, packed, s);
-        return gemm_go<64, 256, 1, 4>(a, batch, packed, s);
+        if ((long)(a.M / 64) * (a.N / 256) * batch < 200) return gemm_go<32, 256, 2, 4>(a, batch, packed, s);      // latency-bound K loop: three stages in flight
+        return gemm_go<64, 256, 2, 4>(a, batch, packed, s);
     }
     if (cfg == 4) {
         CV2_CHECK(a.N % 128 == 0 && a.A_lo && batch == 1, "gemm cfg4: N=%d %% 128, A_lo required", a.N);
-        return gemm_go<128, 128, 2, 2, true>(a, batch, packed, s);
+        return gemm_go<128, 128, 2, 4, true>(a, batch, packed, s);
     }
     CV2_CHECK(a.N % 64 == 0, "gemm cfg2: N=%d %% 64", a.N);
-    return gemm_go<128, 64, 2, 2>(a, batch, packed, s);
+    return gemm_go<128, 64, 2, 4>(a, batch, packed, s);
 }
 
 static GemmArgs gemm_args(const uint16_t* A, long lda, long a_off, const uint16_t* W, int M, int N, int K) {
