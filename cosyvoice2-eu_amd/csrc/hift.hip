@@ -81,18 +81,41 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
             d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
         __syncthreads();
-        for (int tap = 0; tap < a.taps; tap++) {
-            const float* xr = xs + (wave * 32 + li + tap * a.dil) * CV_LD + lk;
-            const float* wb = a.wp + (((size_t)tap * (a.CinP / 2) + c0 / 2) * ntile + co0 / 32) * 64 + lane;
-#pragma unroll 8
-            for (int kk = 0; kk < CV_CK / 2; kk++) {
-                const float av = xr[2 * kk];
-                const float b0 = wb[(size_t)kk * ntile * 64];
-                const float b1 = wb[(size_t)kk * ntile * 64 + 64];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
-            }
+        // weights: groups of 8 k-steps, the NEXT group's 16 fragments are loaded (L2) while the current group's 16 MFMAs run
+        constexpr int GK = 8, NG = CV_CK / 2 / GK;               // 4 groups per tap
+        const size_t wstride = (size_t)ntile * 64;
+        const float* wb = a.wp + (((size_t)0 * (a.CinP / 2) + c0 / 2) * ntile + co0 / 32) * 64 + lane;
+        const size_t tapstride = (size_t)(a.CinP / 2) * ntile * 64;
+        // two register sets (A, B) alternate without copies: while the 16 MFMAs of one group run, the other set's 16 loads fly
+        float bA0[GK], bA1[GK], bB0[GK], bB1[GK];
+#define CV_LOAD(SET0, SET1, GI)                                                                                     \
+        {                                                                                                           \
+            const float* wn_ = wb + ((GI) / NG) * tapstride + (size_t)((GI) % NG) * GK * wstride;                     \
+            _Pragma("unroll") for (int u = 0; u < GK; u++) { SET0[u] = wn_[u * wstride]; SET1[u] = wn_[u * wstride + 64]; } \
         }
+#define CV_MMA(SET0, SET1, GI)                                                                                      \
+        {                                                                                                           \
+            const float* xr_ = xs + (wave * 32 + li + ((GI) / NG) * a.dil) * CV_LD + lk + 2 * ((GI) % NG) * GK;       \
+            _Pragma("unroll") for (int u = 0; u < GK; u++) {                                                          \
+                const float av = xr_[2 * u];                                                                        \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, SET0[u], acc0, 0, 0, 0);                              \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, SET1[u], acc1, 0, 0, 0);                              \
+            }                                                                                                       \
+        }
+        const int ngroups = a.taps * NG;                         // even (NG = 4)
+        CV_LOAD(bA0, bA1, 0)
+        for (int gi = 0; gi < ngroups; gi += 2) {
+            CV_LOAD(bB0, bB1, gi + 1)
+            __builtin_amdgcn_sched_barrier(0);                   // keep the issue order: hipcc otherwise sinks the loads to their use
+            CV_MMA(bA0, bA1, gi)
+            __builtin_amdgcn_sched_barrier(0);
+            if (gi + 2 < ngroups) CV_LOAD(bA0, bA1, gi + 2)
+            __builtin_amdgcn_sched_barrier(0);
+            CV_MMA(bB0, bB1, gi + 1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef CV_LOAD
+#undef CV_MMA
     }
     // epilogue: lane holds channel co (li) of tile 0 / 1 and 16 frames
 #pragma unroll
