@@ -44,15 +44,31 @@ __device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) 
     lo = f2bf(x - bf2f(hi));
 }
 
+// Wave-wide reductions through DPP row operations: one VALU instruction per step instead of an LDS-routed ds_bpermute per
+// __shfl_xor (~6 x 100+ cycles on the critical path of every norm / softmax / top-k).  row_shr 1/2/4/8 leave each 16-lane row's
+// reduction in its lane 15 (Hillis-Steele scan; lanes without a source contribute the identity), row_bcast 15 / 31 carry it
+// across the rows into lane 63; the result is read back wave-uniform.
+template <int CTRL, int RMASK>
+__device__ __forceinline__ float dpp_mov_f32(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_mov_f32<0x111, 0xf>(0.f, v);
+    v += dpp_mov_f32<0x112, 0xf>(0.f, v);
+    v += dpp_mov_f32<0x114, 0xf>(0.f, v);
+    v += dpp_mov_f32<0x118, 0xf>(0.f, v);
+    v += dpp_mov_f32<0x142, 0xa>(0.f, v);
+    v += dpp_mov_f32<0x143, 0xc>(0.f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_mov_f32<0x111, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov_f32<0x112, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov_f32<0x114, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov_f32<0x118, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov_f32<0x142, 0xa>(v, v));
+    v = fmaxf(v, dpp_mov_f32<0x143, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

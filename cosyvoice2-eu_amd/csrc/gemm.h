@@ -98,8 +98,20 @@ __device__ __forceinline__ void vmcnt_wait() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // conservative for counts without a literal
 }
 
+// sum over aligned groups of LPR lanes, result in every lane of the group (DPP row operations for 64 / 32 lanes, see common.h)
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
+    if (LPR == 64) return wave_sum(v);
+    if (LPR == 32) {
+        v += dpp_mov_f32<0x111, 0xf>(0.f, v);
+        v += dpp_mov_f32<0x112, 0xf>(0.f, v);
+        v += dpp_mov_f32<0x114, 0xf>(0.f, v);
+        v += dpp_mov_f32<0x118, 0xf>(0.f, v);
+        v += dpp_mov_f32<0x142, 0xa>(0.f, v);                      // lanes 31 / 63 now hold the two half-wave totals
+        const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+        return (threadIdx.x & 32) ? hi : lo;
+    }
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
