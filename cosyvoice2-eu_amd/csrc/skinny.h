@@ -137,7 +137,15 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         const int r = tid / k8n, k8 = tid - r * k8n;
         v0 = sk_load_x<ATT>(X, r, K, ks0 * 32 + k8 * 8);
     }
-    if (X.norm_w) {
+    const bool one_row = rows == 1 && nitems <= 128;             // batch-1 decode: the row's items sit in waves 0 and 1
+    float rs_one = 0.f;
+    if (X.norm_w && one_row) {
+        // sum of squares straight from the registers: DPP wave sums, two partials through LDS, ONE barrier
+        float sq = ((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) + ((v0[4] * v0[4] + v0[5] * v0[5]) + (v0[6] * v0[6] + v0[7] * v0[7]));
+        if (wave < 2) { sq = wave_sum(sq); if (lane == 0) rstd[wave] = sq; }
+        __syncthreads();
+        rs_one = rsqrtf((rstd[0] + rstd[1]) / (float)K + X.eps);
+    } else if (X.norm_w) {
         for (int it = tid; it < nitems; it += nthreads) {
             f32x8 v = v0;
             if (it != tid) { const int r = it / k8n, k8 = it - r * k8n; v = sk_load_x<ATT>(X, r, K, ks0 * 32 + k8 * 8); }
@@ -158,7 +166,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         f32x8 v = v0;
         if (it != tid) v = sk_load_x<ATT>(X, r, K, k);
         if (X.x_out && blockIdx.x == 0) *reinterpret_cast<f32x8*>(X.x_out + (size_t)r * K + k) = v;
-        if (X.norm_w) v = *reinterpret_cast<const f32x8*>(X.norm_w + k) * (v * rstd[r]);
+        if (X.norm_w) v = *reinterpret_cast<const f32x8*>(X.norm_w + k) * (v * (one_row ? rs_one : rstd[r]));
         bf16x8 hi, lo;
         split8(v, hi, lo);
         const int s = k8 >> 2, hq = k8 & 3, t = r >> 4;
@@ -186,11 +194,12 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
             }
         }
     }
-    __syncthreads();   // everyone is done with the x stage; reuse it for the cross-wave reduction
-
-    // 4. reduce the NWK K-slices through LDS, leave the tile in res[feature][row]
-    f32x4* red = reinterpret_cast<f32x4*>(smem);                                    // [NWK][NWR][NB][64]
-    float* res = reinterpret_cast<float*>(smem + NWK * NWR * NB * 1024);            // [NWR*16][NB*16+1]
+    // 4. reduce the NWK K-slices through LDS, leave the tile in res[feature][row].  The reduction buffers sit BEHIND the x
+    //    stage (not on top of it) for up to 16 rows, so no barrier is needed between the MFMAs and the partial-sum writes.
+    if (NB > 1) __syncthreads();                                  // 32-row stage is too large to keep: reuse it (x stage fully read)
+    char* rbase = NB > 1 ? smem : smem + sk_xstage_bytes<NB>(nks) + 32 * sizeof(float);
+    f32x4* red = reinterpret_cast<f32x4*>(rbase);                                   // [NWK][NWR][NB][64]
+    float* res = reinterpret_cast<float*>(rbase + NWK * NWR * NB * 1024);           // [NWR*16][NB*16+1]
 #pragma unroll
     for (int t = 0; t < NB; t++) red[((wk * NWR + wr) * NB + t) * 64 + lane] = acc[t];
     __syncthreads();
@@ -245,5 +254,5 @@ template <int NB, int NWR, int NWK>
 static inline size_t skinny_smem_bytes(int nks_block) {
     const size_t xs = (size_t)nks_block * NB * 2 * 1024 + 32 * sizeof(float);
     const size_t rr = (size_t)NWK * NWR * NB * 1024 + (size_t)NWR * 16 * (NB * 16 + 1) * sizeof(float);
-    return xs > rr ? xs : rr;
+    return NB > 1 ? (xs > rr ? xs : rr) : xs + rr + 1024;        // NB == 1: reduction buffers behind the x stage
 }
