@@ -115,12 +115,24 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)pc * 1024),
                                              (__attribute__((address_space(3))) void*)(smem + pc * 1024), 16, 0, 0);
     }
-    // 1. every weight fragment of this wave in flight
+    // 1. this thread's first operand item, THEN every weight fragment of the wave.  Loads return in issue order per wave: with the
+    //    (L2-resident, tiny) operand issued first it arrives after one L2 round trip and the fold / RMS / split below runs while the
+    //    weight stream is still in flight; issued after the weights it would only arrive once the whole stream has landed.
+    const int k8n = nks * 4;
+    const int nitems = rows * k8n;
+    f32x8 v0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!PRE && tid < nitems) {
+        const int r = tid / k8n, k8 = tid - r * k8n;
+        v0 = sk_load_x<ATT>(X, r, K, ks0 * 32 + k8 * 8);
+    }
     const s16x8* wp = reinterpret_cast<const s16x8*>(W) + ((size_t)tile * KS + w0) * 64 + lane;
     s16x8 abuf[MAXKS];
+    // exactly MAXKS loads per wave, unconditionally (slots beyond the wave's share re-read its last fragment): with a
+    // compile-time count hipcc can wait for the OLDER operand loads with a counted vmcnt and leave the weight stream in flight;
+    // a data-dependent number of loads forces vmcnt(0) and serialises the prologue behind the whole stream
+    const int nw = w1 - w0;
 #pragma unroll
-    for (int i = 0; i < MAXKS; i++)
-        if (w0 + i < w1) abuf[i] = __builtin_nontemporal_load(wp + (size_t)i * 64);
+    for (int i = 0; i < MAXKS; i++) abuf[i] = __builtin_nontemporal_load(wp + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 64);
 
   if (PRE) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -128,15 +140,8 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
   } else {
     // 2. fold / normalise / split the block's x slice [ks0*32, ks1*32) into LDS (B-operand order)
     //    item = (row r, group of 8 columns); the first item of every thread stays in registers across the RMS barrier
-    const int k8n = nks * 4;
-    const int nitems = rows * k8n;
     float* isq = reinterpret_cast<float*>(smem);                                  // [nitems] (aliases the x stage)
     float* rstd = reinterpret_cast<float*>(smem + sk_xstage_bytes<NB>(nks));      // [32]
-    f32x8 v0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (tid < nitems) {
-        const int r = tid / k8n, k8 = tid - r * k8n;
-        v0 = sk_load_x<ATT>(X, r, K, ks0 * 32 + k8 * 8);
-    }
     const bool one_row = rows == 1 && nitems <= 128;             // batch-1 decode: the row's items sit in waves 0 and 1
     float rs_one = 0.f;
     if (X.norm_w && one_row) {
