@@ -116,11 +116,13 @@ struct AttnArgs {
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float qs[8 * 64];
     __shared__ __attribute__((aligned(16))) float ps[8 * AT_KB];
+    __shared__ __attribute__((aligned(16))) float po_s[4 * 8 * 64];      // PV partials [key quarter][head][dim]
     __shared__ float run_m[8], run_l[8], tile_scale[8];
     const int rep = a.n_q / a.n_kv;                               // <= 8
     const int g = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit, r = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int d = tid & 63, hq = tid >> 6;                        // PV: thread = (dim, head pair {hq, hq + 4})
+    // PV: thread = (4 dims d4, key quarter kq of 16 keys, head pair {w, w + 4}): V rows are read as float4 (16 loads per thread)
+    const int d4 = tid & 15, kq = (tid >> 4) & 3;
     const int key_t = tid >> 2, qd = tid & 3;                     // scores: thread = (key, 16-dim quarter)
     const int j_lo = sp * a.keys_per_split;
     // The slot is known without touching memory (decode: slot = row), so the first tile's K / V / q loads are issued BEFORE the
@@ -130,13 +132,13 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     const float* K = a.kc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
     const float* V = a.vc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
     f32x4 kk[4];
-    float vv[AT_KB];
+    f32x4 vv[16];
     {
         const int jk = min(j_lo + key_t, a.max_pos - 1);
 #pragma unroll
         for (int i = 0; i < 4; i++) kk[i] = *reinterpret_cast<const f32x4*>(K + (size_t)jk * 64 + qd * 16 + 4 * i);
 #pragma unroll
-        for (int k = 0; k < AT_KB; k++) vv[k] = V[(size_t)min(j_lo + k, a.max_pos - 1) * 64 + d];
+        for (int k = 0; k < 16; k++) vv[k] = *reinterpret_cast<const f32x4*>(V + (size_t)min(j_lo + kq * 16 + k, a.max_pos - 1) * 64 + d4 * 4);
     }
     for (int i = tid; i < rep * 64; i += 256) qs[i] = a.q[(size_t)r * a.n_q * 64 + g * rep * 64 + i];
     int seq, pos;
@@ -147,7 +149,8 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     float* ml = a.part_ml + (((size_t)sp * SK_ROWS_CAP + r) * a.n_q + g * rep) * 2;
     if (j_lo >= j_hi) return;                                     // empty split: the consumer stops at part_cnt
     if (tid < 8) { run_m[tid] = -INFINITY; run_l[tid] = 0.f; }
-    float o0 = 0.f, o1 = 0.f;
+    const int h0 = w, h1 = w + 4 < rep ? w + 4 : w;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
     for (int j0 = j_lo; j0 < j_hi; j0 += AT_KB) {
         const int n = min(AT_KB, j_hi - j0);
         if (j0 != j_lo) {                                         // later tiles of a long split: plain bounded loads
@@ -155,10 +158,11 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
             for (int i = 0; i < 4; i++)
                 kk[i] = key_t < n ? *reinterpret_cast<const f32x4*>(K + (size_t)(j0 + key_t) * 64 + qd * 16 + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < AT_KB; k++) vv[k] = k < n ? V[(size_t)(j0 + k) * 64 + d] : 0.f;
+            for (int k = 0; k < 16; k++)
+                vv[k] = kq * 16 + k < n ? *reinterpret_cast<const f32x4*>(V + (size_t)(j0 + kq * 16 + k) * 64 + d4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         } else {
 #pragma unroll
-            for (int k = 0; k < AT_KB; k++) vv[k] = k < n ? vv[k] : 0.f;     // speculative rows beyond the length may hold anything
+            for (int k = 0; k < 16; k++) vv[k] = kq * 16 + k < n ? vv[k] : (f32x4){0.f, 0.f, 0.f, 0.f};     // speculative rows may hold anything
         }
         __syncthreads();                                          // qs ready; previous tile's ps consumed
 #pragma unroll
@@ -191,22 +195,24 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         }
         __syncthreads();
         {
-            const int h0 = hq, h1 = hq + 4 < rep ? hq + 4 : hq;
             o0 *= tile_scale[h0];
             o1 *= tile_scale[h1];
 #pragma unroll
-            for (int k4 = 0; k4 < AT_KB / 4; k4++) {
-                const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[h0 * AT_KB + 4 * k4]);
-                const f32x4 pb = *reinterpret_cast<const f32x4*>(&ps[h1 * AT_KB + 4 * k4]);
+            for (int k4 = 0; k4 < 4; k4++) {
+                const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[h0 * AT_KB + kq * 16 + 4 * k4]);
+                const f32x4 pb = *reinterpret_cast<const f32x4*>(&ps[h1 * AT_KB + kq * 16 + 4 * k4]);
 #pragma unroll
                 for (int e = 0; e < 4; e++) { o0 += pa[e] * vv[4 * k4 + e]; o1 += pb[e] * vv[4 * k4 + e]; }
             }
         }
     }
-    float* po = a.part_o + ((size_t)sp * SK_ROWS_CAP + r) * a.n_q * 64 + (size_t)g * rep * 64;
-    if (hq < rep) po[hq * 64 + d] = o0;
-    if (hq + 4 < rep) po[(hq + 4) * 64 + d] = o1;
+    // sum the four key quarters through LDS, then store the unnormalised partial output
+    *reinterpret_cast<f32x4*>(&po_s[(kq * 8 + w) * 64 + d4 * 4]) = o0;
+    if (w + 4 < rep) *reinterpret_cast<f32x4*>(&po_s[(kq * 8 + w + 4) * 64 + d4 * 4]) = o1;
     __syncthreads();
+    float* po = a.part_o + ((size_t)sp * SK_ROWS_CAP + r) * a.n_q * 64 + (size_t)g * rep * 64;
+    for (int e = tid; e < rep * 64; e += 256)
+        po[e] = (po_s[e] + po_s[8 * 64 + e]) + (po_s[2 * 8 * 64 + e] + po_s[3 * 8 * 64 + e]);
     if (tid < rep) { ml[tid * 2] = run_m[tid]; ml[tid * 2 + 1] = run_l[tid]; }
 }
 
