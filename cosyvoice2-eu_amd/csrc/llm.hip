@@ -61,18 +61,24 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int head = blockIdx.x >> 1, half = blockIdx.x & 1;   // heads: n_q query, then n_kv key, then n_kv value
     const int wr = (threadIdx.x >> 6) % 2;
-    // epilogue operands of this thread's first element (position, bias, RoPE table entries): fetched now, so the dependent
-    // chain state -> pos -> cos/sin is hidden under the weight stream instead of trailing the GEMV
+    // epilogue operands of this thread's first element.  The position is requested FIRST (it returns first), the bias with it;
+    // the RoPE table entries depend on the position and are requested from the hook, i.e. after the operand and weight loads
+    // have been issued: the chain state -> pos -> cos/sin then runs under the weight stream and delays nothing.
     const bool rot = head < a.n_q + a.n_kv;
+    const bool own = threadIdx.x < a.rows * 32;
+    const int f0 = half * 16 + ((threadIdx.x >> 4) & 1) * 32 + (threadIdx.x & 15);
     int seq0 = 0, pos0 = 0;
-    float pb0 = 0.f, pb1 = 0.f, pc0 = 1.f, ps0 = 0.f;
-    if (threadIdx.x < a.rows * 32) {
-        const int e = threadIdx.x, r = e >> 5, w = (e >> 4) & 1, i16 = e & 15, f = half * 16 + w * 32 + i16;
-        a.rm.get(r, seq0, pos0);
-        pb0 = a.bias[head * 64 + f];
-        if (rot) { pb1 = a.bias[head * 64 + (f ^ 32)]; pc0 = a.cosT[pos0 * 32 + (f & 31)]; ps0 = a.sinT[pos0 * 32 + (f & 31)]; }
-    }
-    float* res = skinny_core<NB, 2, 4, 8, false, PRE>(a.W, head * 4 + half + 2 * wr, a.KS, a.rows, a.K, a.X, smem);
+    float pb0, pb1, pc0, ps0;
+    // all of these are issued by every thread (row clamped), branch-free: a conditional load would make the number of loads in
+    // flight unknown at compile time and turn the counted waits on the operand into waits on the weight stream
+    a.rm.get(min((int)threadIdx.x >> 5, a.rows - 1), seq0, pos0);
+    pb0 = a.bias[head * 64 + f0];
+    pb1 = a.bias[head * 64 + (f0 ^ 32)];
+    auto hook = [&]() {
+        pc0 = a.cosT[pos0 * 32 + (f0 & 31)];
+        ps0 = a.sinT[pos0 * 32 + (f0 & 31)];
+    };
+    float* res = skinny_core<NB, 2, 4, 8, false, PRE>(a.W, head * 4 + half + 2 * wr, a.KS, a.rows, a.K, a.X, smem, hook);
     const int ld = NB * 16 + 1;
     for (int e = threadIdx.x; e < a.rows * 32; e += blockDim.x) {
         const int r = e >> 5, w = (e >> 4) & 1, i16 = e & 15;
@@ -217,11 +223,11 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 }
 
 // split combine as its own pass (used when many rows share a launch: inside the O-projection every block would redo it)
-struct CombArgs { const float* part_o; const float* part_ml; const int* part_cnt; float* out; int K; };
+struct CombArgs { const float* part_o; const float* part_ml; const int* part_cnt; float* out; int K; int nsplit; };
 __global__ __launch_bounds__(128) void k_attn_combine(CombArgs a) {
     const int r = blockIdx.x, k = threadIdx.x * 8;
     if (k >= a.K) return;
-    SkinnyX X{nullptr, a.part_o, 0, nullptr, 0.f, nullptr, a.part_ml, a.part_cnt};
+    SkinnyX X{nullptr, a.part_o, a.nsplit, nullptr, 0.f, nullptr, a.part_ml, a.part_cnt};
     const f32x8 v = sk_load_x<true>(X, r, a.K, k);
     *reinterpret_cast<f32x8*>(a.out + (size_t)r * a.K + k) = v;
 }
@@ -253,6 +259,18 @@ struct GateUpArgs {
     float* h;                                   // [rows][inter]
     uint16_t* hpre;                             // PRE kernels: h written as prepared hi/lo planes for the down projection instead
 };
+#ifdef CV2_STAMPS
+__global__ void k_stamp_set(int v) { if (threadIdx.x == 0) g_stamp_slot = v < 0 ? g_stamp_slot + 1 : v; }
+#define STAMP_SET(v) hipLaunchKernelGGL(k_stamp_set, dim3(1), dim3(64), 0, s, v)
+extern "C" int cv2_debug_stamps(unsigned long long* out_host) {
+    CV2_HIP(hipDeviceSynchronize());
+    CV2_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 8));
+    return 0;
+}
+#endif
+#ifndef CV2_STAMPS
+#define STAMP_SET(v) do { } while (0)
+#endif
 template <int NB, bool PRE = false>
 __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -859,7 +877,9 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             a.cosT = h->w.rope_cos; a.sinT = h->w.rope_sin;
             a.q = h->q; a.kc = h->kc + l * cache_l; a.vc = h->vc + l * cache_l; a.max_pos = d.max_pos; a.rm = rm;
             const size_t sm = skinny_smem_bytes<NB, 2, 4>(KSH);
+            STAMP_SET(l == 1 ? 0 : 100);
             hipLaunchKernelGGL(k_qkv<NB>, dim3(2 * (d.n_q + 2 * d.n_kv), 1), dim3(512), sm, s, a);
+            STAMP_SET(-1);
         }
         {
             AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm};
@@ -868,12 +888,13 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
         if (rows <= 4) {     // few rows: combine the key splits while loading the O-projection operand (saves a launch)
             StoreArgs a{};
             a.W = L.wo; a.bias = nullptr;
-            a.X = SkinnyX{nullptr, h->att, 0, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt};
+            a.X = SkinnyX{nullptr, h->att, h->nsplit, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt};
             a.KS = d.n_q * 64 / 32; a.rows = rows; a.K = d.n_q * 64; a.N = H; a.out = h->o;
             const size_t sm = skinny_smem_bytes<NB, 1, 4>(a.KS);
             hipLaunchKernelGGL((k_store<NB, 8, true>), dim3(H / 16, 1), dim3(256), sm, s, a);
+            STAMP_SET(-1);
         } else {             // many rows: one combine pass, then a plain O-projection
-            CombArgs c{h->att, h->att_ml, h->att_cnt, h->attc, d.n_q * 64};
+            CombArgs c{h->att, h->att_ml, h->att_cnt, h->attc, d.n_q * 64, h->nsplit};
             hipLaunchKernelGGL(k_attn_combine, dim3(rows), dim3(128), 0, s, c);
             StoreArgs a{};
             a.W = L.wo; a.bias = nullptr;
@@ -890,6 +911,7 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             a.KS = KSH; a.rows = rows; a.K = H; a.inter = d.inter; a.h = h->hbuf;
             const size_t sm = skinny_smem_bytes<NB, 2, 4>(KSH);
             hipLaunchKernelGGL(k_gateup<NB>, dim3(d.inter / 16, 1), dim3(512), sm, s, a);
+            STAMP_SET(-1);
         }
         {
             StoreArgs a{};
@@ -898,6 +920,7 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             a.KS = d.inter / 32; a.rows = rows; a.K = d.inter; a.N = H; a.out = h->parts;
             const size_t sm = skinny_smem_bytes<NB, 1, 4>(cdiv(a.KS, SK_MAXNP) + 1);
             hipLaunchKernelGGL((k_store<NB, 10>), dim3(H / 16, SK_MAXNP), dim3(256), sm, s, a);
+            STAMP_SET(-1);
         }
         xcur = x2;
         np = SK_MAXNP;
@@ -944,7 +967,7 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
             AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm};
             hipLaunchKernelGGL(k_attn, dim3(d.n_kv * h->nsplit, rows), dim3(256), 0, s, a);
         }
-        prep(SkinnyX{nullptr, h->att, 0, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt}, NQ, true);
+        prep(SkinnyX{nullptr, h->att, h->nsplit, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt}, NQ, true);
         {
             StoreArgs a{};
             a.W = L.wo; a.X = pre; a.KS = NQ / 32; a.rows = rows; a.K = NQ; a.N = H; a.out = h->o;

@@ -14,6 +14,20 @@
 #include "common.h"
 
 #define SK_ROWS_CAP 32    // row capacity of partial buffers
+
+// Diagnostic build only (-DCV2_STAMPS, tools/dbg_stamps.py): wave 0 of block 0 records s_memtime at the phase boundaries of
+// skinny_core into g_stamps[slot][8]; no output value depends on them and the product build contains none of this.
+#ifdef CV2_STAMPS
+__device__ unsigned long long g_stamps[64][8];
+__device__ int g_stamp_slot;
+#define SK_STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define SK_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_[i] = t_; } while (0)
+#define SK_STAMP_FLUSH do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && g_stamp_slot < 64) for (int i_ = 0; i_ < 8; i_++) g_stamps[g_stamp_slot][i_] = st_[i_]; } while (0)
+#else
+#define SK_STAMP_DECL
+#define SK_STAMP(i) do { } while (0)
+#define SK_STAMP_FLUSH do { } while (0)
+#endif
 #define SK_MAXNP 4        // partial buffers a consumer can fold
 
 typedef __attribute__((ext_vector_type(8))) float f32x8;
@@ -30,7 +44,7 @@ struct SkinnyX {
     // split-key attention combine (flash-decoding): x[r][k] = sum_s w_s o_s[r][k] / sum_s w_s l_s, w_s = exp(m_s - max m),
     // o_s = parts[s][r][k] unnormalised, (m_s, l_s) = att_ml[((s * SK_ROWS_CAP + r) * (K / 64) + k / 64) * 2 + {0, 1}]
     const float* att_ml;
-    const int* att_cnt;   // != null selects this mode (base / np unused): [SK_ROWS_CAP] non-empty splits per row
+    const int* att_cnt;   // != null selects this mode (base unused, np = split slots): [SK_ROWS_CAP] non-empty splits per row
     // PRE kernels: the operand already folded / normalised / split by k_prep, in LDS B-operand order
     // [K/32][NB=2][hi, lo][1 KiB]; the prologue is a straight copy of the block's K slice
     const uint16_t* pre;
@@ -42,67 +56,98 @@ __device__ __forceinline__ void split8(const f32x8 v, bf16x8& hi, bf16x8& lo) {
     lo = __builtin_convertvector(v - back, bf16x8);
 }
 
+// Operand loads come in two halves so that callers can put other loads between them: sk_issue_x only issues (no value is
+// consumed, so no wait is emitted), sk_finish_x folds what arrived.
 template <bool ATT>
-__device__ __forceinline__ f32x8 sk_load_x(const SkinnyX& X, int r, int K, int k) {
-    if (ATT) {
-        const int nq = K >> 6, hd = k >> 6;
-        float mv[SK_MAXSPLIT], lv[SK_MAXSPLIT];
-        f32x8 ov[SK_MAXSPLIT];
-        float M = -INFINITY;
-        // every split slot is loaded unconditionally, together with the split count: nothing waits on the count before issuing
-        // (slots beyond it hold stale values and are only masked out below)
-        const int ns = X.att_cnt[r];
+struct SkRaw;
+template <>
+struct SkRaw<false> { f32x8 v; f32x8 p[SK_MAXNP]; };
+template <>
+struct SkRaw<true> { float mv[SK_MAXSPLIT], lv[SK_MAXSPLIT]; f32x8 ov[SK_MAXSPLIT]; int ns; };
+
+__device__ __forceinline__ void sk_issue_x(const SkinnyX& X, int r, int K, int k, SkRaw<true>& o) {
+    const int nq = K >> 6, hd = k >> 6;
+    // every split slot is loaded unconditionally, together with the split count: nothing waits on the count before issuing
+    // (slots beyond it hold stale values and are only masked out in sk_finish_x).  Addresses are a uniform base (scalar
+    // registers) plus ONE 32-bit per-thread offset shared by all slots: the issue phase is bound by instruction count.
+    o.ns = X.att_cnt[r];
+    const unsigned off_ml = (unsigned)(r * nq + hd) * 2u, off_o = (unsigned)(r * K + k);
 #pragma unroll
-        for (int s = 0; s < SK_MAXSPLIT; s++) {
-            const float* ml = X.att_ml + (((size_t)s * SK_ROWS_CAP + r) * nq + hd) * 2;
-            mv[s] = ml[0]; lv[s] = ml[1];
-            ov[s] = *reinterpret_cast<const f32x8*>(X.parts + ((size_t)s * SK_ROWS_CAP + r) * K + k);
+    for (int s = 0; s < SK_MAXSPLIT; s++) {
+        if (s < X.np) {           // np = number of split slots the engine was created with (uniform): older than the weight loads,
+            const float* ml = X.att_ml + (size_t)s * SK_ROWS_CAP * nq * 2;      // so a run-time count here costs no wait precision
+            const float2 mlv = *reinterpret_cast<const float2*>(ml + off_ml);
+            o.mv[s] = mlv.x; o.lv[s] = mlv.y;
+            o.ov[s] = *reinterpret_cast<const f32x8*>(X.parts + (size_t)s * SK_ROWS_CAP * K + off_o);
         }
-#pragma unroll
-        for (int s = 0; s < SK_MAXSPLIT; s++) if (s < ns) M = fmaxf(M, mv[s]);
-        f32x8 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float den = 0.f;
-#pragma unroll
-        for (int s = 0; s < SK_MAXSPLIT; s++) {
-            if (s < ns) {
-                const float w = __expf(mv[s] - M);
-                den += w * lv[s];
-                acc += w * ov[s];
-            }
-        }
-        return acc * (1.f / den);
     }
-    f32x8 v = *reinterpret_cast<const f32x8*>(X.base + (size_t)r * K + k);
+}
+__device__ __forceinline__ f32x8 sk_finish_x(const SkinnyX& X, const SkRaw<true>& o) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < SK_MAXSPLIT; s++) if (s < o.ns) M = fmaxf(M, o.mv[s]);
+    f32x8 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+#pragma unroll
+    for (int s = 0; s < SK_MAXSPLIT; s++) {
+        if (s < o.ns) {
+            const float w = __expf(o.mv[s] - M);
+            den += w * o.lv[s];
+            acc += w * o.ov[s];
+        }
+    }
+    return acc * (1.f / den);
+}
+__device__ __forceinline__ void sk_issue_x(const SkinnyX& X, int r, int K, int k, SkRaw<false>& o) {
+    const unsigned off = (unsigned)(r * K + k);
+    o.v = *reinterpret_cast<const f32x8*>(X.base + off);
     if (X.np > 0) {
-        f32x8 p[SK_MAXNP];
 #pragma unroll
         for (int i = 0; i < SK_MAXNP; i++) {             // all partial loads in flight together; fixed summation order
             const int ii = i < X.np ? i : X.np - 1;
-            p[i] = *reinterpret_cast<const f32x8*>(X.parts + ((size_t)ii * SK_ROWS_CAP + r) * K + k);
+            o.p[i] = *reinterpret_cast<const f32x8*>(X.parts + (size_t)ii * SK_ROWS_CAP * K + off);
         }
+    }
+}
+__device__ __forceinline__ f32x8 sk_finish_x(const SkinnyX& X, const SkRaw<false>& o) {
+    f32x8 v = o.v;
+    if (X.np > 0) {
 #pragma unroll
         for (int i = 0; i < SK_MAXNP; i++)
-            if (i < X.np) v += p[i];
+            if (i < X.np) v += o.p[i];
     }
     return v;
 }
+template <bool ATT>
+__device__ __forceinline__ f32x8 sk_load_x(const SkinnyX& X, int r, int K, int k) {
+    SkRaw<ATT> raw;
+    sk_issue_x(X, r, K, k, raw);
+    return sk_finish_x(X, raw);
+}
+struct SkNoHook { __device__ __forceinline__ void operator()() const {} };
 
 template <int NB>
 __device__ __host__ constexpr int sk_xstage_bytes(int nks) { return nks * NB * 2 * 1024; }
 
 // Leaves the reduced tile in LDS: res[NWR*16 features][NB*16+1 rows]; returns its address.
 // `tile` = this wave's 16-feature row tile of W.
-template <int NB, int NWR, int NWK, int MAXKS, bool ATT = false, bool PRE = false>
+// `issued` runs right after the last weight load has been issued and before anything is consumed: the place for a caller's
+// dependent loads (k_qkv: position -> RoPE table) that must not delay the stream.
+template <int NB, int NWR, int NWK, int MAXKS, bool ATT = false, bool PRE = false, class HOOK = SkNoHook>
 __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, int tile, int KS, int rows, int K,
-                                               const SkinnyX& X, char* smem) {
+                                               const SkinnyX& X, char* smem, HOOK issued = HOOK()) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // wave-uniform values are made provably uniform (readfirstlane): the weight addresses then live in scalar registers and the
+    // loads use the saddr + 32-bit lane offset form instead of per-lane 64-bit address arithmetic
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    tile = __builtin_amdgcn_readfirstlane(tile);
     const int wr = wave % NWR;
     const int wk = wave / NWR;
     constexpr int nthreads = 64 * NWR * NWK;
-    const int ks0 = (int)(((long)KS * blockIdx.y) / gridDim.y);
-    const int ks1 = (int)(((long)KS * (blockIdx.y + 1)) / gridDim.y);
+    // 32-bit on purpose (KS * gridDim.y is tiny): a 64-bit division is ~150 scalar instructions in front of the first load
+    const int ks0 = gridDim.y == 1 ? 0 : (int)(((unsigned)KS * blockIdx.y) / gridDim.y);
+    const int ks1 = gridDim.y == 1 ? KS : (int)(((unsigned)KS * (blockIdx.y + 1)) / gridDim.y);
     const int nks = ks1 - ks0;
     const int w0 = ks0 + (nks * wk) / NWK;
     const int w1 = ks0 + (nks * (wk + 1)) / NWK;
@@ -115,24 +160,40 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)pc * 1024),
                                              (__attribute__((address_space(3))) void*)(smem + pc * 1024), 16, 0, 0);
     }
+    SK_STAMP_DECL;
+    SK_STAMP(0);
     // 1. this thread's first operand item, THEN every weight fragment of the wave.  Loads return in issue order per wave: with the
     //    (L2-resident, tiny) operand issued first it arrives after one L2 round trip and the fold / RMS / split below runs while the
     //    weight stream is still in flight; issued after the weights it would only arrive once the whole stream has landed.
     const int k8n = nks * 4;
     const int nitems = rows * k8n;
+    // item -> row without an integer division (~30 instructions): (2 it + 1) / (2 k8n) is never within 8e-4 of an integer
+    const float inv2k = 0.5f * __builtin_amdgcn_rcpf((float)k8n);
+    auto row_of = [rows, inv2k](int it) { return rows == 1 ? 0 : (int)((float)(2 * it + 1) * inv2k); };
     f32x8 v0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (!PRE && tid < nitems) {
-        const int r = tid / k8n, k8 = tid - r * k8n;
-        v0 = sk_load_x<ATT>(X, r, K, ks0 * 32 + k8 * 8);
+    SkRaw<ATT> raw0;
+    const bool has0 = !PRE && tid < nitems;
+    const int r0 = row_of(tid), c0 = ks0 * 32 + (tid - r0 * k8n) * 8;
+    f32x8 g0;                                                     // RMSNorm weight of the item (unused without norm)
+    if (has0) {
+        sk_issue_x(X, r0, K, c0, raw0);
+        // unconditional (a valid dummy address without norm): a conditional load would make the in-flight count unknown
+        g0 = *reinterpret_cast<const f32x8*>(X.norm_w ? X.norm_w + c0 : (ATT ? X.parts : X.base) + c0);
     }
-    const s16x8* wp = reinterpret_cast<const s16x8*>(W) + ((size_t)tile * KS + w0) * 64 + lane;
+    const char* wbase = reinterpret_cast<const char*>(W) + ((size_t)tile * KS + w0) * 1024;
+    const unsigned wlane = lane * 16;
     s16x8 abuf[MAXKS];
     // exactly MAXKS loads per wave, unconditionally (slots beyond the wave's share re-read its last fragment): with a
     // compile-time count hipcc can wait for the OLDER operand loads with a counted vmcnt and leave the weight stream in flight;
     // a data-dependent number of loads forces vmcnt(0) and serialises the prologue behind the whole stream
     const int nw = w1 - w0;
 #pragma unroll
-    for (int i = 0; i < MAXKS; i++) abuf[i] = __builtin_nontemporal_load(wp + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 64);
+    for (int i = 0; i < MAXKS; i++)
+        abuf[i] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wbase + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024 + wlane));
+    // the scheduler must not pull the operand fold (and its waits) above the weight loads, nor sink the loads below it
+    __builtin_amdgcn_sched_barrier(0);
+    issued();
+    if (has0) v0 = sk_finish_x(X, raw0);
 
   if (PRE) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -142,6 +203,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     //    item = (row r, group of 8 columns); the first item of every thread stays in registers across the RMS barrier
     float* isq = reinterpret_cast<float*>(smem);                                  // [nitems] (aliases the x stage)
     float* rstd = reinterpret_cast<float*>(smem + sk_xstage_bytes<NB>(nks));      // [32]
+    SK_STAMP(1);                                                 // loads issued
     const bool one_row = rows == 1 && nitems <= 128;             // batch-1 decode: the row's items sit in waves 0 and 1
     float rs_one = 0.f;
     if (X.norm_w && one_row) {
@@ -149,11 +211,12 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         float sq = ((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) + ((v0[4] * v0[4] + v0[5] * v0[5]) + (v0[6] * v0[6] + v0[7] * v0[7]));
         if (wave < 2) { sq = wave_sum(sq); if (lane == 0) rstd[wave] = sq; }
         __syncthreads();
+        SK_STAMP(2);                                             // operand arrived + sum of squares exchanged
         rs_one = rsqrtf((rstd[0] + rstd[1]) / (float)K + X.eps);
     } else if (X.norm_w) {
         for (int it = tid; it < nitems; it += nthreads) {
             f32x8 v = v0;
-            if (it != tid) { const int r = it / k8n, k8 = it - r * k8n; v = sk_load_x<ATT>(X, r, K, ks0 * 32 + k8 * 8); }
+            if (it != tid) { const int r = row_of(it), k8 = it - r * k8n; v = sk_load_x<ATT>(X, r, K, ks0 * 32 + k8 * 8); }
             isq[it] = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
         }
         __syncthreads();
@@ -166,12 +229,12 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         __syncthreads();
     }
     for (int it = tid; it < nitems; it += nthreads) {
-        const int r = it / k8n, k8 = it - r * k8n;
+        const int r = row_of(it), k8 = it - r * k8n;
         const int k = ks0 * 32 + k8 * 8;
-        f32x8 v = v0;
-        if (it != tid) v = sk_load_x<ATT>(X, r, K, k);
-        if (X.x_out && blockIdx.x == 0) *reinterpret_cast<f32x8*>(X.x_out + (size_t)r * K + k) = v;
-        if (X.norm_w) v = *reinterpret_cast<const f32x8*>(X.norm_w + k) * (v * (one_row ? rs_one : rstd[r]));
+        f32x8 v = v0, g = g0;
+        if (it != tid) { v = sk_load_x<ATT>(X, r, K, k); if (X.norm_w) g = *reinterpret_cast<const f32x8*>(X.norm_w + k); }
+        if (X.x_out && blockIdx.x == 0) *reinterpret_cast<f32x8*>(X.x_out + (unsigned)(r * K + k)) = v;
+        if (X.norm_w) v = g * (v * (one_row ? rs_one : rstd[r]));
         bf16x8 hi, lo;
         split8(v, hi, lo);
         const int s = k8 >> 2, hq = k8 & 3, t = r >> 4;
@@ -182,6 +245,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     __syncthreads();
   }
 
+    SK_STAMP(3);                                                 // B operand staged in LDS
     // 3. MFMAs: A = weights (registers), B = x hi / lo (LDS)
     f32x4 acc[NB];
 #pragma unroll
@@ -199,6 +263,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
             }
         }
     }
+    SK_STAMP(4);                                                 // weights arrived, MFMAs issued
     // 4. reduce the NWK K-slices through LDS, leave the tile in res[feature][row].  The reduction buffers sit BEHIND the x
     //    stage (not on top of it) for up to 16 rows, so no barrier is needed between the MFMAs and the partial-sum writes.
     if (NB > 1) __syncthreads();                                  // 32-row stage is too large to keep: reuse it (x stage fully read)
@@ -221,6 +286,8 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         }
     }
     __syncthreads();
+    SK_STAMP(5);                                                 // tile reduced
+    SK_STAMP_FLUSH;
     return res;
 }
 

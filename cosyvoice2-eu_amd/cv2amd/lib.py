@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcv2amd.so')
+LIB_PATH = os.environ.get('CV2_AMD_LIB') or os.path.join(_HERE, 'libcv2amd.so')   # CV2_AMD_LIB: diagnostic builds (tools/)
 _lib = None
 
 STATE_STRIDE = 16
