@@ -115,111 +115,175 @@ struct AttnArgs {
     int* part_cnt;            // [SK_ROWS_CAP] number of non-empty splits of the row
     int n_q, n_kv, max_pos, nsplit, keys_per_split;
     RowMap rm;
+    int rep;                  // n_q / n_kv (<= 8), passed so that no block divides
 };
 #define AT_KB 64
 // No LDS staging of K or V: thread (key, quarter) keeps its 16 dims of one key row in registers for the scores of all
 // heads of the group, thread (dim, head pair) keeps the V column of the tile in registers; one round of global loads.
-__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+// A split of keys_per_split = 64 NSUB keys is handled by NSUB groups of 256 threads, one 64-key tile each, ALL of whose loads
+// are requested at kernel entry: phase stamps showed every serial tile costing a full memory round trip (~1.5 us), so a
+// 256-key split walked tile by tile took four of them.  The groups' (max, sum, output) triples are merged through LDS.
+template <int NSUB>
+__global__ __launch_bounds__(256 * NSUB) void k_attn(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float qs[8 * 64];
-    __shared__ __attribute__((aligned(16))) float ps[8 * AT_KB];
-    __shared__ __attribute__((aligned(16))) float po_s[4 * 8 * 64];      // PV partials [key quarter][head][dim]
-    __shared__ float run_m[8], run_l[8], tile_scale[8];
-    const int rep = a.n_q / a.n_kv;                               // <= 8
-    const int g = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit, r = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // PV: thread = (4 dims d4, key quarter kq of 16 keys, head pair {w, w + 4}): V rows are read as float4 (16 loads per thread)
-    const int d4 = tid & 15, kq = (tid >> 4) & 3;
-    const int key_t = tid >> 2, qd = tid & 3;                     // scores: thread = (key, 16-dim quarter)
-    const int j_lo = sp * a.keys_per_split;
-    // The slot is known without touching memory (decode: slot = row), so the first tile's K / V / q loads are issued BEFORE the
-    // position is read from the state: state -> position is one L2 round trip, the loads a second one; issued this way they
-    // overlap.  Keys beyond the current length are masked once the position has arrived (the cache rows exist up to max_pos).
+    __shared__ __attribute__((aligned(16))) float ps[NSUB][8 * AT_KB];
+    __shared__ __attribute__((aligned(16))) float po_s[NSUB][8 * 8 * 64];      // PV partials [group][key eighth][head][dim]
+    __shared__ float run_m[NSUB][8], run_l[NSUB][8], tile_scale[NSUB][8];
+    const int rep = a.rep;
+    const int sp = blockIdx.x, g = blockIdx.y, r = blockIdx.z;    // grid = (key split, kv head, row)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 8);     // 64-key tile group of this thread
+    const int t = tid & 255, w = t >> 6;
+    // PV: thread = (4 dims d4, key eighth kq of 8 keys, head set hs of 4 heads): V rows are read as float4 (8 loads per thread,
+    // 32 registers: with 16 waves per block the budget is 128)
+    const int d4 = t & 15, kq = (t >> 4) & 7, hs = t >> 7;
+    const int key_t = t >> 2, qd = t & 3;                         // scores: thread = (key, 16-dim quarter)
+    const int split_lo = sp * a.keys_per_split;
+    SK_STAMP_DECL;
+    SK_STAMP(0);
+    // Request order = arrival order: q (written by the previous kernel, needed first), the position, then K, then V.
+    // The slot is known without touching memory (decode: slot = row), so K / V are requested BEFORE the position is known;
+    // rows beyond the current length exist (the cache is allocated up to max_pos) and are masked once it has arrived.
+    float qreg[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int e = tid + i * 256 * NSUB;
+        qreg[i] = a.q[(size_t)r * a.n_q * 64 + g * rep * 64 + min(e, rep * 64 - 1)];
+    }
+    int seq, pos;
+    a.rm.get(r, seq, pos);
     const int seq_s = a.rm.prefill ? a.rm.seq0 : r;
     const float* K = a.kc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
     const float* V = a.vc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
     f32x4 kk[4];
-    f32x4 vv[16];
+    f32x4 vv[8];
     {
-        const int jk = min(j_lo + key_t, a.max_pos - 1);
+        const int j0 = split_lo + sub * AT_KB;
+        // no clamping (one offset register + immediates): rows past max_pos of the last head run into the slack carve() leaves
+        const unsigned ko = (unsigned)(j0 + key_t) * 64u + qd * 16, vo = (unsigned)(j0 + kq * 8) * 64u + d4 * 4;
 #pragma unroll
-        for (int i = 0; i < 4; i++) kk[i] = *reinterpret_cast<const f32x4*>(K + (size_t)jk * 64 + qd * 16 + 4 * i);
+        for (int i = 0; i < 4; i++) kk[i] = *reinterpret_cast<const f32x4*>(K + ko + 4 * i);
 #pragma unroll
-        for (int k = 0; k < 16; k++) vv[k] = *reinterpret_cast<const f32x4*>(V + (size_t)min(j_lo + kq * 16 + k, a.max_pos - 1) * 64 + d4 * 4);
+        for (int k = 0; k < 8; k++) vv[k] = *reinterpret_cast<const f32x4*>(V + vo + 64 * k);
     }
-    for (int i = tid; i < rep * 64; i += 256) qs[i] = a.q[(size_t)r * a.n_q * 64 + g * rep * 64 + i];
-    int seq, pos;
-    a.rm.get(r, seq, pos);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int e = tid + i * 256 * NSUB;
+        if (e < rep * 64) qs[e] = qreg[i];
+    }
     const int L = pos + 1;
-    const int j_hi = min(L, j_lo + a.keys_per_split);
-    if (blockIdx.x == 0 && tid == 0) a.part_cnt[r] = (L + a.keys_per_split - 1) / a.keys_per_split;
+    const int j_hi = min(L, split_lo + a.keys_per_split);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.part_cnt[r] = (L + a.keys_per_split - 1) / a.keys_per_split;
     float* ml = a.part_ml + (((size_t)sp * SK_ROWS_CAP + r) * a.n_q + g * rep) * 2;
-    if (j_lo >= j_hi) return;                                     // empty split: the consumer stops at part_cnt
-    if (tid < 8) { run_m[tid] = -INFINITY; run_l[tid] = 0.f; }
-    const int h0 = w, h1 = w + 4 < rep ? w + 4 : w;
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = j_lo; j0 < j_hi; j0 += AT_KB) {
-        const int n = min(AT_KB, j_hi - j0);
-        if (j0 != j_lo) {                                         // later tiles of a long split: plain bounded loads
+    SK_STAMP(1);                                                  // loads issued, q and position arrived
+    if (split_lo >= j_hi) return;                                 // empty split: the consumer stops at part_cnt
+    if (t < 8) { run_m[sub][t] = -INFINITY; run_l[sub][t] = 0.f; }
+    f32x4 o[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                kk[i] = key_t < n ? *reinterpret_cast<const f32x4*>(K + (size_t)(j0 + key_t) * 64 + qd * 16 + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; i++) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // every group walks the same (block-uniform) number of tile rounds; a group whose tile is empty only keeps the barriers
+    const int rounds = (j_hi - split_lo + AT_KB * NSUB - 1) / (AT_KB * NSUB);
+    for (int it = 0; it < rounds; it++) {
+        const int j0 = split_lo + (it * NSUB + sub) * AT_KB;
+        const int n = max(0, min(AT_KB, j_hi - j0));
+        if (it > 0) {                                             // later rounds of a long split (max_pos > 16 * 64 NSUB): same loads
+            const unsigned ko = (unsigned)(j0 + key_t) * 64u + qd * 16, vo = (unsigned)(j0 + kq * 8) * 64u + d4 * 4;
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                vv[k] = kq * 16 + k < n ? *reinterpret_cast<const f32x4*>(V + (size_t)(j0 + kq * 16 + k) * 64 + d4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        } else {
+            for (int i = 0; i < 4; i++) kk[i] = *reinterpret_cast<const f32x4*>(K + ko + 4 * i);
 #pragma unroll
-            for (int k = 0; k < 16; k++) vv[k] = kq * 16 + k < n ? vv[k] : (f32x4){0.f, 0.f, 0.f, 0.f};     // speculative rows may hold anything
+            for (int k = 0; k < 8; k++) vv[k] = *reinterpret_cast<const f32x4*>(V + vo + 64 * k);
         }
-        __syncthreads();                                          // qs ready; previous tile's ps consumed
 #pragma unroll
-        for (int h = 0; h < 8; h++) {
-            if (h < rep) {
-                float acc = 0.f;
+        for (int k = 0; k < 8; k++) vv[k] = kq * 8 + k < n ? vv[k] : (f32x4){0.f, 0.f, 0.f, 0.f};     // rows past the length may hold anything
+        __syncthreads();                                          // qs ready; previous round's ps consumed
+        if (it == 0) SK_STAMP(2);
+        if (n > 0) {
+#pragma unroll 1
+            for (int h = 0; h < rep; h++) {
+                {
+                    float acc = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[h * 64 + qd * 16 + 4 * i]);
-                    acc += kk[i][0] * qv[0] + kk[i][1] * qv[1] + kk[i][2] * qv[2] + kk[i][3] * qv[3];
+                    for (int i = 0; i < 4; i++) {
+                        const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[h * 64 + qd * 16 + 4 * i]);
+                        acc += kk[i][0] * qv[0] + kk[i][1] * qv[1] + kk[i][2] * qv[2] + kk[i][3] * qv[3];
+                    }
+                    acc += __shfl_xor(acc, 1);
+                    acc += __shfl_xor(acc, 2);
+                    if (qd == 0) ps[sub][h * AT_KB + key_t] = key_t < n ? acc * 0.125f : -INFINITY;
                 }
-                acc += __shfl_xor(acc, 1);
-                acc += __shfl_xor(acc, 2);
-                if (qd == 0) ps[h * AT_KB + key_t] = key_t < n ? acc * 0.125f : -INFINITY;
             }
         }
         __syncthreads();
-        for (int h = w; h < rep; h += 4) {                       // per head: tile max / exp / sum, merged into the running pair
-            const float s0 = ps[h * AT_KB + lane];
-            const float mt = wave_max(s0);
-            const float mo = run_m[h], mn = fmaxf(mo, mt);
-            const float p0 = __expf(s0 - mn);
-            ps[h * AT_KB + lane] = p0;
-            const float lt = wave_sum(p0);
-            if (lane == 0) {
-                tile_scale[h] = __expf(mo - mn);                   // 0 on the first tile (mo = -inf)
-                run_l[h] = run_l[h] * tile_scale[h] + lt;
-                run_m[h] = mn;
+        if (it == 0) SK_STAMP(3);                                 // K arrived, scores done
+        if (n > 0) {
+            for (int h = w; h < rep; h += 4) {                   // per head: tile max / exp / sum, merged into the running pair
+                const float s0 = ps[sub][h * AT_KB + lane];
+                const float mt = wave_max(s0);
+                const float mo = run_m[sub][h], mn = fmaxf(mo, mt);
+                const float p0 = __expf(s0 - mn);
+                ps[sub][h * AT_KB + lane] = p0;
+                const float lt = wave_sum(p0);
+                if (lane == 0) {
+                    tile_scale[sub][h] = __expf(mo - mn);          // 0 on the first tile (mo = -inf)
+                    run_l[sub][h] = run_l[sub][h] * tile_scale[sub][h] + lt;
+                    run_m[sub][h] = mn;
+                }
             }
         }
         __syncthreads();
-        {
-            o0 *= tile_scale[h0];
-            o1 *= tile_scale[h1];
+        if (it == 0) SK_STAMP(4);                                 // softmax done
+        if (n > 0) {
 #pragma unroll
-            for (int k4 = 0; k4 < 4; k4++) {
-                const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[h0 * AT_KB + kq * 16 + 4 * k4]);
-                const f32x4 pb = *reinterpret_cast<const f32x4*>(&ps[h1 * AT_KB + kq * 16 + 4 * k4]);
+            for (int i = 0; i < 4; i++) {
+                const int h = min(hs * 4 + i, rep - 1);               // a head beyond the group repeats the last one (not stored)
+                o[i] *= tile_scale[sub][h];
 #pragma unroll
-                for (int e = 0; e < 4; e++) { o0 += pa[e] * vv[4 * k4 + e]; o1 += pb[e] * vv[4 * k4 + e]; }
+                for (int k4 = 0; k4 < 2; k4++) {
+                    const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[sub][h * AT_KB + kq * 8 + 4 * k4]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[i] += pa[e] * vv[4 * k4 + e];
+                }
             }
         }
     }
-    // sum the four key quarters through LDS, then store the unnormalised partial output
-    *reinterpret_cast<f32x4*>(&po_s[(kq * 8 + w) * 64 + d4 * 4]) = o0;
-    if (w + 4 < rep) *reinterpret_cast<f32x4*>(&po_s[(kq * 8 + w + 4) * 64 + d4 * 4]) = o1;
+    SK_STAMP(5);                                                  // V arrived, PV done (all rounds)
+    // sum the eight key eighths and merge the groups through LDS, then store the unnormalised partial output
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (hs * 4 + i < rep) *reinterpret_cast<f32x4*>(&po_s[sub][(kq * 8 + hs * 4 + i) * 64 + d4 * 4]) = o[i];
     __syncthreads();
     float* po = a.part_o + ((size_t)sp * SK_ROWS_CAP + r) * a.n_q * 64 + (size_t)g * rep * 64;
-    for (int e = tid; e < rep * 64; e += 256)
-        po[e] = (po_s[e] + po_s[8 * 64 + e]) + (po_s[2 * 8 * 64 + e] + po_s[3 * 8 * 64 + e]);
-    if (tid < rep) { ml[tid * 2] = run_m[tid]; ml[tid * 2 + 1] = run_l[tid]; }
+    for (int e = tid; e < rep * 64; e += 256 * NSUB) {
+        const int h = e >> 6;
+        float M = run_m[0][h];
+#pragma unroll
+        for (int u = 1; u < NSUB; u++) M = fmaxf(M, run_m[u][h]);
+        float o = 0.f;
+#pragma unroll
+        for (int u = 0; u < NSUB; u++) {
+            const float sc = NSUB == 1 ? 1.f : __expf(run_m[u][h] - M);          // 0 for a group that saw no key (max = -inf)
+            const float* pp = &po_s[u][e];
+            o += sc * (((pp[0] + pp[512]) + (pp[1024] + pp[1536])) + ((pp[2048] + pp[2560]) + (pp[3072] + pp[3584])));
+        }
+        po[e] = o;
+    }
+    if (tid < rep) {
+        float M = run_m[0][tid], l = 0.f;
+#pragma unroll
+        for (int u = 1; u < NSUB; u++) M = fmaxf(M, run_m[u][tid]);
+#pragma unroll
+        for (int u = 0; u < NSUB; u++) l += (NSUB == 1 ? 1.f : __expf(run_m[u][tid] - M)) * run_l[u][tid];
+        ml[tid * 2] = M; ml[tid * 2 + 1] = l;
+    }
+    SK_STAMP(6);
+    SK_STAMP_FLUSH;
+}
+static void launch_attn(const AttnArgs& a, int rows, hipStream_t s) {
+    const dim3 grid(a.nsplit, a.n_kv, rows);
+    const int nsub = a.keys_per_split / AT_KB;
+    if (nsub >= 4) hipLaunchKernelGGL(k_attn<4>, grid, dim3(1024), 0, s, a);
+    else if (nsub == 2) hipLaunchKernelGGL(k_attn<2>, grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(k_attn<1>, grid, dim3(256), 0, s, a);
 }
 
 // split combine as its own pass (used when many rows share a launch: inside the O-projection every block would redo it)
@@ -788,6 +852,7 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     char* p;
     p = take(cache); if (h) h->kc = (float*)p;
     p = take(cache); if (h) h->vc = (float*)p;
+    (void)take((size_t)4 * AT_KB * 64 * sizeof(float));      // k_attn requests whole 64-key tiles before it knows the length
     p = take((size_t)32 * d.hidden * 4); if (h) h->xa = (float*)p;
     p = take((size_t)32 * d.hidden * 4); if (h) h->xb = (float*)p;
     p = take((size_t)32 * d.hidden * 4); if (h) h->xnext = (float*)p;
@@ -882,8 +947,9 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             STAMP_SET(-1);
         }
         {
-            AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm};
-            hipLaunchKernelGGL(k_attn, dim3(d.n_kv * h->nsplit, rows), dim3(256), 0, s, a);
+            AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm, d.n_q / d.n_kv};
+            launch_attn(a, rows, s);
+            STAMP_SET(-1);
         }
         if (rows <= 4) {     // few rows: combine the key splits while loading the O-projection operand (saves a launch)
             StoreArgs a{};
@@ -964,8 +1030,8 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
             { const size_t sm = skinny_smem_bytes<2, 2, 4>(KSH); hipLaunchKernelGGL((k_qkv<2, true>), dim3(2 * (d.n_q + 2 * d.n_kv), 1), dim3(512), sm, s, a); }
         }
         {
-            AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm};
-            hipLaunchKernelGGL(k_attn, dim3(d.n_kv * h->nsplit, rows), dim3(256), 0, s, a);
+            AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm, d.n_q / d.n_kv};
+            launch_attn(a, rows, s);
         }
         prep(SkinnyX{nullptr, h->att, h->nsplit, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt}, NQ, true);
         {
