@@ -198,17 +198,17 @@ __global__ __launch_bounds__(256 * NSUB) void k_attn(AttnArgs a) {
         __syncthreads();                                          // qs ready; previous round's ps consumed
         if (it == 0) SK_STAMP(2);
         if (n > 0) {
-#pragma unroll 1
-            for (int h = 0; h < rep; h++) {
-                {
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                if (h < rep) {
                     float acc = 0.f;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[h * 64 + qd * 16 + 4 * i]);
                         acc += kk[i][0] * qv[0] + kk[i][1] * qv[1] + kk[i][2] * qv[2] + kk[i][3] * qv[3];
                     }
-                    acc += __shfl_xor(acc, 1);
-                    acc += __shfl_xor(acc, 2);
+                    acc += dpp_mov_f32<0xB1, 0xf>(0.f, acc);      // quad_perm [1,0,3,2]: the four dim quarters of a key sit in one quad
+                    acc += dpp_mov_f32<0x4E, 0xf>(0.f, acc);      // quad_perm [2,3,0,1]
                     if (qd == 0) ps[sub][h * AT_KB + key_t] = key_t < n ? acc * 0.125f : -INFINITY;
                 }
             }
