@@ -325,7 +325,8 @@ struct GateUpArgs {
 };
 #ifdef CV2_STAMPS
 __global__ void k_stamp_set(int v) { if (threadIdx.x == 0) g_stamp_slot = v < 0 ? g_stamp_slot + 1 : v; }
-#define STAMP_SET(v) hipLaunchKernelGGL(k_stamp_set, dim3(1), dim3(64), 0, s, v)
+#define STAMP_SET_ON(st_, v) hipLaunchKernelGGL(k_stamp_set, dim3(1), dim3(64), 0, st_, v)
+#define STAMP_SET(v) STAMP_SET_ON(s, v)
 extern "C" int cv2_debug_stamps(unsigned long long* out_host) {
     CV2_HIP(hipDeviceSynchronize());
     CV2_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 8));
@@ -334,6 +335,7 @@ extern "C" int cv2_debug_stamps(unsigned long long* out_host) {
 #endif
 #ifndef CV2_STAMPS
 #define STAMP_SET(v) do { } while (0)
+#define STAMP_SET_ON(st_, v) do { } while (0)
 #endif
 template <int NB, bool PRE = false>
 __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
@@ -437,70 +439,167 @@ __device__ __forceinline__ double shfl_up_f64(double v, int o) {
     const int lo = __shfl_up((int)b, o), hi = __shfl_up((int)(b >> 32), o);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+#define SM_NE ((6592 + SM_T - 1) / SM_T)                                      // logits per thread (strided: tid + e * SM_T)
+#define SM_CAP 1024                                                           // candidate buffer of the top-k selection
+__device__ __forceinline__ unsigned block_umax(unsigned k, unsigned* sh) {    // sh[SM_W]; every thread gets the block maximum
+    k = wave_umax(k);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = k;
+    __syncthreads();
+    unsigned r = sh[0];
+#pragma unroll
+    for (int w = 1; w < SM_W; w++) r = sh[w] > r ? sh[w] : r;
+    return r;
+}
 __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
     __shared__ float lp[6592];
     __shared__ ArgMax sam[SM_W];
     __shared__ float ssum[SM_W];
+    __shared__ unsigned smax[SM_W];
     __shared__ double rd[SM_T];
     __shared__ float candp[SM_TOPK];
     __shared__ int candi[SM_TOPK];
-    __shared__ int s_top, s_need, s_done, s_ncand;
+    __shared__ int s_top, s_need, s_done, s_ncand, s_cnt;
+    __shared__ unsigned s_thr;
     __shared__ unsigned wl_v[SM_W * SM_TOPK];
     __shared__ int wl_i[SM_W * SM_TOPK];
+    __shared__ unsigned rowmax[SM_T / 16];
+    __shared__ unsigned ck[SM_CAP];
+    __shared__ int ci[SM_CAP];
     __shared__ double s_u2;
     const int tid = threadIdx.x;
     const int seq = a.prefill_seq >= 0 ? a.prefill_seq : blockIdx.x;
     const int row = a.prefill_seq >= 0 ? a.row : blockIdx.x;
     int* st = a.state + seq * ST;
-    const int done = st[CV2_ST_DONE];
-    const int step = st[CV2_ST_STEP];
     const int V = a.vocab;
-    if (!done) {
+    SK_STAMP_DECL;
+    SK_STAMP(0);
+    // the logits (written by the head GEMV just before) are requested first, then the state record (uniform address: one scalar
+    // load, read once instead of field by field where it is used), then the repetition window: three round trips in flight together
+    float lv[SM_NE];
+    {
         const float* lg = a.logits + (size_t)row * a.ldl;
-        const bool ignore_eos = step < st[CV2_ST_MINLEN];
-        const bool force = st[CV2_ST_FORCE] != 0;
-        const int mode = st[CV2_ST_MODE];
+#pragma unroll
+        for (int e = 0; e < SM_NE; e++) lv[e] = lg[min(tid + e * SM_T, V - 1)];
+    }
+    int sv[ST];
+    {
+        const int* __restrict__ stc = st;
+#pragma unroll
+        for (int i = 0; i < ST; i++) sv[i] = stc[i];
+    }
+    const int done = sv[CV2_ST_DONE];
+    const int step = sv[CV2_ST_STEP];
+    // repetition window (last 10 emitted tokens): lanes 0..9 of wave 0 hold one entry each; a serial loop of dependent global
+    // loads in the sampling thread cost ~10 memory round trips per step
+    const int nhist = sv[CV2_ST_NOUT];
+    int hv = -1;
+    if (tid < 10 && nhist - 10 + tid >= 0) hv = a.out_tokens[(size_t)seq * a.max_out + nhist - 10 + tid];
+    if (!done) {
+        const bool ignore_eos = step < sv[CV2_ST_MINLEN];
+        const bool force = sv[CV2_ST_FORCE] != 0;
+        const int mode = sv[CV2_ST_MODE];
         // masks on logits == masks on logp (log_softmax is monotone):
         //   step 0 never EOS (llm.py:693-694); forced-length mode never draws ids >= eos
-        ArgMax best{-INFINITY, 0x7fffffff};
-        for (int i = tid; i < V; i += SM_T) {
-            float v = lg[i];
-            if ((step == 0 && i == a.eos) || (force && i >= a.eos)) v = -INFINITY;
-            lp[i] = v;
-            if (!(ignore_eos && i == a.eos)) best = am_better(best, ArgMax{v, i});
+#pragma unroll
+        for (int e = 0; e < SM_NE; e++) {
+            const int i = tid + e * SM_T;
+            if (i >= V || (step == 0 && i == a.eos) || (force && i >= a.eos)) lv[e] = -INFINITY;
         }
         if (mode == 0) {
             // greedy: argmax with EOS excluded while ignore_eos; ties -> lowest id
+            ArgMax best{-INFINITY, 0x7fffffff};
+#pragma unroll
+            for (int e = 0; e < SM_NE; e++) {
+                const int i = tid + e * SM_T;
+                if (i < V && !(ignore_eos && i == a.eos)) best = am_better(best, ArgMax{lv[e], i});
+            }
             best = block_argmax(best, sam);
             if (tid == 0) s_top = best.i;
         } else {
             // RAS (utils/common.py:111-139): top-p 0.8 / top-k 25 nucleus, repetition window 10, tau 0.1
-            __syncthreads();
-            constexpr int NE = (6592 + SM_T - 1) / SM_T;                      // elements per thread (strided: tid + e * SM_T)
-            float lv[NE];
-            ArgMax mx{-INFINITY, 0x7fffffff};
+            const int lane = tid & 63, w = tid >> 6;
+            unsigned tk = 0u;                                                 // this thread's largest key (0 = none: every real key is > 0)
 #pragma unroll
-            for (int e = 0; e < NE; e++) {
-                const int i = tid + e * SM_T;
-                lv[e] = i < V ? lp[i] : -INFINITY;
-                mx = am_better(mx, ArgMax{lv[e], i < V ? i : 0x7fffffff});
-            }
-            const float m = block_argmax(mx, sam).v;
+            for (int e = 0; e < SM_NE; e++) if (tid + e * SM_T < V) { const unsigned k = fkey(lv[e]); tk = k > tk ? k : tk; }
+            SK_STAMP(1);                                                      // logits arrived
+            const float m = fkey_inv(block_umax(tk, smax));
             float sum = 0.f;
 #pragma unroll
-            for (int e = 0; e < NE; e++) if (tid + e * SM_T < V) sum += __expf(lv[e] - m);
+            for (int e = 0; e < SM_NE; e++) if (tid + e * SM_T < V) sum += __expf(lv[e] - m);
             const float lse = m + __logf(block_sum(sum, ssum));
+            tk = 0u;
 #pragma unroll
-            for (int e = 0; e < NE; e++) {                                    // log_softmax (llm.py:690)
+            for (int e = 0; e < SM_NE; e++) {                                 // log_softmax (llm.py:690)
                 lv[e] -= lse;
-                if (tid + e * SM_T < V) lp[tid + e * SM_T] = lv[e];
+                if (tid + e * SM_T < V) { lp[tid + e * SM_T] = lv[e]; const unsigned k = fkey(lv[e]); tk = k > tk ? k : tk; }
             }
+            if (tid == 0) s_cnt = 0;
+            SK_STAMP(2);                                                      // log-softmax
             if (mode == 2) { if (tid == 0) s_top = 0; goto sample_done; }       // diagnostic exit points (tools/dbg_sample.py): after log-softmax
-            // nucleus candidates (common.py:120-134) = head of the stable descending order (value desc, id asc).  Two stages, one
-            // block barrier: every wave extracts the top 25 of its own 1/16 of the vocabulary, wave 0 merges the 16 sorted lists.
-            // Cross-lane maxima go through DPP row operations (one VALU instruction per step) instead of LDS-routed shuffles.
+            // nucleus candidates (common.py:120-134) = head of the stable descending order (value desc, id asc).
+            // Selection by a bound instead of 25 extract-max rounds (phase stamps: 39k of the kernel's 56k cycles):
+            //   (a) the maximum of every 16-lane row (112 logits) through DPP row operations: 64 distinct elements;
+            //   (b) their 25th largest value T (rank by counting, one wave) bounds the global 25th largest from below, so every
+            //       nucleus candidate has key >= T; typically ~40 logits do;
+            //   (c) those are compacted into LDS and ranked by counting under the total order (key desc, id asc): rank r < 25 is
+            //       candidate r.  More than SM_CAP survivors (massively tied logits) take the extract-max path below instead.
             {
-                const int lane = tid & 63, w = tid >> 6;
+                unsigned rk = tk;
+                rk = dpp_umax<0x111, 0xf>(rk); rk = dpp_umax<0x112, 0xf>(rk); rk = dpp_umax<0x114, 0xf>(rk); rk = dpp_umax<0x118, 0xf>(rk);
+                if ((lane & 15) == 15) rowmax[tid >> 4] = rk;
+            }
+            __syncthreads();
+            if (w == 0) {
+                const unsigned mine = rowmax[lane];
+                int r = 0;
+#pragma unroll
+                for (int j = 0; j < SM_T / 16; j++) { const unsigned o = rowmax[j]; r += (o > mine || (o == mine && j < lane)) ? 1 : 0; }
+                if (r == SM_TOPK - 1) s_thr = mine;
+            }
+            __syncthreads();
+            const unsigned thr = s_thr;
+#pragma unroll
+            for (int e = 0; e < SM_NE; e++) {
+                const int i = tid + e * SM_T;
+                const unsigned k = fkey(lv[e]);
+                if (i < V && k >= thr) {
+                    const int slot = atomicAdd(&s_cnt, 1);
+                    if (slot < SM_CAP) { ck[slot] = k; ci[slot] = i; }
+                }
+            }
+            __syncthreads();
+            const int ncnd = s_cnt;
+            SK_STAMP(3);                                                      // candidates compacted
+            if (ncnd <= SM_CAP && mode != 5) {                                // mode 5 (tests): force the extract-max path
+                if (tid < ncnd) {
+                    const unsigned mk = ck[tid]; const int mi = ci[tid];
+                    int r = 0;
+                    for (int j0 = 0; j0 < ncnd; j0 += 8) {                     // 8 independent LDS reads per wait (slots >= ncnd: masked)
+                        unsigned o[8]; int oi[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { o[u] = ck[(j0 + u) & (SM_CAP - 1)]; oi[u] = ci[(j0 + u) & (SM_CAP - 1)]; }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) r += (j0 + u < ncnd && (o[u] > mk || (o[u] == mk && oi[u] < mi))) ? 1 : 0;
+                    }
+                    if (r < SM_TOPK) { candi[r] = mi; candp[r] = __expf(fkey_inv(mk)); }
+                }
+                if (tid >= ncnd && tid < SM_TOPK) { candi[tid] = 0; candp[tid] = 0.f; }   // vocabulary smaller than the nucleus
+                __syncthreads();
+                if (tid == 0) {
+                    float cp[SM_TOPK];
+#pragma unroll
+                    for (int c = 0; c < SM_TOPK; c++) cp[c] = candp[c];        // all reads in flight, then the serial fp32 sum of the reference
+                    int nc = 0; float cum = 0.f;
+#pragma unroll
+                    for (int c = 0; c < SM_TOPK; c++) if (nc == c && cum < 0.8f) { cum += cp[c]; nc++; }
+                    s_ncand = nc;
+                }
+                __syncthreads();
+            } else {
+                // Two stages, one block barrier: every wave extracts the top 25 of its own 1/16 of the vocabulary, wave 0 merges the
+                // 16 sorted lists.  Cross-lane maxima go through DPP row operations instead of LDS-routed shuffles.
+                constexpr int NE = SM_NE;
                 unsigned kk[NE]; int ki[NE];                                   // this lane's elements, sorted: key desc, id asc
 #pragma unroll
                 for (int e = 0; e < NE; e++) {
@@ -513,9 +612,9 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
 #pragma unroll
                     for (int q = 0; q < NE - 1 - p; q++) {                     // ids increase with q: strict > keeps equal keys in id order
                         const bool sw = kk[q + 1] > kk[q];
-                        const unsigned tk = sw ? kk[q] : kk[q + 1]; const int ti = sw ? ki[q] : ki[q + 1];
+                        const unsigned tk2 = sw ? kk[q] : kk[q + 1]; const int ti = sw ? ki[q] : ki[q + 1];
                         kk[q] = sw ? kk[q + 1] : kk[q]; ki[q] = sw ? ki[q + 1] : ki[q];
-                        kk[q + 1] = tk; ki[q + 1] = ti;
+                        kk[q + 1] = tk2; ki[q + 1] = ti;
                     }
                 for (int c = 0; c < SM_TOPK; c++) {
                     const unsigned M = wave_umax(kk[0]);
@@ -529,7 +628,6 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                     }
                 }
                 __syncthreads();
-                if (mode == 3) { if (tid == 0) s_top = 0; goto sample_done; }   // after the per-wave top-25
                 if (w == 0) {
                     int ptr = 0;
                     unsigned hk = lane < SM_W ? wl_v[lane * SM_TOPK] : 0u;
@@ -554,31 +652,43 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                 __syncthreads();
             }
             const int ncand = s_ncand;
-            if (mode == 4) { if (tid == 0) s_top = 0; goto sample_done; }       // after the 16-way merge
-            const int nhist = st[CV2_ST_NOUT];
-            const int* hist = a.out_tokens + (size_t)seq * a.max_out;
+            SK_STAMP(4);                                                      // candidates ranked
+            if (mode == 4) { if (tid == 0) s_top = 0; goto sample_done; }       // after the candidate selection
             const int chunk = (V + SM_T - 1) / SM_T;
             bool rd_ready = false;
             int trial = 0;
             for (;;) {
-                if (tid == 0) {
-                    uint32_t rn[4];
-                    philox4x32((uint32_t)seq, (uint32_t)step, (uint32_t)trial, 0u, (uint32_t)st[CV2_ST_SEED_LO], (uint32_t)st[CV2_ST_SEED_HI], rn);
-                    const double u1 = u53(rn[0], rn[1]);
-                    s_u2 = u53(rn[2], rn[3]);
-                    // nucleus draw: inverse cdf over the candidate probabilities (float64 running sum)
-                    double csum = 0.0; for (int c = 0; c < ncand; c++) csum += (double)candp[c];
-                    const double thr = u1 * csum; double run = 0.0; int pick = ncand - 1;
-                    for (int c = 0; c < ncand; c++) { run += (double)candp[c]; if (run > thr) { pick = c; break; } }
-                    const int top = candi[pick];
-                    int rep = 0;
-                    for (int q = max(0, nhist - 10); q < nhist; q++) rep += (hist[q] == top);
-                    s_top = top;
-                    s_need = rep >= 1;                                         // win_size * tau_r = 1 -> random_sampling over the full vocabulary
-                    s_done = 0;
-                    if (!s_need) {
-                        if (!ignore_eos || top != a.eos) s_done = 1;
-                        else if (trial + 1 > 100) { st[CV2_ST_ERR] = 1; s_done = 1; }
+                if (tid < 64) {                                                // wave 0: lane 0 draws, all lanes check the window
+                    int top_l = 0;
+                    if (tid == 0) {
+                        uint32_t rn[4];
+                        philox4x32((uint32_t)seq, (uint32_t)step, (uint32_t)trial, 0u, (uint32_t)sv[CV2_ST_SEED_LO], (uint32_t)sv[CV2_ST_SEED_HI], rn);
+                        const double u1 = u53(rn[0], rn[1]);
+                        s_u2 = u53(rn[2], rn[3]);
+                        // nucleus draw: inverse cdf over the candidate probabilities (float64 running sum); the probabilities are
+                        // fetched from LDS together, not one dependent read per step of the serial sums
+                        float cp[SM_TOPK];
+#pragma unroll
+                        for (int c = 0; c < SM_TOPK; c++) cp[c] = candp[c];
+                        double csum = 0.0;
+#pragma unroll
+                        for (int c = 0; c < SM_TOPK; c++) if (c < ncand) csum += (double)cp[c];
+                        const double thr = u1 * csum; double run = 0.0; int pick = ncand - 1; bool found = false;
+#pragma unroll
+                        for (int c = 0; c < SM_TOPK; c++)
+                            if (c < ncand && !found) { run += (double)cp[c]; if (run > thr) { pick = c; found = true; } }
+                        top_l = candi[pick];
+                    }
+                    const int top = __builtin_amdgcn_readfirstlane(top_l);     // lane 0 is the first active lane
+                    const int rep = __popcll(__ballot(hv == top));             // hv = -1 where the window has no entry
+                    if (tid == 0) {
+                        s_top = top;
+                        s_need = rep >= 1;                                     // win_size * tau_r = 1 -> random_sampling over the full vocabulary
+                        s_done = 0;
+                        if (!s_need) {
+                            if (!ignore_eos || top != a.eos) s_done = 1;
+                            else if (trial + 1 > 100) { st[CV2_ST_ERR] = 1; s_done = 1; }
+                        }
                     }
                 }
                 __syncthreads();
@@ -626,11 +736,12 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
     }
 sample_done:
     __syncthreads();
-    const int top = done ? st[CV2_ST_LAST] : s_top;
+    SK_STAMP(5);                                                              // token drawn
+    const int top = done ? sv[CV2_ST_LAST] : s_top;
     // next input embedding (llm.py:711, 719); harmless for finished slots
     for (int k = tid; k < a.hidden; k += SM_T) a.x_next[(size_t)seq * a.hidden + k] = a.speech_emb[(size_t)top * a.hidden + k];
     if (tid == 0 && !done) {
-        int nout = st[CV2_ST_NOUT];
+        int nout = sv[CV2_ST_NOUT];
         int fin = 0;
         if (top == a.eos) fin = 1;                                        // llm.py:707-708
         else if (top < a.eos) {                                           // normal token: emit
@@ -638,13 +749,15 @@ sample_done:
             nout++;
         }                                                                 // top > eos: fed back, not emitted (llm.py:712-714)
         const int nstep = step + 1;
-        if (nstep >= st[CV2_ST_MAXLEN]) fin = 1;                          // for i in range(max_len)
-        if (st[CV2_ST_ERR]) fin = 1;
-        const int pos = a.prefill_seq >= 0 ? a.prefill_pos : st[CV2_ST_POS] + 1;
+        if (nstep >= sv[CV2_ST_MAXLEN]) fin = 1;                          // for i in range(max_len)
+        if (st[CV2_ST_ERR]) fin = 1;                                      // (may have been raised above: read back)
+        const int pos = a.prefill_seq >= 0 ? a.prefill_pos : sv[CV2_ST_POS] + 1;
         if (pos + 1 >= a.max_pos) fin = 1;
         st[CV2_ST_NOUT] = nout; st[CV2_ST_STEP] = nstep; st[CV2_ST_LAST] = top; st[CV2_ST_DONE] = fin;
         if (!fin || a.prefill_seq >= 0) st[CV2_ST_POS] = pos;    // a finished slot idles on its last position
     }
+    SK_STAMP(6);
+    SK_STAMP_FLUSH;
 }
 
 // ------------------------------------------------------------------ batched prefill (rows of several prompts at once)
@@ -1209,6 +1322,7 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, hipGraphExec_t* out) {
         int rc = 0;
         for (int u = 0; u < unroll && !rc; u++) {
             rc = n_seqs <= 16 ? run_layers<1>(h, n_seqs, h->xnext, rm, cs) : run_layers_pre(h, n_seqs, h->xnext, rm, cs);
+            STAMP_SET_ON(cs, 5);
             if (!rc) rc = launch_sample(h, n_seqs, -1, 0, 0, cs);
         }
         hipError_t e = hipStreamEndCapture(cs, &g);

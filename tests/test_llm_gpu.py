@@ -127,6 +127,17 @@ def test_ras_sampling_matches_oracle_with_same_noise(small):
         assert ids == want
 
 
+def test_ras_candidate_selection_paths_agree(small):
+    """The nucleus candidates come from a bound + rank-by-counting selection; massively tied logits fall back to 25 extract-max
+    rounds.  Sampler mode 5 forces that fallback: both must draw the same ids from the same Philox stream."""
+    from cv2amd.llm import MODE_RAS
+    sd, sdr, eng = small
+    reqs = _requests(3, seed=33)
+    a = eng.generate(reqs, mode=MODE_RAS, seed=99, max_ratio=8)
+    b = eng.generate(reqs, mode=5, seed=99, max_ratio=8)
+    assert a == b and all(len(x) > 0 for x in a)
+
+
 def test_eos_guard_raises(dev):
     """A model that always prefers EOS: the sampler re-draws 100 times then the host raises RuntimeError (llm.py:249)."""
     from cv2amd import synth
