@@ -443,9 +443,12 @@ struct Layout {
     int S = 0, rows = 0;
     std::vector<int> start, len, ext;          // ext = padded extent in rows (multiple of 128)
     int* d_tile_seq = nullptr; int* d_start = nullptr; int* d_len = nullptr;   // device copies (workspace slices)
-    SeqTable tab() const { return SeqTable{d_tile_seq, d_start, d_len}; }
+    const int4* d_tile_info = nullptr;
+    SeqTable tab() const { return SeqTable{d_tile_seq, d_start, d_len, d_tile_info}; }
 };
 static int pad_rows(int len) { return (len + 8 + 127) / 128 * 128; }
+// ints per layout slice of the int-table region: per-tile records (int4) + tile_seq + per-sequence tables, 16-B aligned
+static size_t itab_per(int R, int max_seqs) { return ((size_t)5 * (R / 64) + 4 * max_seqs + 64 + 3) / 4 * 4; }
 
 struct cv2_flow {
     cv2_flow_dims d;
@@ -499,11 +502,18 @@ static size_t flow_carve(const cv2_flow_dims& d, cv2_flow* h, char* base) {
     f.e_a = c.take<uint16_t>(RG * 512); f.e_b = c.take<uint16_t>(RG * 512); f.e_ln = c.take<uint16_t>(RG * 512);
     f.e_qkv = c.take<uint16_t>(RG * 1536); f.e_vt = c.take<uint16_t>((size_t)(512 + 64) * RG); f.e_att = c.take<uint16_t>(RG * 512);
     f.e_ff = c.take<uint16_t>(RG * 2048); f.e_x = c.take<float>(R * 512); f.e_tmp = c.take<float>(R * 512);
-    f.itab = c.take<int>((size_t)6 * (R / 64 + 4 * d.max_seqs + 64));
+    f.itab = c.take<int>((size_t)6 * itab_per(R, d.max_seqs));
     f.ptab = c.take<void*>((size_t)8 * d.max_seqs + 64);
     return c.off;
 }
 
+#ifdef CV2_STAMPS
+extern "C" int cv2_debug_stamps_flow(unsigned long long* out_host) {       // this translation unit's copy of the stamp ring
+    CV2_HIP(hipDeviceSynchronize());
+    CV2_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 8));
+    return 0;
+}
+#endif
 extern "C" size_t cv2_flow_workspace_bytes(const cv2_flow_dims* d) { return flow_carve(*d, nullptr, nullptr); }
 
 // guard-offset views: bf16 row buffers are addressed from their first real row
@@ -511,19 +521,25 @@ extern "C" size_t cv2_flow_workspace_bytes(const cv2_flow_dims* d) { return flow
 
 static int upload_layout(cv2_flow* h, Layout& L, int slot, hipStream_t s) {
     // slot selects a disjoint slice of the int-table region
-    const int per = h->R / 64 + 4 * h->d.max_seqs + 64;
+    const int per = (int)itab_per(h->R, h->d.max_seqs);
     int* base = h->itab + (size_t)slot * per;
-    std::vector<int> host(L.rows / 64 + 2 * L.S);
-    for (int i = 0; i < L.rows / 64; i++) host[i] = -1;
+    const int nt = L.rows / 64;
+    std::vector<int> host(4 * nt + nt + 2 * L.S);              // [tile_info int4 x nt][tile_seq nt][start S][len S]
+    int* ts = host.data() + 4 * nt;
+    for (int i = 0; i < nt; i++) { ts[i] = -1; host[4 * i] = -1; host[4 * i + 1] = 0; host[4 * i + 2] = 0; host[4 * i + 3] = 0; }
     for (int q = 0; q < L.S; q++) {
-        for (int r = L.start[q]; r < L.start[q] + L.ext[q]; r += 64) host[r / 64] = q;
-        host[L.rows / 64 + q] = L.start[q];
-        host[L.rows / 64 + L.S + q] = L.len[q];
+        for (int r = L.start[q]; r < L.start[q] + L.ext[q]; r += 64) {
+            ts[r / 64] = q;
+            host[4 * (r / 64)] = q; host[4 * (r / 64) + 1] = L.start[q]; host[4 * (r / 64) + 2] = L.len[q];
+        }
+        ts[nt + q] = L.start[q];
+        ts[nt + L.S + q] = L.len[q];
     }
     CV2_CHECK((int)host.size() <= per, "flow: layout table overflow");
     CV2_HIP(hipMemcpyAsync(base, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     CV2_HIP(hipStreamSynchronize(s));            // host vector goes out of scope
-    L.d_tile_seq = base; L.d_start = base + L.rows / 64; L.d_len = L.d_start + L.S;
+    L.d_tile_info = reinterpret_cast<const int4*>(base);
+    L.d_tile_seq = base + 4 * nt; L.d_start = L.d_tile_seq + nt; L.d_len = L.d_start + L.S;
     return 0;
 }
 
@@ -860,7 +876,7 @@ extern "C" int cv2_flow_encoder(cv2_flow* h, const float* xs, int32_t T, const f
     if (upload_layout(h, LA, 0, s) || upload_layout(h, LT, 1, s) || upload_layout(h, L2, 2, s)) return -1;
     // fp32 rows -> bf16 e_a (context rows appended)
     int zero = 0;
-    int* off = h->itab + (size_t)4 * (h->R / 64 + 4 * h->d.max_seqs + 64);
+    int* off = h->itab + (size_t)4 * itab_per(h->R, h->d.max_seqs);
     CV2_HIP(hipMemcpyAsync(off, &zero, sizeof(int), hipMemcpyHostToDevice, s));
     CV2_HIP(hipStreamSynchronize(s));
     CastArgs ca{xs, GB(h->e_a, 512), LT.tab(), LT.rows, 512, off};
@@ -900,7 +916,7 @@ extern "C" int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t
             ints[u] = utts[u].n_prompt_feat;
         }
         CV2_HIP(hipMemcpyAsync(h->ptab, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, s));
-        int* ibase = h->itab + (size_t)4 * (h->R / 64 + 4 * h->d.max_seqs + 64);
+        int* ibase = h->itab + (size_t)4 * itab_per(h->R, h->d.max_seqs);
         CV2_HIP(hipMemcpyAsync(ibase, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice, s));
         CV2_HIP(hipStreamSynchronize(s));
         const void* const* dp = (const void* const*)h->ptab;

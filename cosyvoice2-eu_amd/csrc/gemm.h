@@ -23,6 +23,7 @@ struct SeqTable {
     const int* tile_seq;    // [rows / 64]: sequence id of every 64-row tile, -1 = padding tile
     const int* seq_start;   // [S] first row (multiple of 128)
     const int* seq_len;     // [S] valid rows
+    const int4* tile_info;  // [rows / 64]: {sequence id or -1, its first row, its valid rows, 0}: the three lookups above in one load
 };
 
 struct GemmArgs {
@@ -172,6 +173,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     const int a_off = subtile_off(lane & 15, lane >> 4);
     const int w_off = WPACKED ? lane * 16 : a_off;
 
+    SK_STAMP_DECL;
+    SK_STAMP(0);
     issue(0, 0);
     // epilogue operands that do not depend on the row: fetched now, consumed after the K loop
     constexpr int LPR = BN / 4, RPI = NT_ / LPR, NIT = BM / RPI;   // lanes per row, rows per epilogue iteration, iterations
@@ -185,29 +188,43 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     const f32x4 ep_g2 = a.ln2_g ? *reinterpret_cast<const f32x4*>(a.ln2_g + n) : z4;
     const f32x4 ep_b2 = a.ln2_g ? *reinterpret_cast<const f32x4*>(a.ln2_b + n) : z4;
     constexpr int NTL = (BM + 63) / 64;                            // 64-row sequence tiles touched by this block
-    int ep_start[NTL], ep_len[NTL];
+    // one record per tile (sequence id, start, length): a single load here instead of the chain tile_seq -> seq_start / seq_len
+    // -> rowadd, which held the K loop back by two memory round trips; rowadd (needs the id) is fetched inside the loop
+    int ep_start[NTL], ep_len[NTL], ep_sq[NTL];
     f32x4 ep_radd[NTL];
 #pragma unroll
     for (int t = 0; t < NTL; t++) {
-        int sq = 0;
-        ep_start[t] = 0; ep_len[t] = a.M_valid;
+        ep_start[t] = 0; ep_len[t] = a.M_valid; ep_sq[t] = 0; ep_radd[t] = z4;
         if (a.seq.tile_seq) {
-            sq = a.seq.tile_seq[(m0 >> 6) + t];
-            if (sq >= 0) { ep_start[t] = a.seq.seq_start[sq]; ep_len[t] = a.seq.seq_len[sq]; }
-            else { ep_len[t] = 0; sq = 0; }
+            const int4 ti = a.seq.tile_info[(m0 >> 6) + t];
+            if (ti.x >= 0) { ep_sq[t] = ti.x; ep_start[t] = ti.y; ep_len[t] = ti.z; }
+            else ep_len[t] = 0;
         }
-        ep_radd[t] = a.rowadd ? *reinterpret_cast<const f32x4*>(a.rowadd + (size_t)sq * a.rowadd_ld + n) : z4;
     }
-    if (NSTAGE == 3 && nk > 1) issue(1, 1);
+    // first residual row of this lane: requested now, it has long arrived when the epilogue starts
+    const bool use_res = a.res && !(a.vt && n0 >= a.vt_n0);
+    f32x4 res_next = z4;
+    if (use_res) res_next = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m0 + rsub) * a.ldres + n);
+#pragma unroll
+    for (int st = 1; st < NSTAGE - 1; st++) if (st < nk) issue(st, st);
+    SK_STAMP(1);                                         // prologue loads issued
     for (int kt = 0, buf = 0; kt < nk; kt++, buf = (buf + 1 == NSTAGE ? 0 : buf + 1)) {
         // keep NSTAGE - 1 K-steps in flight: wait only until stage kt has landed (counted vmcnt, loads retire in order)
         const int ahead = NSTAGE - 1;
         if (kt + ahead < nk) issue(kt + ahead, (buf + ahead) % NSTAGE);
         const int inflight = (nk - 1 - kt) < ahead ? (nk - 1 - kt) : ahead;      // younger stages that may stay outstanding
-        if (inflight == 2) vmcnt_wait<2 * PER_WAVE>();
+        if (NSTAGE > 3 && inflight == 3) vmcnt_wait<3 * PER_WAVE>();
+        else if (NSTAGE > 2 && inflight == 2) vmcnt_wait<2 * PER_WAVE>();
         else if (inflight == 1) vmcnt_wait<PER_WAVE>();
         else vmcnt_wait<0>();
         __builtin_amdgcn_s_barrier();                    // stage kt has landed for every wave
+        if (kt == 0) {
+            SK_STAMP(2);                                 // first stage landed (and every older prologue load)
+            if (a.rowadd) {
+#pragma unroll
+                for (int t = 0; t < NTL; t++) ep_radd[t] = *reinterpret_cast<const f32x4*>(a.rowadd + (size_t)ep_sq[t] * a.rowadd_ld + n);
+            }
+        }
         const char* base = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
@@ -232,6 +249,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
         __builtin_amdgcn_s_barrier();                    // everyone is done reading this stage
     }
 
+    SK_STAMP(3);                                         // K loop done
     // ---- accumulators -> LDS C tile [BM][LDC] ----
     float* C = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -242,10 +260,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
             const int n = wn * TN + j * 16 + 4 * (lane >> 4);
             *reinterpret_cast<f32x4*>(&C[m * LDC + n]) = acc[j][i] * a.out_scale;
         }
-    const bool use_res = a.res && !(a.vt && n0 >= a.vt_n0);
-    f32x4 res_next = z4;
-    if (use_res) res_next = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m0 + rsub) * a.ldres + n);
     __syncthreads();
+    SK_STAMP(4);                                         // C tile staged
 
     float* out_f32 = a.out_f32 ? a.out_f32 + (size_t)blockIdx.z * a.o_bstride : nullptr;
     uint16_t* out_bf16 = a.out_bf16 ? a.out_bf16 + (size_t)blockIdx.z * a.o16_bstride : nullptr;
@@ -314,6 +330,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
             *reinterpret_cast<uint2*>(a.out_ln2 + (size_t)m * a.ldo_ln2 + n) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
         }
     }
+    SK_STAMP(5);                                         // row epilogue done
+    SK_STAMP_FLUSH_RING(((unsigned long long)a.K << 32) | (unsigned)a.N,
+                        ((unsigned long long)BM << 48) | ((unsigned long long)BN << 32) | (unsigned)(gridDim.x * gridDim.y * gridDim.z));
 }
 
 template <int BM, int BN, bool SPLITA = false, int NSTAGE = 2>

@@ -12,8 +12,8 @@ static int gemm_go(const GemmArgs& a, int batch, bool packed, hipStream_t s) {
         hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true, SPLITA, NSTAGE>), grid, block, sm, s, a);
     } else if (!SPLITA) {
         static bool once = false;
-        if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false>), grid, block, sm, s, a);
+        if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, false, false, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false, false, NSTAGE>), grid, block, sm, s, a);
     } else {
         return cv2_fail("gemm: the split-A kernels need packed weights");
     }
@@ -26,7 +26,8 @@ static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, h
     CV2_CHECK(a.K % 64 == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of 64", a.K);
     CV2_CHECK(a.M % 128 == 0 && a.M > 0, "gemm: M=%d must be a positive multiple of 128", a.M);
     if (cfg == 0) { CV2_CHECK(a.N % 128 == 0, "gemm cfg0: N=%d %% 128", a.N); 
-        // fewer blocks than ~1.5 per CU: 16 waves per block spread the LDS-DMA issue cost; otherwise 8 waves and two blocks per CU
+        // fewer blocks than ~1.5 per CU: 16 waves per block spread the LDS-DMA issue cost (phase stamps: the K loop runs at ~2x the per-CU
+        // vector-memory bound of 64 B/clk whatever the number of stages in flight); otherwise 8 waves and two blocks per CU
         if ((long)(a.N / 128) * (a.M / 128) * batch < 400) return gemm_go<128, 128, 4, 4>(a, batch, packed, s);
         return gemm_go<128, 128, 2, 4>(a, batch, packed, s);
     }
@@ -34,7 +35,7 @@ static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, h
         CV2_CHECK(a.N % 256 == 0, "gemm cfg1: N=%d %% 256", a.N);
         CV2_CHECK((!a.ln1_g && !a.ln2_g) || a.N == 256, "gemm cfg1: LayerNorm epilogue needs N == 256");
         // few rows (one utterance): 32-row tiles double the blocks that share the latency-bound K loop and the row epilogue
-        if ((long)(a.M / 64) * (a.N / 256) * batch < 200) return gemm_go<32, 256, 2, 8>(a, batch, packed, s);      // latency-bound K loop: three stages in flight
+        if ((long)(a.M / 64) * (a.N / 256) * batch < 200) return gemm_go<32, 256, 2, 8>(a, batch, packed, s);
         return gemm_go<64, 256, 2, 4>(a, batch, packed, s);
     }
     if (cfg == 4) {

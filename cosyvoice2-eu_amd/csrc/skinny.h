@@ -15,19 +15,6 @@
 
 #define SK_ROWS_CAP 32    // row capacity of partial buffers
 
-// Diagnostic build only (-DCV2_STAMPS, tools/dbg_stamps.py): wave 0 of block 0 records s_memtime at the phase boundaries of
-// skinny_core into g_stamps[slot][8]; no output value depends on them and the product build contains none of this.
-#ifdef CV2_STAMPS
-__device__ unsigned long long g_stamps[64][8];
-__device__ int g_stamp_slot;
-#define SK_STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define SK_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_[i] = t_; } while (0)
-#define SK_STAMP_FLUSH do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && g_stamp_slot < 64) for (int i_ = 0; i_ < 8; i_++) g_stamps[g_stamp_slot][i_] = st_[i_]; } while (0)
-#else
-#define SK_STAMP_DECL
-#define SK_STAMP(i) do { } while (0)
-#define SK_STAMP_FLUSH do { } while (0)
-#endif
 #define SK_MAXNP 4        // partial buffers a consumer can fold
 
 typedef __attribute__((ext_vector_type(8))) float f32x8;

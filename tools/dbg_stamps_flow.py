@@ -1,0 +1,33 @@
+"""Phase timing inside the flow GEMMs (diagnostic build only):
+    ./build.sh -DCV2_STAMPS -o cosyvoice2-eu_amd/cv2amd/libcv2amd_dbg.so
+    CV2_AMD_LIB=$PWD/cosyvoice2-eu_amd/cv2amd/libcv2amd_dbg.so python tools/dbg_stamps_flow.py
+Block (0,0,0) of every k_gemm launch stamps s_memtime (shader cycles) at its phase boundaries into a 64-entry ring; this prints
+the last 64 launches of one estimator pass grouped by (tile, K, N, blocks)."""
+import ctypes as C, os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cosyvoice2-eu_amd'))
+import torch
+from cv2amd import synth, lib as L
+from cv2amd.pipeline import Synthesizer, synthetic_request
+
+syn = Synthesizer(synth.make_llm(layers=1), synth.make_flow(), synth.make_hift(), 'cuda:0', max_batch=1, max_text=128,
+                  max_prompt_tokens=320, max_new_tokens=512)
+req = synthetic_request(device='cuda:0')
+toks = [[int(t) for t in torch.randint(0, 6561, (250,))]]
+for rep in range(2):
+    syn.token2wav([req], toks)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * (64 * 8))()
+L.check(L.lib().cv2_debug_stamps_flow(buf))
+ph = ['issue', 'first stage', 'K loop', 'C stage', 'row epilogue']
+groups = collections.defaultdict(list)
+for k in range(64):
+    t = [buf[k * 8 + i] for i in range(8)]
+    if not t[0]: continue
+    key = (t[7] >> 48, (t[7] >> 32) & 0xffff, t[6] >> 32, t[6] & 0xffffffff, t[7] & 0xffffffff)
+    groups[key].append([t[i + 1] - t[i] for i in range(5)])
+for key, rows in sorted(groups.items()):
+    n = len(rows)
+    avg = [sum(r[i] for r in rows) / n for i in range(5)]
+    print(f'tile {key[0]}x{key[1]} K={key[2]} N={key[3]} blocks={key[4]} launches={n}: ' +
+          '  '.join(f'{p}={v:.0f}' for p, v in zip(ph, avg)) + f'   total={sum(avg):.0f} cycles')
