@@ -195,10 +195,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
 #pragma unroll
     for (int t = 0; t < NTL; t++) {
         ep_start[t] = 0; ep_len[t] = a.M_valid; ep_sq[t] = 0; ep_radd[t] = z4;
-        if (a.seq.tile_seq) {
-            const int4 ti = a.seq.tile_info[(m0 >> 6) + t];
-            if (ti.x >= 0) { ep_sq[t] = ti.x; ep_start[t] = ti.y; ep_len[t] = ti.z; }
-            else ep_len[t] = 0;
+        if (a.seq.tile_seq) {                           // padding tiles carry {-1, 0, 0}: branch-free, so the record stays ONE 16-byte load
+            // block-uniform address, read-only table: a scalar load (constant address space), which nothing has to wait for until
+            // the values are used; as a vector load hipcc waits for it (and the stage-0 DMA before it) right here
+            typedef int i32x4_t __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(4))) i32x4_t k_i32x4;
+            const i32x4_t ti = *reinterpret_cast<k_i32x4*>(reinterpret_cast<uintptr_t>(a.seq.tile_info + (m0 >> 6) + t));
+            ep_sq[t] = max(ti.x, 0); ep_start[t] = ti.y; ep_len[t] = ti.z;
         }
     }
     // first residual row of this lane: requested now, it has long arrived when the epilogue starts
