@@ -338,6 +338,120 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
                         ((unsigned long long)BM << 48) | ((unsigned long long)BN << 32) | (unsigned)(gridDim.x * gridDim.y * gridDim.z));
 }
 
+// ------------------------------------------------------------------ row-panel GEMM (few rows: one utterance)
+// Block = 16 rows x 256 columns, 16 waves, wave w owns columns [16 w, 16 w + 16).  Phase stamps of k_gemm<32, 256> on M = 2048
+// showed the K loop bound by LDS traffic (every wave re-reads A and W fragments: 96 KB per 64-wide step against 36 KB staged)
+// and two block barriers per step, and the row epilogue bound by VALU work on only 64 CUs.  Here
+//   * the packed W fragments go straight from global memory to registers (they ARE the MFMA operand: one 1 KiB wave-load each,
+//     every byte of W crosses the CU's vector-memory path once), a ring of CH fragments per wave in flight;
+//   * the block's whole A panel [16][K] is staged in LDS once by DMA: ONE barrier before the K loop and none inside;
+//   * twice as many blocks share the row epilogue (LayerNorm needs the whole row, so the N = 256 columns stay in one block).
+// Same arguments and epilogue semantics as k_gemm (no transposed-V path, packed weights, K % (32 CH) == 0).
+// KS_T = K / 32 at compile time: the K loop is straight-line code, so the waits hipcc derives for the ring are exact counted
+// ones (around a run-time loop it falls back to vmcnt(0) at the loop head, which serialises load and use chunk by chunk).
+template <int CH, int KS_T>
+__global__ __launch_bounds__(1024) void k_gemm_panel(GemmArgs a) {
+    constexpr int BM = 16, BN = 256, NW = 16, LDC = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const uint16_t* A = a.A + (size_t)blockIdx.z * a.a_bstride;
+    const uint16_t* W = a.W + (size_t)blockIdx.z * a.w_bstride;
+    constexpr int KS = KS_T;
+    SK_STAMP_DECL;
+    SK_STAMP(0);
+    // epilogue operands first (oldest loads: they have arrived whenever anything younger has)
+    const int rsub = tid >> 6, cl = lane;                // epilogue: wave = row, lane = 4 columns
+    const int n = n0 + cl * 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 ep_bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : z4;
+    const f32x4 ep_g1 = a.ln1_g ? *reinterpret_cast<const f32x4*>(a.ln1_g + n) : z4;
+    const f32x4 ep_b1 = a.ln1_g ? *reinterpret_cast<const f32x4*>(a.ln1_b + n) : z4;
+    const f32x4 ep_g2 = a.ln2_g ? *reinterpret_cast<const f32x4*>(a.ln2_g + n) : z4;
+    const f32x4 ep_b2 = a.ln2_g ? *reinterpret_cast<const f32x4*>(a.ln2_b + n) : z4;
+    const f32x4 ep_res = a.res ? *reinterpret_cast<const f32x4*>(a.res + (size_t)(m0 + rsub) * a.ldres + n) : z4;
+    int ep_start = 0, ep_len = a.M_valid, ep_sq = 0;
+    if (a.seq.tile_seq) {
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) i32x4_t k_i32x4;
+        const i32x4_t ti = *reinterpret_cast<k_i32x4*>(reinterpret_cast<uintptr_t>(a.seq.tile_info + (m0 >> 6)));
+        ep_sq = max(ti.x, 0); ep_start = ti.y; ep_len = ti.z;
+    }
+    // A panel -> LDS: 1 KiB piece p = rows m0..m0+15, k [32 p, 32 p + 32), st_16x32 swizzle on the source side
+    {
+        const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 5) << 1);
+        const uint16_t* asrc = A + ((long)(m0 + srow) + a.a_row_off) * a.lda + schunk * 8;
+        for (int p = wave; p < KS; p += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + p * 32),
+                                             (__attribute__((address_space(3))) void*)(smem + p * 1024), 16, 0, 0);
+    }
+    const s16x8* wp = reinterpret_cast<const s16x8*>(W) + ((size_t)(n0 / 16 + wave) * KS) * 64 + lane;
+    // ring of CH fragments: slot i is refilled with fragment kb + CH as soon as fragment kb has been consumed, so CH wave-loads
+    // (CH KiB per wave) stay in flight; the last CH fragments are consumed without refills (fixed load counts on both paths)
+    s16x8 wr[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) wr[i] = wp[(size_t)i * 64];     // plain loads: every block of the launch reads the same W, it must stay in L2
+    SK_STAMP(1);
+    vmcnt_wait<CH>();                                    // everything older than the CH weight loads: the panel pieces, the epilogue operands
+    __builtin_amdgcn_s_barrier();                        // (raw: __syncthreads would also wait for the weight loads)
+    SK_STAMP(2);                                         // A panel staged
+    const f32x4 ep_radd = a.rowadd ? *reinterpret_cast<const f32x4*>(a.rowadd + (size_t)ep_sq * a.rowadd_ld + n) : z4;
+    const char* ap = smem + subtile_off(lane & 15, lane >> 4);
+    f32x4 acc = z4;
+#pragma unroll
+    for (int kb = 0; kb < KS; kb++) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + (size_t)kb * 1024);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[kb % CH]), af, acc, 0, 0, 0);
+        if (kb + CH < KS) wr[kb % CH] = wp[(size_t)(kb + CH) * 64];
+    }
+    SK_STAMP(3);                                         // K loop done
+    __syncthreads();                                     // every wave is done reading the panel: its LDS becomes the C tile
+    float* C = reinterpret_cast<float*>(smem);
+    *reinterpret_cast<f32x4*>(&C[(lane & 15) * LDC + wave * 16 + 4 * (lane >> 4)]) = acc * a.out_scale;
+    __syncthreads();
+    SK_STAMP(4);                                         // C tile staged
+    // ---- row epilogue: one wave per row, 4 consecutive features per lane (the order of k_gemm's) ----
+    {
+        const int m = m0 + rsub;
+        const bool valid = (m - ep_start) < ep_len;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&C[rsub * LDC + cl * 4]);
+        v += ep_bias;
+        if (a.ln1_g) {
+            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / BN);
+            const f32x4 d = v - mean;
+            const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / BN);
+            const float rstd = rsqrtf(var + a.ln1_eps);
+            v = d * rstd * ep_g1 + ep_b1;
+        }
+        if (a.act != ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = act_apply(v[e], a.act, a.act_slope);
+        }
+        if (a.rowadd) v += ep_radd;
+        if (a.res) v += ep_res;
+        if (a.mask && !valid) v = z4;
+        const bool wr = n < a.n_store;
+        float* out_f32 = a.out_f32 ? a.out_f32 + (size_t)blockIdx.z * a.o_bstride : nullptr;
+        uint16_t* out_bf16 = a.out_bf16 ? a.out_bf16 + (size_t)blockIdx.z * a.o16_bstride : nullptr;
+        if (out_f32 && wr) *reinterpret_cast<f32x4*>(out_f32 + (size_t)m * a.ldo + n) = v;
+        if (out_bf16 && wr)
+            *reinterpret_cast<uint2*>(out_bf16 + (size_t)m * a.ldo16 + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        if (a.ln2_g) {
+            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / BN);
+            const f32x4 d = v - mean;
+            const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / BN);
+            const float rstd = rsqrtf(var + a.ln2_eps);
+            f32x4 y = (d * rstd * ep_g2 + ep_b2) * a.ln2_scale;
+            if (a.mask && !valid) y = z4;
+            *reinterpret_cast<uint2*>(a.out_ln2 + (size_t)m * a.ldo_ln2 + n) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+        }
+    }
+    SK_STAMP(5);
+    SK_STAMP_FLUSH_RING(((unsigned long long)a.K << 32) | (unsigned)a.N,
+                        ((unsigned long long)BM << 48) | ((unsigned long long)BN << 32) | (unsigned)(gridDim.x * gridDim.y * gridDim.z));
+}
+
 template <int BM, int BN, bool SPLITA = false, int NSTAGE = 2>
 constexpr size_t gemm_smem_bytes() {
     constexpr size_t stages = NSTAGE * (size_t)(((SPLITA ? 2 : 1) * BM + BN) / 16 * 2) * 1024;

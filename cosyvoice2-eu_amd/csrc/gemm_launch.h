@@ -21,6 +21,29 @@ static int gemm_go(const GemmArgs& a, int batch, bool packed, hipStream_t s) {
     return 0;
 }
 
+template <int KS_T>
+static int gemm_go_panel_k(const GemmArgs& a, int batch, hipStream_t s) {
+    constexpr int CH = 8;
+    constexpr size_t panel = (size_t)KS_T * 1024, ctile = (size_t)16 * (256 + 4) * 4;
+    constexpr size_t sm = panel > ctile ? panel : ctile;
+    static bool once = false;
+    if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_panel<CH, KS_T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
+    hipLaunchKernelGGL((k_gemm_panel<CH, KS_T>), dim3(a.N / 256, a.M / 16, batch), dim3(1024), sm, s, a);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+// the K values of the flow estimator's N = 256 layers (256 .. 1536); anything else stays on k_gemm
+static bool gemm_panel_has(int K) { return K == 256 || K == 512 || K == 768 || K == 1024 || K == 1536; }
+static int gemm_go_panel(const GemmArgs& a, int batch, hipStream_t s) {
+    switch (a.K) {
+        case 256: return gemm_go_panel_k<8>(a, batch, s);
+        case 512: return gemm_go_panel_k<16>(a, batch, s);
+        case 768: return gemm_go_panel_k<24>(a, batch, s);
+        case 1024: return gemm_go_panel_k<32>(a, batch, s);
+        default: return gemm_go_panel_k<48>(a, batch, s);
+    }
+}
+
 // cfg 0: 128x128; cfg 1: 64x256 / 32x256 (whole rows of N == 256); cfg 2: 128x64; cfg 4: 128x128 with the hi/lo operand split
 static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, hipStream_t s) {
     CV2_CHECK(a.K % 64 == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of 64", a.K);
@@ -35,7 +58,10 @@ static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, h
         CV2_CHECK(a.N % 256 == 0, "gemm cfg1: N=%d %% 256", a.N);
         CV2_CHECK((!a.ln1_g && !a.ln2_g) || a.N == 256, "gemm cfg1: LayerNorm epilogue needs N == 256");
         // few rows (one utterance): 32-row tiles double the blocks that share the latency-bound K loop and the row epilogue
-        if ((long)(a.M / 64) * (a.N / 256) * batch < 200) return gemm_go<32, 256, 2, 8>(a, batch, packed, s);
+        if ((long)(a.M / 64) * (a.N / 256) * batch < 200) {
+            if (packed && gemm_panel_has(a.K) && !a.vt && !a.A_lo) return gemm_go_panel(a, batch, s);     // row-panel kernel
+            return gemm_go<32, 256, 2, 8>(a, batch, packed, s);
+        }
         return gemm_go<64, 256, 2, 4>(a, batch, packed, s);
     }
     if (cfg == 4) {
