@@ -361,24 +361,10 @@ __global__ __launch_bounds__(1024) void k_gemm_panel(GemmArgs a) {
     constexpr int KS = KS_T;
     SK_STAMP_DECL;
     SK_STAMP(0);
-    // epilogue operands first (oldest loads: they have arrived whenever anything younger has)
     const int rsub = tid >> 6, cl = lane;                // epilogue: wave = row, lane = 4 columns
     const int n = n0 + cl * 4;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 ep_bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : z4;
-    const f32x4 ep_g1 = a.ln1_g ? *reinterpret_cast<const f32x4*>(a.ln1_g + n) : z4;
-    const f32x4 ep_b1 = a.ln1_g ? *reinterpret_cast<const f32x4*>(a.ln1_b + n) : z4;
-    const f32x4 ep_g2 = a.ln2_g ? *reinterpret_cast<const f32x4*>(a.ln2_g + n) : z4;
-    const f32x4 ep_b2 = a.ln2_g ? *reinterpret_cast<const f32x4*>(a.ln2_b + n) : z4;
-    const f32x4 ep_res = a.res ? *reinterpret_cast<const f32x4*>(a.res + (size_t)(m0 + rsub) * a.ldres + n) : z4;
-    int ep_start = 0, ep_len = a.M_valid, ep_sq = 0;
-    if (a.seq.tile_seq) {
-        typedef int i32x4_t __attribute__((ext_vector_type(4)));
-        typedef const __attribute__((address_space(4))) i32x4_t k_i32x4;
-        const i32x4_t ti = *reinterpret_cast<k_i32x4*>(reinterpret_cast<uintptr_t>(a.seq.tile_info + (m0 >> 6)));
-        ep_sq = max(ti.x, 0); ep_start = ti.y; ep_len = ti.z;
-    }
-    // A panel -> LDS: 1 KiB piece p = rows m0..m0+15, k [32 p, 32 p + 32), st_16x32 swizzle on the source side
+    // A panel -> LDS: 1 KiB piece p = rows m0..m0+15, k [32 p, 32 p + 32), st_16x32 swizzle on the source side.  Requested first.
     {
         const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 5) << 1);
         const uint16_t* asrc = A + ((long)(m0 + srow) + a.a_row_off) * a.lda + schunk * 8;
@@ -386,14 +372,36 @@ __global__ __launch_bounds__(1024) void k_gemm_panel(GemmArgs a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + p * 32),
                                              (__attribute__((address_space(3))) void*)(smem + p * 1024), 16, 0, 0);
     }
+    // the five per-column epilogue vectors (bias, LayerNorm 1 / 2 scale and shift; 1 KiB each) go to LDS once per block (wave w
+    // fetches vector w) instead of once per wave: as register loads they were 80 KB of the block's vector-memory traffic
+    constexpr size_t PAR_OFF = (size_t)KS * 1024 > (size_t)BM * LDC * 4 ? (size_t)KS * 1024 : (size_t)BM * LDC * 4;
+    float* par = reinterpret_cast<float*>(smem + PAR_OFF);
+    if (wave < 5) {
+        const float* src = wave == 0 ? a.bias : wave == 1 ? a.ln1_g : wave == 2 ? a.ln1_b : wave == 3 ? a.ln2_g : a.ln2_b;
+        if (wave >= 1 && wave <= 2 && !a.ln1_g) src = nullptr;
+        if (wave >= 3 && !a.ln2_g) src = nullptr;
+        if (src)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + n0 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(par) + wave * 1024), 16, 0, 0);
+    }
+    const f32x4 ep_res = a.res ? *reinterpret_cast<const f32x4*>(a.res + (size_t)(m0 + rsub) * a.ldres + n) : z4;
+    // every wave's panel / vector requests are queued before any weight request (instruction streams only: nothing is waited for)
+    __builtin_amdgcn_s_barrier();
     const s16x8* wp = reinterpret_cast<const s16x8*>(W) + ((size_t)(n0 / 16 + wave) * KS) * 64 + lane;
     // ring of CH fragments: slot i is refilled with fragment kb + CH as soon as fragment kb has been consumed, so CH wave-loads
     // (CH KiB per wave) stay in flight; the last CH fragments are consumed without refills (fixed load counts on both paths)
     s16x8 wr[CH];
 #pragma unroll
     for (int i = 0; i < CH; i++) wr[i] = wp[(size_t)i * 64];     // plain loads: every block of the launch reads the same W, it must stay in L2
+    int ep_start = 0, ep_len = a.M_valid, ep_sq = 0;
+    if (a.seq.tile_seq) {                                // scalar load, requested after everything above: nothing queues behind its miss
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) i32x4_t k_i32x4;
+        const i32x4_t ti = *reinterpret_cast<k_i32x4*>(reinterpret_cast<uintptr_t>(a.seq.tile_info + (m0 >> 6)));
+        ep_sq = max(ti.x, 0); ep_start = ti.y; ep_len = ti.z;
+    }
     SK_STAMP(1);
-    vmcnt_wait<CH>();                                    // everything older than the CH weight loads: the panel pieces, the epilogue operands
+    vmcnt_wait<CH>();                                    // everything older than the CH weight loads: the panel, the vectors, the residual
     __builtin_amdgcn_s_barrier();                        // (raw: __syncthreads would also wait for the weight loads)
     SK_STAMP(2);                                         // A panel staged
     const f32x4 ep_radd = a.rowadd ? *reinterpret_cast<const f32x4*>(a.rowadd + (size_t)ep_sq * a.rowadd_ld + n) : z4;
@@ -416,7 +424,9 @@ __global__ __launch_bounds__(1024) void k_gemm_panel(GemmArgs a) {
         const int m = m0 + rsub;
         const bool valid = (m - ep_start) < ep_len;
         f32x4 v = *reinterpret_cast<const f32x4*>(&C[rsub * LDC + cl * 4]);
-        v += ep_bias;
+        const f32x4* pv = reinterpret_cast<const f32x4*>(par) + cl;          // [5][64] f32x4: bias, g1, b1, g2, b2
+        if (a.bias) v += pv[0];
+        const f32x4 ep_g1 = pv[64], ep_b1 = pv[128], ep_g2 = pv[192], ep_b2 = pv[256];   // (unused ones: stale LDS, never consumed)
         if (a.ln1_g) {
             const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / BN);
             const f32x4 d = v - mean;

@@ -25,7 +25,7 @@ template <int KS_T>
 static int gemm_go_panel_k(const GemmArgs& a, int batch, hipStream_t s) {
     constexpr int CH = 8;
     constexpr size_t panel = (size_t)KS_T * 1024, ctile = (size_t)16 * (256 + 4) * 4;
-    constexpr size_t sm = panel > ctile ? panel : ctile;
+    constexpr size_t sm = (panel > ctile ? panel : ctile) + 5 * 1024;      // + the five epilogue vectors
     static bool once = false;
     if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_panel<CH, KS_T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
     hipLaunchKernelGGL((k_gemm_panel<CH, KS_T>), dim3(a.N / 256, a.M / 16, batch), dim3(1024), sm, s, a);
