@@ -80,17 +80,19 @@ __device__ unsigned long long g_stamps[64][8];
 __device__ int g_stamp_slot;
 #define SK_STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define SK_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_[i] = t_; } while (0)
+#define SK_ACC(i, expr) do { unsigned long long t0_, t1_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); expr; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory"); st_[i] += t1_ - t0_; } while (0)
 #define SK_STAMP_FLUSH do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && g_stamp_slot < 64) for (int i_ = 0; i_ < 8; i_++) g_stamps[g_stamp_slot][i_] = st_[i_]; } while (0)
 #else
 #define SK_STAMP_DECL
 #define SK_STAMP(i) do { } while (0)
+#define SK_ACC(i, expr) do { expr; } while (0)
 #define SK_STAMP_FLUSH do { } while (0)
 #endif
 #ifdef CV2_STAMPS
 __device__ int g_stamp_ring;
 // ring variant for kernels launched from many places (GEMM): block (0,0,0) takes the next slot itself; entries 6 / 7 carry tags
 #define SK_STAMP_FLUSH_RING(tag6, tag7) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { \
-    const int sl_ = atomicAdd(&g_stamp_ring, 1) & 63; for (int i_ = 0; i_ < 6; i_++) g_stamps[sl_][i_] = st_[i_]; \
+    const int sl_ = atomicAdd(&g_stamp_ring, 1) % 56; for (int i_ = 0; i_ < 6; i_++) g_stamps[sl_][i_] = st_[i_]; \
     g_stamps[sl_][6] = (tag6); g_stamps[sl_][7] = (tag7); } } while (0)
 #else
 #define SK_STAMP_FLUSH_RING(tag6, tag7) do { } while (0)

@@ -292,6 +292,79 @@ struct AttnEstArgs {
 };
 #define AK_LD 72    // K tile row stride (bf16 elements): 64 + 8
 #define AV_LD 68    // V^T tile row stride: 64 + 4
+// one 64-key tile of the flash loop: scores, running softmax, O^T update (Kt / Vt = the staged tile in LDS)
+template <int QS>
+__device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t* Vt, const bf16x8 (&qf)[QS][2], f32x4 (&o)[QS][4],
+                                             float (&mrun)[QS], float (&lrun)[QS], const int (&kmax_q)[QS], int kt, int q16, int g) {
+        // S^T: 4 key tiles x (d = 64 in two k-steps), K fragments shared by the QS query sub-tiles
+        f32x4 sacc[QS][4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+#pragma unroll
+            for (int u = 0; u < QS; u++) sacc[u][k4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kt[(16 * k4 + q16) * AK_LD + ks * 32 + g * 8]);
+#pragma unroll
+                for (int u = 0; u < QS; u++) sacc[u][k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][k4], 0, 0, 0);
+            }
+        }
+        bf16x8 pf[QS][2];
+        // softmax in the exp2 domain on the RAW scores: p = 2^(s C - m C), C = log2(e) / sqrt(64), one FMA + one v_exp_f32 per score.
+        // Masking and the rescale of O are wave-uniform branches: only the last tile(s) of a sequence mask, and the running maximum
+        // stops moving after the first few tiles.
+        constexpr float SC = 0.125f * 1.4426950408889634f;
+#pragma unroll
+        for (int u = 0; u < QS; u++) {
+            if (!__all(kt * 64 + 64 <= kmax_q[u])) {
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (kt * 64 + 16 * k4 + 4 * g + r >= kmax_q[u]) sacc[u][k4][r] = -INFINITY;
+            }
+            float mloc = fmaxf(fmaxf(fmaxf(sacc[u][0][0], sacc[u][0][1]), fmaxf(sacc[u][0][2], sacc[u][0][3])),
+                               fmaxf(fmaxf(sacc[u][1][0], sacc[u][1][1]), fmaxf(sacc[u][1][2], sacc[u][1][3])));
+            mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(sacc[u][2][0], sacc[u][2][1]), fmaxf(sacc[u][2][2], sacc[u][2][3])),
+                                     fmaxf(fmaxf(sacc[u][3][0], sacc[u][3][1]), fmaxf(sacc[u][3][2], sacc[u][3][3]))));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float mnew = fmaxf(mrun[u], mloc);                   // raw-score domain
+            const float msafe = mnew == -INFINITY ? 0.f : mnew;
+            const float mc = msafe * SC;
+            const float alpha = __builtin_amdgcn_exp2f((mrun[u] - msafe) * SC);     // mrun = -inf -> 0
+            float psum = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; k4++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const float p = __builtin_amdgcn_exp2f(fmaf(sacc[u][k4][r], SC, -mc)); sacc[u][k4][r] = p; psum += p; }
+            lrun[u] = lrun[u] * alpha + psum;
+            mrun[u] = mnew;
+            if (__any(alpha != 1.f)) {
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++) o[u][dt] *= alpha;
+            }
+#pragma unroll
+            for (int kp = 0; kp < 2; kp++) {
+                typedef __attribute__((ext_vector_type(8))) float f32x8;
+                const f32x8 pv = {sacc[u][2 * kp][0], sacc[u][2 * kp][1], sacc[u][2 * kp][2], sacc[u][2 * kp][3],
+                                  sacc[u][2 * kp + 1][0], sacc[u][2 * kp + 1][1], sacc[u][2 * kp + 1][2], sacc[u][2 * kp + 1][3]};
+                pf[u][kp] = __builtin_convertvector(pv, bf16x8);
+            }
+        }
+        // O^T += V^T P^T ; k slots of key-pair tile kp: j < 4 -> key 32kp + 4g + j, j >= 4 -> key 32kp + 16 + 4g + (j - 4)
+#pragma unroll
+        for (int kp = 0; kp < 2; kp++)
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                const uint16_t* vrow = &Vt[(16 * dt + q16) * AV_LD + 32 * kp + 4 * g];
+                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+                for (int u = 0; u < QS; u++) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][kp], o[u][dt], 0, 0, 0);
+            }
+}
 // QS query sub-tiles of 16 rows per wave, NW waves (block = 16*NW*QS rows): K / V^T fragments read from LDS once serve QS MFMAs;
 // NW = 2 doubles the block count for single-utterance calls, whose 64-row tiles would not even fill the chip once.
 template <int QS, int NW>
@@ -331,24 +404,29 @@ __global__ __launch_bounds__(64 * NW) void k_attn_est(AttnEstArgs a) {
         for (int ks = 0; ks < 2; ks++)
             qf[u][ks] = *reinterpret_cast<const bf16x8*>(a.qk + (size_t)(m0 + RB * u + 16 * w + q16) * 1024 + h * 64 + ks * 32 + g * 8);
 
-    // staging: thread -> NCH K chunks (row, 16-B chunk) and NCH V^T chunks of the 64-key tile
+    // staging: thread -> NCH K chunks (row, 16-B chunk) and NCH V^T chunks of the 64-key tile.  TWO register sets (A, B) keep the
+    // next two tiles in flight: with one set the loop ran at the latency of a tile load (~3000 cycles per 64 keys at one
+    // utterance, where only two small blocks share a CU), not at its cost.
     constexpr int NCH = 512 / (64 * NW);
-    uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
-    kreg2 = kreg3 = vreg2 = vreg3 = make_uint4(0u, 0u, 0u, 0u);
-#define ATT_GLOAD1(C, KROW)                                                                                                  \
+    uint4 kregA0, kregA1, kregA2, kregA3, vregA0, vregA1, vregA2, vregA3;
+    uint4 kregB0, kregB1, kregB2, kregB3, vregB0, vregB1, vregB2, vregB3;
+    kregA2 = kregA3 = vregA2 = vregA3 = kregB2 = kregB3 = vregB2 = vregB3 = make_uint4(0u, 0u, 0u, 0u);
+    kregA0 = kregA1 = vregA0 = vregA1 = kregB0 = kregB1 = vregB0 = vregB1 = make_uint4(0u, 0u, 0u, 0u);
+#define ATT_GLOAD1(S, C, KROW)                                                                                               \
     if (NCH > C) {                                                                                                           \
         const int idx = tid + 64 * NW * C, kr = idx >> 3, kc = idx & 7;                                                       \
-        kreg##C = *reinterpret_cast<const uint4*>(a.qk + (size_t)((KROW) + kr) * 1024 + 512 + h * 64 + kc * 8);               \
-        vreg##C = *reinterpret_cast<const uint4*>(a.vt + (size_t)(h * 64 + kr) * a.R + (KROW) + kc * 8);                      \
+        kreg##S##C = *reinterpret_cast<const uint4*>(a.qk + (size_t)((KROW) + kr) * 1024 + 512 + h * 64 + kc * 8);            \
+        vreg##S##C = *reinterpret_cast<const uint4*>(a.vt + (size_t)(h * 64 + kr) * a.R + (KROW) + kc * 8);                   \
     }
-#define ATT_GLOAD(KT) { const long krow_ = (long)start + (KT) * 64; ATT_GLOAD1(0, krow_) ATT_GLOAD1(1, krow_) ATT_GLOAD1(2, krow_) ATT_GLOAD1(3, krow_) }
-#define ATT_LSTORE1(C, BUF)                                                                                                  \
+#define ATT_GLOAD(S, KT) { const long krow_ = (long)start + (KT) * 64; ATT_GLOAD1(S, 0, krow_) ATT_GLOAD1(S, 1, krow_) ATT_GLOAD1(S, 2, krow_) ATT_GLOAD1(S, 3, krow_) }
+#define ATT_LSTORE1(S, C, BUF)                                                                                               \
     if (NCH > C) {                                                                                                           \
         const int idx = tid + 64 * NW * C, kr = idx >> 3, kc = idx & 7;                                                       \
-        *reinterpret_cast<uint4*>(&Ks[BUF][kr * AK_LD + kc * 8]) = kreg##C;                                                   \
+        *reinterpret_cast<uint4*>(&Ks[BUF][kr * AK_LD + kc * 8]) = kreg##S##C;                                                \
         uint2* vd = reinterpret_cast<uint2*>(&Vs[BUF][kr * AV_LD + kc * 8]);                                                  \
-        vd[0] = make_uint2(vreg##C.x, vreg##C.y); vd[1] = make_uint2(vreg##C.z, vreg##C.w);                                   \
+        vd[0] = make_uint2(vreg##S##C.x, vreg##S##C.y); vd[1] = make_uint2(vreg##S##C.z, vreg##S##C.w);                       \
     }
+#define ATT_LSTORE(S, BUF) { ATT_LSTORE1(S, 0, BUF) ATT_LSTORE1(S, 1, BUF) ATT_LSTORE1(S, 2, BUF) ATT_LSTORE1(S, 3, BUF) }
 
     f32x4 o[QS][4];
     float mrun[QS], lrun[QS];
@@ -359,73 +437,24 @@ __global__ __launch_bounds__(64 * NW) void k_attn_est(AttnEstArgs a) {
         for (int dt = 0; dt < 4; dt++) o[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    ATT_GLOAD(0)
-    for (int kt = 0; kt < ntiles; kt++) {
-        const int buf = kt & 1;
-        ATT_LSTORE1(0, buf) ATT_LSTORE1(1, buf) ATT_LSTORE1(2, buf) ATT_LSTORE1(3, buf)
-        __syncthreads();
-        if (kt + 1 < ntiles) ATT_GLOAD(kt + 1)
-        // S^T: 4 key tiles x (d = 64 in two k-steps), K fragments shared by the QS query sub-tiles
-        f32x4 sacc[QS][4];
-#pragma unroll
-        for (int k4 = 0; k4 < 4; k4++) {
-#pragma unroll
-            for (int u = 0; u < QS; u++) sacc[u][k4] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[buf][(16 * k4 + q16) * AK_LD + ks * 32 + g * 8]);
-#pragma unroll
-                for (int u = 0; u < QS; u++) sacc[u][k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][k4], 0, 0, 0);
-            }
-        }
-        bf16x8 pf[QS][2];
-#pragma unroll
-        for (int u = 0; u < QS; u++) {
-            float mloc = -INFINITY;
-#pragma unroll
-            for (int k4 = 0; k4 < 4; k4++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int key = kt * 64 + 16 * k4 + 4 * g + r;
-                    const float v = key < kmax_q[u] ? sacc[u][k4][r] * 0.125f : -INFINITY;
-                    sacc[u][k4][r] = v;
-                    mloc = fmaxf(mloc, v);
-                }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            const float mnew = fmaxf(mrun[u], mloc);
-            const float msafe = mnew == -INFINITY ? 0.f : mnew;
-            const float alpha = __expf(mrun[u] - msafe);               // mrun = -inf -> 0
-            float psum = 0.f;
-#pragma unroll
-            for (int k4 = 0; k4 < 4; k4++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) { const float p = __expf(sacc[u][k4][r] - msafe); sacc[u][k4][r] = p; psum += p; }
-            lrun[u] = lrun[u] * alpha + psum;
-            mrun[u] = mnew;
-#pragma unroll
-            for (int dt = 0; dt < 4; dt++) o[u][dt] *= alpha;
-#pragma unroll
-            for (int kp = 0; kp < 2; kp++) {
-                typedef __attribute__((ext_vector_type(8))) float f32x8;
-                const f32x8 pv = {sacc[u][2 * kp][0], sacc[u][2 * kp][1], sacc[u][2 * kp][2], sacc[u][2 * kp][3],
-                                  sacc[u][2 * kp + 1][0], sacc[u][2 * kp + 1][1], sacc[u][2 * kp + 1][2], sacc[u][2 * kp + 1][3]};
-                pf[u][kp] = __builtin_convertvector(pv, bf16x8);
-            }
-        }
-        // O^T += V^T P^T ; k slots of key-pair tile kp: j < 4 -> key 32kp + 4g + j, j >= 4 -> key 32kp + 16 + 4g + (j - 4)
-#pragma unroll
-        for (int kp = 0; kp < 2; kp++)
-#pragma unroll
-            for (int dt = 0; dt < 4; dt++) {
-                const uint16_t* vrow = &Vs[buf][(16 * dt + q16) * AV_LD + 32 * kp + 4 * g];
-                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-#pragma unroll
-                for (int u = 0; u < QS; u++) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][kp], o[u][dt], 0, 0, 0);
-            }
+    // tile kt sits in set A for even kt, in set B for odd kt; LDS buffer = kt & 1.  The loads are unconditional (a tile index past
+    // the end is clamped to the last tile) so that the number in flight is fixed and the waits stay counted.
+    const int last = ntiles - 1;
+    SK_STAMP_DECL;
+    SK_STAMP(0);
+    ATT_GLOAD(A, 0)
+    ATT_GLOAD(B, min(1, last))
+    SK_STAMP(1);
+    for (int kt = 0; kt < ntiles; kt += 2) {
+        SK_ACC(2, ATT_LSTORE(A, 0) __syncthreads());                 // [2] staging incl. the wait for the tile's loads
+        ATT_GLOAD(A, min(kt + 2, last))
+        SK_ACC(3, att_est_tile<QS>(Ks[0], Vs[0], qf, o, mrun, lrun, kmax_q, kt, q16, g));     // [3] tile compute
+        if (kt + 1 >= ntiles) break;
+        SK_ACC(2, ATT_LSTORE(B, 1) __syncthreads());
+        ATT_GLOAD(B, min(kt + 3, last))
+        SK_ACC(3, att_est_tile<QS>(Ks[1], Vs[1], qf, o, mrun, lrun, kmax_q, kt + 1, q16, g));
     }
+    SK_STAMP(4);
 #pragma unroll
     for (int u = 0; u < QS; u++) {
         float l = lrun[u];
@@ -436,6 +465,13 @@ __global__ __launch_bounds__(64 * NW) void k_attn_est(AttnEstArgs a) {
         for (int dt = 0; dt < 4; dt++)
             *reinterpret_cast<uint2*>(orow[u] + 16 * dt) = make_uint2(pack_bf16x2(o[u][dt][0] * inv, o[u][dt][1] * inv), pack_bf16x2(o[u][dt][2] * inv, o[u][dt][3] * inv));
     }
+#ifdef CV2_STAMPS
+    SK_STAMP(5);
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int i_ = 0; i_ < 6; i_++) g_stamps[60][i_] = st_[i_];       // slot 60: last attention launch (tools/dbg_stamps_flow.py)
+        g_stamps[60][6] = ntiles; g_stamps[60][7] = gridDim.x * gridDim.y;
+    }
+#endif
 }
 
 // =========================================================================== host side

@@ -20,8 +20,10 @@ torch.cuda.synchronize()
 buf = (C.c_ulonglong * (64 * 8))()
 L.check(L.lib().cv2_debug_stamps_flow(buf))
 ph = ['issue', 'first stage', 'K loop', 'C stage', 'row epilogue']
+t = [buf[60 * 8 + i] for i in range(8)]
+print(f'k_attn_est block 0: prologue={t[1]-t[0]}  staging+wait(sum)={t[2]}  compute(sum)={t[3]}  loop total={t[4]-t[1]}  store={t[5]-t[4]}  tiles={t[6]} blocks={t[7]}')
 groups = collections.defaultdict(list)
-for k in range(64):
+for k in range(56):
     t = [buf[k * 8 + i] for i in range(8)]
     if not t[0]: continue
     key = (t[7] >> 48, (t[7] >> 32) & 0xffff, t[6] >> 32, t[6] & 0xffffffff, t[7] & 0xffffffff)
