@@ -367,11 +367,18 @@ __device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t*
 }
 // QS query sub-tiles of 16 rows per wave, NW waves (block = 16*NW*QS rows): K / V^T fragments read from LDS once serve QS MFMAs;
 // NW = 2 doubles the block count for single-utterance calls, whose 64-row tiles would not even fill the chip once.
-template <int QS, int NW>
-__global__ __launch_bounds__(64 * NW) void k_attn_est(AttnEstArgs a) {
-    __shared__ __attribute__((aligned(16))) uint16_t Ks[2][64 * AK_LD];
-    __shared__ __attribute__((aligned(16))) uint16_t Vs[2][64 * AV_LD];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// KSP = 2: a second group of NW waves works on the odd key tiles of the same queries (own LDS tiles, own register sets) and the two
+// (max, sum, O) states are merged through LDS at the end.  One utterance gives only one wave per SIMD otherwise, and every LDS /
+// MFMA / transcendental latency of the tile body is then exposed (phase stamps: ~1400 cycles of compute per 64-key tile).
+template <int QS, int NW, int KSP = 1>
+__global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ks_[KSP][2][64 * AK_LD];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs_[KSP][2][64 * AV_LD];
+    const int lane = threadIdx.x & 63;
+    const int kgrp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (64 * NW));      // key group of this wave
+    const int tid = threadIdx.x - kgrp * 64 * NW, w = tid >> 6;                         // thread / wave index within the group
+    uint16_t (*Ks)[64 * AK_LD] = Ks_[kgrp];
+    uint16_t (*Vs)[64 * AV_LD] = Vs_[kgrp];
     constexpr int RB = 16 * NW;                                  // rows per query sub-tile group
     const int m0 = blockIdx.x * RB * QS, h = blockIdx.y;
     const int q16 = lane & 15, g = lane >> 4;
@@ -439,22 +446,68 @@ __global__ __launch_bounds__(64 * NW) void k_attn_est(AttnEstArgs a) {
 
     // tile kt sits in set A for even kt, in set B for odd kt; LDS buffer = kt & 1.  The loads are unconditional (a tile index past
     // the end is clamped to the last tile) so that the number in flight is fixed and the waits stay counted.
+    // This group's tiles are kgrp, kgrp + KSP, ...; every group runs the same number of rounds (block barriers inside): a tile index
+    // past the end is loaded from the last tile and fully masked (kt_eff >= ntiles makes every key invalid).
     const int last = ntiles - 1;
+    const int rounds = (ntiles + KSP - 1) / KSP;
+    int kmask_q[QS];                                                 // kmax_q, or 0 for a tile past the end
     SK_STAMP_DECL;
     SK_STAMP(0);
-    ATT_GLOAD(A, 0)
-    ATT_GLOAD(B, min(1, last))
+    ATT_GLOAD(A, min(kgrp, last))
+    ATT_GLOAD(B, min(kgrp + KSP, last))
     SK_STAMP(1);
-    for (int kt = 0; kt < ntiles; kt += 2) {
-        SK_ACC(2, ATT_LSTORE(A, 0) __syncthreads());                 // [2] staging incl. the wait for the tile's loads
-        ATT_GLOAD(A, min(kt + 2, last))
-        SK_ACC(3, att_est_tile<QS>(Ks[0], Vs[0], qf, o, mrun, lrun, kmax_q, kt, q16, g));     // [3] tile compute
-        if (kt + 1 >= ntiles) break;
-        SK_ACC(2, ATT_LSTORE(B, 1) __syncthreads());
-        ATT_GLOAD(B, min(kt + 3, last))
-        SK_ACC(3, att_est_tile<QS>(Ks[1], Vs[1], qf, o, mrun, lrun, kmax_q, kt + 1, q16, g));
+    for (int r = 0; r < rounds; r += 2) {
+        {
+            const int kt = r * KSP + kgrp;
+#pragma unroll
+            for (int u = 0; u < QS; u++) kmask_q[u] = kt < ntiles ? kmax_q[u] : 0;
+            SK_ACC(2, ATT_LSTORE(A, 0) __syncthreads());             // [2] staging incl. the wait for the tile's loads
+            ATT_GLOAD(A, min(kt + 2 * KSP, last))
+            SK_ACC(3, att_est_tile<QS>(Ks[0], Vs[0], qf, o, mrun, lrun, kmask_q, kt, q16, g));     // [3] tile compute
+        }
+        if (r + 1 >= rounds) break;
+        {
+            const int kt = (r + 1) * KSP + kgrp;
+#pragma unroll
+            for (int u = 0; u < QS; u++) kmask_q[u] = kt < ntiles ? kmax_q[u] : 0;
+            SK_ACC(2, ATT_LSTORE(B, 1) __syncthreads());
+            ATT_GLOAD(B, min(kt + 2 * KSP, last))
+            SK_ACC(3, att_est_tile<QS>(Ks[1], Vs[1], qf, o, mrun, lrun, kmask_q, kt, q16, g));
+        }
     }
     SK_STAMP(4);
+    if (KSP > 1) {
+        // merge: group 1 parks (m, l, O) in LDS (its own tile buffers are free now), group 0 folds them in
+        constexpr float SC = 0.125f * 1.4426950408889634f;
+        __syncthreads();
+        float* mg = reinterpret_cast<float*>(&Ks_[KSP - 1][0][0]);      // [NW*64 threads][QS][18]
+        if (kgrp == 1) {
+#pragma unroll
+            for (int u = 0; u < QS; u++) {
+                float* d = mg + ((size_t)tid * QS + u) * 18;
+                d[0] = mrun[u]; d[1] = lrun[u];
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) d[2 + dt * 4 + e] = o[u][dt][e];
+            }
+        }
+        __syncthreads();
+        if (kgrp != 0) return;
+#pragma unroll
+        for (int u = 0; u < QS; u++) {
+            const float* d = mg + ((size_t)tid * QS + u) * 18;
+            const float m1 = d[0], l1 = d[1];
+            const float M = fmaxf(mrun[u], m1);
+            const float ms = M == -INFINITY ? 0.f : M;
+            const float a0 = __builtin_amdgcn_exp2f((mrun[u] - ms) * SC), a1 = __builtin_amdgcn_exp2f((m1 - ms) * SC);
+            lrun[u] = lrun[u] * a0 + l1 * a1;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[u][dt][e] = o[u][dt][e] * a0 + d[2 + dt * 4 + e] * a1;
+        }
+    }
 #pragma unroll
     for (int u = 0; u < QS; u++) {
         float l = lrun[u];
@@ -686,7 +739,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         AttnEstArgs a{GB(h->qk, 1024), h->vt + GUARD, GB(h->att, 512), c.L->tab(), c.chunk, (long)(h->R + GUARD + 8)};
         if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(M / 128, 8), dim3(256), 0, c.s, a);   // enough blocks to fill the chip twice
         else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(M / 64, 8), dim3(256), 0, c.s, a);
-        else hipLaunchKernelGGL((k_attn_est<1, 2>), dim3(M / 32, 8), dim3(128), 0, c.s, a);
+        else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(M / 32, 8), dim3(256), 0, c.s, a);       // one utterance: split keys over two wave groups
     }
     {
         GemmArgs a = gemm_args(GB(h->att, 512), 512, 0, tb.out.w, M, 256, 512);
