@@ -3,7 +3,7 @@ import csv, glob, sys
 d, counter = sys.argv[1], sys.argv[2]
 f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter]
-dec = [r for r in rows if any(k in r['Kernel_Name'] for k in ('k_qkv<1', 'k_attn(', 'k_store<1', 'k_gateup<1', 'k_sample'))]
+dec = [r for r in rows if any(k in r['Kernel_Name'] for k in ('k_qkv<1', 'k_attn<', 'k_store<1', 'k_gateup<1', 'k_sample'))]
 tot = sum(float(r['Counter_Value']) for r in dec)
 nsample = sum(1 for r in dec if 'k_sample' in r['Kernel_Name'])
 per = {}
