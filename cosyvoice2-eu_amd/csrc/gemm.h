@@ -204,10 +204,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
             ep_sq[t] = max(ti.x, 0); ep_start[t] = ti.y; ep_len[t] = ti.z;
         }
     }
-    // first residual row of this lane: requested now, it has long arrived when the epilogue starts
+    // first residual row of this lane: the 16-wave (small-grid, latency-bound) configurations request it now, so that it has long
+    // arrived when the epilogue starts; the 8-wave configurations cannot afford its 4 registers across the K loop (they sit at the
+    // 128-VGPR step that decides whether two blocks share a CU) and request it after the loop
+    constexpr bool EARLY_RES = NW >= 16;
     const bool use_res = a.res && !(a.vt && n0 >= a.vt_n0);
     f32x4 res_next = z4;
-    if (use_res) res_next = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m0 + rsub) * a.ldres + n);
+    if (EARLY_RES && use_res) res_next = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m0 + rsub) * a.ldres + n);
 #pragma unroll
     for (int st = 1; st < NSTAGE - 1; st++) if (st < nk) issue(st, st);
     SK_STAMP(1);                                         // prologue loads issued
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
         __builtin_amdgcn_s_barrier();                    // stage kt has landed for every wave
         if (kt == 0) {
             SK_STAMP(2);                                 // first stage landed (and every older prologue load)
-            if (a.rowadd) {
+            if (EARLY_RES && a.rowadd) {
 #pragma unroll
                 for (int t = 0; t < NTL; t++) ep_radd[t] = *reinterpret_cast<const f32x4*>(a.rowadd + (size_t)ep_sq[t] * a.rowadd_ld + n);
             }
@@ -263,6 +266,11 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
             const int n = wn * TN + j * 16 + 4 * (lane >> 4);
             *reinterpret_cast<f32x4*>(&C[m * LDC + n]) = acc[j][i] * a.out_scale;
         }
+    if (!EARLY_RES && use_res) res_next = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m0 + rsub) * a.ldres + n);
+    if (!EARLY_RES && a.rowadd) {
+#pragma unroll
+        for (int t = 0; t < NTL; t++) ep_radd[t] = *reinterpret_cast<const f32x4*>(a.rowadd + (size_t)ep_sq[t] * a.rowadd_ld + n);
+    }
     __syncthreads();
     SK_STAMP(4);                                         // C tile staged
 
