@@ -12,10 +12,15 @@ What is different, by design:
     never sleeps; first-chunk latency is the work itself, not a poll quantum;
   * tokens stay on the device between the LLM and the flow (the reference round-trips a Python list, model.py:385);
   * the cross-fade runs on the device (the reference's fade_in_out moves both tensors to the CPU, utils/common.py:144);
-  * one model object serialises concurrent tts() calls (the evaluation harness calls it from 8 threads,
-    evaluation/cosyvoice_synthesizer.py:219,260): a call holds `self.run_lock` from its first to its last device op.
+  * one model object is shared by concurrent tts() calls (the evaluation harness calls it from up to 8 threads,
+    evaluation/cosyvoice_synthesizer.py:219,260).  Streaming calls hold `self.run_lock` from their first to their last device
+    op.  Non-streaming calls are COALESCED: each call queues its request, the first caller to get the lock becomes the batch
+    leader, waits `coalesce_ms` for stragglers, and runs up to `max_batch` queued requests as one batch through the three
+    stages (one decode step serves all of them, the flow runs over the packed ragged batch, HiFT on a pool of streams) —
+    SURVEY.md §8(b) "Threading", §8(f) rank 2.
 """
 import threading
+import time
 import uuid
 
 import numpy as np
@@ -23,14 +28,14 @@ import torch
 import torch.nn.functional as F
 
 from cv2amd.flow import FlowEngine
-from cv2amd.hift import HiftEngine
+from cv2amd.hift import HiftEngine, HiftPool
 from cv2amd.llm import LLMEngine, MODE_RAS, MODE_GREEDY
 from cv2amd import lib as L
 
 
 class CosyVoice2Model:
     def __init__(self, llm_sd=None, flow_sd=None, hift_sd=None, fp16=False, device=None, max_text=512, max_prompt_tokens=750,
-                 max_new_tokens=3000, sampling='ras', seed=0):
+                 max_new_tokens=3000, sampling='ras', seed=0, max_batch=8, coalesce_ms=2.0):
         if not torch.cuda.is_available():
             raise L.Cv2Error('CosyVoice2Model (MI355X build) needs a GPU: the hot path has no CPU fallback')
         self.device = torch.device(device or 'cuda')
@@ -48,6 +53,10 @@ class CosyVoice2Model:
         self.sampling_mode = MODE_RAS if sampling == 'ras' else MODE_GREEDY
         self.seed = seed
         self._limits = (max_text, max_prompt_tokens, max_new_tokens)
+        self.max_batch = max(1, int(max_batch))  # concurrent non-streaming calls coalesced into one batch (1 = serialise only)
+        self.coalesce_ms = coalesce_ms
+        self._pending = []                     # queued non-streaming requests, guarded by self.lock
+        self.batch_sizes = []                  # sizes of the coalesced batches run so far (diagnostics / tests)
         self.llm = self.flow = self.hift = None
         self._noise_hook = None                # tests: callable(T) -> [1, 480 T, 9] N(0,1) injected in place of the device Philox draws
         self._trace = None                     # tests: list receiving (flow mel, token_offset, finalize, noise) per token2wav call
@@ -66,9 +75,11 @@ class CosyVoice2Model:
 
     def load_state_dicts(self, llm_sd, flow_sd, hift_sd):
         max_text, max_prompt, max_new = self._limits
-        self.llm = LLMEngine(llm_sd, self.device, max_seqs=1, max_pos=max_text + max_prompt + max_new + 8, max_out=max_new)
-        self.flow = FlowEngine(flow_sd, self.device, max_utts=1, max_len=2 * (max_prompt + max_new))
-        self.hift = HiftEngine(hift_sd, self.device, max_frames=2 * max_new + self.mel_cache_len)
+        B = self.max_batch
+        self.llm = LLMEngine(llm_sd, self.device, max_seqs=B, max_pos=max_text + max_prompt + max_new + 8, max_out=max_new)
+        self.flow = FlowEngine(flow_sd, self.device, max_utts=B, max_len=2 * (max_prompt + max_new))
+        self.hift_pool = HiftPool(hift_sd, self.device, max_frames=2 * max_new + self.mel_cache_len, n=min(4, B))
+        self.hift = self.hift_pool.engines[0]
         self._window_dev = torch.from_numpy(self.speech_window).float().to(self.device)
 
     def load_jit(self, *a, **k):
@@ -136,6 +147,60 @@ class CosyVoice2Model:
         self.llm_end_dict[this_uuid] = bool(st[0, L.ST_DONE])
         return toks[0]
 
+    # ---- coalesced non-streaming calls ---------------------------------------------------------------------------
+    class _Pending:
+        __slots__ = ('text', 'prompt_text', 'llm_ptok', 'fpt', 'feat', 'femb', 'speed', 'uuid', 'done', 'speech', 'exc')
+
+    def _run_batch(self, batch):
+        """llm_job + token2wav(finalize=True) of model.py:118-139,300-334 for several queued calls at once."""
+        self.batch_sizes.append(len(batch))
+        try:
+            self.seed += 1
+            toks = self.llm.generate([(p.text, p.prompt_text, p.llm_ptok) for p in batch], mode=self.sampling_mode, seed=self.seed)
+            with self.lock:
+                for p, t in zip(batch, toks):
+                    self.tts_speech_token_dict[p.uuid], self.llm_end_dict[p.uuid] = t, True
+            utts = [dict(token=torch.tensor(t, dtype=torch.int32).unsqueeze(0), prompt_token=p.fpt, prompt_feat=p.feat, embedding=p.femb)
+                    for p, t in zip(batch, toks)]
+            mels = self.flow.inference_batch(utts, streaming=False, finalize=True)
+            for i, p in enumerate(batch):
+                if p.speed != 1.0:                                            # model.py:328-330
+                    mels[i] = F.interpolate(mels[i], size=int(mels[i].shape[2] / p.speed), mode='linear')
+            outs = self.hift_pool.inference_many([m.contiguous() for m in mels])
+            torch.cuda.synchronize(self.device)
+            for p, (wav, _) in zip(batch, outs):
+                p.speech = wav.cpu()
+        except BaseException as e:                                            # every caller of the batch sees the failure
+            for p in batch:
+                p.exc = e
+        finally:
+            for p in batch:
+                p.done.set()
+
+    def _tts_coalesced(self, p):
+        with self.lock:
+            self._pending.append(p)
+        while not p.done.wait(timeout=0.0005):
+            if not self.run_lock.acquire(blocking=False):
+                continue                                                       # a leader (or a streaming call) holds the device
+            try:
+                if p.done.is_set():
+                    break
+                if self.coalesce_ms > 0:
+                    t_end = time.perf_counter() + self.coalesce_ms * 1e-3      # give concurrent callers a moment to queue up
+                    while time.perf_counter() < t_end and len(self._pending) < self.max_batch:
+                        time.sleep(0.0002)
+                with self.lock:
+                    batch = self._pending[:self.max_batch]
+                    del self._pending[:len(batch)]
+                if batch:
+                    self._run_batch(batch)
+            finally:
+                self.run_lock.release()
+        if p.exc is not None:
+            raise p.exc
+        return p.speech
+
     # ---- model.py:336-401 -------------------------------------------------------------------------------------
     def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192), llm_embedding=torch.zeros(0, 192),
             prompt_text=torch.zeros(1, 0, dtype=torch.int32),
@@ -154,6 +219,19 @@ class CosyVoice2Model:
         fpt = flow_prompt_speech_token.to(dev)
         feat = prompt_speech_feat.to(dev)
         femb = flow_embedding.to(dev)
+        if stream is not True and self.max_batch > 1 and self._noise_hook is None and self._trace is None:
+            p = self._Pending()
+            p.text, p.prompt_text, p.llm_ptok = text.to(dev), prompt_text.to(dev), llm_prompt_speech_token.to(dev)
+            p.fpt, p.feat, p.femb, p.speed, p.uuid = fpt, feat, femb, speed, this_uuid
+            p.done, p.speech, p.exc = threading.Event(), None, None
+            try:
+                yield {'tts_speech': self._tts_coalesced(p)}
+            finally:
+                with self.lock:
+                    self.tts_speech_token_dict.pop(this_uuid, None)
+                    self.llm_end_dict.pop(this_uuid, None)
+                    self.hift_cache_dict.pop(this_uuid, None)
+            return
         if not self.run_lock.acquire(timeout=3600):
             raise RuntimeError('CosyVoice2Model.tts: another synthesis call held the model for more than an hour')
         try:

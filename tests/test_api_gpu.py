@@ -97,22 +97,49 @@ def test_streaming_scheduler_matches_reference_logic(cv):
     assert total == 960 * n_tok
 
 
-def test_concurrent_calls_are_serialised(cv):
-    """The evaluation harness calls one model from several threads (evaluation/cosyvoice_synthesizer.py:219,260)."""
-    ref = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr'))[0]['tts_speech']
-    res, errs = [None] * 3, []
+def test_concurrent_calls_are_coalesced(cv):
+    """The evaluation harness calls one model from several threads (evaluation/cosyvoice_synthesizer.py:219,260): concurrent
+    non-streaming calls must all succeed, and they run as ONE batch (ragged: two different texts) instead of one after the other."""
+    ref = {t: list(cv.inference_zero_shot(t, 'salut', None, zero_shot_spk_id='fr'))[0]['tts_speech'] for t in ('bonjour', 'guten tag')}
+    texts = ['bonjour', 'guten tag', 'bonjour', 'guten tag']
+    res, errs = [None] * len(texts), []
+    n0 = len(cv.model.batch_sizes)
+    old = cv.model.coalesce_ms
+    cv.model.coalesce_ms = 100.0          # generous window: the threads below start within microseconds of each other
 
     def work(i):
         try:
-            res[i] = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr'))[0]['tts_speech']
+            res[i] = list(cv.inference_zero_shot(texts[i], 'salut', None, zero_shot_spk_id='fr'))[0]['tts_speech']
         except Exception as e:      # noqa: BLE001
             errs.append(e)
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    try:
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(texts))]
+        [t.start() for t in ths]
+        [t.join(300) for t in ths]
+    finally:
+        cv.model.coalesce_ms = old
+    assert not errs, errs
+    sizes = cv.model.batch_sizes[n0:]
+    assert sum(sizes) == len(texts) and max(sizes) >= 2, sizes
+    for t, r in zip(texts, res):
+        assert r.dtype == torch.float32 and r.device.type == 'cpu' and torch.isfinite(r).all()
+        assert r.shape == ref[t].shape    # greedy tokens are deterministic; HiFT noise differs per call (device Philox)
+    assert not cv.model.tts_speech_token_dict and not cv.model.llm_end_dict and not cv.model._pending
+
+
+def test_stream_and_batch_calls_share_the_device(cv):
+    """A streaming call holds the device while it runs; a concurrent non-streaming call waits and then completes."""
+    out = {}
+
+    def streamer():
+        out['s'] = [c['tts_speech'] for c in cv.inference_zero_shot('guten tag', 'salut', None, zero_shot_spk_id='fr', stream=True)]
+
+    def batcher():
+        out['b'] = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr'))[0]['tts_speech']
+    ths = [threading.Thread(target=streamer), threading.Thread(target=batcher)]
     [t.start() for t in ths]
     [t.join(300) for t in ths]
-    assert not errs
-    for r in res:
-        assert r.shape == ref.shape       # greedy tokens are deterministic; HiFT noise differs per call (device Philox)
+    assert len(out['s']) >= 1 and all(torch.isfinite(c).all() for c in out['s']) and torch.isfinite(out['b']).all()
 
 
 def test_speed_changes_length(cv):
