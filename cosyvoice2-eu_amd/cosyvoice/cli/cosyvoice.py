@@ -101,5 +101,7 @@ class CosyVoice2:
         raise NotImplementedError('inference_instruct is not implemented for CosyVoice2!')
 
     def inference_instruct2(self, tts_text, instruct_text, prompt_speech_16k, zero_shot_spk_id='', stream=False, speed=1.0, text_frontend=True):
-        raise NotImplementedError('inference_instruct2 (cli/cosyvoice.py:284) shares the three stages but needs frontend_instruct2; '
-                                  'outside the zero-shot hot path of this build (SURVEY.md §8f #4)')
+        """cli/cosyvoice.py:284-295: same three stages, the instruction rides in the prompt-text slot."""
+        for i in self.frontend.text_normalize(tts_text, split=True, text_frontend=text_frontend):
+            model_input = self.frontend.frontend_instruct2(i, instruct_text, prompt_speech_16k, self.sample_rate, zero_shot_spk_id)
+            yield from self._run(model_input, stream, speed, i)

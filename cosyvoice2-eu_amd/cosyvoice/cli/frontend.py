@@ -77,6 +77,15 @@ class PrecomputedFrontEnd:
         return model_input
 
 
+    def frontend_instruct2(self, tts_text, instruct_text, prompt_speech_16k, resample_rate, zero_shot_spk_id):
+        """frontend.py:533-537: zero-shot input whose prompt text is the instruction + '<|endofprompt|>', without the LLM's prompt
+        speech tokens.  As in the reference, a registered speaker id takes its stored prompt text (frontend.py:509-510)."""
+        model_input = self.frontend_zero_shot(tts_text, instruct_text + '<|endofprompt|>', prompt_speech_16k, resample_rate, zero_shot_spk_id)
+        for k in ('llm_prompt_speech_token', 'llm_prompt_speech_token_len'):
+            model_input.pop(k, None)
+        return model_input
+
+
 class CosyVoiceFrontEnd(PrecomputedFrontEnd):
     """The reference's frontend on its own third-party stack (frontend.py:38-127).  Raises FrontEndUnavailable at construction
     when that stack (onnxruntime, whisper, transformers tokenizer files) is not installed."""

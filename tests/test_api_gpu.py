@@ -44,6 +44,16 @@ def test_cross_lingual_drops_llm_prompt(cv):
     assert a.shape[1] > 0 and (a.shape != b.shape or not torch.equal(a, b))
 
 
+def test_instruct2_runs_without_llm_prompt_tokens(cv):
+    """cli/cosyvoice.py:284-295 + frontend.py:533-537: the LLM sees [sos, prompt text, text, task] only, the flow keeps its prompt."""
+    out = list(cv.inference_instruct2('bonjour', 'parle lentement', None, zero_shot_spk_id='fr'))
+    cl = list(cv.inference_cross_lingual('bonjour', None, zero_shot_spk_id='fr'))
+    zs = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr'))
+    assert len(out) == 1 and out[0]['tts_speech'].dtype == torch.float32 and torch.isfinite(out[0]['tts_speech']).all()
+    assert out[0]['tts_speech'].shape[1] % 480 == 0 and out[0]['tts_speech'].shape[1] > 0
+    assert len(cl) == 1 and len(zs) == 1
+
+
 def test_streaming_scheduler_matches_reference_logic(cv):
     """Chunking / caches / cross-fade of model.py:300-381 restated on the CPU oracle, fed with the SAME flow mels and the same
     injected noise the device run used: waveform chunks must agree to 1e-3; the flow mels themselves are checked against the

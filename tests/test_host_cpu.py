@@ -163,6 +163,8 @@ def test_api_surface_matches_reference_signatures():
                                                      ('zero_shot_spk_id', ''), ('stream', False), ('speed', 1.0), ('text_frontend', True)]
     assert params(CosyVoice2.inference_cross_lingual) == [('tts_text', inspect._empty), ('prompt_speech_16k', inspect._empty), ('zero_shot_spk_id', ''),
                                                          ('stream', False), ('speed', 1.0), ('text_frontend', True)]
+    assert params(CosyVoice2.inference_instruct2) == [('tts_text', inspect._empty), ('instruct_text', inspect._empty), ('prompt_speech_16k', inspect._empty),
+                                                     ('zero_shot_spk_id', ''), ('stream', False), ('speed', 1.0), ('text_frontend', True)]
     assert [n for n, _ in params(CosyVoice2Model.token2wav)] == ['token', 'prompt_token', 'prompt_feat', 'embedding', 'token_offset', 'uuid', 'stream',
                                                                  'finalize', 'speed']
     assert [n for n, _ in params(CosyVoice2Model.tts)][:10] == ['text', 'flow_embedding', 'llm_embedding', 'prompt_text', 'llm_prompt_speech_token',
@@ -171,6 +173,24 @@ def test_api_surface_matches_reference_signatures():
                                                           'final', 'backbone']
     assert dict(params(cosyvoice2_eu.load))['setting'] == 'llm_flow_hifigan'
     assert [n for n, _ in params(cosyvoice2_eu.Cosy2EU.tts)] == ['text', 'prompt', 'speed', 'text_frontend']
+
+
+def test_frontend_modes_build_the_reference_model_input():
+    """frontend_zero_shot / cross_lingual / instruct2 (cli/frontend.py:491-537) for a registered speaker: which keys reach tts()."""
+    from cosyvoice.cli.frontend import PrecomputedFrontEnd
+    spk = {'prompt_text': torch.tensor([[1, 2, 3]], dtype=torch.int32), 'prompt_text_len': torch.tensor([3]),
+           'llm_prompt_speech_token': torch.zeros(1, 5, dtype=torch.int32), 'llm_prompt_speech_token_len': torch.tensor([5]),
+           'flow_prompt_speech_token': torch.zeros(1, 5, dtype=torch.int32), 'flow_prompt_speech_token_len': torch.tensor([5]),
+           'prompt_speech_feat': torch.zeros(1, 10, 80), 'prompt_speech_feat_len': torch.tensor([10]),
+           'llm_embedding': torch.zeros(1, 192), 'flow_embedding': torch.zeros(1, 192)}
+    fe = PrecomputedFrontEnd(lambda t: [ord(c) for c in t], {'a': spk})
+    z = fe.frontend_zero_shot('hi', 'x', None, 24000, 'a')
+    assert set(z) == set(spk) | {'text', 'text_len'} and z['text'].tolist() == [[104, 105]] and z['text'].dtype == torch.int32
+    c = fe.frontend_cross_lingual('hi', None, 24000, 'a')
+    assert set(c) == set(z) - {'prompt_text', 'prompt_text_len', 'llm_prompt_speech_token', 'llm_prompt_speech_token_len'}
+    i2 = fe.frontend_instruct2('hi', 'speak fast', None, 24000, 'a')
+    assert set(i2) == set(z) - {'llm_prompt_speech_token', 'llm_prompt_speech_token_len'}
+    assert set(spk) == set(fe.spk2info['a'])                  # the registered speaker record is not mutated by the pops
 
 
 def test_load_wav_mono_and_resample(tmp_path):
