@@ -51,7 +51,7 @@ static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, h
     if (cfg == 0) { CV2_CHECK(a.N % 128 == 0, "gemm cfg0: N=%d %% 128", a.N); 
         // fewer blocks than ~1.5 per CU: 16 waves per block spread the LDS-DMA issue cost (phase stamps: the K loop runs at ~2x the per-CU
         // vector-memory bound of 64 B/clk whatever the number of stages in flight); otherwise 8 waves and two blocks per CU
-        if ((long)(a.N / 128) * (a.M / 128) * batch < 200) return gemm_go<64, 128, 4, 4>(a, batch, packed, s);      // < 1 block per CU: halve the tile, the row epilogue (GELU, V^T) is VALU-bound
+        if ((long)(a.N / 128) * (a.M / 128) * batch < 200) return gemm_go<64, 128, 2, 4>(a, batch, packed, s);      // < 1 block per CU: halve the tile, the row epilogue (GELU, V^T) is VALU-bound
         if ((long)(a.N / 128) * (a.M / 128) * batch < 400) return gemm_go<128, 128, 4, 4>(a, batch, packed, s);
         return gemm_go<128, 128, 2, 4>(a, batch, packed, s);
     }
