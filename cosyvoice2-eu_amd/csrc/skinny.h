@@ -149,6 +149,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     }
     SK_STAMP_DECL;
     SK_STAMP(0);
+    float rs_def = 1.f;                                          // deferred RMS scale of the single row (batch-1 fast path)
     // 1. this thread's first operand item, THEN every weight fragment of the wave.  Loads return in issue order per wave: with the
     //    (L2-resident, tiny) operand issued first it arrives after one L2 round trip and the fold / RMS / split below runs while the
     //    weight stream is still in flight; issued after the weights it would only arrive once the whole stream has landed.
@@ -187,33 +188,43 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     __syncthreads();
   } else {
     // 2. fold / normalise / split the block's x slice [ks0*32, ks1*32) into LDS (B-operand order)
-    //    item = (row r, group of 8 columns); the first item of every thread stays in registers across the RMS barrier
-    float* isq = reinterpret_cast<float*>(smem);                                  // [nitems] (aliases the x stage)
+    //    item = (row r, group of 8 columns); the first item of every thread stays in registers.
+    //    Up to 16 rows (NB == 1) the RMS statistic is DEFERRED: W (g . x) rs = rs (W (g . x)), so g . x is staged without waiting
+    //    for the row's sum of squares, which travels through LDS under the staging barrier and scales the reduced tile in step 4
+    //    (one barrier and one dependent LDS round trip less between the operand's arrival and the MFMAs).
+    constexpr bool DEFER = NB == 1;
+    float* isq = reinterpret_cast<float*>(DEFER ? smem + sk_xstage_bytes<NB>(nks) + 32 * sizeof(float) + NWK * NWR * NB * 1024 +
+                                                      NWR * 16 * (NB * 16 + 1) * sizeof(float)
+                                                : smem);                          // [nitems]; NB > 1: aliases the x stage
     float* rstd = reinterpret_cast<float*>(smem + sk_xstage_bytes<NB>(nks));      // [32]
     SK_STAMP(1);                                                 // loads issued
     const bool one_row = rows == 1 && nitems <= 128;             // batch-1 decode: the row's items sit in waves 0 and 1
     float rs_one = 0.f;
     if (X.norm_w && one_row) {
-        // sum of squares straight from the registers: DPP wave sums, two partials through LDS, ONE barrier
+        // sum of squares straight from the registers: DPP wave sums, two partials through LDS
         float sq = ((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) + ((v0[4] * v0[4] + v0[5] * v0[5]) + (v0[6] * v0[6] + v0[7] * v0[7]));
         if (wave < 2) { sq = wave_sum(sq); if (lane == 0) rstd[wave] = sq; }
-        __syncthreads();
-        SK_STAMP(2);                                             // operand arrived + sum of squares exchanged
-        rs_one = rsqrtf((rstd[0] + rstd[1]) / (float)K + X.eps);
+        if (!DEFER) {
+            __syncthreads();
+            rs_one = rsqrtf((rstd[0] + rstd[1]) / (float)K + X.eps);
+        }
+        SK_STAMP(2);                                             // operand arrived
     } else if (X.norm_w) {
         for (int it = tid; it < nitems; it += nthreads) {
             f32x8 v = v0;
             if (it != tid) { const int r = row_of(it), k8 = it - r * k8n; v = sk_load_x<ATT>(X, r, K, ks0 * 32 + k8 * 8); }
             isq[it] = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
         }
-        __syncthreads();
-        for (int r = wave; r < rows; r += NWR * NWK) {
-            float s = 0.f;
-            for (int i = lane; i < k8n; i += 64) s += isq[r * k8n + i];
-            s = wave_sum(s);
-            if (lane == 0) rstd[r] = rsqrtf(s / (float)K + X.eps);
+        if (!DEFER) {
+            __syncthreads();
+            for (int r = wave; r < rows; r += NWR * NWK) {
+                float s = 0.f;
+                for (int i = lane; i < k8n; i += 64) s += isq[r * k8n + i];
+                s = wave_sum(s);
+                if (lane == 0) rstd[r] = rsqrtf(s / (float)K + X.eps);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     for (int it = tid; it < nitems; it += nthreads) {
         const int r = row_of(it), k8 = it - r * k8n;
@@ -221,7 +232,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         f32x8 v = v0, g = g0;
         if (it != tid) { v = sk_load_x<ATT>(X, r, K, k); if (X.norm_w) g = *reinterpret_cast<const f32x8*>(X.norm_w + k); }
         if (X.x_out && blockIdx.x == 0) *reinterpret_cast<f32x8*>(X.x_out + (unsigned)(r * K + k)) = v;
-        if (X.norm_w) v = g * (v * (one_row ? rs_one : rstd[r]));
+        if (X.norm_w) v = DEFER ? g * v : g * (v * (one_row ? rs_one : rstd[r]));
         bf16x8 hi, lo;
         split8(v, hi, lo);
         const int s = k8 >> 2, hq = k8 & 3, t = r >> 4;
@@ -230,6 +241,18 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         dst[64] = lo;
     }
     __syncthreads();
+    if (DEFER && X.norm_w) {                                     // row statistics -> rstd[row]; consumed after the barrier of step 4
+        if (one_row) {
+            rs_def = rsqrtf((rstd[0] + rstd[1]) / (float)K + X.eps);
+        } else {
+            for (int r = wave; r < rows; r += NWR * NWK) {
+                float s = 0.f;
+                for (int i = lane; i < k8n; i += 64) s += isq[r * k8n + i];
+                s = wave_sum(s);
+                if (lane == 0) rstd[16 + r] = rsqrtf(s / (float)K + X.eps);       // [16..31]: [0..1] may still be read as partials
+            }
+        }
+    }
   }
 
     SK_STAMP(3);                                                 // B operand staged in LDS
@@ -268,6 +291,10 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
             for (int q = 1; q < NWK; q++) v += red[((q * NWR + wr) * NB + t) * 64 + lane];
             const int b = 16 * t + (lane & 15);
             const int n0 = wr * 16 + 4 * (lane >> 4);
+            if (NB == 1 && !PRE && X.norm_w) {                    // deferred RMS scale of row b (rows >= `rows` are never read)
+                const float* rstd_ = reinterpret_cast<const float*>(smem + sk_xstage_bytes<NB>(nks));
+                v *= (rows == 1 && nitems <= 128) ? rs_def : rstd_[16 + (lane & 15)];
+            }
 #pragma unroll
             for (int r = 0; r < 4; r++) res[(n0 + r) * (NB * 16 + 1) + b] = v[r];
         }
@@ -313,5 +340,6 @@ template <int NB, int NWR, int NWK>
 static inline size_t skinny_smem_bytes(int nks_block) {
     const size_t xs = (size_t)nks_block * NB * 2 * 1024 + 32 * sizeof(float);
     const size_t rr = (size_t)NWK * NWR * NB * 1024 + (size_t)NWR * 16 * (NB * 16 + 1) * sizeof(float);
-    return NB > 1 ? (xs > rr ? xs : rr) : xs + rr + 1024;        // NB == 1: reduction buffers behind the x stage
+    // NB == 1: reduction buffers behind the x stage, then the per-item sums of squares of the deferred RMS (16 rows x 4 nks items)
+    return NB > 1 ? (xs > rr ? xs : rr) : xs + rr + 1024 + (size_t)16 * nks_block * 4 * sizeof(float);
 }
