@@ -7,7 +7,9 @@
 //
 // k_conv: Conv1d as an LDS line-buffered implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, bit-exact
 // fp32 FMA chains at the vector-FMA peak rate, leaving the VALU to the activation and address work):
-//   * block = 128 output frames x 64 output channels, 4 waves of 32 frames each;
+//   * block = 128 output frames x 64 output channels; wave (fw, cw) owns 64 frames x 32 channels = two MFMA tiles that share
+//     every WEIGHT fragment (one 256 B L2 read per two MFMAs; sharing the x fragment instead, as a first version did, made the
+//     weight reads saturate the CU's 64 B/clk vector-memory path exactly at the MFMA rate);
 //   * per 64-input-channel chunk the block loads the frames [t0 - pad, t0 + 128 + (k-1)*dil - pad) ONCE into an LDS
 //     line buffer, applying the pre-activation (Snake / leaky-ReLU) and the zero padding while loading, and every tap
 //     then reads its shifted window from LDS (row stride 65 floats: conflict-free ds_read_b32 across frames);
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
     const int li = lane & 31, lk = lane >> 5;
+    const int fw = wave >> 1, cw = wave & 1;                        // frame half (64 frames), 32-channel output tile
     for (int c0 = 0; c0 < a.CinP; c0 += CV_CK) {
         __syncthreads();
         // line buffer: frames t0 - pad_left + r, channels c0 .. c0+63 ; 16 lanes x float4 per frame
@@ -84,48 +87,48 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         // weights: groups of 8 k-steps, the NEXT group's 16 fragments are loaded (L2) while the current group's 16 MFMAs run
         constexpr int GK = 8, NG = CV_CK / 2 / GK;               // 4 groups per tap
         const size_t wstride = (size_t)ntile * 64;
-        const float* wb = a.wp + (((size_t)0 * (a.CinP / 2) + c0 / 2) * ntile + co0 / 32) * 64 + lane;
+        const float* wb = a.wp + (((size_t)0 * (a.CinP / 2) + c0 / 2) * ntile + co0 / 32 + cw) * 64 + lane;
         const size_t tapstride = (size_t)(a.CinP / 2) * ntile * 64;
-        // two register sets (A, B) alternate without copies: while the 16 MFMAs of one group run, the other set's 16 loads fly
-        float bA0[GK], bA1[GK], bB0[GK], bB1[GK];
-#define CV_LOAD(SET0, SET1, GI)                                                                                     \
+        // two register sets (A, B) alternate without copies: while the 16 MFMAs of one group run, the other set's 8 loads fly
+        float bA[GK], bB[GK];
+#define CV_LOAD(SET, GI)                                                                                            \
         {                                                                                                           \
             const float* wn_ = wb + ((GI) / NG) * tapstride + (size_t)((GI) % NG) * GK * wstride;                     \
-            _Pragma("unroll") for (int u = 0; u < GK; u++) { SET0[u] = wn_[u * wstride]; SET1[u] = wn_[u * wstride + 64]; } \
+            _Pragma("unroll") for (int u = 0; u < GK; u++) SET[u] = wn_[u * wstride];                                 \
         }
-#define CV_MMA(SET0, SET1, GI)                                                                                      \
+#define CV_MMA(SET, GI)                                                                                             \
         {                                                                                                           \
-            const float* xr_ = xs + (wave * 32 + li + ((GI) / NG) * a.dil) * CV_LD + lk + 2 * ((GI) % NG) * GK;       \
+            const float* xr_ = xs + (fw * 64 + li + ((GI) / NG) * a.dil) * CV_LD + lk + 2 * ((GI) % NG) * GK;         \
             _Pragma("unroll") for (int u = 0; u < GK; u++) {                                                          \
-                const float av = xr_[2 * u];                                                                        \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, SET0[u], acc0, 0, 0, 0);                              \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, SET1[u], acc1, 0, 0, 0);                              \
+                const float av0 = xr_[2 * u], av1 = xr_[32 * CV_LD + 2 * u];                                          \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, SET[u], acc0, 0, 0, 0);                              \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, SET[u], acc1, 0, 0, 0);                              \
             }                                                                                                       \
         }
         const int ngroups = a.taps * NG;                         // even (NG = 4)
-        CV_LOAD(bA0, bA1, 0)
+        CV_LOAD(bA, 0)
         for (int gi = 0; gi < ngroups; gi += 2) {
-            CV_LOAD(bB0, bB1, gi + 1)
+            CV_LOAD(bB, gi + 1)
             __builtin_amdgcn_sched_barrier(0);                   // keep the issue order: hipcc otherwise sinks the loads to their use
-            CV_MMA(bA0, bA1, gi)
+            CV_MMA(bA, gi)
             __builtin_amdgcn_sched_barrier(0);
-            if (gi + 2 < ngroups) CV_LOAD(bA0, bA1, gi + 2)
+            if (gi + 2 < ngroups) CV_LOAD(bA, gi + 2)
             __builtin_amdgcn_sched_barrier(0);
-            CV_MMA(bB0, bB1, gi + 1)
+            CV_MMA(bB, gi + 1)
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef CV_LOAD
 #undef CV_MMA
     }
-    // epilogue: lane holds channel co (li) of tile 0 / 1 and 16 frames
+    // epilogue: lane holds channel co (li) of its output tile and 16 frames of each of its two frame tiles
 #pragma unroll
     for (int tile = 0; tile < 2; tile++) {
-        const int co = co0 + tile * 32 + li;
+        const int co = co0 + cw * 32 + li;
         if (co >= a.Cout_store) continue;
         const float b = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int t = t0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int t = t0 + fw * 64 + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             if (t >= a.L_out) continue;
             float v = (tile == 0 ? acc0[r] : acc1[r]) + b;
             if (a.res) v += a.res[(size_t)t * a.ldres + co];
