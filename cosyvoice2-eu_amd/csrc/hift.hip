@@ -67,21 +67,33 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     const int fw = wave >> 1, cw = wave & 1;                        // frame half (64 frames), 32-channel output tile
     for (int c0 = 0; c0 < a.CinP; c0 += CV_CK) {
         __syncthreads();
-        // line buffer: frames t0 - pad_left + r, channels c0 .. c0+63 ; 16 lanes x float4 per frame
-        for (int it = tid; it < rows * 16; it += 256) {
-            const int r = it >> 4, c4 = (it & 15) * 4;
-            const int t = t0 - a.pad_left + r, c = c0 + c4;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < a.L_in) {
-                const float* src = a.x + (size_t)t * a.Cin + c;
-                if (c + 3 < a.Cin) { const f32x4 q = *reinterpret_cast<const f32x4*>(src); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
-                else for (int e = 0; e < 4; e++) if (c + e < a.Cin) v[e] = src[e];
-                if (a.pre != PRE_NONE)
+        // line buffer: frames t0 - pad_left + r, channels c0 .. c0+63 ; 16 lanes x float4 per frame.  Four items per thread are
+        // requested before the first is used: one item at a time, every item paid a full memory round trip before its activation
+        for (int it0 = tid; it0 < rows * 16; it0 += 256 * 4) {
+            f32x4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int it = it0 + 256 * u;
+                const int r = it >> 4, c = c0 + (it & 15) * 4, t = t0 - a.pad_left + r;
+                q[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (it < rows * 16 && t >= 0 && t < a.L_in) {
+                    const float* src = a.x + (size_t)t * a.Cin + c;
+                    if (c + 3 < a.Cin) q[u] = *reinterpret_cast<const f32x4*>(src);
+                    else for (int e = 0; e < 4; e++) if (c + e < a.Cin) q[u][e] = src[e];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int it = it0 + 256 * u;
+                if (it >= rows * 16) break;
+                const int r = it >> 4, c4 = (it & 15) * 4, c = c0 + c4, t = t0 - a.pad_left + r;
+                f32x4 v = q[u];
+                if (a.pre != PRE_NONE && t >= 0 && t < a.L_in)
                     for (int e = 0; e < 4; e++)
                         if (c + e < a.Cin) v[e] = pre_apply(v[e], a.pre, a.pre == PRE_SNAKE ? a.alpha[c + e] : 0.f, a.slope);
+                float* d = xs + r * CV_LD + c4;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             }
-            float* d = xs + r * CV_LD + c4;
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
         __syncthreads();
         // weights: groups of 8 k-steps, the NEXT group's 16 fragments are loaded (L2) while the current group's 16 MFMAs run
