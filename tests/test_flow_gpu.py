@@ -44,7 +44,10 @@ def test_gemm_bf16_matches_fp64(dev):
     lib = L.lib()
     F._bind(lib)
     g = torch.Generator().manual_seed(0)
-    for m, n, k in ((128, 128, 64), (256, 256, 256), (384, 1536, 256), (128, 256, 768), (256, 1024, 1024), (128, 512, 2560)):
+    # the last three shapes reach the large-grid tile configurations (k_gemm<64,256,2,4>, <128,128,2,4>, <128,128,4,4>) that the
+    # one-utterance tests never select; (256, 256, 256) and (128, 256, 768) go through the row-panel kernel
+    for m, n, k in ((128, 128, 64), (256, 256, 256), (384, 1536, 256), (128, 256, 768), (256, 1024, 1024), (128, 512, 2560),
+                    (16384, 256, 512), (6400, 1024, 256), (3072, 1536, 256)):
         a = torch.randn(m, k, generator=g)
         w = torch.randn(n, k, generator=g) / k ** 0.5
         b = torch.randn(n, generator=g)
@@ -129,6 +132,28 @@ def test_ragged_batch_equals_single(eng):
     for s, b in zip(single, batch):
         assert s.shape == b.shape
         assert torch.equal(s, b)
+
+
+def test_large_batch_tile_configurations_agree_with_single(dev, flow_sd):
+    """Eight ~10 s utterances packed together select the large-grid kernels (k_gemm<64,256,2,4>, <128,128,2,4>, k_attn_est<2,4>);
+    one utterance alone runs on the row-panel GEMM, the 64x128 tiles and the key-split attention that the golden-vector tests
+    cover.  Same arithmetic class (bf16 operands, fp32 accumulate), different summation order: agreement to bf16 round-off
+    after the 10 Euler steps, not bit equality."""
+    from cv2amd import synth
+    from cv2amd.flow import FlowEngine
+    big = FlowEngine(flow_sd, dev, max_utts=8, max_len=1100)
+    utts = []
+    for i in range(8):
+        inp = synth.synthetic_inputs(seed=70 + i, prompt_len=40 + 3 * i)
+        g = torch.Generator().manual_seed(100 + i)
+        utts.append(dict(token=torch.randint(0, 6561, (1, 440 + 7 * i), generator=g, dtype=torch.int32), prompt_token=inp['prompt_token'],
+                         prompt_feat=inp['prompt_feat'], embedding=inp['embedding']))
+    batch = [m.clone() for m in big.inference_batch(utts)]
+    for i in (0, 3, 7):
+        single = big.inference_batch([utts[i]])[0]
+        torch.cuda.synchronize()
+        assert single.shape == batch[i].shape and torch.isfinite(batch[i]).all()
+        assert rel(batch[i].cpu(), single.cpu()) < 3e-2, f'utterance {i}: {rel(batch[i].cpu(), single.cpu()):.3e}'
 
 
 def test_oracle_full_size_estimator_random(eng, dev, flow_sd):
