@@ -103,6 +103,25 @@ def test_forced_length_batch(small):
         assert ids == OL.inference(sdr, text, ptxt, ptok, force_len=24)
 
 
+@pytest.mark.parametrize('max_pos', [1536, 4400])
+def test_long_context_attention_splits(dev, small, max_pos):
+    """Larger KV capacities change the decode attention's key splits: 128-key splits with two wave groups per block (max_pos 1536),
+    512-key splits with four groups and a second round of tiles (max_pos 4400).  A 300-token prompt crosses the tile and round
+    boundaries; greedy ids must still equal the oracle's."""
+    from cv2amd import synth
+    from cv2amd.llm import LLMEngine
+    from oracle import llm as OL
+    sd, sdr, _ = small
+    eng = LLMEngine(sd, dev, max_seqs=2, max_pos=max_pos, max_out=64)
+    reqs = []
+    for i, plen in enumerate((300, 41)):
+        inp = synth.synthetic_inputs(seed=400 + i, text_len=9, prompt_len=plen, prompt_text_len=3)
+        reqs.append((inp['text'], inp['prompt_text'], inp['prompt_token']))
+    got = eng.generate(reqs, force_len=12)
+    for (text, ptxt, ptok), ids in zip(reqs, got):
+        assert ids == OL.inference(sdr, text, ptxt, ptok, force_len=12)
+
+
 def test_many_row_decode_path(small):
     """More than 16 sequences per step take the prepared-operand kernels (k_prep + PRE variants): ids still equal the oracle's."""
     from oracle import llm as OL
