@@ -45,7 +45,7 @@ class CosyVoice2Model:
         self.source_cache_len = int(self.mel_cache_len * 480)
         self.speech_window = np.hamming(2 * self.source_cache_len)
         self.lock = threading.Lock()           # guards the per-uuid dicts, as in the reference
-        self.run_lock = threading.Lock()       # serialises device work of concurrent tts() calls (held from first to last device op)
+        self.run_lock = threading.Lock()       # owner of the device: a streaming call for its whole life, or the leader of a coalesced batch
         self.tts_speech_token_dict = {}
         self.llm_end_dict = {}
         self.hift_cache_dict = {}
