@@ -237,7 +237,7 @@ def main():
                        'flow_mfma': {'achieved': round(flow_tf, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(flow_tf / MFMA_BF16_PEAK, 4)},
                        'hift_fp32_mfma': {'achieved': round(hift_tf, 2), 'peak': FP32_MFMA_PEAK, 'unit': 'TFLOP/s', 'frac': round(hift_tf / FP32_MFMA_PEAK, 4)}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is a rank-0, one-GPU-run item
             out['cpu_baseline'] = cpu_baseline(host_cores())
         print(json.dumps(out), flush=True)
     if use_dist:
