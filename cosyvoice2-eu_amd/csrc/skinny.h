@@ -85,6 +85,39 @@ __device__ __forceinline__ f32x8 sk_finish_x(const SkinnyX& X, const SkRaw<true>
     }
     return acc * (1.f / den);
 }
+// Half-range variant for the one-row O-projection: two thread groups fold SK_MAXSPLIT / 2 split slots each (half the loads and
+// half the exp / FMA work per thread) and merge their (max, denominator, numerator) through LDS.
+#define SK_HALFSPLIT (SK_MAXSPLIT / 2)
+struct SkRawHalf { float mv[SK_HALFSPLIT], lv[SK_HALFSPLIT]; f32x8 ov[SK_HALFSPLIT]; int ns; };
+__device__ __forceinline__ void sk_issue_att_half(const SkinnyX& X, int r, int K, int k, int s_lo, SkRawHalf& o) {
+    const int nq = K >> 6, hd = k >> 6;
+    o.ns = X.att_cnt[r];
+    const unsigned off_ml = (unsigned)(r * nq + hd) * 2u, off_o = (unsigned)(r * K + k);
+#pragma unroll
+    for (int i = 0; i < SK_HALFSPLIT; i++) {
+        const int s = s_lo + i;
+        if (s < X.np) {
+            const float2 mlv = *reinterpret_cast<const float2*>(X.att_ml + (size_t)s * SK_ROWS_CAP * nq * 2 + off_ml);
+            o.mv[i] = mlv.x; o.lv[i] = mlv.y;
+            o.ov[i] = *reinterpret_cast<const f32x8*>(X.parts + (size_t)s * SK_ROWS_CAP * K + off_o);
+        }
+    }
+}
+__device__ __forceinline__ void sk_partial_att_half(const SkRawHalf& o, int s_lo, float& M, float& den, f32x8& acc) {
+    M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SK_HALFSPLIT; i++) if (s_lo + i < o.ns) M = fmaxf(M, o.mv[i]);
+    acc = (f32x8){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    den = 0.f;
+#pragma unroll
+    for (int i = 0; i < SK_HALFSPLIT; i++) {
+        if (s_lo + i < o.ns) {
+            const float w = __expf(o.mv[i] - M);
+            den += w * o.lv[i];
+            acc += w * o.ov[i];
+        }
+    }
+}
 __device__ __forceinline__ void sk_issue_x(const SkinnyX& X, int r, int K, int k, SkRaw<false>& o) {
     const unsigned off = (unsigned)(r * K + k);
     o.v = *reinterpret_cast<const f32x8*>(X.base + off);
@@ -160,7 +193,15 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     auto row_of = [rows, inv2k](int it) { return rows == 1 ? 0 : (int)((float)(2 * it + 1) * inv2k); };
     f32x8 v0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     SkRaw<ATT> raw0;
-    const bool has0 = !PRE && tid < nitems;
+    // one-row O-projection (ATT, 256 threads, <= 128 items): threads 0..127 fold the first half of the split slots, threads
+    // 128..255 the second half; the other shapes fold every slot in the item's own thread
+    const bool half_fold = ATT && !PRE && nthreads == 256 && rows == 1 && nitems <= 128;
+    SkRawHalf rawh;
+    const int hgrp = tid >> 7, htid = tid & 127;
+    if (ATT && half_fold) {
+        if (htid < nitems) sk_issue_att_half(X, 0, K, ks0 * 32 + htid * 8, hgrp * SK_HALFSPLIT, rawh);
+    }
+    const bool has0 = !PRE && !half_fold && tid < nitems;
     const int r0 = row_of(tid), c0 = ks0 * 32 + (tid - r0 * k8n) * 8;
     f32x8 g0;                                                     // RMSNorm weight of the item (unused without norm)
     if (has0) {
@@ -182,6 +223,29 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     __builtin_amdgcn_sched_barrier(0);
     issued();
     if (has0) v0 = sk_finish_x(X, raw0);
+    if (ATT && half_fold) {
+        float hM = -INFINITY, hden = 0.f;
+        f32x8 hacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (htid < nitems) sk_partial_att_half(rawh, hgrp * SK_HALFSPLIT, hM, hden, hacc);
+        // exchange through the (still unused) reduction area behind the x stage: [item][10] floats
+        float* xch = reinterpret_cast<float*>(smem + sk_xstage_bytes<NB>(nks) + 32 * sizeof(float));
+        if (hgrp == 1 && htid < nitems) {
+            float* d = xch + htid * 10;
+            d[0] = hM; d[1] = hden;
+#pragma unroll
+            for (int e = 0; e < 8; e++) d[2 + e] = hacc[e];
+        }
+        __syncthreads();
+        if (hgrp == 0 && htid < nitems) {
+            const float* d = xch + htid * 10;
+            const float M1 = d[0], M = fmaxf(hM, M1);
+            const float w0 = __expf(hM - M), w1 = __expf(M1 - M);         // a group without live slots has max = -inf: weight 0
+            const float den = hden * w0 + d[1] * w1;
+#pragma unroll
+            for (int e = 0; e < 8; e++) v0[e] = (hacc[e] * w0 + d[2 + e] * w1) * (1.f / den);
+        }
+        // (no second barrier: the area becomes the reduction buffer of step 4 only after the staging barrier below)
+    }
 
   if (PRE) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
