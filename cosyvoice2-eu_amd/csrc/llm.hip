@@ -152,6 +152,10 @@ __global__ __launch_bounds__(256 * NSUB) void k_attn(AttnArgs a) {
     }
     int seq, pos;
     a.rm.get(r, seq, pos);
+    // Many rows per launch (batched decode: hundreds of blocks, throughput-bound): wait for the position and skip the splits past
+    // the sequence's length BEFORE fetching their tiles - speculative tiles of empty splits were twice the live KV traffic at 32
+    // rows.  Few rows (latency-bound): fetch first, mask later.
+    if (gridDim.z > 4 && split_lo >= pos + 1) return;
     const int seq_s = a.rm.prefill ? a.rm.seq0 : r;
     const float* K = a.kc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
     const float* V = a.vc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
