@@ -13,11 +13,15 @@ What is different, by design:
   * tokens stay on the device between the LLM and the flow (the reference round-trips a Python list, model.py:385);
   * the cross-fade runs on the device (the reference's fade_in_out moves both tensors to the CPU, utils/common.py:144);
   * one model object is shared by concurrent tts() calls (the evaluation harness calls it from up to 8 threads,
-    evaluation/cosyvoice_synthesizer.py:219,260).  Streaming calls hold `self.run_lock` from their first to their last device
-    op.  Non-streaming calls are COALESCED: each call queues its request, the first caller to get the lock becomes the batch
-    leader, waits `coalesce_ms` for stragglers, and runs up to `max_batch` queued requests as one batch through the three
-    stages (one decode step serves all of them, the flow runs over the packed ragged batch, HiFT on a pool of streams) —
-    SURVEY.md §8(b) "Threading", §8(f) rank 2.
+    evaluation/cosyvoice_synthesizer.py:219,260; BASELINE config 5 runs 8 streams at once) — SURVEY.md §8(b) "Threading", §8(f) rank 2:
+      - STREAMING calls each own one LLM slot (KV cache + sampler state) and share the decode steps: whenever one of them needs
+        tokens, a step advances every active slot (continuous batching of the LLM; a stream that already has its tokens simply
+        runs ahead, as the reference's LLM thread does); each device operation (prefill, step, poll, token2wav of one chunk) is a
+        short critical section under `self.run_lock`, so the chunks of different streams interleave instead of queueing whole calls;
+      - NON-STREAMING calls are COALESCED: each call queues its request, one caller becomes the batch leader, waits `coalesce_ms`
+        for stragglers, and runs up to `max_batch` queued requests as one batch through the three stages (one decode step serves
+        all of them, the flow runs over the packed ragged batch, HiFT on a pool of streams);
+      - the two kinds exclude each other (a batch uses slots 0..n-1): streams hold the model in shared mode, a batch in exclusive mode.
 """
 import threading
 import time
@@ -33,6 +37,30 @@ from cv2amd.llm import LLMEngine, MODE_RAS, MODE_GREEDY
 from cv2amd import lib as L
 
 
+class _FairLock:
+    """FIFO mutex (ticket lock).  threading.Lock lets a thread that releases and immediately re-acquires win again and again: one
+    stream would then run all its chunks before the others get their first.  With tickets the streams' operations go round-robin."""
+
+    def __init__(self):
+        self._cv = threading.Condition()
+        self._next, self._serving = 0, 0
+
+    def acquire(self):
+        with self._cv:
+            t = self._next
+            self._next += 1
+            while self._serving != t:
+                self._cv.wait()
+
+    def release(self):
+        with self._cv:
+            self._serving += 1
+            self._cv.notify_all()
+
+    __enter__ = lambda self: self.acquire()
+    __exit__ = lambda self, *a: self.release()
+
+
 class CosyVoice2Model:
     def __init__(self, llm_sd=None, flow_sd=None, hift_sd=None, fp16=False, device=None, max_text=512, max_prompt_tokens=750,
                  max_new_tokens=3000, sampling='ras', seed=0, max_batch=8, coalesce_ms=2.0):
@@ -45,7 +73,11 @@ class CosyVoice2Model:
         self.source_cache_len = int(self.mel_cache_len * 480)
         self.speech_window = np.hamming(2 * self.source_cache_len)
         self.lock = threading.Lock()           # guards the per-uuid dicts, as in the reference
-        self.run_lock = threading.Lock()       # owner of the device: a streaming call for its whole life, or the leader of a coalesced batch
+        self.run_lock = _FairLock()            # one device operation at a time (a chunk's work, or a whole coalesced batch), FIFO
+        self._leader_lock = threading.Lock()   # election of the batch leader among queued non-streaming callers
+        self._mode = threading.Condition()     # shared (streams, one LLM slot each) / exclusive (a batch) use of the engines
+        self._n_shared, self._excl, self._excl_waiting = 0, False, 0
+        self._slot_free, self._active_slots = [], set()
         self.tts_speech_token_dict = {}
         self.llm_end_dict = {}
         self.hift_cache_dict = {}
@@ -80,6 +112,9 @@ class CosyVoice2Model:
         self.flow = FlowEngine(flow_sd, self.device, max_utts=B, max_len=2 * (max_prompt + max_new))
         self.hift_pool = HiftPool(hift_sd, self.device, max_frames=2 * max_new + self.mel_cache_len, n=min(4, B))
         self.hift = self.hift_pool.engines[0]
+        self.llm.park()                            # no slot is live: decode steps that cover a free slot leave it alone
+        torch.cuda.synchronize(self.device)
+        self._slot_free, self._active_slots = list(range(B)), set()
         self._window_dev = torch.from_numpy(self.speech_window).float().to(self.device)
 
     def load_jit(self, *a, **k):
@@ -128,24 +163,61 @@ class CosyVoice2Model:
         return tts_speech
 
     # ---- llm side: llm_job (model.py:118-139) as bursts on the LLM stream -------------------------------------------
-    def _llm_start(self, text, prompt_text, llm_prompt_speech_token):
+    def _enter_shared(self):
+        """A streaming / serial call takes one LLM slot; waits while a coalesced batch runs (or waits to run) or no slot is free."""
+        with self._mode:
+            while self._excl or self._excl_waiting > 0 or not self._slot_free:
+                self._mode.wait(0.05)
+            self._n_shared += 1
+            slot = self._slot_free.pop(0)
+            self._active_slots.add(slot)
+        return slot
+
+    def _exit_shared(self, slot):
+        with self._mode:
+            self._active_slots.discard(slot)
+            self._slot_free.append(slot)
+            self._slot_free.sort()
+            self._n_shared -= 1
+            self._mode.notify_all()
+
+    def _enter_excl(self):
+        with self._mode:
+            self._excl_waiting += 1
+            while self._excl or self._n_shared > 0:
+                self._mode.wait(0.05)
+            self._excl_waiting -= 1
+            self._excl = True
+
+    def _exit_excl(self):
+        with self._mode:
+            self._excl = False
+            self._mode.notify_all()
+
+    # the helpers below run under self.run_lock
+    def _llm_start(self, slot, text, prompt_text, llm_prompt_speech_token):
         min_len, max_len = int(text.shape[1] * 2), int(text.shape[1] * 20)       # llm.py:643-644 (target text only)
         with torch.cuda.stream(self.llm_stream):
             x = self.llm.build_lm_input(text, prompt_text, llm_prompt_speech_token)
             self.seed += 1
-            self.llm.add_requests([0], [x], [(min_len, max_len)], self.sampling_mode, self.seed)
+            self.llm.add_requests([slot], [x], [(min_len, max_len)], self.sampling_mode, self.seed)
 
     def _llm_advance(self, n_steps):
+        """n_steps decode steps for EVERY active slot (slots 0..highest active; parked slots in between idle)."""
+        if n_steps <= 0:
+            return
+        with self._mode:
+            hi = max(self._active_slots) + 1
         with torch.cuda.stream(self.llm_stream):
-            self.llm.step(1, n_steps)
+            self.llm.step(hi, n_steps)
 
-    def _llm_poll(self, this_uuid):
+    def _llm_poll(self, this_uuid, slot):
         """Wait for the enqueued LLM work, publish the tokens so far (the reference's thread appends to the same list)."""
         self.llm_stream.synchronize()
-        st, toks = self.llm.read(1)
-        self.tts_speech_token_dict[this_uuid] = toks[0]
-        self.llm_end_dict[this_uuid] = bool(st[0, L.ST_DONE])
-        return toks[0]
+        st, toks = self.llm.read_slot(slot)
+        self.tts_speech_token_dict[this_uuid] = toks
+        self.llm_end_dict[this_uuid] = bool(st[L.ST_DONE])
+        return toks
 
     # ---- coalesced non-streaming calls ---------------------------------------------------------------------------
     class _Pending:
@@ -181,22 +253,27 @@ class CosyVoice2Model:
         with self.lock:
             self._pending.append(p)
         while not p.done.wait(timeout=0.0005):
-            if not self.run_lock.acquire(blocking=False):
-                continue                                                       # a leader (or a streaming call) holds the device
+            if not self._leader_lock.acquire(blocking=False):
+                continue                                                       # another caller is the leader
             try:
                 if p.done.is_set():
                     break
-                if self.coalesce_ms > 0:
-                    t_end = time.perf_counter() + self.coalesce_ms * 1e-3      # give concurrent callers a moment to queue up
-                    while time.perf_counter() < t_end and len(self._pending) < self.max_batch:
-                        time.sleep(0.0002)
-                with self.lock:
-                    batch = self._pending[:self.max_batch]
-                    del self._pending[:len(batch)]
-                if batch:
-                    self._run_batch(batch)
+                self._enter_excl()                                             # streams drain first; new ones wait for the batch
+                try:
+                    if self.coalesce_ms > 0:
+                        t_end = time.perf_counter() + self.coalesce_ms * 1e-3  # give concurrent callers a moment to queue up
+                        while time.perf_counter() < t_end and len(self._pending) < self.max_batch:
+                            time.sleep(0.0002)
+                    with self.lock:
+                        batch = self._pending[:self.max_batch]
+                        del self._pending[:len(batch)]
+                    if batch:
+                        with self.run_lock:
+                            self._run_batch(batch)
+                finally:
+                    self._exit_excl()
             finally:
-                self.run_lock.release()
+                self._leader_lock.release()
         if p.exc is not None:
             raise p.exc
         return p.speech
@@ -232,45 +309,59 @@ class CosyVoice2Model:
                     self.llm_end_dict.pop(this_uuid, None)
                     self.hift_cache_dict.pop(this_uuid, None)
             return
-        if not self.run_lock.acquire(timeout=3600):
-            raise RuntimeError('CosyVoice2Model.tts: another synthesis call held the model for more than an hour')
+        slot = self._enter_shared()
+        hop, la = self.token_hop_len, self.flow.pre_lookahead_len
         try:
-            self._llm_start(text.to(dev), prompt_text.to(dev), llm_prompt_speech_token.to(dev))
-            la = self.flow.pre_lookahead_len
+            text_d, ptext_d, lptok_d = text.to(dev), prompt_text.to(dev), llm_prompt_speech_token.to(dev)
             if stream is True:
                 token_offset = 0
-                prompt_token_pad = int(np.ceil(fpt.shape[1] / self.token_hop_len) * self.token_hop_len - fpt.shape[1])
-                need = self.token_hop_len + prompt_token_pad + la           # tokens the first chunk needs (model.py:353-357)
-                self._llm_advance(need - 1)                                    # the prefill already drew token 0
-                while True:
-                    toks = self._llm_poll(this_uuid)
-                    this_token_hop_len = self.token_hop_len + prompt_token_pad if token_offset == 0 else self.token_hop_len
-                    ended = self.llm_end_dict[this_uuid]
-                    if len(toks) - token_offset >= this_token_hop_len + la:
-                        if not ended:                                          # next burst overlaps this chunk's flow + HiFT
-                            self._llm_advance(self.token_hop_len)
-                        this_tok = torch.tensor(toks[:token_offset + this_token_hop_len + la], dtype=torch.int32).unsqueeze(0)
-                        speech = self.token2wav(this_tok, fpt, feat, femb, token_offset, this_uuid, stream=stream, finalize=False)
-                        token_offset += this_token_hop_len
-                        yield {'tts_speech': speech.cpu()}
-                        continue
-                    if ended:
+                prompt_token_pad = int(np.ceil(fpt.shape[1] / hop) * hop - fpt.shape[1])
+                with self.run_lock:
+                    self._llm_start(slot, text_d, ptext_d, lptok_d)            # prefill draws token 0; the first pass of the loop below
+                while True:                                                    # requests the rest of the first chunk's tokens
+                    speech, finished = None, False
+                    with self.run_lock:
+                        toks = self._llm_poll(this_uuid, slot)
+                        ended = self.llm_end_dict[this_uuid]
+                        this_token_hop_len = hop + prompt_token_pad if token_offset == 0 else hop
+                        have = len(toks) - token_offset
+                        if have >= this_token_hop_len + la:
+                            if not ended:                                      # the next chunk's missing tokens: their burst overlaps this
+                                self._llm_advance(this_token_hop_len + hop + la - have)   # chunk's flow + HiFT (other streams ride along)
+                            this_tok = torch.tensor(toks[:token_offset + this_token_hop_len + la], dtype=torch.int32).unsqueeze(0)
+                            speech = self.token2wav(this_tok, fpt, feat, femb, token_offset, this_uuid, stream=stream, finalize=False).cpu()
+                            token_offset += this_token_hop_len
+                        elif ended:
+                            finished = True
+                        else:
+                            self._llm_advance(this_token_hop_len + la - have)  # fill tokens skipped (ids > eos)
+                    if speech is not None:
+                        yield {'tts_speech': speech}
+                    if finished:
                         break
-                    self._llm_advance(this_token_hop_len + la - (len(toks) - token_offset))   # fill tokens skipped (ids > eos)
-                this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid], dtype=torch.int32).unsqueeze(0)
-                speech = self.token2wav(this_tok, fpt, feat, femb, token_offset, this_uuid, finalize=True)
-                yield {'tts_speech': speech.cpu()}
+                with self.run_lock:
+                    this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid], dtype=torch.int32).unsqueeze(0)
+                    speech = self.token2wav(this_tok, fpt, feat, femb, token_offset, this_uuid, finalize=True).cpu()
+                yield {'tts_speech': speech}
             else:
+                with self.run_lock:
+                    self._llm_start(slot, text_d, ptext_d, lptok_d)
                 while True:
-                    self._llm_advance(64)
-                    toks = self._llm_poll(this_uuid)
+                    with self.run_lock:
+                        self._llm_advance(64)
+                        toks = self._llm_poll(this_uuid, slot)
                     if self.llm_end_dict[this_uuid]:
                         break
-                this_tok = torch.tensor(toks, dtype=torch.int32).unsqueeze(0)
-                speech = self.token2wav(this_tok, fpt, feat, femb, 0, this_uuid, finalize=True, speed=speed)
-                yield {'tts_speech': speech.cpu()}
+                with self.run_lock:
+                    this_tok = torch.tensor(toks, dtype=torch.int32).unsqueeze(0)
+                    speech = self.token2wav(this_tok, fpt, feat, femb, 0, this_uuid, finalize=True, speed=speed).cpu()
+                yield {'tts_speech': speech}
         finally:
-            self.run_lock.release()
+            with self.run_lock:                                               # an abandoned generator leaves a live slot behind: park it
+                with torch.cuda.stream(self.llm_stream):
+                    self.llm.park(slot)
+                self.llm_stream.synchronize()
+            self._exit_shared(slot)
             with self.lock:
                 self.tts_speech_token_dict.pop(this_uuid, None)
                 self.llm_end_dict.pop(this_uuid, None)

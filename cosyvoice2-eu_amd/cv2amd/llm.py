@@ -135,6 +135,21 @@ class LLMEngine:
                 raise RuntimeError('sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!')
         return st, [toks[b, :min(int(st[b, L.ST_NOUT]), self.max_out)].tolist() for b in range(n_seqs)]
 
+    def read_slot(self, slot):
+        """(state row [16] int32 cpu, emitted tokens of one slot).  One device->host sync."""
+        st = self.state[slot].cpu()
+        if int(st[L.ST_ERR]):
+            raise RuntimeError('sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!')
+        n = min(int(st[L.ST_NOUT]), self.max_out)
+        return st, self.out_tokens[slot, :n].cpu().tolist()
+
+    def park(self, slot=None):
+        """Mark a slot (or every slot) finished: a parked slot idles on its last position when a decode step covers it."""
+        if slot is None:
+            self.state[:, L.ST_DONE] = 1
+        else:
+            self.state[slot, L.ST_DONE] = 1
+
     def generate(self, requests, mode=MODE_GREEDY, seed=0, force_len=None, sync_every=16, min_ratio=2, max_ratio=20, batch_prefill=True):
         """requests: list of (text, prompt_text, prompt_speech_token) int tensors.  Returns list of token lists."""
         n = len(requests)

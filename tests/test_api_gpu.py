@@ -152,6 +152,47 @@ def test_stream_and_batch_calls_share_the_device(cv):
     assert len(out['s']) >= 1 and all(torch.isfinite(c).all() for c in out['s']) and torch.isfinite(out['b']).all()
 
 
+def test_concurrent_streams_share_decode_steps(cv):
+    """BASELINE config 5 runs several streams at once: each streaming call owns one LLM slot and the calls share the decode steps
+    (chunks interleave).  Every stream must deliver exactly its own audio: greedy tokens are deterministic, so each stream's total
+    length equals the length of the same text synthesised alone."""
+    import time
+    texts = ['bonjour', 'guten tag', 'bonjour', 'guten tag']
+    alone = {t: sum(c['tts_speech'].shape[1] for c in cv.inference_zero_shot(t, 'salut', None, zero_shot_spk_id='fr', stream=True))
+             for t in set(texts)}
+    out, first, errs = [None] * len(texts), [None] * len(texts), []
+    t0 = time.perf_counter()
+
+    def work(i):
+        try:
+            chunks = []
+            for c in cv.inference_zero_shot(texts[i], 'salut', None, zero_shot_spk_id='fr', stream=True):
+                if first[i] is None:
+                    first[i] = time.perf_counter() - t0
+                chunks.append(c['tts_speech'])
+            out[i] = chunks
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(texts))]
+    [t.start() for t in ths]
+    [t.join(300) for t in ths]
+    assert not errs, errs
+    for t, chunks in zip(texts, out):
+        assert len(chunks) >= 1 and all(torch.isfinite(c).all() for c in chunks)
+        assert sum(c.shape[1] for c in chunks) == alone[t]
+    assert sorted(cv.model._slot_free) == list(range(cv.model.max_batch)) and not cv.model._active_slots
+    assert not cv.model.tts_speech_token_dict and not cv.model.hift_cache_dict
+
+
+def test_abandoned_stream_releases_its_slot(cv):
+    g = cv.inference_zero_shot('guten tag', 'salut', None, zero_shot_spk_id='fr', stream=True)
+    next(g)
+    g.close()                                   # consumer walks away after the first chunk
+    assert sorted(cv.model._slot_free) == list(range(cv.model.max_batch))
+    again = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr'))
+    assert torch.isfinite(again[0]['tts_speech']).all()
+
+
 def test_speed_changes_length(cv):
     a = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr', speed=1.0))[0]['tts_speech']
     b = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr', speed=2.0))[0]['tts_speech']

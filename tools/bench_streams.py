@@ -1,0 +1,43 @@
+"""First-chunk latency of N concurrent streaming calls on ONE model (BASELINE config 5: streaming, B = 8):
+python tools/bench_streams.py [streams] [rounds].  Each round starts N threads at once; reports p50 / max of t(first chunk)."""
+import os, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cosyvoice2-eu_amd'))
+import torch
+from cv2amd import synth
+from cosyvoice.cli.model import CosyVoice2Model
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+m = CosyVoice2Model(synth.make_llm(), synth.make_flow(), synth.make_hift(), max_text=128, max_prompt_tokens=320, max_new_tokens=1100,
+                    max_batch=8)
+inp = synth.synthetic_inputs(seed=1986, text_len=12, prompt_len=255, prompt_text_len=20)     # 12 text tokens -> <= 240 speech tokens
+kw = dict(text=inp['text'], prompt_text=inp['prompt_text'], llm_prompt_speech_token=inp['prompt_token'],
+          flow_prompt_speech_token=inp['prompt_token'], prompt_speech_feat=inp['prompt_feat'], flow_embedding=inp['embedding'],
+          llm_embedding=inp['embedding'])
+
+
+def run(n):
+    first, total = [None] * n, [0.0] * n
+    t0 = time.perf_counter()
+
+    def work(i):
+        for out in m.tts(**kw, stream=True):
+            if first[i] is None:
+                first[i] = time.perf_counter() - t0
+            total[i] += out['tts_speech'].shape[1] / 24000.0
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    return first, sum(total), time.perf_counter() - t0
+
+
+run(1); run(N)                                   # warm-up (graphs for 1..N slots)
+for n in (1, N):
+    firsts = []
+    for _ in range(R):
+        f, audio, dt = run(n)
+        firsts += f
+    firsts.sort()
+    print(f'{n} concurrent stream(s): first chunk p50 {firsts[len(firsts) // 2] * 1e3:.1f} ms, max {firsts[-1] * 1e3:.1f} ms; '
+          f'last round {audio:.1f} s of audio in {dt:.2f} s = {audio / dt:.1f} audio-s/s')
