@@ -88,6 +88,8 @@ class CosyVoice2Model:
         self.max_batch = max(1, int(max_batch))  # concurrent non-streaming calls coalesced into one batch (1 = serialise only)
         self.coalesce_ms = coalesce_ms
         self._pending = []                     # queued non-streaming requests, guarded by self.lock
+        self._chunk_q = []                     # queued chunks of streaming calls, guarded by self.lock
+        self._prefill_q = []                   # queued prefills of calls that start together, guarded by self.lock
         self.batch_sizes = []                  # sizes of the coalesced batches run so far (diagnostics / tests)
         self.llm = self.flow = self.hift = None
         self._noise_hook = None                # tests: callable(T) -> [1, 480 T, 9] N(0,1) injected in place of the device Philox draws
@@ -131,6 +133,10 @@ class CosyVoice2Model:
         tts_mel, _ = self.flow.inference(token=token, token_len=None, prompt_token=prompt_token, prompt_token_len=None,
                                          prompt_feat=prompt_feat, prompt_feat_len=None, embedding=embedding, streaming=stream,
                                          finalize=finalize)
+        return self._mel2wav(tts_mel, token_offset, uuid, finalize, speed)
+
+    def _mel2wav(self, tts_mel, token_offset, uuid, finalize, speed):
+        """model.py:311-334: everything of token2wav after the flow (slice, mel / source / speech caches, HiFT, cross-fade)."""
         flow_mel = tts_mel
         tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio:]
         cache = self.hift_cache_dict[uuid]
@@ -161,6 +167,44 @@ class CosyVoice2Model:
             if cache is not None:
                 self.hift.fade_in_out(tts_speech, cache['speech'], self._window_dev)
         return tts_speech
+
+    # ---- chunks of concurrent streams: one ragged flow batch for every chunk that is ready -------------------------------
+    class _Chunk:
+        __slots__ = ('token', 'fpt', 'feat', 'femb', 'offset', 'uuid', 'stream', 'finalize', 'done', 'speech', 'exc')
+
+    def _run_chunks(self, batch):
+        try:
+            for key in sorted({(c.stream, c.finalize) for c in batch}):
+                grp = [c for c in batch if (c.stream, c.finalize) == key]
+                mels = self.flow.inference_batch([dict(token=c.token, prompt_token=c.fpt, prompt_feat=c.feat, embedding=c.femb) for c in grp],
+                                                 streaming=key[0], finalize=key[1])
+                for c, mel in zip(grp, mels):
+                    c.speech = self._mel2wav(mel, c.offset, c.uuid, c.finalize, 1.0).cpu()
+        except BaseException as e:                                            # every stream of the batch sees the failure
+            for c in batch:
+                if c.speech is None:
+                    c.exc = e
+        finally:
+            for c in batch:
+                c.done = True
+
+    def _chunk_submit(self, token, fpt, feat, femb, offset, this_uuid, stream, finalize):
+        """token2wav for one chunk of a streaming call.  The chunk is queued; whoever gets the device next runs the flow over ALL
+        queued chunks as one ragged batch (streams that share decode steps become ready together), then HiFT per chunk."""
+        c = self._Chunk()
+        c.token, c.fpt, c.feat, c.femb, c.offset, c.uuid, c.stream, c.finalize = token, fpt, feat, femb, offset, this_uuid, stream, finalize
+        c.done, c.speech, c.exc = False, None, None
+        with self.lock:
+            self._chunk_q.append(c)
+        with self.run_lock:
+            if not c.done:
+                with self.lock:
+                    batch = self._chunk_q[:self.max_batch]
+                    del self._chunk_q[:len(batch)]
+                self._run_chunks(batch)
+        if c.exc is not None:
+            raise c.exc
+        return c.speech
 
     # ---- llm side: llm_job (model.py:118-139) as bursts on the LLM stream -------------------------------------------
     def _enter_shared(self):
@@ -194,14 +238,41 @@ class CosyVoice2Model:
             self._excl = False
             self._mode.notify_all()
 
-    # the helpers below run under self.run_lock
-    def _llm_start(self, slot, text, prompt_text, llm_prompt_speech_token):
-        min_len, max_len = int(text.shape[1] * 2), int(text.shape[1] * 20)       # llm.py:643-644 (target text only)
-        with torch.cuda.stream(self.llm_stream):
-            x = self.llm.build_lm_input(text, prompt_text, llm_prompt_speech_token)
-            self.seed += 1
-            self.llm.add_requests([slot], [x], [(min_len, max_len)], self.sampling_mode, self.seed)
+    class _Prefill:
+        __slots__ = ('slot', 'text', 'prompt_text', 'ptok', 'done', 'exc')
 
+    def _llm_start(self, slot, text, prompt_text, llm_prompt_speech_token):
+        """llm.py:684-719 step 0 (prefill + first draw) for one call.  Calls that start together are prefilled TOGETHER: the request
+        is queued, whoever gets the device next runs one batched prefill (one pass over the weights) for every queued request."""
+        p = self._Prefill()
+        p.slot, p.text, p.prompt_text, p.ptok, p.done, p.exc = slot, text, prompt_text, llm_prompt_speech_token, False, None
+        with self.lock:
+            self._prefill_q.append(p)
+        with self.run_lock:
+            if not p.done:
+                with self.lock:
+                    batch = self._prefill_q[:]
+                    self._prefill_q.clear()
+                try:
+                    with torch.cuda.stream(self.llm_stream):
+                        xs = [self.llm.build_lm_input(b.text, b.prompt_text, b.ptok) for b in batch]
+                        mms = [(int(b.text.shape[1] * 2), int(b.text.shape[1] * 20)) for b in batch]     # llm.py:643-644 (target text only)
+                        self.seed += 1
+                        if sum(x.shape[0] for x in xs) <= self.llm.dims.max_prefill_rows:
+                            self.llm.add_requests([b.slot for b in batch], xs, mms, self.sampling_mode, self.seed)
+                        else:
+                            for b, x, mm in zip(batch, xs, mms):
+                                self.llm.add_requests([b.slot], [x], [mm], self.sampling_mode, self.seed)
+                except BaseException as e:
+                    for b in batch:
+                        b.exc = e
+                finally:
+                    for b in batch:
+                        b.done = True
+        if p.exc is not None:
+            raise p.exc
+
+    # the helpers below run under self.run_lock
     def _llm_advance(self, n_steps):
         """n_steps decode steps for EVERY active slot (slots 0..highest active; parked slots in between idle)."""
         if n_steps <= 0:
@@ -316,10 +387,9 @@ class CosyVoice2Model:
             if stream is True:
                 token_offset = 0
                 prompt_token_pad = int(np.ceil(fpt.shape[1] / hop) * hop - fpt.shape[1])
-                with self.run_lock:
-                    self._llm_start(slot, text_d, ptext_d, lptok_d)            # prefill draws token 0; the first pass of the loop below
+                self._llm_start(slot, text_d, ptext_d, lptok_d)                # prefill draws token 0; the first pass of the loop below
                 while True:                                                    # requests the rest of the first chunk's tokens
-                    speech, finished = None, False
+                    this_tok, finished = None, False
                     with self.run_lock:
                         toks = self._llm_poll(this_uuid, slot)
                         ended = self.llm_end_dict[this_uuid]
@@ -329,23 +399,21 @@ class CosyVoice2Model:
                             if not ended:                                      # the next chunk's missing tokens: their burst overlaps this
                                 self._llm_advance(this_token_hop_len + hop + la - have)   # chunk's flow + HiFT (other streams ride along)
                             this_tok = torch.tensor(toks[:token_offset + this_token_hop_len + la], dtype=torch.int32).unsqueeze(0)
-                            speech = self.token2wav(this_tok, fpt, feat, femb, token_offset, this_uuid, stream=stream, finalize=False).cpu()
-                            token_offset += this_token_hop_len
                         elif ended:
                             finished = True
                         else:
                             self._llm_advance(this_token_hop_len + la - have)  # fill tokens skipped (ids > eos)
-                    if speech is not None:
+                    if this_tok is not None:
+                        speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, True, False)
+                        token_offset += this_token_hop_len
                         yield {'tts_speech': speech}
                     if finished:
                         break
-                with self.run_lock:
-                    this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid], dtype=torch.int32).unsqueeze(0)
-                    speech = self.token2wav(this_tok, fpt, feat, femb, token_offset, this_uuid, finalize=True).cpu()
+                this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid], dtype=torch.int32).unsqueeze(0)
+                speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, False, True)
                 yield {'tts_speech': speech}
             else:
-                with self.run_lock:
-                    self._llm_start(slot, text_d, ptext_d, lptok_d)
+                self._llm_start(slot, text_d, ptext_d, lptok_d)
                 while True:
                     with self.run_lock:
                         self._llm_advance(64)
