@@ -135,8 +135,9 @@ class CosyVoice2Model:
                                          finalize=finalize)
         return self._mel2wav(tts_mel, token_offset, uuid, finalize, speed)
 
-    def _mel2wav(self, tts_mel, token_offset, uuid, finalize, speed):
+    def _mel2wav(self, tts_mel, token_offset, uuid, finalize, speed, hift=None):
         """model.py:311-334: everything of token2wav after the flow (slice, mel / source / speech caches, HiFT, cross-fade)."""
+        hift = hift or self.hift
         flow_mel = tts_mel
         tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio:]
         cache = self.hift_cache_dict[uuid]
@@ -152,9 +153,9 @@ class CosyVoice2Model:
         if self._trace is not None:
             self._trace.append((flow_mel.cpu(), token_offset, finalize, noise))
         if finalize is False:
-            tts_speech, tts_source = self.hift.inference(speech_feat=tts_mel.contiguous(), cache_source=hift_cache_source, noise=noise)
+            tts_speech, tts_source = hift.inference(speech_feat=tts_mel.contiguous(), cache_source=hift_cache_source, noise=noise)
             if cache is not None:
-                self.hift.fade_in_out(tts_speech, cache['speech'], self._window_dev)
+                hift.fade_in_out(tts_speech, cache['speech'], self._window_dev)
             self.hift_cache_dict[uuid] = {'mel': tts_mel[:, :, -self.mel_cache_len:].clone(),
                                           'source': tts_source[:, :, -self.source_cache_len:].clone(),
                                           'speech': tts_speech[:, -self.source_cache_len:].clone()}
@@ -163,9 +164,9 @@ class CosyVoice2Model:
             if speed != 1.0:
                 assert cache is None, 'speed change only support non-stream inference mode'
                 tts_mel = F.interpolate(tts_mel, size=int(tts_mel.shape[2] / speed), mode='linear')
-            tts_speech, tts_source = self.hift.inference(speech_feat=tts_mel.contiguous(), cache_source=hift_cache_source, noise=noise)
+            tts_speech, tts_source = hift.inference(speech_feat=tts_mel.contiguous(), cache_source=hift_cache_source, noise=noise)
             if cache is not None:
-                self.hift.fade_in_out(tts_speech, cache['speech'], self._window_dev)
+                hift.fade_in_out(tts_speech, cache['speech'], self._window_dev)
         return tts_speech
 
     # ---- chunks of concurrent streams: one ragged flow batch for every chunk that is ready -------------------------------
@@ -178,8 +179,21 @@ class CosyVoice2Model:
                 grp = [c for c in batch if (c.stream, c.finalize) == key]
                 mels = self.flow.inference_batch([dict(token=c.token, prompt_token=c.fpt, prompt_feat=c.feat, embedding=c.femb) for c in grp],
                                                  streaming=key[0], finalize=key[1])
-                for c, mel in zip(grp, mels):
-                    c.speech = self._mel2wav(mel, c.offset, c.uuid, c.finalize, 1.0).cpu()
+                if len(grp) == 1:
+                    grp[0].speech = self._mel2wav(mels[0], grp[0].offset, grp[0].uuid, grp[0].finalize, 1.0).cpu()
+                    continue
+                # HiFT (and the cache / cross-fade bookkeeping) of the chunks on the pool's HIP streams, joined before anything is read
+                pool, main, sp = self.hift_pool, torch.cuda.current_stream(), []
+                for st in pool.streams:
+                    st.wait_stream(main)
+                for i, (c, mel) in enumerate(zip(grp, mels)):
+                    k = i % len(pool.engines)
+                    with torch.cuda.stream(pool.streams[k]):
+                        sp.append(self._mel2wav(mel, c.offset, c.uuid, c.finalize, 1.0, hift=pool.engines[k]))
+                for st in pool.streams:
+                    main.wait_stream(st)
+                for c, w in zip(grp, sp):
+                    c.speech = w.cpu()
         except BaseException as e:                                            # every stream of the batch sees the failure
             for c in batch:
                 if c.speech is None:
