@@ -17,7 +17,9 @@ What is different, by design:
       - STREAMING calls each own one LLM slot (KV cache + sampler state) and share the decode steps: whenever one of them needs
         tokens, a step advances every active slot (continuous batching of the LLM; a stream that already has its tokens simply
         runs ahead, as the reference's LLM thread does); each device operation (prefill, step, poll, token2wav of one chunk) is a
-        short critical section under `self.run_lock`, so the chunks of different streams interleave instead of queueing whole calls;
+        short critical section under `self.run_lock` (FIFO), so the chunks of different streams interleave instead of queueing whole
+        calls; calls that start together share one batched prefill, and every round of ready chunks runs the flow as one ragged
+        batch and HiFT on the pool's HIP streams;
       - NON-STREAMING calls are COALESCED: each call queues its request, one caller becomes the batch leader, waits `coalesce_ms`
         for stragglers, and runs up to `max_batch` queued requests as one batch through the three stages (one decode step serves
         all of them, the flow runs over the packed ragged batch, HiFT on a pool of streams);
