@@ -741,6 +741,17 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(M / 64, 8), dim3(256), 0, c.s, a);
         else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(M / 32, 8), dim3(256), 0, c.s, a);       // one utterance: split keys over two wave groups
     }
+    if ((long)(M / 64) < 200) {
+        // one utterance: O-projection, norm3, feed-forward and the next block's norm1 are row-local -> one launch per 16-row panel
+        TailArgs t{};
+        t.att = GB(h->att, 512); t.lda = 512;
+        t.Wo = tb.out.w; t.bo = tb.out.b; t.g3 = tb.norm3.g; t.b3 = tb.norm3.b; t.eps3 = 1e-5f;
+        t.W1 = tb.ff1.w; t.b1 = tb.ff1.b; t.W2 = tb.ff2.w; t.b2 = tb.ff2.b;
+        t.gn = next_ln ? next_ln->g : nullptr; t.bn = next_ln ? next_ln->b : nullptr; t.epsn = 1e-5f;
+        t.xf = h->xf; t.out_ln = GB(h->lnb, 256); t.ldo_ln = 256; t.out_x = xout; t.ldo_x = ldx;
+        t.seq = c.L->tab(); t.M_valid = M;
+        return tail_panel_go(t, M, c.s);
+    }
     {
         GemmArgs a = gemm_args(GB(h->att, 512), 512, 0, tb.out.w, M, 256, 512);
         a.bias = tb.out.b; a.res = h->xf; a.ldres = 256; a.out_f32 = h->xf; a.ldo = 256;

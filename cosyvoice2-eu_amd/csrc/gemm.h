@@ -610,6 +610,149 @@ __global__ __launch_bounds__(1024) void k_ff_panel(FfArgs f) {
 }
 constexpr size_t ff_panel_smem(int RT) { return (size_t)(8 + 32) * RT * 1024 + 5 * 1024; }
 
+// ------------------------------------------------------------------ transformer-block tail for few rows (one utterance)
+// Everything of a BasicTransformerBlock after the attention is row-local: x += att Wo^T + bo; y = LN3(x); x += GELU(y W1^T + b1) W2^T
+// + b2; next = LN(x).  One launch per 16-row panel chains the three GEMMs (K = 512, 256, 1024) with the weights streamed
+// global -> registers, the operands of GEMM 2 and 3 written to LDS in MFMA operand layout by the previous epilogue, and the
+// residual row kept in registers.  Replaces k_gemm_panel<K=512> + k_ff_panel (two launches, two prologues, one xf round trip).
+struct TailArgs {
+    const uint16_t* att; long lda;                           // attention output [M][512] bf16
+    const uint16_t* Wo; const float* bo;                     // packed [256][512]
+    const float* g3; const float* b3; float eps3;            // norm3
+    const uint16_t* W1; const float* b1;                     // packed [1024][256]
+    const uint16_t* W2; const float* b2;                     // packed [256][1024]
+    const float* gn; const float* bn; float epsn;            // next block's norm1 (null: last block of the group)
+    float* xf;                                               // residual stream fp32 [M][256], read and (gn != null) rewritten
+    uint16_t* out_ln; long ldo_ln;                           // gn != null: LN'd bf16 [M][256]
+    uint16_t* out_x; long ldo_x;                             // gn == null: x as bf16
+    SeqTable seq; int M_valid;
+};
+template <int V>          // (template only so that the header can be included by several translation units)
+__global__ __launch_bounds__(1024) void k_tail_panel(TailArgs a) {
+    constexpr int NW = 16, LDC = 260, KS0 = 16, KS1 = 8, KS2 = 32, CH = 8;
+    constexpr size_t ATT_BYTES = (size_t)KS0 * 1024, X_OFF = 17 * 1024, H_OFF = X_OFF + KS1 * 1024, PAR_OFF = H_OFF + KS2 * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // [att panel 16 K | C tile 16.25 K (overlays it)][x panel 8 K][h panel 32 K][6 vectors]
+    char* xs = smem + X_OFF;
+    char* hs = smem + H_OFF;
+    float* par = reinterpret_cast<float*>(smem + PAR_OFF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * 16, m = m0 + wave, n = lane * 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    {   // attention panel: piece kb = 16 rows x 32 k, one per wave
+        const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 5) << 1);
+        const uint16_t* src = a.att + (long)(m0 + srow) * a.lda + wave * 32 + schunk * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + wave * 1024), 16, 0, 0);
+    }
+    if (wave < 6) {                                          // per-column vectors: bo, g3, b3, b2, gn, bn
+        const float* src = wave == 0 ? a.bo : wave == 1 ? a.g3 : wave == 2 ? a.b3 : wave == 3 ? a.b2 : wave == 4 ? a.gn : a.bn;
+        if (src)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(par) + wave * 1024), 16, 0, 0);
+    }
+    f32x4 xrow = *reinterpret_cast<const f32x4*>(a.xf + (size_t)m * 256 + n);       // residual row of this wave
+    __builtin_amdgcn_s_barrier();
+    const s16x8* wop = reinterpret_cast<const s16x8*>(a.Wo) + ((size_t)wave * KS0) * 64 + lane;
+    s16x8 wr[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) wr[i] = wop[(size_t)i * 64];
+    int ep_start = 0, ep_len = a.M_valid;
+    if (a.seq.tile_seq) {
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) i32x4_t k_i32x4;
+        const i32x4_t ti = *reinterpret_cast<k_i32x4*>(reinterpret_cast<uintptr_t>(a.seq.tile_info + (m0 >> 6)));
+        ep_start = ti.y; ep_len = ti.z;
+    }
+    const bool valid = (m - ep_start) < ep_len;
+    vmcnt_wait<CH>();
+    __builtin_amdgcn_s_barrier();
+    const int a_off = subtile_off(lane & 15, lane >> 4);
+    const f32x4* pv = reinterpret_cast<const f32x4*>(par) + lane;
+    float* C = reinterpret_cast<float*>(smem);
+    // ---- GEMM 0: O-projection, wave owns output columns [16 w, 16 w + 16)
+    f32x4 acc = z4;
+#pragma unroll
+    for (int kb = 0; kb < KS0; kb++) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(smem + (size_t)kb * 1024 + a_off);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[kb % CH]), af, acc, 0, 0, 0);
+        if (kb + CH < KS0) wr[kb % CH] = wop[(size_t)(kb + CH) * 64];
+    }
+    // first fragments of W1 requested now: they fly during the epilogue below
+    const s16x8* w1p = reinterpret_cast<const s16x8*>(a.W1) + ((size_t)(wave * 4) * KS1) * 64 + lane;
+    s16x8 wa[KS1], wb[KS1];
+#pragma unroll
+    for (int i = 0; i < KS1; i++) wa[i] = w1p[(size_t)i * 64];
+    __syncthreads();                                         // attention panel fully read: its LDS becomes the C tile
+    *reinterpret_cast<f32x4*>(&C[(lane & 15) * LDC + wave * 16 + 4 * (lane >> 4)]) = acc;
+    __syncthreads();
+    {   // x += o + bo ; y = LN3(x) -> x panel (bf16, operand layout of GEMM 1: row = wave, 4 consecutive k per lane)
+        f32x4 v = *reinterpret_cast<const f32x4*>(&C[wave * LDC + n]) + pv[0] + xrow;
+        if (!valid) v = z4;
+        xrow = v;
+        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256);
+        const f32x4 d = v - mean;
+        const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256);
+        f32x4 y = d * rsqrtf(var + a.eps3) * pv[64] + pv[128];
+        if (!valid) y = z4;
+        char* dst = xs + (size_t)(n >> 5) * 1024 + subtile_off(wave, (n & 31) >> 3) + (n & 7) * 2;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+    }
+    __syncthreads();
+    // ---- GEMM 1: 4 column tiles of 16 hidden columns per wave, bias + GELU, hidden panel in operand layout
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        s16x8 (&cur)[KS1] = (t & 1) ? wb : wa;
+        s16x8 (&nxt)[KS1] = (t & 1) ? wa : wb;
+        if (t + 1 < 4) {
+#pragma unroll
+            for (int i = 0; i < KS1; i++) nxt[i] = w1p[(size_t)((t + 1) * KS1 + i) * 64];
+        }
+        f32x4 a1 = z4;
+#pragma unroll
+        for (int kb = 0; kb < KS1; kb++) {
+            const bf16x8 xf_ = *reinterpret_cast<const bf16x8*>(xs + (size_t)kb * 1024 + a_off);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[kb]), xf_, a1, 0, 0, 0);
+        }
+        const int c = wave * 64 + t * 16 + 4 * (lane >> 4);
+        f32x4 v = a1 + *reinterpret_cast<const f32x4*>(a.b1 + c);
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = act_apply(v[e], ACT_GELU, 0.f);
+        char* d = hs + (size_t)(c >> 5) * 1024 + subtile_off(lane & 15, (c & 31) >> 3) + (c & 7) * 2;
+        *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+    // ---- GEMM 2
+    const s16x8* w2p = reinterpret_cast<const s16x8*>(a.W2) + ((size_t)wave * KS2) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < CH; i++) wr[i] = w2p[(size_t)i * 64];
+    __syncthreads();                                         // hidden panel complete (and the C tile of GEMM 0 consumed)
+    f32x4 acc2 = z4;
+#pragma unroll
+    for (int kb = 0; kb < KS2; kb++) {
+        const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (size_t)kb * 1024 + a_off);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[kb % CH]), hf, acc2, 0, 0, 0);
+        if (kb + CH < KS2) wr[kb % CH] = w2p[(size_t)(kb + CH) * 64];
+    }
+    *reinterpret_cast<f32x4*>(&C[(lane & 15) * LDC + wave * 16 + 4 * (lane >> 4)]) = acc2;
+    __syncthreads();
+    {   // x += ff + b2 ; stores
+        f32x4 v = *reinterpret_cast<const f32x4*>(&C[wave * LDC + n]) + pv[192] + xrow;
+        if (!valid) v = z4;
+        if (a.gn) {
+            *reinterpret_cast<f32x4*>(a.xf + (size_t)m * 256 + n) = v;
+            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256);
+            const f32x4 d = v - mean;
+            const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256);
+            f32x4 y = d * rsqrtf(var + a.epsn) * pv[256] + pv[320];
+            if (!valid) y = z4;
+            *reinterpret_cast<uint2*>(a.out_ln + (size_t)m * a.ldo_ln + n) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+        } else {
+            *reinterpret_cast<uint2*>(a.out_x + (size_t)m * a.ldo_x + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+    }
+}
+constexpr size_t tail_panel_smem() { return (size_t)(17 + 8 + 32 + 6) * 1024; }
+
 template <int BM, int BN, bool SPLITA = false, int NSTAGE = 2>
 constexpr size_t gemm_smem_bytes() {
     constexpr size_t stages = NSTAGE * (size_t)(((SPLITA ? 2 : 1) * BM + BN) / 16 * 2) * 1024;

@@ -60,6 +60,15 @@ static int ff_panel_go(const GemmArgs& a, const uint16_t* W1, const float* b1, h
     return 0;
 }
 
+static int tail_panel_go(const TailArgs& a, int M, hipStream_t s) {
+    constexpr size_t sm = tail_panel_smem();
+    static bool once = false;
+    if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_panel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
+    hipLaunchKernelGGL(k_tail_panel<0>, dim3(1, M / 16, 1), dim3(1024), sm, s, a);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
 // cfg 0: 128x128; cfg 1: 64x256 / 32x256 (whole rows of N == 256); cfg 2: 128x64; cfg 4: 128x128 with the hi/lo operand split
 static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, hipStream_t s) {
     CV2_CHECK(a.K % 64 == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of 64", a.K);
