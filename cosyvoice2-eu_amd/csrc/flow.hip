@@ -767,11 +767,6 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         } else {
             a.out_bf16 = xout; a.ldo16 = ldx;
         }
-        a.seq = c.L->tab(); a.mask = 1;
-        if (ff_panel_ok(a, 1)) {                 // one utterance: both GEMMs in one launch, the hidden activations stay in LDS
-            a.A = GB(h->lnb, 256); a.lda = 256;
-            return ff_panel_go(a, tb.ff1.w, tb.ff1.b, c.s);
-        }
         GemmArgs a1 = gemm_args(GB(h->lnb, 256), 256, 0, tb.ff1.w, M, 1024, 256);
         a1.bias = tb.ff1.b; a1.act = ACT_GELU; a1.out_bf16 = GB(h->ff, 1024); a1.ldo16 = 1024;
         if (est_gemm(c, a1, 0)) return -1;

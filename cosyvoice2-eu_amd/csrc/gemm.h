@@ -470,151 +470,12 @@ __global__ __launch_bounds__(1024) void k_gemm_panel(GemmArgs a) {
                         ((unsigned long long)BM << 48) | ((unsigned long long)BN << 32) | (unsigned)(gridDim.x * gridDim.y * gridDim.z));
 }
 
-// ------------------------------------------------------------------ fused feed-forward for few rows (one utterance)
-// out = epilogue(GELU(x W1^T + b1) W2^T): block = 16 RT rows, 16 waves.  GEMM 1 (K = 256 -> 1024): wave w owns hidden columns
-// [64 w, 64 w + 64); its W1 fragments go global -> registers, x comes from a once-staged LDS panel; bias + GELU + bf16 rounding, and
-// the hidden panel [16 RT][1024] is written to LDS directly in the MFMA operand layout of GEMM 2 (it never exists in HBM).
-// GEMM 2 (K = 1024 -> 256): wave w owns output columns [16 w, 16 w + 16), W2 fragments through the same register ring as
-// k_gemm_panel, then the usual row epilogue (bias, residual, LayerNorm of the next block, stores).  Replaces one k_gemm<64,128>
-// launch + one k_gemm_panel launch per transformer block; every byte of W1 and W2 crosses the CU's vector-memory path once.
-struct FfArgs { GemmArgs g; const uint16_t* W1; const float* b1; };   // g: A = x [M][256] bf16, W = packed W2, K = 1024, N = 256, epilogue
-template <int RT>
-__global__ __launch_bounds__(1024) void k_ff_panel(FfArgs f) {
-    const GemmArgs& a = f.g;
-    constexpr int BM = 16 * RT, BN = 256, NW = 16, LDC = BN + 4, KS1 = 8, KS2 = 32, CH = 8;
-    constexpr size_t A_BYTES = (size_t)KS1 * RT * 1024, H_BYTES = (size_t)KS2 * RT * 1024;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* hs = smem + A_BYTES;                              // hidden panel, pieces [kb2][rt]
-    float* par = reinterpret_cast<float*>(smem + A_BYTES + H_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * BM;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const int n = lane * 4;                                  // epilogue: wave = row (per row tile), lane = 4 columns
-    // x panel -> LDS: piece p = kb * RT + rt (16 rows x 32 k), one piece per wave for RT = 2
-    {
-        const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 5) << 1);
-        for (int p = wave; p < KS1 * RT; p += NW) {
-            const int kb = p / RT, rt = p % RT;
-            const uint16_t* src = a.A + ((long)(m0 + rt * 16 + srow) + a.a_row_off) * a.lda + kb * 32 + schunk * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(smem + p * 1024), 16, 0, 0);
-        }
-    }
-    if (wave < 5) {                                          // the five per-column epilogue vectors, once per block
-        const float* src = wave == 0 ? a.bias : wave == 1 ? a.ln1_g : wave == 2 ? a.ln1_b : wave == 3 ? a.ln2_g : a.ln2_b;
-        if (wave >= 1 && wave <= 2 && !a.ln1_g) src = nullptr;
-        if (wave >= 3 && !a.ln2_g) src = nullptr;
-        if (src)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 4),
-                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(par) + wave * 1024), 16, 0, 0);
-    }
-    f32x4 ep_res[RT];
-#pragma unroll
-    for (int it = 0; it < RT; it++)
-        ep_res[it] = a.res ? *reinterpret_cast<const f32x4*>(a.res + (size_t)(m0 + it * 16 + wave) * a.ldres + n) : z4;
-    __builtin_amdgcn_s_barrier();                            // panel / vector requests of every wave are queued before any weight request
-    // ---- GEMM 1: 4 column tiles of 16 hidden columns per wave, 8 fragments each, two register sets alternate
-    const s16x8* w1p = reinterpret_cast<const s16x8*>(f.W1) + ((size_t)(wave * 4) * KS1) * 64 + lane;
-    s16x8 wa[KS1], wb[KS1];
-#pragma unroll
-    for (int i = 0; i < KS1; i++) wa[i] = w1p[(size_t)i * 64];
-    int ep_start = 0, ep_len = a.M_valid;
-    if (a.seq.tile_seq) {
-        typedef int i32x4_t __attribute__((ext_vector_type(4)));
-        typedef const __attribute__((address_space(4))) i32x4_t k_i32x4;
-        const i32x4_t ti = *reinterpret_cast<k_i32x4*>(reinterpret_cast<uintptr_t>(a.seq.tile_info + (m0 >> 6)));
-        ep_start = ti.y; ep_len = ti.z;
-    }
-    vmcnt_wait<KS1>();                                       // everything older than the first 8 weight loads has landed
-    __builtin_amdgcn_s_barrier();
-    const int a_off = subtile_off(lane & 15, lane >> 4);
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        s16x8 (&cur)[KS1] = (t & 1) ? wb : wa;
-        s16x8 (&nxt)[KS1] = (t & 1) ? wa : wb;
-        if (t + 1 < 4) {
-#pragma unroll
-            for (int i = 0; i < KS1; i++) nxt[i] = w1p[(size_t)((t + 1) * KS1 + i) * 64];
-        }
-        f32x4 acc[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++) acc[rt] = z4;
-#pragma unroll
-        for (int kb = 0; kb < KS1; kb++)
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++) {
-                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(smem + (size_t)(kb * RT + rt) * 1024 + a_off);
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[kb]), xf, acc[rt], 0, 0, 0);
-            }
-        // bias + GELU + bf16, straight into the operand layout of GEMM 2: lane = (row m, 4 consecutive hidden columns)
-        const int c = wave * 64 + t * 16 + 4 * (lane >> 4);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(f.b1 + c);
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
-            f32x4 v = acc[rt] + b1;
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = act_apply(v[e], ACT_GELU, 0.f);
-            char* d = hs + (size_t)((c >> 5) * RT + rt) * 1024 + subtile_off(lane & 15, (c & 31) >> 3) + (c & 7) * 2;
-            *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        }
-    }
-    // ---- GEMM 2: 16 output columns per wave over K = 1024, ring of CH fragments (straight-line: exact counted waits)
-    const s16x8* w2p = reinterpret_cast<const s16x8*>(a.W) + ((size_t)wave * KS2) * 64 + lane;
-    s16x8 wr[CH];
-#pragma unroll
-    for (int i = 0; i < CH; i++) wr[i] = w2p[(size_t)i * 64];
-    __syncthreads();                                         // hidden panel complete
-    f32x4 acc2[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++) acc2[rt] = z4;
-#pragma unroll
-    for (int kb = 0; kb < KS2; kb++) {
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++) {
-            const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (size_t)(kb * RT + rt) * 1024 + a_off);
-            acc2[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[kb % CH]), hf, acc2[rt], 0, 0, 0);
-        }
-        if (kb + CH < KS2) wr[kb % CH] = w2p[(size_t)(kb + CH) * 64];
-    }
-    __syncthreads();                                         // panels fully read: their LDS becomes the C tile
-    float* C = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++)
-        *reinterpret_cast<f32x4*>(&C[(rt * 16 + (lane & 15)) * LDC + wave * 16 + 4 * (lane >> 4)]) = acc2[rt] * a.out_scale;
-    __syncthreads();
-    // ---- row epilogue (k_gemm_panel's): one wave per row of each row tile
-    const f32x4* pv = reinterpret_cast<const f32x4*>(par) + lane;          // [5][64] f32x4: bias, g1, b1, g2, b2
-    const f32x4 ep_g2 = pv[192], ep_b2 = pv[256];
-#pragma unroll
-    for (int it = 0; it < RT; it++) {
-        const int ml = it * 16 + wave, m = m0 + ml;
-        const bool valid = (m - ep_start) < ep_len;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&C[ml * LDC + lane * 4]);
-        if (a.bias) v += pv[0];
-        if (a.res) v += ep_res[it];
-        if (a.mask && !valid) v = z4;
-        if (a.out_f32) *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * a.ldo + n) = v;
-        if (a.out_bf16)
-            *reinterpret_cast<uint2*>(a.out_bf16 + (size_t)m * a.ldo16 + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        if (a.ln2_g) {
-            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / BN);
-            const f32x4 d = v - mean;
-            const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / BN);
-            const float rstd = rsqrtf(var + a.ln2_eps);
-            f32x4 y = (d * rstd * ep_g2 + ep_b2) * a.ln2_scale;
-            if (a.mask && !valid) y = z4;
-            *reinterpret_cast<uint2*>(a.out_ln2 + (size_t)m * a.ldo_ln2 + n) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
-        }
-    }
-}
-constexpr size_t ff_panel_smem(int RT) { return (size_t)(8 + 32) * RT * 1024 + 5 * 1024; }
-
 // ------------------------------------------------------------------ transformer-block tail for few rows (one utterance)
 // Everything of a BasicTransformerBlock after the attention is row-local: x += att Wo^T + bo; y = LN3(x); x += GELU(y W1^T + b1) W2^T
 // + b2; next = LN(x).  One launch per 16-row panel chains the three GEMMs (K = 512, 256, 1024) with the weights streamed
 // global -> registers, the operands of GEMM 2 and 3 written to LDS in MFMA operand layout by the previous epilogue, and the
-// residual row kept in registers.  Replaces k_gemm_panel<K=512> + k_ff_panel (two launches, two prologues, one xf round trip).
+// residual row kept in registers.  Replaces three launches (k_gemm_panel<K=512>, k_gemm<64,128> for FF1, k_gemm_panel<K=1024>), their
+// prologues, the HBM round trip of the 1024-wide hidden activations and one of xf.
 struct TailArgs {
     const uint16_t* att; long lda;                           // attention output [M][512] bf16
     const uint16_t* Wo; const float* bo;                     // packed [256][512]

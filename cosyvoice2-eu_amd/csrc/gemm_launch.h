@@ -44,22 +44,6 @@ static int gemm_go_panel(const GemmArgs& a, int batch, hipStream_t s) {
     }
 }
 
-// fused GELU feed-forward (256 -> 1024 -> 256) for one-utterance grids; `a` describes the second GEMM and the epilogue
-static bool ff_panel_ok(const GemmArgs& a, int batch) {
-    return a.N == 256 && a.K == 1024 && batch == 1 && !a.vt && !a.A_lo && !a.ln1_g && a.act == ACT_NONE && !a.rowadd &&
-           a.M % 32 == 0 && (long)(a.M / 64) < 200;
-}
-static int ff_panel_go(const GemmArgs& a, const uint16_t* W1, const float* b1, hipStream_t s) {
-    constexpr int RT = 1;
-    constexpr size_t sm = ff_panel_smem(RT);
-    static bool once = false;
-    if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ff_panel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
-    FfArgs f{a, W1, b1};
-    hipLaunchKernelGGL(k_ff_panel<RT>, dim3(1, a.M / (16 * RT), 1), dim3(1024), sm, s, f);
-    CV2_LAUNCH_CHECK();
-    return 0;
-}
-
 static int tail_panel_go(const TailArgs& a, int M, hipStream_t s) {
     constexpr size_t sm = tail_panel_smem();
     static bool once = false;
