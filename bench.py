@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: CosyVoice2-0.5B-EU zero-shot synthesis throughput on MI355X (BASELINE.json metric).
 
-A "step" = `--batch` utterances (default 1 = BASELINE configs[1]: zero-shot FR, batch 1, bf16 weights, non-streaming)
-through the whole hot path on this rank's GPU: LLM prefill + autoregressive decode with the RAS sampler, flow encoder +
-10 Euler steps with CFG, HiFT vocoder.  Inputs (text ids, prompt speech tokens, prompt mel, speaker embedding) are
-resident in HBM before the timed region.  Weights are synthetic at the real shapes (no checkpoints offline), decode
-length forced to 250 tokens = 10 s of audio per utterance.
+  python bench.py --gpus N --steps K --warmup W
 
-  python bench.py --gpus N --steps K --warmup W [--batch B]
-N > 1: launched by torch.distributed.run, one rank per GPU, every rank synthesises its own utterances (weak scaling, no
-data-path collective); time = max over ranks between barriers.
+N = 1 (default): a "step" = ONE utterance of BASELINE configs[1] (zero-shot FR, batch 1, bf16 weights, non-streaming) through the
+  PRODUCT call `CosyVoice2Model.tts()` — scheduler, LLM prefill + autoregressive decode with the RAS sampler, flow encoder + 10
+  Euler steps with CFG, HiFT vocoder, and the device->host copy of the waveform.  Inputs (text ids, prompt speech tokens, prompt
+  mel, speaker embedding) are resident in HBM before the timed region.  Weights are synthetic at the real shapes (no checkpoints
+  offline), decode length forced to 250 tokens = 10 s of audio.  The same run also measures, as `extra`:
+  configs[2] (32 concurrent calls coalesced into one batch, FR + DE, ragged lengths), configs[4] (8 concurrent streams: p50
+  first-chunk latency) and the CPU fp32 oracle on one whole utterance (`cpu_baseline`).
+N > 1: configs[3] — 32 N utterances sharded over N ranks (one process per GPU): rank 0 broadcasts the shared prompt, scatters the
+  text ids, every rank synthesises its 32 utterances as the evaluation harness does (a thread pool calling tts(), coalesced into
+  one batch by the scheduler), rank 0 gathers the waveforms; RCCL broadcast / scatter / gather only, nothing per step.  The driver
+  launches the ranks with torch.distributed.run; started WITHOUT a launcher (`python bench.py --gpus N`) this script spawns that
+  launcher as a child process before anything touches the GPU.  Weak scaling: per-GPU work (32 utterances) is fixed; the N = 1
+  reference for it is the N = 1 line's `extra.batch32`.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel group, the LLM decode step (HBM-bound weight
-stream): algorithmic bytes per step / average step duration from HIP events on the launch stream.
-`cpu_baseline` is the CPU fp32 oracle (oracle/, a port of the reference's algorithm) timed on this box's host cores on a
-bounded sample and extrapolated linearly to the full utterance.
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel group, the LLM decode step (HBM-bound weight stream):
+algorithmic bytes per step / average step duration from HIP events recorded on the LLM's launch stream around every
+decode burst of the timed region.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,16 +35,18 @@ sys.path.insert(0, os.path.join(ROOT, 'cosyvoice2-eu_amd'))
 
 N_TOK = 250          # generated speech tokens per utterance (10 s)
 P_TOK = 255          # FR prompt: 10.22 s -> 255 speech tokens
+P_TOK_DE = 310       # DE prompt: 12.42 s
 TEXT_LEN = 50
 PROMPT_TEXT_LEN = 20
+PER_GPU = 32         # utterances per GPU in the sharded configuration (configs[3]: 256 over 8 GPUs)
 HBM_PEAK_GBS = 8000.0
 MFMA_BF16_PEAK = 2500.0   # TFLOP/s dense
 FP32_MFMA_PEAK = 157.3
 
 
-def llm_step_bytes(weight_bytes, kv_positions_sum):
-    # bf16 weights once per step + fp32 KV read: 24 layers x 2 (k, v) x 2 kv heads x 64 x 4 B per cached position
-    return weight_bytes + 24 * 2 * 2 * 64 * 4 * kv_positions_sum
+def llm_step_bytes(weight_bytes, kv_positions_sum, layers=24, n_kv=2):
+    # bf16 weights once per step + fp32 KV read: layers x {k, v} x kv heads x 64 x 4 B per cached position
+    return weight_bytes + layers * 2 * n_kv * 64 * 4 * kv_positions_sum
 
 
 def flow_flops(T):
@@ -46,8 +55,8 @@ def flow_flops(T):
 
 
 def host_cores():
-    """CPU share of this process: cgroup quota if any, else the affinity mask (a GPU box exposes 256 logical CPUs but
-    grants ~16 to one GPU's container; oversubscribing torch threads makes the baseline meaningless)."""
+    """CPU share of this process: cgroup quota if any, else the affinity mask (a GPU box exposes 256 logical CPUs but grants ~16 to
+    one GPU's container; oversubscribing torch threads makes the baseline meaningless)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     try:
         q, p = open('/sys/fs/cgroup/cpu.max').read().split()
@@ -59,7 +68,8 @@ def host_cores():
 
 
 def cpu_baseline(n_threads):
-    """CPU fp32 oracle on a bounded sample, extrapolated linearly to the full C2 utterance."""
+    """The CPU fp32 oracle (oracle/, a port of the reference's algorithm) on ONE WHOLE configs[1] utterance: same inputs as the GPU
+    run, 250 forced greedy tokens through 24 layers, flow encoder + 10 Euler steps with CFG at T = 1010, HiFT on 500 frames."""
     import torch
     from cv2amd import synth
     from oracle import llm as OL, flow as OF, hift as OH
@@ -67,123 +77,157 @@ def cpu_baseline(n_threads):
     inp = synth.synthetic_inputs(text_len=TEXT_LEN, prompt_len=P_TOK, prompt_text_len=PROMPT_TEXT_LEN)
     with torch.inference_mode():
         sd = synth.make_llm()
-        d = OL.LLMDims(sd)
-        x = OL.build_lm_input(sd, inp['text'], inp['prompt_text'], inp['prompt_token'])
-        cache = [None] * d.layers
         t0 = time.time()
-        y = OL.qwen2_step(sd, d, x, cache)
-        t_prefill = time.time() - t0
-        n_dec = 6
-        t0 = time.time()
-        for i in range(n_dec):
-            logp = torch.nn.functional.linear(y[-1], sd['llm_decoder.weight'], sd['llm_decoder.bias']).log_softmax(-1)
-            top = int(logp[:6561].argmax())
-            y = OL.qwen2_step(sd, d, sd['speech_embedding.weight'][top:top + 1], cache)
-        t_step = (time.time() - t0) / n_dec
-        del sd, cache
+        toks = OL.inference(sd, inp['text'], inp['prompt_text'], inp['prompt_token'], force_len=N_TOK)
+        t_llm = time.time() - t0
+        del sd
         fsd = synth.make_flow()
-        T = 2 * (P_TOK + N_TOK)
-        g = torch.Generator().manual_seed(0)
-        tok = torch.randint(0, 6561, (1, P_TOK + N_TOK), generator=g)
         t0 = time.time()
-        h = OF.encoder(fsd, fsd['input_embedding.weight'][tok], None, False)
-        t_enc = time.time() - t0
-        mu = OF.lin(fsd, 'encoder_proj', h).transpose(1, 2).contiguous()
-        z = OF.rand_noise()[:, :, :T]
-        t0 = time.time()
-        OF.solve_euler(fsd, z, mu, torch.ones(1, 1, T), torch.zeros(1, 80), torch.zeros(1, 80, T), n_timesteps=1)
-        t_est = time.time() - t0
+        mel = OF.inference(fsd, torch.tensor([toks], dtype=torch.int32), inp['prompt_token'], inp['prompt_feat'], inp['embedding'], False, True)
+        t_flow = time.time() - t0
         del fsd
         hsd = synth.make_hift()
-        Th = 100
-        mel = (torch.randn(1, 80, Th, generator=g) * 2 - 4).clamp(-11.5, 2)
+        g = torch.Generator().manual_seed(1)
+        T = mel.shape[2]
         t0 = time.time()
-        OH.inference(hsd, mel, torch.zeros(1, 1, 0), torch.rand(1, 9), torch.randn(1, 480 * Th, 9))
+        wav, _ = OH.inference(hsd, mel, torch.zeros(1, 1, 0), torch.rand(1, 9, generator=g), torch.randn(1, 480 * T, 9, generator=g))
         t_hift = time.time() - t0
-    total = t_prefill + N_TOK * t_step + t_enc + 10 * t_est + (2 * N_TOK / Th) * t_hift
-    audio_s = N_TOK / 25.0
+    total = t_llm + t_flow + t_hift
+    audio_s = wav.shape[1] / 24000.0
     return {'value': round(audio_s / total, 4), 'unit': 'audio-s/s', 'cores': n_threads, 'kind': 'port',
-            'sample': f'oracle/ (torch CPU fp32): LLM prefill {x.shape[0]} rows ({t_prefill:.2f}s) + {n_dec} decode steps ({t_step * 1e3:.0f} ms/step), '
-                      f'flow encoder ({t_enc:.2f}s) + 1 of 10 Euler steps at T={T} ({t_est:.2f}s), HiFT on {Th} of {2 * N_TOK} frames ({t_hift:.2f}s); '
-                      f'extrapolated linearly to one full 10 s utterance = {total:.1f}s (RTF {total / audio_s:.2f})'}
+            'sample': f'oracle/ (torch CPU fp32) on one whole configs[1] utterance ({audio_s:.1f} s of audio): LLM prefill + {N_TOK} decode steps '
+                      f'{t_llm:.1f}s, flow (encoder + 10 Euler steps, T={2 * (P_TOK + N_TOK)}) {t_flow:.1f}s, HiFT {T} frames {t_hift:.1f}s; '
+                      f'total {total:.1f}s (RTF {total / audio_s:.2f}); nothing extrapolated'}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=6)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=1)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ helpers (GPU ranks)
+class StepTimer:
+    """HIP events on the LLM's launch stream around every decode burst (`LLMEngine.step` runs under `torch.cuda.stream(llm_stream)`
+    in the scheduler, or on the current stream in a coalesced batch: the events are recorded on whichever stream is current there,
+    i.e. the stream the graph replays are launched on)."""
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
+    def __init__(self, llm):
+        import torch
+        self.torch, self.llm, self.rec, self.on = torch, llm, [], False
+        self._orig = llm.step
+        llm.step = self._step
+
+    def _step(self, n_seqs, n_steps=1):
+        if not self.on:
+            return self._orig(n_seqs, n_steps)
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._orig(n_seqs, n_steps)
+        e1.record()
+        self.rec.append((e0, e1, n_seqs, n_steps))
+
+    def result(self):
+        """(total ms, total steps) of the recorded bursts; call after a device synchronize."""
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.rec)
+        return ms, sum(k for _, _, _, k in self.rec)
+
+
+class StageTimer:
+    """Events on the current stream around a bound method (flow / HiFT stage split of the B = 1 run; diagnostics only)."""
+
+    def __init__(self, obj, name):
+        import torch
+        self.torch, self.rec, self.on = torch, [], False
+        self._orig = getattr(obj, name)
+        setattr(obj, name, self._call)
+
+    def _call(self, *a, **k):
+        if not self.on:
+            return self._orig(*a, **k)
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = self._orig(*a, **k)
+        e1.record()
+        self.rec.append((e0, e1))
+        return r
+
+    def ms(self):
+        return sum(e0.elapsed_time(e1) for e0, e1 in self.rec)
+
+
+def request(seed, prompt_len, text_len, dev, prompt_text_len=PROMPT_TEXT_LEN):
+    """model_input of frontend_zero_shot (cli/frontend.py:504-512) on synthetic data, resident on the device."""
+    from cv2amd import synth
+    inp = synth.synthetic_inputs(seed=seed, text_len=text_len, prompt_len=prompt_len, prompt_text_len=prompt_text_len)
+    d = dev
+    return dict(text=inp['text'].to(d), prompt_text=inp['prompt_text'].to(d), llm_prompt_speech_token=inp['prompt_token'].to(d),
+                flow_prompt_speech_token=inp['prompt_token'].to(d), prompt_speech_feat=inp['prompt_feat'].to(d),
+                flow_embedding=inp['embedding'].to(d), llm_embedding=inp['embedding'].to(d))
+
+
+def run_calls(model, reqs, forces, stream=False):
+    """The evaluation harness pattern (evaluation/cosyvoice_synthesizer.py:219,260): one thread per utterance calling tts() on ONE
+    model.  Returns (list of waveforms [1, n] CPU, list of first-yield times relative to the common start)."""
+    n = len(reqs)
+    if n == 1:
+        t0 = time.perf_counter()
+        outs, first = [], None
+        for o in model.tts(**reqs[0], stream=stream, force_len=forces[0]):
+            first = first if first is not None else time.perf_counter() - t0
+            outs.append(o['tts_speech'])
+        import torch
+        return [outs[0] if len(outs) == 1 else torch.cat(outs, 1)], [first]
     import torch
-    import torch.distributed as dist
+    wavs, first, errs = [None] * n, [None] * n, []
+    t0 = time.perf_counter()
+
+    def work(i):
+        try:
+            outs = []
+            for o in model.tts(**reqs[i], stream=stream, force_len=forces[i]):
+                if first[i] is None:
+                    first[i] = time.perf_counter() - t0
+                outs.append(o['tts_speech'])
+            wavs[i] = outs[0] if len(outs) == 1 else torch.cat(outs, 1)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    if errs:
+        raise errs[0]
+    return wavs, first
+
+
+def kv_positions_mean(L0s, forces):
+    """mean over the decode steps of (sum over live sequences of cached positions): step i of a sequence attends L0 + i keys."""
+    n_steps = max(forces) - 1
+    tot = 0
+    for l0, f in zip(L0s, forces):
+        tot += sum(l0 + i for i in range(1, f))
+    return tot / n_steps, n_steps
+
+
+def lm_rows(r):
+    return 1 + r['prompt_text'].numel() + r['text'].numel() + 1 + r['llm_prompt_speech_token'].numel()
+
+
+def build_model(dev, max_batch):
+    from cv2amd import synth
+    from cosyvoice.cli.model import CosyVoice2Model
+    m = CosyVoice2Model(synth.make_llm(), synth.make_flow(), synth.make_hift(), device=dev, max_batch=max_batch, max_text=128,
+                        max_prompt_tokens=320, max_new_tokens=512, coalesce_ms=0.0)
+    return m
+
+
+# ------------------------------------------------------------------------------------------------ N = 1
+def run_single(args):
+    import torch
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the hot path has no CPU fallback)'
-    # test hooks (one-GPU boxes): CV2_BENCH_DEVICE pins every rank to one GPU, CV2_BENCH_BACKEND=gloo replaces RCCL for the barriers
-    dev_index = int(os.environ.get('CV2_BENCH_DEVICE', local_rank))
-    backend = os.environ.get('CV2_BENCH_BACKEND', 'nccl')
+    dev_index = int(os.environ.get('CV2_BENCH_DEVICE', os.environ.get('LOCAL_RANK', 0)))
     torch.cuda.set_device(dev_index)
-    dev = f'cuda:{dev_index}'
-    if world > 1 or 'RANK' in os.environ:
+    dev = torch.device('cuda', dev_index)
+    use_dist = 'RANK' in os.environ
+    if use_dist:
+        import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device(dev))
-        else:
-            dist.init_process_group(backend)
-    use_dist = dist.is_initialized()
-
-    from cv2amd import lib as L
-    if not os.path.exists(L.LIB_PATH):
-        import __graft_entry__
-        __graft_entry__.build()
-    from cv2amd import synth
-    from cv2amd.llm import MODE_RAS
-    from cv2amd.pipeline import Synthesizer, synthetic_request
-
-    B = args.batch
-    syn = Synthesizer(synth.make_llm(), synth.make_flow(), synth.make_hift(), dev, max_batch=B, max_text=128,
-                      max_prompt_tokens=320, max_new_tokens=512)
-    # C2: FR prompt; C3 (batch 32): half FR (P=255), half DE (P=310), N ~ U{150..500} seeded
-    g = torch.Generator().manual_seed(1986)
-    reqs, ntoks = [], []
-    for b in range(B):
-        P = P_TOK if (B == 1 or b % 2 == 0) else 310
-        reqs.append(synthetic_request(seed=1986 + 100 * rank + b, text_len=TEXT_LEN, prompt_len=P, device=dev, prompt_text_len=PROMPT_TEXT_LEN))
-        ntoks.append(N_TOK if B == 1 else int(torch.randint(150, 501, (1,), generator=g)))
-    n_fixed = N_TOK if B == 1 else max(ntoks)
-    llm_reqs = [(r['text'], r['prompt_text'], r['llm_prompt_speech_token']) for r in reqs]
-    L0 = [1 + r['prompt_text'].numel() + r['text'].numel() + 1 + r['llm_prompt_speech_token'].numel() for r in reqs]
-
-    ev = lambda: torch.cuda.Event(enable_timing=True)
-    stage_ms = {'llm_prefill': 0.0, 'llm_decode': 0.0, 'flow': 0.0, 'hift': 0.0}
-    dec_steps = 0
-
-    def step(timed, seed):
-        nonlocal dec_steps
-        e = [ev() for _ in range(4)]
-        e[0].record()
-        toks, (d0, d1) = syn.llm.generate_fixed(llm_reqs, n_fixed, mode=MODE_RAS, seed=seed)
-        toks = [t[:n] for t, n in zip(toks, ntoks)]          # batch 32: ragged lengths (the LLM ran max(N) steps for all)
-        e[1].record()
-        utts = [dict(token=torch.tensor(t, dtype=torch.int32, device=dev).unsqueeze(0), prompt_token=r['flow_prompt_speech_token'],
-                     prompt_feat=r['prompt_speech_feat'], embedding=r['flow_embedding']) for r, t in zip(reqs, toks)]
-        mels = syn.flow.inference_batch(utts, streaming=False, finalize=True)
-        e[2].record()
-        wavs = [w for w, _ in syn.hift_pool.inference_many(mels)]
-        e[3].record()
-        if timed:
-            torch.cuda.synchronize()
-            stage_ms['llm_decode'] += d0.elapsed_time(d1)
-            stage_ms['llm_prefill'] += e[0].elapsed_time(e[1]) - d0.elapsed_time(d1)
-            stage_ms['flow'] += e[1].elapsed_time(e[2])
-            stage_ms['hift'] += e[2].elapsed_time(e[3])
-            dec_steps += n_fixed - 1
-        return wavs
+        dist.init_process_group('nccl', device_id=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -191,58 +235,261 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        wavs = step(False, i)
+    B = args.batch
+    model = build_model(dev, max(B, 1) if args.no_extra else 32)
+    st = StepTimer(model.llm)
+    flow_t, hift_t = StageTimer(model.flow, 'inference_batch'), StageTimer(model.hift_pool, 'inference_many')
+    if model.max_batch == 1:                  # serial scheduler path: HiFT runs inside _mel2wav (slice + vocoder), not through the pool
+        hift_t = StageTimer(model, '_mel2wav')
+    if B == 1:
+        reqs, forces = [request(1986, P_TOK, TEXT_LEN, dev)], [N_TOK]
+    else:
+        g = torch.Generator().manual_seed(1986)
+        reqs = [request(1986 + b, P_TOK if b % 2 == 0 else P_TOK_DE, TEXT_LEN, dev) for b in range(B)]
+        forces = [int(torch.randint(150, 501, (1,), generator=g)) for _ in range(B)]
+    model.coalesce_ms = 0.0 if B == 1 else 20.0
+
+    for _ in range(args.warmup):
+        wavs, _ = run_calls(model, reqs, forces)
     barrier()
+    st.on = flow_t.on = hift_t.on = True
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        wavs = step(True, 1000 + i)
+    for _ in range(args.steps):
+        wavs, _ = run_calls(model, reqs, forces)          # yields CPU tensors: the device->host copy is inside the timed region
     barrier()
     dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert all(torch.isfinite(w).all() for w in wavs)
+    st.on = flow_t.on = hift_t.on = False
+    assert all(w.device.type == 'cpu' and torch.isfinite(w).all() for w in wavs)
+    assert [w.shape[1] for w in wavs] == [960 * f for f in forces], 'forced-length run must produce 2 frames x 480 samples per token'
     audio_per_step = sum(w.shape[1] for w in wavs) / 24000.0
-    value = audio_per_step * world * args.steps / dt
+    value = audio_per_step * args.steps / dt
 
-    if rank == 0:
-        # roofline of the dominant kernel group: LLM decode step
-        kv_sum = sum(sum(l0 + i for i in range(1, n_fixed)) for l0 in L0) / (n_fixed - 1)     # mean cached positions per step, all sequences
-        step_ms = stage_ms['llm_decode'] / dec_steps
-        step_bytes = llm_step_bytes(syn.llm.weight_bytes, kv_sum)
-        achieved = step_bytes / (step_ms * 1e-3) / 1e9
-        Ts = [2 * (r['flow_prompt_speech_token'].numel() + n) for r, n in zip(reqs, ntoks)]
-        flow_tf = sum(flow_flops(T) for T in Ts) * args.steps / (stage_ms['flow'] * 1e-3) / 1e12
-        hift_tf = 30.6e9 * audio_per_step * args.steps / (stage_ms['hift'] * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, 'profiles', 'r1_pmc_decode.json')
+    dec_ms, dec_steps = st.result()
+    kv_mean, n_steps = kv_positions_mean([lm_rows(r) for r in reqs], forces)
+    assert dec_steps == n_steps * args.steps, (dec_steps, n_steps, args.steps)
+    step_us = dec_ms / dec_steps * 1e3
+    step_bytes = llm_step_bytes(model.llm.weight_bytes, kv_mean)
+    achieved = step_bytes / (step_us * 1e-6) / 1e9
+    Ts = [2 * (r['flow_prompt_speech_token'].numel() + f) for r, f in zip(reqs, forces)]
+    flow_tf = sum(flow_flops(T) for T in Ts) * args.steps / (flow_t.ms() * 1e-3) / 1e12
+    hift_tf = 30.6e9 * audio_per_step * args.steps / (hift_t.ms() * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    for name in ('r2_pmc_decode.json', 'r1_pmc_decode.json'):
+        pmc = os.path.join(ROOT, 'profiles', name)
         if B == 1 and os.path.exists(pmc):          # PMC counters cannot be read from inside the bench: committed rocprofv3 --pmc measurement
             pj = json.load(open(pmc))
-            traffic, traffic_src = pj['hbm_bytes_per_step'], 'profiles/r1_pmc_decode.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)'
-        out = {
-            'metric': 'audio-sec/sec, CosyVoice2-0.5B-EU zero-shot FR', 'value': round(value, 3), 'unit': 'audio-s/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'rtf': round(dt / (audio_per_step * args.steps), 5),
-            'config': {'workload': f'configs[{1 if B == 1 else 2}]: zero-shot FR{"+DE" if B > 1 else ""}, batch={B} per GPU, non-streaming, P=255{"/310" if B > 1 else ""} prompt tokens, '
-                                   f'{TEXT_LEN} text tokens, {"250" if B == 1 else "U{150..500}"} generated tokens (forced), 10 Euler steps + CFG, RAS sampler; '
-                                   f'LLM bf16 weights / fp32 KV, flow bf16 MFMA, HiFT fp32 MFMA', 'batch_per_gpu': B,
-                       'audio_s_per_step_per_gpu': round(audio_per_step, 3)},
-            'roofline': {'bound': 'hbm', 'kernel': 'LLM decode step = one hipGraph replay (24 x {k_qkv, k_attn, k_store(o), k_gateup, k_store(down)} + head + k_sample)',
-                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': traffic, 'traffic_source': traffic_src, 'bytes_per_launch': int(step_bytes), 'avg_launch_us': round(step_ms * 1e3, 2)},
-            'stages': {'ms_per_step': {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
-                       'flow_mfma': {'achieved': round(flow_tf, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(flow_tf / MFMA_BF16_PEAK, 4)},
-                       'hift_fp32_mfma': {'achieved': round(hift_tf, 2), 'peak': FP32_MFMA_PEAK, 'unit': 'TFLOP/s', 'frac': round(hift_tf / FP32_MFMA_PEAK, 4)}},
-        }
-        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is a rank-0, one-GPU-run item
-            out['cpu_baseline'] = cpu_baseline(host_cores())
-        print(json.dumps(out), flush=True)
+            traffic = pj['hbm_bytes_per_step']
+            traffic_src = f'profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)'
+            break
+    out = {
+        'metric': 'audio-sec/sec, CosyVoice2-0.5B-EU zero-shot FR', 'value': round(value, 3), 'unit': 'audio-s/s',
+        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'rtf': round(dt / (audio_per_step * args.steps), 5),
+        'config': {'workload': f'configs[{1 if B == 1 else 2}]: zero-shot FR{"+DE" if B > 1 else ""}, batch={B}, non-streaming, through CosyVoice2Model.tts() '
+                               f'(scheduler + D2H of the waveform inside the timed region), P=255{"/310" if B > 1 else ""} prompt tokens, '
+                               f'{TEXT_LEN} text tokens, {"250" if B == 1 else "U{150..500}"} generated tokens (forced), 10 Euler steps + CFG, RAS sampler; '
+                               f'LLM bf16 weights / fp32 KV, flow bf16 MFMA, HiFT fp32 MFMA', 'batch_per_gpu': B,
+                   'audio_s_per_step_per_gpu': round(audio_per_step, 3)},
+        'roofline': {'bound': 'hbm', 'kernel': model.llm.decode_kernel_desc(B),
+                     'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                     'traffic': traffic, 'traffic_source': traffic_src, 'bytes_per_launch': int(step_bytes), 'avg_launch_us': round(step_us, 2)},
+        'stages': {'ms_per_step': {'llm_decode': round(dec_ms / args.steps, 3), 'flow': round(flow_t.ms() / args.steps, 3),
+                                   'hift': round(hift_t.ms() / args.steps, 3),
+                                   'rest (prefill, scheduler, D2H)': round((dt * 1e3 - dec_ms - flow_t.ms() - hift_t.ms()) / args.steps, 3)},
+                   'flow_mfma': {'achieved': round(flow_tf, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(flow_tf / MFMA_BF16_PEAK, 4)},
+                   'hift_fp32_mfma': {'achieved': round(hift_tf, 2), 'peak': FP32_MFMA_PEAK, 'unit': 'TFLOP/s', 'frac': round(hift_tf / FP32_MFMA_PEAK, 4)}},
+    }
+    if not args.no_extra and B == 1:
+        out['extra'] = extras(model, st, flow_t, hift_t, dev)
+    if not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(host_cores())
+    print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(model, st, flow_t, hift_t, dev):
+    """configs[2] and configs[4] measured in the same run, on the same model object."""
+    import torch
+    ex = {}
+    # ---- configs[2]: 32 concurrent non-streaming calls (16 FR + 16 DE), ragged forced lengths, coalesced into one batch
+    g = torch.Generator().manual_seed(1986)
+    reqs = [request(1986 + b, P_TOK if b % 2 == 0 else P_TOK_DE, TEXT_LEN, dev) for b in range(32)]
+    forces = [int(torch.randint(150, 501, (1,), generator=g)) for _ in range(32)]
+    model.coalesce_ms = 50.0
+    run_calls(model, reqs, forces)
+    torch.cuda.synchronize()
+    st.rec, flow_t.rec, hift_t.rec = [], [], []
+    st.on = flow_t.on = hift_t.on = True
+    n0 = len(model.batch_sizes)
+    K = 2
+    t0 = time.perf_counter()
+    for _ in range(K):
+        wavs, _ = run_calls(model, reqs, forces)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st.on = flow_t.on = hift_t.on = False
+    audio = sum(w.shape[1] for w in wavs) / 24000.0
+    dec_ms, dec_steps = st.result()
+    kv_mean, _ = kv_positions_mean([lm_rows(r) for r in reqs], forces)
+    step_us = dec_ms / dec_steps * 1e3
+    sb = llm_step_bytes(model.llm.weight_bytes, kv_mean)
+    Ts = [2 * (r['flow_prompt_speech_token'].numel() + f) for r, f in zip(reqs, forces)]
+    ex['batch32'] = {'workload': 'configs[2]: 32 concurrent tts() calls on one model (16 FR P=255 + 16 DE P=310, U{150..500} forced tokens), coalesced',
+                     'value': round(audio * K / dt, 2), 'unit': 'audio-s/s', 'rtf': round(dt / (audio * K), 5), 'ms_per_step': round(dt / K * 1e3, 1),
+                     'batch_sizes': model.batch_sizes[n0:],
+                     'roofline': {'bound': 'hbm', 'kernel': model.llm.decode_kernel_desc(32), 'achieved': round(sb / (step_us * 1e-6) / 1e9, 1),
+                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(sb / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                  'bytes_per_launch': int(sb), 'avg_launch_us': round(step_us, 1)},
+                     'stages_ms': {'llm_decode': round(dec_ms / K, 1), 'flow': round(flow_t.ms() / K, 1), 'hift': round(hift_t.ms() / K, 1)},
+                     'flow_mfma_frac': round(sum(flow_flops(T) for T in Ts) * K / (flow_t.ms() * 1e-3) / 1e12 / MFMA_BF16_PEAK, 4),
+                     'hift_fp32_mfma_frac': round(30.6e9 * audio * K / (hift_t.ms() * 1e-3) / 1e12 / FP32_MFMA_PEAK, 4)}
+    # ---- configs[4]: streaming, 8 concurrent calls on one model; 12 text tokens -> at most 240 speech tokens per stream (EOS is live)
+    sreq = request(1986, P_TOK, 12, dev)
+    out = {}
+    for n in (1, 8):
+        run_calls(model, [sreq] * n, [None] * n, stream=True)            # warm-up: graphs for 1..n slots
+        firsts, audio, dts = [], 0.0, 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            wavs, first = run_calls(model, [sreq] * n, [None] * n, stream=True)
+            dts += time.perf_counter() - t0
+            audio += sum(w.shape[1] for w in wavs) / 24000.0
+            firsts += first
+        firsts.sort()
+        out[n] = {'first_chunk_ms_p50': round(firsts[len(firsts) // 2] * 1e3, 1), 'first_chunk_ms_max': round(firsts[-1] * 1e3, 1),
+                  'audio_s_per_s': round(audio / dts, 1)}
+    ex['streaming'] = {'workload': 'configs[4]: streaming (hop 25, look-ahead 3), P=255: the first chunk needs prefill + 48 tokens, chunk-masked flow at '
+                                   'T=600, HiFT on 90 frames; time from the tts() call to its first yielded chunk, 3 rounds',
+                       'streams_1': out[1], 'streams_8': out[8]}
+    return ex
+
+
+# ------------------------------------------------------------------------------------------------ N > 1: configs[3]
+def run_sharded(args):
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    backend = os.environ.get('CV2_BENCH_BACKEND', 'nccl')
+    fake = os.environ.get('CV2_BENCH_FAKE_SYNTH') == '1'          # CPU plumbing test (tests/test_host_cpu.py): no model, gloo
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29531')
+    if fake:
+        dev = torch.device('cpu')
+        dist.init_process_group(backend)
+    else:
+        assert torch.cuda.is_available(), 'bench.py needs a GPU (the hot path has no CPU fallback)'
+        dev_index = int(os.environ.get('CV2_BENCH_DEVICE', os.environ.get('LOCAL_RANK', 0)))
+        torch.cuda.set_device(dev_index)
+        dev = torch.device('cuda', dev_index)
+        dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
+    from cv2amd import shard, synth
+
+    def sync():
+        if not fake:
+            torch.cuda.synchronize()
+
+    def barrier():
+        sync()
+        dist.barrier()
+        sync()
+
+    per = int(os.environ.get('CV2_BENCH_PER_GPU', PER_GPU))
+    n_utts = per * world
+    # rank 0 owns the inputs: texts of 30..100 tokens (the forced speech length is 5 x the text length: 150..500 tokens, so the
+    # length-balanced dealing of shard.assign balances the work), one shared FR prompt
+    texts, prompt = None, None
+    if rank == 0:
+        g = torch.Generator().manual_seed(1986)
+        texts = [torch.randint(0, 151000, (int(torch.randint(30, 101, (1,), generator=g)),), generator=g, dtype=torch.int32) for _ in range(n_utts)]
+        inp = synth.synthetic_inputs(seed=1986, text_len=1, prompt_len=P_TOK, prompt_text_len=PROMPT_TEXT_LEN)
+        prompt = dict(prompt_text=inp['prompt_text'], prompt_token=inp['prompt_token'], prompt_feat=inp['prompt_feat'], embedding=inp['embedding'])
+    model = None if fake else build_model(dev, per)
+    if model is not None:
+        model.coalesce_ms = 50.0
+    st = StepTimer(model.llm) if model is not None else None
+
+    def synth_fn(my_texts, p):
+        if fake:
+            return [torch.full((960 * 5 * t.numel(),), float(t.numel())) for t in my_texts]
+        base = dict(prompt_text=p['prompt_text'].to(dev), llm_prompt_speech_token=p['prompt_token'].to(dev),
+                    flow_prompt_speech_token=p['prompt_token'].to(dev), prompt_speech_feat=p['prompt_feat'].to(dev),
+                    flow_embedding=p['embedding'].to(dev), llm_embedding=p['embedding'].to(dev))
+        reqs = [dict(base, text=t.reshape(1, -1).to(dev)) for t in my_texts]
+        wavs, _ = run_calls(model, reqs, [5 * t.numel() for t in my_texts])
+        return [w.reshape(-1) for w in wavs]
+
+    for _ in range(args.warmup):
+        shard.synthesize_sharded(texts, prompt, synth_fn)
+    barrier()
+    if st is not None:
+        st.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        waves = shard.synthesize_sharded(texts, prompt, synth_fn)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        assert len(waves) == n_utts and all(w.numel() == 960 * 5 * x.numel() for w, x in zip(waves, texts)), 'gather returned the wrong waveforms'
+        audio_per_step = sum(w.numel() for w in waves) / 24000.0
+        out = {'metric': 'audio-sec/sec, CosyVoice2-0.5B-EU zero-shot FR', 'value': round(audio_per_step * args.steps / dt, 3), 'unit': 'audio-s/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'FAKE (plumbing test, no model)' if fake else 'synthetic',
+               'rtf': round(dt / (audio_per_step * args.steps), 5),
+               'config': {'workload': f'configs[3]: {n_utts} utterances sharded over {world} ranks ({per} per GPU, length-balanced), zero-shot FR, P=255, texts of '
+                                      f'30..100 tokens, 5 x text length forced speech tokens (150..500), non-streaming; broadcast prompt / scatter text ids / '
+                                      f'gather waveforms over {"RCCL" if backend == "nccl" else backend} inside the timed region; every rank runs its shard as '
+                                      f'one coalesced batch through CosyVoice2Model.tts()', 'batch_per_gpu': per,
+                          'audio_s_per_step_total': round(audio_per_step, 2),
+                          'scaling_reference': "per-GPU work is fixed at 32 utterances: compare with N x the N=1 line's extra.batch32.value"}}
+        if st is not None:
+            sync()
+            dec_ms, dec_steps = st.result()
+            out['roofline'] = {'bound': 'hbm', 'kernel': model.llm.decode_kernel_desc(per) + ' (rank 0)', 'avg_launch_us': round(dec_ms / max(dec_steps, 1) * 1e3, 1),
+                               'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
+                               'note': 'bytes per step depend on the shard; the per-GPU roofline is the N=1 line (extra.batch32.roofline)'}
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--batch', type=int, default=1, help='N=1 only: utterances per step (1 = configs[1], 32 = configs[2])')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='N=1: skip the configs[2] / configs[4] measurements')
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 6 if args.gpus == 1 else 2
+    if args.warmup is None:
+        args.warmup = 2 if args.gpus == 1 else 1
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # started without a launcher: spawn one rank per GPU as CHILD processes before anything in this process touches the GPU
+        # (a process that has initialised the GPU must never exec another program on this pool)
+        port = os.environ.get('MASTER_PORT', '29531')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus} '
+                 f'(or without a launcher: the script spawns it)')
+    from cv2amd import lib as L
+    if not os.path.exists(L.LIB_PATH) and os.environ.get('CV2_BENCH_FAKE_SYNTH') != '1':
+        import __graft_entry__
+        __graft_entry__.build()
+    if world == 1:
+        run_single(args)
+    else:
+        run_sharded(args)
 
 
 if __name__ == '__main__':

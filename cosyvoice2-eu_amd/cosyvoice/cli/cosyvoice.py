@@ -27,6 +27,33 @@ class CosyVoice2:
             logging.warning('load_jit / load_trt / load_vllm are NVIDIA-path accelerators of the reference; ignored on MI355X')
         if state_dicts is None and not os.path.exists(model_dir):
             raise ValueError('model_dir {} does not exist'.format(model_dir))
+        # cosyvoice2.yaml (cli/cosyvoice.py:176-226): required next to the checkpoints, read for the run-time hyper-parameters and
+        # checked against the fixed architecture; `backbone` selects qwen_pretrain_path exactly as the reference does
+        from cv2amd.config import Config
+        config = Config()
+        if state_dicts is None:
+            hyper_yaml_path = '{}/cosyvoice2.yaml'.format(model_dir)
+            if not os.path.exists(hyper_yaml_path):
+                raise ValueError('{} not found!'.format(hyper_yaml_path))
+            overrides, qwen = {}, None
+            blank = os.path.join(model_dir, 'CosyVoice-BlankEN')
+            if backbone is not None:
+                if backbone == 'blanken':
+                    qwen = blank if os.path.exists(blank) else None
+                elif backbone.startswith('hf:'):
+                    qwen = backbone[3:]
+                elif backbone.startswith('local:'):
+                    qwen = backbone[6:]
+                else:
+                    qwen = backbone
+            elif os.path.exists(blank) and not os.environ.get('COSYV2_IGNORE_BLANKEN'):
+                qwen = blank
+            if qwen:
+                overrides['qwen_pretrain_path'] = qwen
+                logging.info('Using LLM backbone: {}'.format(qwen))
+            config = Config.from_file(hyper_yaml_path, overrides)
+            self.sample_rate = config.sample_rate
+        self.config = config
         # checkpoint selection, cli/cosyvoice.py:240-265
         if final:
             tokens = {'llm', 'flow', 'hifigan'}
@@ -46,7 +73,7 @@ class CosyVoice2:
             else:
                 suffix = '-original'
             chosen[key] = '{}/{}{}.pt'.format(model_dir, key, suffix)
-        self.model = CosyVoice2Model(fp16=fp16)
+        self.model = CosyVoice2Model(fp16=fp16, config=config)
         if state_dicts is not None:
             self.model.load_state_dicts(*state_dicts)
         else:

@@ -53,9 +53,33 @@ class PrecomputedFrontEnd:
         self.tokenize = tokenize
         self.spk2info = dict(spk2info or {})
 
-    def text_normalize(self, text, split=True, text_frontend=True):
-        # text_frontend=False path of frontend.py:436-437: no normalisation, no splitting
-        return [text] if split else text
+    def text_normalize(self, text, split=True, text_frontend=True, multilingual=True, pack_mode='sentence', target_token_len=512):
+        """cli/frontend.py:419-480.  A generator passes through untouched (bistream input); text_frontend=False or an empty string
+        means no normalisation and no splitting; otherwise sentence-level normalisation, then `split_paragraph` packs the sentences
+        into segments of at most ~80 tokens (60 minimum, a tail under 20 tokens joins its predecessor), so the LLM never sees more
+        text per request than it was trained on; punctuation-only segments are dropped."""
+        from collections.abc import Generator
+        from cosyvoice.utils import frontend_utils as U
+        if isinstance(text, Generator):
+            return [text]
+        if text_frontend is False or text == '':
+            return [text] if split else text
+        text = text.strip()
+        if not text:
+            return [''] if split else ''
+        sents = U.split_sentences(text) if multilingual else [text]
+        normalized = [U.normalize_sentence(s, U.detect_lang(s)) for s in sents]
+        tok = self.tokenize
+        if pack_mode == 'paragraph':
+            n = int(target_token_len)
+            segs = U.split_paragraph(' '.join(normalized).strip(), tok, 'en', token_max_n=n, token_min_n=max(1, int(0.75 * n)),
+                                     merge_len=max(1, int(0.25 * n)), comma_split=False)
+        else:
+            segs = []
+            for s in normalized:
+                segs.extend(U.split_paragraph(s, tok, 'en', token_max_n=80, token_min_n=60, merge_len=20, comma_split=False))
+        texts = [t for t in segs if not U.is_only_punctuation(t)]
+        return texts if split else ' '.join(texts)
 
     def _extract_text_token(self, text):
         ids = self.tokenize(text)

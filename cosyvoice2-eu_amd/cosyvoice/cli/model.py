@@ -65,11 +65,14 @@ class _FairLock:
 
 class CosyVoice2Model:
     def __init__(self, llm_sd=None, flow_sd=None, hift_sd=None, fp16=False, device=None, max_text=512, max_prompt_tokens=750,
-                 max_new_tokens=3000, sampling='ras', seed=0, max_batch=8, coalesce_ms=2.0):
+                 max_new_tokens=3000, sampling='ras', seed=0, max_batch=8, coalesce_ms=2.0, config=None):
         if not torch.cuda.is_available():
             raise L.Cv2Error('CosyVoice2Model (MI355X build) needs a GPU: the hot path has no CPU fallback')
         self.device = torch.device(device or 'cuda')
         self.fp16 = fp16                       # accepted for signature compatibility; the HIP path fixes its own dtypes
+        from cv2amd.config import Config
+        self.config = config or Config()       # hyper-parameters of cosyvoice2.yaml (the reference receives built modules instead)
+        self.min_token_text_ratio, self.max_token_text_ratio = 2, 20    # defaults of Qwen2LM.inference (llm.py:586-587)
         self.token_hop_len = 25                # must match the training static_chunk_size (model.py:271)
         self.mel_cache_len = 8
         self.source_cache_len = int(self.mel_cache_len * 480)
@@ -83,6 +86,7 @@ class CosyVoice2Model:
         self.tts_speech_token_dict = {}
         self.llm_end_dict = {}
         self.hift_cache_dict = {}
+        self._hift_pin, self._pin_rr = {}, -1  # uuid -> index of the HiftPool engine / HIP stream serving that call's chunks
         self.llm_stream = torch.cuda.Stream(self.device)
         self.sampling_mode = MODE_RAS if sampling == 'ras' else MODE_GREEDY
         self.seed = seed
@@ -95,25 +99,30 @@ class CosyVoice2Model:
         self.batch_sizes = []                  # sizes of the coalesced batches run so far (diagnostics / tests)
         self.llm = self.flow = self.hift = None
         self._noise_hook = None                # tests: callable(T) -> [1, 480 T, 9] N(0,1) injected in place of the device Philox draws
+        self._noise_hook_takes_uuid = False    # tests with concurrent calls: callable(T, uuid)
+        self._on_call = None                   # tests: callable(uuid), invoked in the caller's thread when a tts() call starts
         self._trace = None                     # tests: list receiving (flow mel, token_offset, finalize, noise) per token2wav call
         if llm_sd is not None:
             self.load_state_dicts(llm_sd, flow_sd, hift_sd)
 
     # ---- model.py:67-90 ---------------------------------------------------------------------------------------
     def load(self, llm_model, flow_model, hift_model):
-        llm_sd = torch.load(llm_model, map_location='cpu')
-        flow_sd = torch.load(flow_model, map_location='cpu')
-        hift_sd = {k.replace('generator.', ''): v for k, v in torch.load(hift_model, map_location='cpu').items()}
-        for sd in (llm_sd, flow_sd):
-            for k in ('epoch', 'step'):                      # training checkpoints carry these (train_utils.py:214)
-                sd.pop(k, None)
+        """model.py:67-90: strict key / shape validation of the three checkpoints (strict=False fallback for the LLM only), the
+        hifigan `generator.` prefix stripped, training metadata dropped (cv2amd/checkpoint.py)."""
+        from cv2amd import checkpoint
+        llm_sd, flow_sd, hift_sd = checkpoint.validate(torch.load(llm_model, map_location='cpu'), torch.load(flow_model, map_location='cpu'),
+                                                       torch.load(hift_model, map_location='cpu'))
         self.load_state_dicts(llm_sd, flow_sd, hift_sd)
 
     def load_state_dicts(self, llm_sd, flow_sd, hift_sd):
         max_text, max_prompt, max_new = self._limits
         B = self.max_batch
-        self.llm = LLMEngine(llm_sd, self.device, max_seqs=B, max_pos=max_text + max_prompt + max_new + 8, max_out=max_new)
-        self.flow = FlowEngine(flow_sd, self.device, max_utts=B, max_len=2 * (max_prompt + max_new))
+        cfg = self.config
+        self.llm = LLMEngine(llm_sd, self.device, max_seqs=B, max_pos=max_text + max_prompt + max_new + 8, max_out=max_new,
+                             sampling=cfg.sampling)
+        self.flow = FlowEngine(flow_sd, self.device, max_utts=B, max_len=2 * (max_prompt + max_new), n_timesteps=cfg.n_timesteps,
+                               cfg_rate=cfg.inference_cfg_rate)
+        self.flow.pre_lookahead_len, self.flow.token_mel_ratio, self.flow.input_frame_rate = cfg.pre_lookahead_len, cfg.token_mel_ratio, cfg.input_frame_rate
         self.hift_pool = HiftPool(hift_sd, self.device, max_frames=2 * max_new + self.mel_cache_len, n=min(4, B))
         self.hift = self.hift_pool.engines[0]
         self.llm.park()                            # no slot is live: decode steps that cover a free slot leave it alone
@@ -151,9 +160,9 @@ class CosyVoice2Model:
         noise = None
         if self._noise_hook is not None:
             n_frames = int(tts_mel.shape[2] / speed) if (finalize and speed != 1.0) else tts_mel.shape[2]
-            noise = self._noise_hook(n_frames)
+            noise = self._noise_hook(n_frames, uuid) if self._noise_hook_takes_uuid else self._noise_hook(n_frames)
         if self._trace is not None:
-            self._trace.append((flow_mel.cpu(), token_offset, finalize, noise))
+            self._trace.append((flow_mel.cpu(), token_offset, finalize, noise, uuid))
         if finalize is False:
             tts_speech, tts_source = hift.inference(speech_feat=tts_mel.contiguous(), cache_source=hift_cache_source, noise=noise)
             if cache is not None:
@@ -176,33 +185,60 @@ class CosyVoice2Model:
         __slots__ = ('token', 'fpt', 'feat', 'femb', 'offset', 'uuid', 'stream', 'finalize', 'done', 'speech', 'exc')
 
     def _run_chunks(self, batch):
+        """One round of ready chunks.  A failure is delivered only to the call it belongs to (an utterance failure must not poison its
+        batch, SURVEY.md §5: evaluation/cosyvoice_synthesizer.py:265-297 records per-sample errors): the ragged flow batch is retried
+        chunk by chunk when it fails as a whole, HiFT / cache / cross-fade errors stay with their chunk."""
         try:
             for key in sorted({(c.stream, c.finalize) for c in batch}):
                 grp = [c for c in batch if (c.stream, c.finalize) == key]
-                mels = self.flow.inference_batch([dict(token=c.token, prompt_token=c.fpt, prompt_feat=c.feat, embedding=c.femb) for c in grp],
-                                                 streaming=key[0], finalize=key[1])
-                if len(grp) == 1:
-                    grp[0].speech = self._mel2wav(mels[0], grp[0].offset, grp[0].uuid, grp[0].finalize, 1.0).cpu()
-                    continue
-                # HiFT (and the cache / cross-fade bookkeeping) of the chunks on the pool's HIP streams, joined before anything is read
+                try:
+                    mels = self.flow.inference_batch([dict(token=c.token, prompt_token=c.fpt, prompt_feat=c.feat, embedding=c.femb) for c in grp],
+                                                     streaming=key[0], finalize=key[1])
+                except Exception:                                              # find the offender: run the chunks one by one
+                    mels = []
+                    for c in grp:
+                        try:
+                            mels.append(self.flow.inference_batch([dict(token=c.token, prompt_token=c.fpt, prompt_feat=c.feat, embedding=c.femb)],
+                                                                  streaming=key[0], finalize=key[1])[0])
+                        except Exception as e:
+                            c.exc = e
+                            mels.append(None)
+                # HiFT (and the cache / cross-fade bookkeeping) of a chunk always runs on the pool engine + HIP stream its call was pinned
+                # to at its first chunk: the per-uuid caches are then allocated, read and freed on ONE stream (a cache block freed on
+                # stream A while stream B still reads it could be handed out again by the caching allocator), joined before anything is read
                 pool, main, sp = self.hift_pool, torch.cuda.current_stream(), []
-                for st in pool.streams:
-                    st.wait_stream(main)
-                for i, (c, mel) in enumerate(zip(grp, mels)):
-                    k = i % len(pool.engines)
-                    with torch.cuda.stream(pool.streams[k]):
-                        sp.append(self._mel2wav(mel, c.offset, c.uuid, c.finalize, 1.0, hift=pool.engines[k]))
-                for st in pool.streams:
-                    main.wait_stream(st)
+                used = sorted({self._hift_pin.setdefault(c.uuid, self._next_pin()) for c in grp})
+                for k in used:
+                    pool.streams[k].wait_stream(main)
+                for c, mel in zip(grp, mels):
+                    if mel is None:
+                        sp.append(None)
+                        continue
+                    k = self._hift_pin[c.uuid]
+                    try:
+                        with torch.cuda.stream(pool.streams[k]):
+                            mel.record_stream(pool.streams[k])                 # produced on the main stream, consumed on the pinned one
+                            sp.append(self._mel2wav(mel, c.offset, c.uuid, c.finalize, 1.0, hift=pool.engines[k]))
+                    except Exception as e:
+                        c.exc = e
+                        sp.append(None)
+                for k in used:
+                    main.wait_stream(pool.streams[k])
                 for c, w in zip(grp, sp):
-                    c.speech = w.cpu()
-        except BaseException as e:                                            # every stream of the batch sees the failure
+                    if w is not None:
+                        w.record_stream(main)
+                        c.speech = w.cpu()
+        except BaseException as e:                                            # not attributable to one chunk: every waiting stream sees it
             for c in batch:
-                if c.speech is None:
+                if c.speech is None and c.exc is None:
                     c.exc = e
         finally:
             for c in batch:
                 c.done = True
+
+    def _next_pin(self):
+        self._pin_rr = (self._pin_rr + 1) % len(self.hift_pool.engines)
+        return self._pin_rr
 
     def _chunk_submit(self, token, fpt, feat, femb, offset, this_uuid, stream, finalize):
         """token2wav for one chunk of a streaming call.  The chunk is queued; whoever gets the device next runs the flow over ALL
@@ -255,13 +291,13 @@ class CosyVoice2Model:
             self._mode.notify_all()
 
     class _Prefill:
-        __slots__ = ('slot', 'text', 'prompt_text', 'ptok', 'done', 'exc')
+        __slots__ = ('slot', 'text', 'prompt_text', 'ptok', 'done', 'exc', 'force_len')
 
-    def _llm_start(self, slot, text, prompt_text, llm_prompt_speech_token):
+    def _llm_start(self, slot, text, prompt_text, llm_prompt_speech_token, force_len=None):
         """llm.py:684-719 step 0 (prefill + first draw) for one call.  Calls that start together are prefilled TOGETHER: the request
         is queued, whoever gets the device next runs one batched prefill (one pass over the weights) for every queued request."""
         p = self._Prefill()
-        p.slot, p.text, p.prompt_text, p.ptok, p.done, p.exc = slot, text, prompt_text, llm_prompt_speech_token, False, None
+        p.slot, p.text, p.prompt_text, p.ptok, p.done, p.exc, p.force_len = slot, text, prompt_text, llm_prompt_speech_token, False, None, force_len
         with self.lock:
             self._prefill_q.append(p)
         with self.run_lock:
@@ -272,13 +308,19 @@ class CosyVoice2Model:
                 try:
                     with torch.cuda.stream(self.llm_stream):
                         xs = [self.llm.build_lm_input(b.text, b.prompt_text, b.ptok) for b in batch]
-                        mms = [(int(b.text.shape[1] * 2), int(b.text.shape[1] * 20)) for b in batch]     # llm.py:643-644 (target text only)
+                        mms = [(int(b.text.shape[1] * self.min_token_text_ratio), int(b.text.shape[1] * self.max_token_text_ratio))
+                               if b.force_len is None else (b.force_len, b.force_len) for b in batch]     # llm.py:643-644 (target text only)
                         self.seed += 1
-                        if sum(x.shape[0] for x in xs) <= self.llm.dims.max_prefill_rows:
-                            self.llm.add_requests([b.slot for b in batch], xs, mms, self.sampling_mode, self.seed)
-                        else:
-                            for b, x, mm in zip(batch, xs, mms):
-                                self.llm.add_requests([b.slot], [x], [mm], self.sampling_mode, self.seed)
+                        groups = [[b for b in batch if b.force_len is None], [b for b in batch if b.force_len is not None]]
+                        for grp, forced in zip(groups, (False, True)):
+                            if not grp:
+                                continue
+                            gx, gm = [xs[batch.index(b)] for b in grp], [mms[batch.index(b)] for b in grp]
+                            if sum(x.shape[0] for x in gx) <= self.llm.dims.max_prefill_rows:
+                                self.llm.add_requests([b.slot for b in grp], gx, gm, self.sampling_mode, self.seed, forced)
+                            else:
+                                for b, x, mm in zip(grp, gx, gm):
+                                    self.llm.add_requests([b.slot], [x], [mm], self.sampling_mode, self.seed, forced)
                 except BaseException as e:
                     for b in batch:
                         b.exc = e
@@ -308,30 +350,54 @@ class CosyVoice2Model:
 
     # ---- coalesced non-streaming calls ---------------------------------------------------------------------------
     class _Pending:
-        __slots__ = ('text', 'prompt_text', 'llm_ptok', 'fpt', 'feat', 'femb', 'speed', 'uuid', 'done', 'speech', 'exc')
+        __slots__ = ('text', 'prompt_text', 'llm_ptok', 'fpt', 'feat', 'femb', 'speed', 'uuid', 'done', 'speech', 'exc', 'force_len')
 
     def _run_batch(self, batch):
-        """llm_job + token2wav(finalize=True) of model.py:118-139,300-334 for several queued calls at once."""
+        """llm_job + token2wav(finalize=True) of model.py:118-139,300-334 for several queued calls at once.  Only the caller whose
+        request failed gets the exception (the sampler's RuntimeError of llm.py:249 is per request): the others' audio is delivered."""
         self.batch_sizes.append(len(batch))
         try:
             self.seed += 1
-            toks = self.llm.generate([(p.text, p.prompt_text, p.llm_ptok) for p in batch], mode=self.sampling_mode, seed=self.seed)
+            fl = [p.force_len for p in batch]
+            if any(f is None for f in fl):
+                assert all(f is None for f in fl), 'forced-length (synthetic-weights) calls cannot share a batch with free-running ones'
+                fl = None
+            toks, errs = self.llm.generate([(p.text, p.prompt_text, p.llm_ptok) for p in batch], mode=self.sampling_mode, seed=self.seed,
+                                           return_errors=True, min_ratio=self.min_token_text_ratio, max_ratio=self.max_token_text_ratio,
+                                           force_len=fl)
             with self.lock:
                 for p, t in zip(batch, toks):
                     self.tts_speech_token_dict[p.uuid], self.llm_end_dict[p.uuid] = t, True
+            for p, err in zip(batch, errs):
+                if err is not None:
+                    p.exc = err
+            live = [(p, t) for p, t, err in zip(batch, toks, errs) if err is None]
             utts = [dict(token=torch.tensor(t, dtype=torch.int32).unsqueeze(0), prompt_token=p.fpt, prompt_feat=p.feat, embedding=p.femb)
-                    for p, t in zip(batch, toks)]
-            mels = self.flow.inference_batch(utts, streaming=False, finalize=True)
-            for i, p in enumerate(batch):
+                    for p, t in live]
+            try:
+                mels = self.flow.inference_batch(utts, streaming=False, finalize=True) if utts else []
+            except Exception:                                                  # e.g. one utterance beyond the flow's length limit
+                mels = []
+                for (p, _), u in zip(live, utts):
+                    try:
+                        mels.append(self.flow.inference_batch([u], streaming=False, finalize=True)[0])
+                    except Exception as e:
+                        p.exc = e
+                        mels.append(None)
+            good = [(p, m) for (p, _), m in zip(live, mels) if m is not None]
+            gm = []
+            for p, m in good:
                 if p.speed != 1.0:                                            # model.py:328-330
-                    mels[i] = F.interpolate(mels[i], size=int(mels[i].shape[2] / p.speed), mode='linear')
-            outs = self.hift_pool.inference_many([m.contiguous() for m in mels])
+                    m = F.interpolate(m, size=int(m.shape[2] / p.speed), mode='linear')
+                gm.append(m.contiguous())
+            outs = self.hift_pool.inference_many(gm) if gm else []
             torch.cuda.synchronize(self.device)
-            for p, (wav, _) in zip(batch, outs):
+            for (p, _), (wav, _s) in zip(good, outs):
                 p.speech = wav.cpu()
-        except BaseException as e:                                            # every caller of the batch sees the failure
+        except BaseException as e:                                            # not attributable to one request
             for p in batch:
-                p.exc = e
+                if p.speech is None and p.exc is None:
+                    p.exc = e
         finally:
             for p in batch:
                 p.done.set()
@@ -339,9 +405,10 @@ class CosyVoice2Model:
     def _tts_coalesced(self, p):
         with self.lock:
             self._pending.append(p)
-        while not p.done.wait(timeout=0.0005):
+        while not p.done.is_set():
             if not self._leader_lock.acquire(blocking=False):
-                continue                                                       # another caller is the leader
+                p.done.wait(timeout=0.0005)                                    # another caller is the leader
+                continue
             try:
                 if p.done.is_set():
                     break
@@ -370,12 +437,17 @@ class CosyVoice2Model:
             prompt_text=torch.zeros(1, 0, dtype=torch.int32),
             llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
             flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
-            prompt_speech_feat=torch.zeros(1, 0, 80), source_speech_token=torch.zeros(1, 0, dtype=torch.int32), stream=False, speed=1.0, **kwargs):
+            prompt_speech_feat=torch.zeros(1, 0, 80), source_speech_token=torch.zeros(1, 0, dtype=torch.int32), stream=False, speed=1.0,
+            force_len=None, **kwargs):
+        """force_len (an extension; the reference swallows unknown keywords in **kwargs): synthetic-weights mode of SURVEY.md §8(d) —
+        exactly that many speech tokens, EOS and fill ids never drawn — so that benchmark work is deterministic without a checkpoint."""
         if source_speech_token.shape[1] != 0:
             raise NotImplementedError('voice conversion (vc_job, model.py:141-143) is outside the zero-shot hot path')
         if isinstance(text, torch.Tensor) is False:
             raise NotImplementedError('generator text input (inference_bistream, llm.py:721-834) is not supported yet')
         this_uuid = str(uuid.uuid1())
+        if self._on_call is not None:
+            self._on_call(this_uuid)
         with self.lock:
             self.tts_speech_token_dict[this_uuid], self.llm_end_dict[this_uuid] = [], False
             self.hift_cache_dict[this_uuid] = None
@@ -386,7 +458,7 @@ class CosyVoice2Model:
         if stream is not True and self.max_batch > 1 and self._noise_hook is None and self._trace is None:
             p = self._Pending()
             p.text, p.prompt_text, p.llm_ptok = text.to(dev), prompt_text.to(dev), llm_prompt_speech_token.to(dev)
-            p.fpt, p.feat, p.femb, p.speed, p.uuid = fpt, feat, femb, speed, this_uuid
+            p.fpt, p.feat, p.femb, p.speed, p.uuid, p.force_len = fpt, feat, femb, speed, this_uuid, force_len
             p.done, p.speech, p.exc = threading.Event(), None, None
             try:
                 yield {'tts_speech': self._tts_coalesced(p)}
@@ -395,6 +467,7 @@ class CosyVoice2Model:
                     self.tts_speech_token_dict.pop(this_uuid, None)
                     self.llm_end_dict.pop(this_uuid, None)
                     self.hift_cache_dict.pop(this_uuid, None)
+                self._hift_pin.pop(this_uuid, None)
             return
         slot = self._enter_shared()
         hop, la = self.token_hop_len, self.flow.pre_lookahead_len
@@ -403,7 +476,7 @@ class CosyVoice2Model:
             if stream is True:
                 token_offset = 0
                 prompt_token_pad = int(np.ceil(fpt.shape[1] / hop) * hop - fpt.shape[1])
-                self._llm_start(slot, text_d, ptext_d, lptok_d)                # prefill draws token 0; the first pass of the loop below
+                self._llm_start(slot, text_d, ptext_d, lptok_d, force_len)     # prefill draws token 0; the first pass of the loop below
                 while True:                                                    # requests the rest of the first chunk's tokens
                     this_tok, finished = None, False
                     with self.run_lock:
@@ -429,10 +502,16 @@ class CosyVoice2Model:
                 speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, False, True)
                 yield {'tts_speech': speech}
             else:
-                self._llm_start(slot, text_d, ptext_d, lptok_d)
+                self._llm_start(slot, text_d, ptext_d, lptok_d, force_len)
+                n_min = force_len if force_len is not None else int(text.shape[1] * self.min_token_text_ratio)
+                n_max = force_len if force_len is not None else int(text.shape[1] * self.max_token_text_ratio)
+                done_steps = 1                                                 # the prefill drew step 0
                 while True:
                     with self.run_lock:
-                        self._llm_advance(64)
+                        # the call cannot end before min_len steps (llm.py:242-250): one burst up to there, then 32 at a time
+                        burst = max(1, min(max(32, n_min - done_steps), n_max - done_steps))
+                        self._llm_advance(burst)
+                        done_steps += burst
                         toks = self._llm_poll(this_uuid, slot)
                     if self.llm_end_dict[this_uuid]:
                         break
@@ -450,3 +529,4 @@ class CosyVoice2Model:
                 self.tts_speech_token_dict.pop(this_uuid, None)
                 self.llm_end_dict.pop(this_uuid, None)
                 self.hift_cache_dict.pop(this_uuid, None)
+                self._hift_pin.pop(this_uuid, None)

@@ -386,6 +386,7 @@ struct SampleArgs {
     int* state; int* out_tokens; int max_out;
     const float* speech_emb; float* x_next; int hidden;
     int vocab, eos, max_pos;
+    float top_p; int top_k, win; float rep_thr; // ras_sampling constants (conf/cosyvoice2.yaml:33-37): nucleus mass / size, repetition window, win_size * tau_r
     int prefill_seq, row, prefill_pos;          // prefill: one block, reads logits row `row`, updates slot prefill_seq,
 };                                              // whose next KV position becomes prefill_pos (= prompt length)
 #define SM_T 1024
@@ -496,9 +497,9 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
     const int step = sv[CV2_ST_STEP];
     // repetition window (last 10 emitted tokens): lanes 0..9 of wave 0 hold one entry each; a serial loop of dependent global
     // loads in the sampling thread cost ~10 memory round trips per step
-    const int nhist = sv[CV2_ST_NOUT];
+    const int nhist = min(sv[CV2_ST_NOUT], a.max_out);                      // (nout never passes max_out: the slot finishes there)
     int hv = -1;
-    if (tid < 10 && nhist - 10 + tid >= 0) hv = a.out_tokens[(size_t)seq * a.max_out + nhist - 10 + tid];
+    if (tid < a.win && nhist - a.win + tid >= 0) hv = a.out_tokens[(size_t)seq * a.max_out + nhist - a.win + tid];
     if (!done) {
         const bool ignore_eos = step < sv[CV2_ST_MINLEN];
         const bool force = sv[CV2_ST_FORCE] != 0;
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                 int r = 0;
 #pragma unroll
                 for (int j = 0; j < SM_T / 16; j++) { const unsigned o = rowmax[j]; r += (o > mine || (o == mine && j < lane)) ? 1 : 0; }
-                if (r == SM_TOPK - 1) s_thr = mine;
+                if (r == a.top_k - 1) s_thr = mine;
             }
             __syncthreads();
             const unsigned thr = s_thr;
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
 #pragma unroll
                         for (int u = 0; u < 8; u++) r += (j0 + u < ncnd && (o[u] > mk || (o[u] == mk && oi[u] < mi))) ? 1 : 0;
                     }
-                    if (r < SM_TOPK) { candi[r] = mi; candp[r] = __expf(fkey_inv(mk)); }
+                    if (r < a.top_k) { candi[r] = mi; candp[r] = __expf(fkey_inv(mk)); }
                 }
                 if (tid >= ncnd && tid < SM_TOPK) { candi[tid] = 0; candp[tid] = 0.f; }   // vocabulary smaller than the nucleus
                 __syncthreads();
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                     for (int c = 0; c < SM_TOPK; c++) cp[c] = candp[c];        // all reads in flight, then the serial fp32 sum of the reference
                     int nc = 0; float cum = 0.f;
 #pragma unroll
-                    for (int c = 0; c < SM_TOPK; c++) if (nc == c && cum < 0.8f) { cum += cp[c]; nc++; }
+                    for (int c = 0; c < SM_TOPK; c++) if (nc == c && c < a.top_k && cum < a.top_p) { cum += cp[c]; nc++; }
                     s_ncand = nc;
                 }
                 __syncthreads();
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                     }
                     if (lane == 0) {
                         int nc = 0; float cum = 0.f;
-                        while (nc < SM_TOPK && cum < 0.8f) { cum += candp[nc]; nc++; }
+                        while (nc < a.top_k && cum < a.top_p) { cum += candp[nc]; nc++; }
                         s_ncand = nc;
                     }
                 }
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                     const int rep = __popcll(__ballot(hv == top));             // hv = -1 where the window has no entry
                     if (tid == 0) {
                         s_top = top;
-                        s_need = rep >= 1;                                     // win_size * tau_r = 1 -> random_sampling over the full vocabulary
+                        s_need = (float)rep >= a.rep_thr;                      // rep_num >= win_size * tau_r -> random_sampling over the full vocabulary
                         s_done = 0;
                         if (!s_need) {
                             if (!ignore_eos || top != a.eos) s_done = 1;
@@ -754,6 +755,8 @@ sample_done:
         }                                                                 // top > eos: fed back, not emitted (llm.py:712-714)
         const int nstep = step + 1;
         if (nstep >= sv[CV2_ST_MAXLEN]) fin = 1;                          // for i in range(max_len)
+        if (nout >= a.max_out) fin = 1;                                   // output buffer full (the host clamps max_len to max_out, so
+                                                                          // this only guards a state record written behind its back)
         if (st[CV2_ST_ERR]) fin = 1;                                      // (may have been raised above: read back)
         const int pos = a.prefill_seq >= 0 ? a.prefill_pos : sv[CV2_ST_POS] + 1;
         if (pos + 1 >= a.max_pos) fin = 1;
@@ -1010,8 +1013,11 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
     CV2_CHECK(d->n_q % d->n_kv == 0 && d->n_q / d->n_kv <= 8 && d->max_seqs >= 1 && d->max_seqs <= 32, "cv2_llm_create: bad head counts / max_seqs");
     CV2_CHECK(d->vocab <= 6592 && d->eos < d->vocab, "cv2_llm_create: vocab too large for the sampler");
     CV2_CHECK(ws_bytes >= cv2_llm_workspace_bytes(d), "cv2_llm_create: workspace too small (%zu < %zu)", ws_bytes, cv2_llm_workspace_bytes(d));
+    CV2_CHECK(d->top_k == 0 || (d->top_k >= 1 && d->top_k <= SM_TOPK && d->win_size >= 0 && d->win_size <= 64 && d->top_p > 0.f),
+              "cv2_llm_create: sampler constants out of range (top_k 1..%d, win_size 0..64)", SM_TOPK);
     cv2_llm* h = new cv2_llm();
     h->d = *d;
+    if (h->d.top_k == 0) { h->d.top_p = 0.8f; h->d.top_k = 25; h->d.win_size = 10; h->d.tau_r = 0.1f; }   // conf/cosyvoice2.yaml:33-37
     h->layers.assign(w->layers, w->layers + d->layers);
     h->w = *w;
     h->w.layers = h->layers.data();
@@ -1205,7 +1211,7 @@ static int init_attrs_once() {
 static int launch_sample(cv2_llm* h, int nblocks, int prefill_seq, int row, int prefill_pos, hipStream_t s) {
     const cv2_llm_dims& d = h->d;
     SampleArgs a{h->io.logits, d.vocab_pad, h->io.state, h->io.out_tokens, d.max_out, h->w.speech_emb, h->xnext,
-                 d.hidden, d.vocab, d.eos, d.max_pos, prefill_seq, row, prefill_pos};
+                 d.hidden, d.vocab, d.eos, d.max_pos, d.top_p, d.top_k, d.win_size, (float)d.win_size * d.tau_r, prefill_seq, row, prefill_pos};
     hipLaunchKernelGGL(k_sample, dim3(nblocks), dim3(SM_T), 0, s, a);
     CV2_LAUNCH_CHECK();
     return 0;

@@ -1,0 +1,102 @@
+"""Checkpoint validation: the `load_state_dict(strict=True)` of cosyvoice/cli/model.py:67-90 for engines that are not nn.Modules.
+
+The reference's classes define which keys (and shapes) `llm.pt`, `flow.pt`, `hift.pt` must hold; a surplus key such as
+`decoder.estimator...attn1.to_q.bias` (diffusers Attention built with `bias=True`) means the checkpoint was trained with
+arithmetic the HIP kernels do not implement and must be refused, not ignored.  The schema is the key set of cv2amd/synth.py,
+which tests/golden/make_golden.py loads into the reference's own classes with strict=True (so it equals their state_dict()).
+
+Semantics kept from the reference (model.py:67-90):
+  * flow / hift: strict — missing or unexpected keys, or a shape mismatch, raise RuntimeError with torch's message layout;
+  * llm: strict first; on missing keys / size mismatch a warning and a non-strict second pass (unexpected keys ignored,
+    missing keys tolerated only where the MI355X engine does not read them — a missing weight it needs raises, there being
+    no "random initialisation" worth synthesising with);
+  * hift keys may carry a `generator.` prefix (stripped, model.py:88); `epoch` / `step` entries of training checkpoints
+    (utils/train_utils.py:214) are dropped.
+"""
+import logging
+
+import torch
+
+from . import synth
+
+# tensors of llm.pt that the decode path never reads (the tied lm_head of the HF backbone, llm.py:322 is training-only)
+LLM_UNUSED = ('llm.model.lm_head.weight',)
+
+
+def schema(kind, llm_layers=24):
+    """{key: shape} of `kind` in ('llm', 'flow', 'hift') at the cosyvoice2.yaml dimensions."""
+    if kind == 'llm':
+        sd = synth.make_llm(layers=llm_layers, meta=True)
+    elif kind == 'flow':
+        sd = synth.make_flow(meta=True)
+    elif kind == 'hift':
+        sd = synth.make_hift(meta=True)
+    else:
+        raise ValueError(kind)
+    return {k: tuple(v.shape) for k, v in sd.items()}
+
+
+def strip(sd, kind):
+    """Checkpoint dict -> state dict: drop training metadata, strip the hifigan `generator.` prefix (model.py:88)."""
+    out = {}
+    for k, v in sd.items():
+        if k in ('epoch', 'step') and not torch.is_tensor(v):
+            continue
+        if kind == 'hift':
+            k = k.replace('generator.', '')
+        out[k] = v
+    return out
+
+
+def _llm_layers(sd):
+    n = 0
+    while 'llm.model.model.layers.{}.input_layernorm.weight'.format(n) in sd:
+        n += 1
+    return n
+
+
+def check(sd, kind, strict=True):
+    """Returns (missing, unexpected, mismatched) key lists; raises RuntimeError like load_state_dict(strict=True) when strict."""
+    want = schema(kind, _llm_layers(sd) or 24) if kind == 'llm' else schema(kind)
+    missing = [k for k in want if k not in sd]
+    unexpected = [k for k in sd if k not in want]
+    mism = ['size mismatch for {}: copying a param with shape {} from checkpoint, the shape in current model is {}.'.format(
+        k, tuple(sd[k].shape), want[k]) for k in want if k in sd and torch.is_tensor(sd[k]) and tuple(sd[k].shape) != want[k]]
+    if strict and (missing or unexpected or mism):
+        msgs = []
+        if unexpected:
+            msgs.append('Unexpected key(s) in state_dict: {}. '.format(', '.join('"{}"'.format(k) for k in unexpected)))
+        if missing:
+            msgs.append('Missing key(s) in state_dict: {}. '.format(', '.join('"{}"'.format(k) for k in missing)))
+        msgs += mism
+        raise RuntimeError('Error(s) in loading state_dict for {}:\n\t{}'.format(kind, '\n\t'.join(msgs)))
+    return missing, unexpected, mism
+
+
+def validate_llm(sd):
+    """model.py:67-82: strict, then the strict=False fallback for backbone mismatches."""
+    try:
+        check(sd, 'llm', strict=True)
+        logging.info('Successfully validated LLM checkpoint with strict=True')
+        return sd
+    except RuntimeError as e:
+        if 'Missing key(s) in state_dict' not in str(e) and 'size mismatch' not in str(e):
+            raise
+        logging.warning('Strict loading failed, trying with strict=False: %s', e)
+    missing, unexpected, mism = check(sd, 'llm', strict=False)
+    if unexpected:
+        logging.warning('Unexpected keys (will be ignored): %s', unexpected)
+    needed = [k for k in missing if k not in LLM_UNUSED]
+    if needed or mism:
+        raise RuntimeError('LLM checkpoint cannot drive the MI355X engine: missing {} ; {}'.format(needed, ' '.join(mism)))
+    if missing:
+        logging.warning('Missing keys (not read by the decode path): %s', missing)
+    return {k: v for k, v in sd.items() if k not in unexpected}
+
+
+def validate(llm_sd, flow_sd, hift_sd):
+    llm_sd, flow_sd, hift_sd = strip(llm_sd, 'llm'), strip(flow_sd, 'flow'), strip(hift_sd, 'hift')
+    llm_sd = validate_llm(llm_sd)
+    check(flow_sd, 'flow', strict=True)
+    check(hift_sd, 'hift', strict=True)
+    return llm_sd, flow_sd, hift_sd

@@ -5,6 +5,8 @@ Mirrors `HiFTGenerator.inference(speech_feat, cache_source)` (cosyvoice/hifigan/
 `(wav [1, 480 T], source [1, 1, 480 T])`.  There is no CPU fallback.
 """
 import ctypes as C
+import os
+import threading
 
 import torch
 
@@ -122,6 +124,7 @@ class HiftEngine:
         L.check(self.lib.cv2_hift_create(C.byref(self.dims), C.byref(w), self.workspace.data_ptr(), nbytes, C.byref(h)))
         self.handle = h
         self.seed = 0
+        self._seed_fn = None
 
     @staticmethod
     def _pack(sd, conv, resblock, f32):
@@ -164,8 +167,11 @@ class HiftEngine:
             cs = cache_source.to(dev, torch.float32).contiguous()
         nz = noise.to(dev, torch.float32).contiguous() if noise is not None else None
         if seed is None:
-            self.seed += 1
-            seed = self.seed
+            if self._seed_fn is not None:                 # engines of a pool draw from ONE counter (no two chunks share a noise stream)
+                seed = self._seed_fn()
+            else:
+                self.seed += 1
+                seed = self.seed
         L.check(self.lib.cv2_hift_inference(self.handle, L.ptr(mel), T, L.ptr(cs), cs.numel() if cs is not None else 0,
                                             L.ptr(nz), C.c_uint64(seed), L.ptr(wav), L.ptr(src), L.stream_ptr()))
         return wav, src
@@ -187,6 +193,17 @@ class HiftPool:
             self.engines.append(HiftEngine(sd, device, max_frames, share_weights_with=self.engines[0]))
         self.streams = [torch.cuda.Stream(device) for _ in self.engines]
         self._seed = 0
+        self._seed_lock = threading.Lock()
+        # one Philox seed counter for the whole pool, salted with the rank: concurrent streams served by different engines, other
+        # model instances' pools on other ranks, never replay each other's noise (the reference draws from the device RNG)
+        self._salt = (int(os.environ.get('RANK', '0')) + 1) << 40
+        for e in self.engines:
+            e._seed_fn = self.next_seed
+
+    def next_seed(self):
+        with self._seed_lock:
+            self._seed += 1
+            return self._salt ^ self._seed
 
     def inference_many(self, mels):
         """mels: list of [1,80,T] device tensors.  Returns list of (wav, source)."""
@@ -196,9 +213,8 @@ class HiftPool:
             st.wait_stream(main)
         for i, mel in enumerate(mels):
             k = i % len(self.engines)
-            self._seed += 1
             with torch.cuda.stream(self.streams[k]):
-                outs[i] = self.engines[k].inference(mel, None, seed=self._seed)
+                outs[i] = self.engines[k].inference(mel, None, seed=self.next_seed())
             for t in outs[i]:
                 t.record_stream(main)
         for st in self.streams:

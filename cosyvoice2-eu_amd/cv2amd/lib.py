@@ -19,7 +19,8 @@ class Cv2Error(RuntimeError):
 
 class LlmDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('hidden', 'inter', 'layers', 'n_q', 'n_kv', 'vocab', 'vocab_pad', 'eos',
-                                         'max_seqs', 'max_pos', 'max_out')] + [('rms_eps', C.c_float), ('max_prefill_rows', C.c_int32)]
+                                         'max_seqs', 'max_pos', 'max_out')] + [('rms_eps', C.c_float), ('max_prefill_rows', C.c_int32),
+                                                                        ('top_p', C.c_float), ('top_k', C.c_int32), ('win_size', C.c_int32), ('tau_r', C.c_float)]
 
 
 class LlmLayer(C.Structure):

@@ -15,7 +15,8 @@ MODE_GREEDY, MODE_RAS = 0, 1
 
 
 class LLMEngine:
-    def __init__(self, sd, device='cuda:0', max_seqs=32, max_pos=2048, max_out=2048, max_prefill_rows=None):
+    def __init__(self, sd, device='cuda:0', max_seqs=32, max_pos=2048, max_out=2048, max_prefill_rows=None, sampling=None):
+        """sampling: dict(top_p, top_k, win_size, tau_r) of ras_sampling (conf/cosyvoice2.yaml:33-37); None = those defaults."""
         self.device = torch.device(device)
         self.lib = L.lib()
         dev = self.device
@@ -32,7 +33,8 @@ class LLMEngine:
         self.dims = L.LlmDims(hidden=hidden, inter=inter, layers=layers, n_q=n_q, n_kv=n_kv, vocab=vocab,
                               vocab_pad=vocab_pad, eos=EOS, max_seqs=max_seqs, max_pos=max_pos, max_out=max_out,
                               rms_eps=1e-6,
-                              max_prefill_rows=(max_prefill_rows if max_prefill_rows is not None else min(max_seqs * 512, max_seqs * max_pos)))
+                              max_prefill_rows=(max_prefill_rows if max_prefill_rows is not None else min(max_seqs * 512, max_seqs * max_pos)),
+                              **{k: (sampling or {}).get(k, v) for k, v in (('top_p', 0.8), ('top_k', 25), ('win_size', 10), ('tau_r', 0.1))})
         self.hidden, self.max_seqs, self.max_out, self.vocab, self.vocab_pad = hidden, max_seqs, max_out, vocab, vocab_pad
         keep = []
 
@@ -98,15 +100,18 @@ class LLMEngine:
 
     def add_request(self, slot, lm_input, min_len, max_len, mode=MODE_GREEDY, seed=0, force_len=False):
         """Step 0 of inference_wrapper (llm.py:684-719): prefill + first draw for `slot`."""
-        st = torch.zeros(L.STATE_STRIDE, dtype=torch.int32)
-        st[L.ST_MINLEN], st[L.ST_MAXLEN], st[L.ST_MODE], st[L.ST_FORCE] = min_len, max_len, mode, int(force_len)
-        st[L.ST_SEED_LO] = (seed & 0x7FFFFFFF) - (seed & 0x80000000)
-        st[L.ST_SEED_HI] = ((seed >> 32) & 0x7FFFFFFF) - ((seed >> 32) & 0x80000000)
-        self.state[slot].copy_(st)
+        self._init_state(slot, min_len, max_len, mode, seed, force_len)
         assert lm_input.dtype == torch.float32 and lm_input.is_contiguous() and lm_input.shape[1] == self.hidden
         L.check(self.lib.cv2_llm_prefill(self.handle, slot, L.ptr(lm_input), lm_input.shape[0], L.stream_ptr()))
 
     def _init_state(self, slot, min_len, max_len, mode, seed, force_len):
+        # every step emits at most one token into out_tokens[slot, :max_out]: a request may not run longer than the buffer
+        # (the reference has no such buffer: `for i in range(max_len)`, llm.py:684; max_out is sized for 20 x the text limit)
+        if max_len > self.max_out:
+            import logging
+            logging.warning('LLM request max_len %d exceeds the output buffer (%d tokens): decode is capped there', max_len, self.max_out)
+            max_len = self.max_out
+        min_len = min(min_len, max_len)
         st = torch.zeros(L.STATE_STRIDE, dtype=torch.int32)
         st[L.ST_MINLEN], st[L.ST_MAXLEN], st[L.ST_MODE], st[L.ST_FORCE] = min_len, max_len, mode, int(force_len)
         st[L.ST_SEED_LO] = (seed & 0x7FFFFFFF) - (seed & 0x80000000)
@@ -123,23 +128,35 @@ class LLMEngine:
         ln = (C.c_int32 * n)(*[x.shape[0] for x in lm_inputs])
         L.check(self.lib.cv2_llm_prefill_batch(self.handle, n, sl, ln, L.ptr(emb), L.stream_ptr()))
 
+    def decode_kernel_desc(self, n_seqs):
+        """What one decode step launches (for bench.py's roofline record)."""
+        L24 = self.dims.layers
+        if n_seqs <= 16:
+            return f'LLM decode step = one hipGraph replay ({L24} x {{k_qkv, k_attn, k_store(o), k_gateup, k_store(down)}} + head + k_sample), {n_seqs} row(s)'
+        return (f'LLM decode step = one hipGraph replay ({L24} x {{k_prep, k_qkv, k_attn, k_prep, k_store(o), k_prep, k_gateup, k_store(down)}} + head + '
+                f'k_sample), {n_seqs} rows')
+
     def step(self, n_seqs, n_steps=1):
         L.check(self.lib.cv2_llm_decode(self.handle, n_seqs, n_steps, L.stream_ptr()))
 
-    def read(self, n_seqs):
-        """(state [n, 16] int32 cpu, list of emitted-token lists). One device->host sync."""
+    ERR_MSG = 'sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!'      # llm.py:249
+
+    def read(self, n_seqs, raise_on_error=True):
+        """(state [n, 16] int32 cpu, list of emitted-token lists). One device->host sync.  A slot whose sampler gave up (ST_ERR,
+        llm.py:242-250) is finished; with raise_on_error=False the caller inspects st[:, ST_ERR] and fails only that request."""
         st = self.state[:n_seqs].cpu()
         toks = self.out_tokens[:n_seqs].cpu()
-        for b in range(n_seqs):
-            if int(st[b, L.ST_ERR]):
-                raise RuntimeError('sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!')
+        if raise_on_error:
+            for b in range(n_seqs):
+                if int(st[b, L.ST_ERR]):
+                    raise RuntimeError(self.ERR_MSG)
         return st, [toks[b, :min(int(st[b, L.ST_NOUT]), self.max_out)].tolist() for b in range(n_seqs)]
 
     def read_slot(self, slot):
         """(state row [16] int32 cpu, emitted tokens of one slot).  One device->host sync."""
         st = self.state[slot].cpu()
         if int(st[L.ST_ERR]):
-            raise RuntimeError('sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!')
+            raise RuntimeError(self.ERR_MSG)
         n = min(int(st[L.ST_NOUT]), self.max_out)
         return st, self.out_tokens[slot, :n].cpu().tolist()
 
@@ -150,27 +167,39 @@ class LLMEngine:
         else:
             self.state[slot, L.ST_DONE] = 1
 
-    def generate(self, requests, mode=MODE_GREEDY, seed=0, force_len=None, sync_every=16, min_ratio=2, max_ratio=20, batch_prefill=True):
-        """requests: list of (text, prompt_text, prompt_speech_token) int tensors.  Returns list of token lists."""
+    def generate(self, requests, mode=MODE_GREEDY, seed=0, force_len=None, sync_every=16, min_ratio=2, max_ratio=20, batch_prefill=True,
+                 return_errors=False):
+        """requests: list of (text, prompt_text, prompt_speech_token) int tensors.  Returns list of token lists; with
+        return_errors=True also a list holding None or the RuntimeError of each request (a failing request finishes its own slot and
+        never stops the others), otherwise the first error is raised."""
         n = len(requests)
         assert n <= self.max_seqs
         xs, mm = [], []
+        forced = force_len is not None
+        fl = list(force_len) if isinstance(force_len, (list, tuple)) else [force_len] * n     # one forced length for all, or one per request
         for b, (text, ptxt, ptok) in enumerate(requests):
             mn, mx = int(text.numel() * min_ratio), int(text.numel() * max_ratio)
-            if force_len is not None:
-                mn, mx = force_len, force_len
+            if forced:
+                mn, mx = fl[b], fl[b]
             xs.append(self.build_lm_input(text, ptxt, ptok))
             mm.append((mn, mx))
         if batch_prefill and sum(x.shape[0] for x in xs) <= self.dims.max_prefill_rows:
-            self.add_requests(list(range(n)), xs, mm, mode, seed, force_len is not None)
+            self.add_requests(list(range(n)), xs, mm, mode, seed, forced)
         else:
             for b in range(n):
-                self.add_request(b, xs[b], mm[b][0], mm[b][1], mode, seed, force_len is not None)
+                self.add_request(b, xs[b], mm[b][0], mm[b][1], mode, seed, forced)
         while True:
-            st, toks = self.read(n)
+            st, toks = self.read(n, raise_on_error=not return_errors)
             if bool(st[:, L.ST_DONE].all()):
+                if return_errors:
+                    return toks, [RuntimeError(self.ERR_MSG) if int(st[b, L.ST_ERR]) else None for b in range(n)]
                 return toks
-            self.step(n, sync_every)
+            # no live request can finish before its min_len (EOS is re-drawn until then, llm.py:242-250): poll again only after the
+            # earliest possible finish, then every sync_every steps (a finished slot idles inside a burst)
+            live = [b for b in range(n) if not int(st[b, L.ST_DONE])]
+            to_min = min(int(st[b, L.ST_MINLEN]) - int(st[b, L.ST_STEP]) for b in live)
+            to_max = max(int(st[b, L.ST_MAXLEN]) - int(st[b, L.ST_STEP]) for b in live)
+            self.step(n, max(1, min(max(sync_every, to_min), to_max)))
 
     def generate_fixed(self, requests, n_tokens, mode=MODE_RAS, seed=0):
         """Synthetic-weights mode: exactly n_tokens per request, EOS never drawn, no host sync inside the

@@ -17,13 +17,17 @@ LLM_DIMS = dict(hidden=896, inter=4864, layers=24, n_q=14, n_kv=2, vocab=151936,
 
 
 class _Gen:
-    def __init__(self, seed, dtype=torch.float32):
+    def __init__(self, seed, dtype=torch.float32, meta=False):
         self.g = torch.Generator(device='cpu')
         self.g.manual_seed(seed)
         self.sd = {}
         self.dtype = dtype
+        self.meta = meta             # shapes only (cv2amd/checkpoint.py builds the key schema from the same code path)
 
     def normal(self, name, shape, std):
+        if self.meta:
+            self.sd[name] = torch.empty(shape, dtype=self.dtype, device='meta')
+            return
         self.sd[name] = (torch.randn(shape, generator=self.g) * std).to(self.dtype)
 
     def mat(self, name, shape, gain=1.0, fan_in=None):
@@ -48,6 +52,12 @@ class _Gen:
 
     def wn_conv(self, name, shape, gain=1.0, fan_in=None, bias=True, n_bias=None):
         fi = fan_in if fan_in is not None else int(torch.tensor(shape[1:]).prod())
+        if self.meta:
+            self.sd[name + '.parametrizations.weight.original1'] = torch.empty(shape, dtype=self.dtype, device='meta')
+            self.sd[name + '.parametrizations.weight.original0'] = torch.empty((shape[0],) + (1,) * (len(shape) - 1), dtype=self.dtype, device='meta')
+            if bias:
+                self.bias(name + '.bias', n_bias if n_bias is not None else shape[0])
+            return
         v = torch.randn(shape, generator=self.g) * (gain / math.sqrt(fi))
         self.sd[name + '.parametrizations.weight.original1'] = v.to(self.dtype)
         self.sd[name + '.parametrizations.weight.original0'] = v.flatten(1).norm(dim=1).view(-1, *([1] * (len(shape) - 1))).to(self.dtype)
@@ -55,9 +65,9 @@ class _Gen:
             self.bias(name + '.bias', n_bias if n_bias is not None else shape[0])
 
 
-def make_llm(seed=1986, layers=24, hidden=896, inter=4864, n_q=14, n_kv=2, vocab=151936, tie_lm_head=True):
+def make_llm(seed=1986, layers=24, hidden=896, inter=4864, n_q=14, n_kv=2, vocab=151936, tie_lm_head=True, meta=False):
     """llm.pt schema: Qwen2LM over HFBackbone(Qwen2ForCausalLM) (cosyvoice/llm/llm.py:350-413)."""
-    g = _Gen(seed)
+    g = _Gen(seed, meta=meta)
     g.normal('llm.model.model.embed_tokens.weight', (vocab, hidden), 1.0)
     for i in range(layers):
         p = f'llm.model.model.layers.{i}.'
@@ -114,9 +124,9 @@ def _resnet(g, p, cin):
     g.bias(p + '.res_conv.bias', 256)
 
 
-def make_flow(seed=1987, num_mid_blocks=12, n_blocks=4, enc_blocks=6, up_blocks=4):
+def make_flow(seed=1987, num_mid_blocks=12, n_blocks=4, enc_blocks=6, up_blocks=4, meta=False):
     """flow.pt schema: CausalMaskedDiffWithXvec (cosyvoice/flow/flow.py:150-196 and sub-modules)."""
-    g = _Gen(seed)
+    g = _Gen(seed, meta=meta)
     g.normal('input_embedding.weight', (6561, 512), 1.0)
     g.lin('spk_embed_affine_layer', 80, 192, gain=math.sqrt(192))      # unit-norm input -> O(1) output
     for e in ('embed', 'up_embed'):
@@ -157,9 +167,9 @@ def make_flow(seed=1987, num_mid_blocks=12, n_blocks=4, enc_blocks=6, up_blocks=
     return g.sd
 
 
-def make_hift(seed=1988):
+def make_hift(seed=1988, meta=False):
     """hift.pt schema: HiFTGenerator (cosyvoice/hifigan/generator.py:392-503)."""
-    g = _Gen(seed)
+    g = _Gen(seed, meta=meta)
     g.lin('m_source.l_linear', 1, 9, gain=3.0)
     g.wn_conv('conv_pre', (512, 80, 7))
     chans = [512, 256, 128, 64]

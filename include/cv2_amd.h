@@ -50,6 +50,11 @@ typedef struct {
     int32_t max_out;    /* capacity of out_tokens per sequence */
     float rms_eps;      /* 1e-6 */
     int32_t max_prefill_rows; /* capacity of cv2_llm_prefill_batch in prompt rows (0: only the 32-row cv2_llm_prefill) */
+    /* ras_sampling constants (utils/common.py:111-139, values from conf/cosyvoice2.yaml:33-37); top_k == 0 selects 0.8 / 25 / 10 / 0.1 */
+    float top_p;        /* nucleus mass */
+    int32_t top_k;      /* nucleus size, 1..25 */
+    int32_t win_size;   /* repetition window, <= 64 */
+    float tau_r;        /* full-vocabulary re-draw when the drawn id occurs >= win_size * tau_r times in the window */
 } cv2_llm_dims;
 
 typedef struct {
@@ -80,7 +85,7 @@ enum {
     CV2_ST_DONE = 3,     /* 1 once EOS was drawn or max_len reached */
     CV2_ST_MINLEN = 4,   /* int(text_len * min_token_text_ratio) */
     CV2_ST_MAXLEN = 5,   /* int(text_len * max_token_text_ratio) */
-    CV2_ST_MODE = 6,     /* 0 greedy (harness-defined), 1 RAS top-p 0.8 / top-k 25 / win 10 / tau 0.1 */
+    CV2_ST_MODE = 6,     /* 0 greedy (harness-defined), 1 RAS with the constants of cv2_llm_dims */
     CV2_ST_FORCE = 7,    /* 1: synthetic-weights mode, ids >= eos never drawn (fixed decode length) */
     CV2_ST_SEED_LO = 8,
     CV2_ST_SEED_HI = 9,

@@ -10,6 +10,8 @@ What is pinned (reference symbol -> file):
   CausalConditionalDecoder.forward (decoder.py:405-494)      flow_estimator.npz  (T = 16, 50, 101; full and chunk mask)
   UpsampleConformerEncoder.forward (upsample_encoder.py:243) flow_encoder.npz    (T_tok = 28, 53; full/chunk/context)
   Qwen2LM.inference greedy (llm.py:575-719)                  llm_greedy.npz      (24 layers; zero-shot and cross-lingual)
+                                                             llm_greedy_bf16w.npz (same, GEMM weights rounded to bf16 first)
+  flow.inference at T=1010 + HiFTGenerator.inference on 500 frames     fullsize.npz        (BASELINE configs[1] shapes)
   nucleus_sampling candidate set (common.py:120-134)         sampler.npz
 Each block also asserts that oracle/ reproduces the reference before writing.
 """
@@ -124,9 +126,14 @@ def gen_flow():
     save('flow_encoder.npz', seeds='200+T', **out)
 
 
-def gen_llm():
+def gen_llm(rounded=False):
+    """rounded=True: the GEMM matrices are rounded to bf16 first (cv2amd.weights.round_llm_sd), i.e. the reference runs in fp32 on
+    exactly the weight values the HIP path multiplies by -> llm_greedy_bf16w.npz, which the GPU parity test consumes in full."""
+    from cv2amd import weights as W
     l = R.build_llm(num_layers=24)
     sd = synth.make_llm(layers=24)
+    if rounded:
+        sd = W.round_llm_sd(sd)
     l.load_state_dict(sd, strict=True)
     l.sampling_ids = types.MethodType(R.greedy_sampling_ids, l)
     inp = synth.synthetic_inputs(text_len=6, prompt_len=12, prompt_text_len=4)
@@ -143,7 +150,83 @@ def gen_llm():
         out['ids_' + tag] = np.asarray(ref, dtype=np.int32)
         out['margin_' + tag] = (top2[:, 0] - top2[:, 1]).numpy()
         out['logp_head_' + tag] = torch.stack(logps[:3])[:, ::16].numpy()
-    save('llm_greedy.npz', text_len=6, prompt_len=12, prompt_text_len=4, **out)
+    save('llm_greedy_bf16w.npz' if rounded else 'llm_greedy.npz', text_len=6, prompt_len=12, prompt_text_len=4, **out)
+
+
+def gen_llm_bf16w():
+    gen_llm(rounded=True)
+
+
+def gen_fullsize():
+    """BASELINE configs[1] shapes through the reference itself: flow at P=255 prompt tokens + 250 generated (T = 1010 mel frames in
+    the estimator) and HiFT on the resulting 500 frames with injected noise.  Stored: the full mel, every 8th waveform / source sample."""
+    inp = synth.synthetic_inputs(prompt_len=255)
+    g = torch.Generator().manual_seed(5)
+    tok = torch.randint(0, 6561, (1, 250), generator=g, dtype=torch.int32)
+    f = R.build_flow()
+    fsd = synth.make_flow()
+    f.load_state_dict(fsd, strict=True)
+    with torch.inference_mode():
+        mel, _ = f.inference(token=tok, token_len=torch.tensor([250]), prompt_token=inp['prompt_token'],
+                             prompt_token_len=torch.tensor([255]), prompt_feat=inp['prompt_feat'],
+                             prompt_feat_len=torch.tensor([510]), embedding=inp['embedding'], streaming=False, finalize=True)
+    mo = OF.inference(fsd, tok, inp['prompt_token'], inp['prompt_feat'], inp['embedding'], False, True)
+    assert mel.shape == (1, 80, 500) and (mel - mo).abs().max() < 5e-5, 'oracle != reference (flow, T=1010)'
+    del f
+    h = R.build_hift()
+    hsd = synth.make_hift()
+    h.load_state_dict(hsd, strict=True)
+    seed, T = 13, 500
+    ri, nz = hift_noise(seed, T)
+    real_randn_like, real_rand = torch.randn_like, torch.rand
+    draws = [nz, torch.zeros(1, 480 * T, 1)]
+    torch.randn_like = lambda x, *a, **k: draws.pop(0)
+    torch.rand = lambda *a, **k: ri.clone()
+    try:
+        with torch.inference_mode():
+            wav, src = h.inference(mel, torch.zeros(1, 1, 0))
+    finally:
+        torch.randn_like, torch.rand = real_randn_like, real_rand
+    wo, so = OH.inference(hsd, mel, torch.zeros(1, 1, 0), ri, nz)
+    assert torch.equal(wo, wav) and torch.equal(so, src), 'oracle != reference (hift, 500 frames)'
+    save('fullsize.npz', token=tok, prompt_len=255, mel=mel[0], noise_seed=seed, wav8=wav[0, ::8], source8=src[0, 0, ::8],
+         wav_absmax=wav.abs().max(), mel_absmax=mel.abs().max())
+
+
+TEXT_SAMPLES = [
+    "Bonjour, je m'appelle Claire et j'habite à Lyon. Aujourd'hui nous allons parler de la synthèse vocale ! Est-ce que vous êtes prêts ? "
+    "La première partie concerne les modèles de langage : ils prédisent des jetons de parole; la seconde partie concerne le vocodeur. "
+    "Enfin, nous verrons comment mesurer la qualité. Merci.",
+    "Guten Tag. Heute sprechen wir über Sprachsynthese und darüber, wie man sie schnell macht! Ist das nicht spannend? Ja: sehr. "
+    "Die Modelle sind groß; die Rechner sind schnell. Am Ende hören wir ein Beispiel.",
+    'He said "stop." Then she answered "why?" and left. Nobody knew what to do next; everyone waited: ten minutes, twenty minutes, an hour',
+    "短句。这是一个测试句子，用来检查分段逻辑是否正确！我们还需要更多的文字来超过长度限制；所以这里继续写一些内容、再写一些内容。最后一句",
+    "One two three four five six seven eight nine ten eleven twelve thirteen fourteen fifteen sixteen seventeen eighteen nineteen twenty. " * 12,
+    "...", "Ok",
+]
+
+
+def gen_text():
+    """split_paragraph / is_only_punctuation / _split_sentences of the reference on sample paragraphs (whitespace tokenizer)."""
+    import json
+    import re
+    from cosyvoice.utils import frontend_utils as RU
+    tok = lambda t: t.split()      # noqa: E731
+    cases = []
+    for text in TEXT_SAMPLES:
+        for lang, kw in (('en', dict(token_max_n=80, token_min_n=60, merge_len=20)), ('en', dict(token_max_n=12, token_min_n=8, merge_len=4)),
+                         ('zh', dict(token_max_n=30, token_min_n=20, merge_len=8)), ('en', dict(token_max_n=12, token_min_n=8, merge_len=4, comma_split=True))):
+            try:
+                out = RU.split_paragraph(text, tok, lang, **kw)
+            except IndexError:
+                out = 'IndexError'
+            cases.append(dict(text=text, lang=lang, kw=kw, out=out))
+    sents = [[s.strip() for s in re.split(r'(?<=[\.\?\!\u2026\u3002\uff01\uff1f])\s+', t) if s.strip()] for t in TEXT_SAMPLES]   # frontend.py:293-294
+    punct = {t: RU.is_only_punctuation(t) for t in ('...', '', 'a.', '。！', '$+', ' ', 'Ok')}
+    french = {t: RU.contains_french(t) for t in TEXT_SAMPLES}
+    with open(os.path.join(HERE, 'split_paragraph.json'), 'w') as f:
+        json.dump(dict(cases=cases, sentences=sents, punct=punct, french=french), f, ensure_ascii=False, indent=0)
+    print('wrote split_paragraph.json', len(cases))
 
 
 def gen_sampler():
@@ -169,6 +252,6 @@ def gen_sampler():
 if __name__ == '__main__':
     assert R.available(), 'needs /root/reference'
     R.activate()
-    which = sys.argv[1:] or ['hift', 'flow', 'llm', 'sampler']
+    which = sys.argv[1:] or ['hift', 'flow', 'llm', 'llm_bf16w', 'fullsize', 'text', 'sampler']
     for w in which:
         globals()['gen_' + w]()

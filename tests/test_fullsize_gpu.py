@@ -1,0 +1,375 @@
+"""Parity at the sizes BASELINE.json names.  Run with -m gpu on an MI355X.
+
+configs[0]  plumbing: `.pt` checkpoints + cosyvoice2.yaml on disk -> CosyVoice2(model_dir, final=True) -> synthesis
+configs[1]  B=1, P=255 prompt tokens, 50 text tokens, 250 forced tokens: 24-layer LLM ids vs the reference golden and vs the
+            oracle (greedy and RAS with the Philox stream), flow at T=1010 and HiFT on 500 frames vs vectors captured from the
+            reference itself (tests/golden/fullsize.npz, tests/golden/make_golden.py gen_fullsize)
+configs[2]  B=32 FR (P=255) + DE (P=310): ids of all 32 slots vs the oracle, the packed flow batch vs the oracle
+configs[4]  8 concurrent streams at P=255: every chunk vs the reference's chunk / cache / cross-fade logic restated on the oracle
+Bars: ids bit-exact; flow mel <= 5e-2 of range and 2e-2 mean-relative (bf16 operands, precedent rtol 1e-2 bin/export_onnx.py:133);
+HiFT waveform 5e-4 abs / source 2e-3 abs with identical mel and injected noise (fp32 MFMA vs torch CPU fp32).
+"""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, 'gpurun_out')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs a GPU'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def llm_sd():
+    from cv2amd import synth
+    return synth.make_llm(layers=24)
+
+
+@pytest.fixture(scope='module')
+def llm_sdr(llm_sd):
+    from cv2amd import weights as W
+    return W.round_llm_sd(llm_sd)
+
+
+@pytest.fixture(scope='module')
+def eng24(dev, llm_sd):
+    from cv2amd.llm import LLMEngine
+    return LLMEngine(llm_sd, dev, max_seqs=32, max_pos=1024, max_out=512)
+
+
+def rel(got, ref):
+    return (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ configs[1]: LLM
+def test_llm_24_layers_vs_reference_golden(golden, eng24):
+    """All 120 greedy ids of the REFERENCE's Qwen2LM.inference (24 layers, GEMM weights rounded to bf16 = the values the HIP path
+    multiplies by; tests/golden/llm_greedy_bf16w.npz), zero-shot and cross-lingual."""
+    from cv2amd import synth
+    gd = golden('llm_greedy_bf16w.npz')
+    inp = synth.synthetic_inputs(text_len=int(gd['text_len']), prompt_len=int(gd['prompt_len']), prompt_text_len=int(gd['prompt_text_len']))
+    e0 = torch.zeros(1, 0, dtype=torch.int32)
+    for tag, ptxt, ptok in (('zero_shot', inp['prompt_text'], inp['prompt_token']), ('cross_lingual', e0, e0)):
+        got = eng24.generate([(inp['text'], ptxt, ptok)])[0]
+        want = gd['ids_' + tag].tolist()
+        assert got == want, f'{tag}: first difference at step {next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)}, ' \
+                            f'min top-1 margin of the fixture {float(gd["margin_" + tag].min()):.2e}'
+
+
+def test_llm_config1_shape_greedy_and_ras_vs_oracle(eng24, llm_sdr):
+    """configs[1]: P=255, 20 prompt-text + 50 text tokens, 250 forced tokens through 24 layers (hi/lo-split error accumulates over
+    24 layers x 250 steps): greedy ids == oracle, RAS ids == oracle with the same Philox uniforms; records the top-1 margins."""
+    from cv2amd import philox, synth
+    from cv2amd.llm import MODE_RAS
+    from oracle import llm as OL
+    inp = synth.synthetic_inputs(text_len=50, prompt_len=255, prompt_text_len=20)
+    req = (inp['text'], inp['prompt_text'], inp['prompt_token'])
+    got = eng24.generate([req], force_len=250)[0]
+    want, logps = OL.inference(llm_sdr, *req, force_len=250, return_logp=True)
+    margins = np.array([float(lp.topk(2).values[0] - lp.topk(2).values[1]) for lp in logps])
+    os.makedirs(OUT, exist_ok=True)
+    hist, edges = np.histogram(np.log10(np.maximum(margins, 1e-9)), bins=np.arange(-6, 2.5, 0.5))
+    with open(os.path.join(OUT, 'llm_margin_histogram.json'), 'w') as f:
+        json.dump({'config': 'configs[1] 24 layers, 250 forced greedy steps', 'min': float(margins.min()), 'median': float(np.median(margins)),
+                   'log10_bin_edges': edges.tolist(), 'counts': hist.tolist()}, f)
+    assert got == want, f'greedy: min top-1 margin {margins.min():.2e}'
+    seed = 0x5EED1986
+    got = eng24.generate([req], mode=MODE_RAS, seed=seed, force_len=250)[0]
+    want = OL.inference(llm_sdr, *req, mode='ras', force_len=250, uniforms=lambda step, trial: philox.uniforms(0, step, trial, seed))
+    assert got == want
+
+
+# ------------------------------------------------------------------------------------------------ configs[1]: flow, HiFT
+@pytest.fixture(scope='module')
+def flow1(dev):
+    from cv2amd import synth
+    from cv2amd.flow import FlowEngine
+    return FlowEngine(synth.make_flow(), dev, max_utts=1, max_len=1100)
+
+
+def test_flow_T1010_vs_reference_golden(golden, flow1):
+    """One utterance at the headline length (M = 2048 packed rows): the row-panel GEMM, the fused transformer-block tail and the
+    key-split attention against the reference's own flow.inference output."""
+    from cv2amd import synth
+    gd = golden('fullsize.npz')
+    inp = synth.synthetic_inputs(prompt_len=int(gd['prompt_len']))
+    mel, _ = flow1.inference(torch.from_numpy(gd['token']), None, inp['prompt_token'], None, inp['prompt_feat'], None, inp['embedding'], False, True)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(gd['mel']).unsqueeze(0)
+    got = mel.cpu()
+    assert got.shape == ref.shape == (1, 80, 500) and torch.isfinite(got).all()
+    assert rel(got, ref) < 5e-2, f'rel max err {rel(got, ref):.3e}'
+    assert ((got - ref).abs().mean() / ref.abs().mean()).item() < 2e-2
+
+
+def test_hift_500_frames_vs_reference_golden(golden, dev):
+    from cv2amd import synth
+    from cv2amd.hift import HiftEngine
+    gd = golden('fullsize.npz')
+    T = 500
+    g = torch.Generator().manual_seed(int(gd['noise_seed']))
+    _ri, nz = torch.rand(1, 9, generator=g), torch.randn(1, 480 * T, 9, generator=g)
+    eng = HiftEngine(synth.make_hift(), dev, max_frames=512)
+    mel = torch.from_numpy(gd['mel']).unsqueeze(0).to(dev)
+    wav, src = eng.inference(mel, None, noise=nz)
+    torch.cuda.synchronize()
+    assert wav.shape == (1, 240000) and src.shape == (1, 1, 240000)
+    ew = (wav.cpu()[0, ::8] - torch.from_numpy(gd['wav8'])).abs().max().item()
+    es = (src.cpu()[0, 0, ::8] - torch.from_numpy(gd['source8'])).abs().max().item()
+    assert es < 2e-3, f'source abs err {es:.3e}'
+    assert ew < 5e-4, f'waveform abs err {ew:.3e} (range {float(gd["wav_absmax"]):.3f})'
+
+
+# ------------------------------------------------------------------------------------------------ configs[2]: B = 32, FR + DE
+def _b32_requests():
+    from cv2amd import synth
+    reqs = []
+    for b in range(32):
+        P = 255 if b % 2 == 0 else 310                                        # FR / DE prompts
+        inp = synth.synthetic_inputs(seed=5000 + b, text_len=40 + (b % 7), prompt_len=P, prompt_text_len=20 if b % 4 < 2 else 0)
+        ptok = inp['prompt_token'] if b % 4 < 2 else torch.zeros(1, 0, dtype=torch.int32)      # zero-shot / cross-lingual
+        reqs.append((inp['text'], inp['prompt_text'], ptok, inp))
+    return reqs
+
+
+def test_b32_fr_de_ids_vs_oracle(eng24, llm_sdr):
+    """32 slots in lock step (prepared-operand kernels, batched MFMA prefill): every slot's 32 forced greedy ids == the oracle's."""
+    from oracle import llm as OL
+    reqs = _b32_requests()
+    got = eng24.generate([r[:3] for r in reqs], force_len=32)
+    for b, (r, ids) in enumerate(zip(reqs, got)):
+        assert ids == OL.inference(llm_sdr, *r[:3], force_len=32), f'slot {b}'
+
+
+def test_b32_flow_batch_vs_oracle(dev):
+    """The packed ragged batch of configs[2] (16 FR + 16 DE, N ~ U{150..500}): two sampled utterances against the oracle."""
+    from cv2amd import synth
+    from cv2amd.flow import FlowEngine
+    from oracle import flow as OF
+    fsd = synth.make_flow()
+    big = FlowEngine(fsd, dev, max_utts=32, max_len=2 * (310 + 500) + 8)
+    g = torch.Generator().manual_seed(1986)
+    utts, keep = [], {}
+    for b in range(32):
+        P = 255 if b % 2 == 0 else 310
+        n = int(torch.randint(150, 501, (1,), generator=g))
+        inp = synth.synthetic_inputs(seed=6000 + b, prompt_len=P)
+        tok = torch.randint(0, 6561, (1, n), generator=g, dtype=torch.int32)
+        utts.append(dict(token=tok, prompt_token=inp['prompt_token'], prompt_feat=inp['prompt_feat'], embedding=inp['embedding']))
+        keep[b] = (inp, tok)
+    mels = [m.clone() for m in big.inference_batch(utts, streaming=False, finalize=True)]
+    torch.cuda.synchronize()
+    shortest = min(range(32), key=lambda b: utts[b]['token'].shape[1] + utts[b]['prompt_token'].shape[1])
+    for b in (shortest, 1 if shortest != 1 else 3):
+        inp, tok = keep[b]
+        ref = OF.inference(fsd, tok, inp['prompt_token'], inp['prompt_feat'], inp['embedding'], False, True)
+        got = mels[b].cpu()
+        assert got.shape == ref.shape and torch.isfinite(got).all()
+        assert rel(got, ref) < 5e-2, f'utterance {b}: rel max err {rel(got, ref):.3e}'
+        assert ((got - ref).abs().mean() / ref.abs().mean()).item() < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ configs[0] / [4]: the product API
+TEXTS = {'bonjour': list(range(100, 130)), 'guten tag': list(range(200, 236))}
+
+
+def _spk(P, seed):
+    from cv2amd import synth
+    inp = synth.synthetic_inputs(seed=seed, prompt_len=P, prompt_text_len=6)
+    return {'prompt_text': inp['prompt_text'], 'prompt_text_len': torch.tensor([6]), 'llm_prompt_speech_token': inp['prompt_token'],
+            'llm_prompt_speech_token_len': torch.tensor([P]), 'flow_prompt_speech_token': inp['prompt_token'],
+            'flow_prompt_speech_token_len': torch.tensor([P]), 'prompt_speech_feat': inp['prompt_feat'],
+            'prompt_speech_feat_len': torch.tensor([2 * P]), 'llm_embedding': inp['embedding'], 'flow_embedding': inp['embedding']}
+
+
+YAML = """
+sample_rate: 24000
+qwen_pretrain_path: ''
+token_frame_rate: 25
+token_mel_ratio: 2
+chunk_size: 25
+llm: !new:cosyvoice.llm.llm.Qwen2LM
+    speech_token_size: 6561
+    llm: !new:cosyvoice.llm.llm.HFBackbone
+        pretrain_path: !ref <qwen_pretrain_path>
+    sampling: !name:cosyvoice.utils.common.ras_sampling
+        top_p: 0.8
+        top_k: 25
+        win_size: 10
+        tau_r: 0.1
+flow: !new:cosyvoice.flow.flow.CausalMaskedDiffWithXvec
+    input_frame_rate: !ref <token_frame_rate>
+    token_mel_ratio: !ref <token_mel_ratio>
+    pre_lookahead_len: 3
+    decoder: !new:cosyvoice.flow.flow_matching.CausalConditionalCFM
+        cfm_params: !new:omegaconf.DictConfig
+            content:
+                t_scheduler: 'cosine'
+                inference_cfg_rate: 0.7
+hift: !new:cosyvoice.hifigan.generator.HiFTGenerator
+    sampling_rate: !ref <sample_rate>
+"""
+
+
+@pytest.fixture(scope='module')
+def cv_from_disk(tmp_path_factory, llm_sd):
+    """configs[0] plumbing: llm.pt (with training metadata), flow.pt, hift.pt (hifigan checkpoint with the `generator.` prefix) and
+    cosyvoice2.yaml in a model directory -> CosyVoice2(model_dir, final=True): yaml reader, strict validation, weight packing."""
+    from cv2amd import synth
+    from cosyvoice.cli.cosyvoice import CosyVoice2
+    from cosyvoice.cli.frontend import PrecomputedFrontEnd
+    d = tmp_path_factory.mktemp('model_dir')
+    torch.save(dict(llm_sd, epoch=7, step=12345), d / 'llm.pt')
+    torch.save(synth.make_flow(), d / 'flow.pt')
+    torch.save({'generator.' + k: v for k, v in synth.make_hift().items()}, d / 'hift.pt')
+    (d / 'cosyvoice2.yaml').write_text(YAML)
+    fe = PrecomputedFrontEnd(lambda t: TEXTS[t.rstrip('.')], {'fr': _spk(255, 1986), 'de': _spk(310, 1987)})
+    m = CosyVoice2(str(d), final=True, frontend=fe)
+    m.model.sampling_mode = 0                     # harness-defined greedy: deterministic tokens
+    m.model.max_token_text_ratio = 5              # 150-180 tokens per utterance keep the streaming runs short
+    return m
+
+
+def test_config0_checkpoint_files_to_audio(cv_from_disk, llm_sdr):
+    cv = cv_from_disk
+    assert cv.sample_rate == 24000 and cv.config.sampling['top_k'] == 25
+    out = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr', stream=False))
+    assert len(out) == 1
+    wav = out[0]['tts_speech']
+    assert wav.dtype == torch.float32 and wav.device.type == 'cpu' and torch.isfinite(wav).all() and wav.abs().max() <= 0.99
+    # the tokens behind that audio are the oracle's (the .pt -> HBM path packed the right weights)
+    from oracle import llm as OL
+    spk = cv.frontend.spk2info['fr']
+    want = OL.inference(llm_sdr, torch.tensor([TEXTS['bonjour']]), spk['prompt_text'], spk['llm_prompt_speech_token'], max_ratio=5)
+    assert wav.shape[1] == 960 * len(want)
+    with pytest.raises(ValueError, match='cosyvoice2.yaml'):
+        from cosyvoice.cli.cosyvoice import CosyVoice2
+        CosyVoice2(os.path.dirname(cv.model_dir), final=True)
+
+
+def test_config4_eight_streams_every_chunk_vs_reference_logic(cv_from_disk):
+    """8 concurrent streaming calls (FR P=255 and DE P=310 prompts) on one model: shared decode steps, ragged flow batches, HiFT on
+    the pool's streams.  For EVERY chunk of EVERY stream: chunk boundaries follow model.py:351-381, and the audio equals the
+    reference's token2wav tail (mel slice, mel / source / speech caches, Hamming cross-fade; model.py:311-334) restated on the CPU
+    oracle and fed with the same flow mels and the same injected noise.  The flow mels of the concurrent run are compared with the
+    same call run alone (bf16 round-off: batched grids pick other tile shapes)."""
+    from cv2amd import synth
+    from oracle import hift as OH
+    cv = cv_from_disk
+    mdl = cv.model
+    calls = [('bonjour', 'fr'), ('guten tag', 'de')] * 4
+    cnt, lock = {}, threading.Lock()
+
+    def hook(T, uuid):
+        with lock:
+            k = cnt.get(uuid, 0)
+            cnt[uuid] = k + 1
+        return torch.randn(1, 480 * T, 9, generator=torch.Generator().manual_seed(9000 + k))
+    mdl._noise_hook, mdl._noise_hook_takes_uuid = hook, True
+    hsd = synth.make_hift()
+    win = torch.from_numpy(np.hamming(2 * 3840)).float()
+
+    def restate(trace):
+        cache, ref = None, []
+        for (mel, off, fin, nz, _u) in trace:
+            mel = mel[:, :, off * 2:]
+            cs = torch.zeros(1, 1, 0)
+            if cache is not None:
+                mel, cs = torch.cat([cache['mel'], mel], dim=2), cache['source']
+            speech, src = OH.inference(hsd, mel, cs, torch.zeros(1, 9), nz)
+            if cache is not None:
+                speech[..., :3840] = speech[..., :3840] * win[:3840] + cache['speech'][..., -3840:] * win[3840:]
+            if not fin:
+                cache = {'mel': mel[:, :, -8:], 'source': src[:, :, -3840:], 'speech': speech[:, -3840:]}
+                speech = speech[:, :-3840]
+            ref.append(speech)
+        return ref
+    try:
+        alone = {}
+        for text, spk in calls[:2]:
+            mdl._trace = []
+            chunks = [o['tts_speech'] for o in cv.inference_zero_shot(text, 'salut', None, zero_shot_spk_id=spk, stream=True)]
+            alone[(text, spk)] = (chunks, mdl._trace)
+            cnt.clear()
+        mdl._trace = []
+        out, errs, uuid_of, tl = [None] * len(calls), [], {}, threading.local()
+        mdl._on_call = lambda u: uuid_of.__setitem__(tl.i, u)
+
+        def work(i):
+            tl.i = i
+            try:
+                out[i] = [o['tts_speech'] for o in cv.inference_zero_shot(calls[i][0], 'salut', None, zero_shot_spk_id=calls[i][1], stream=True)]
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(calls))]
+        [t.start() for t in ths]
+        [t.join(900) for t in ths]
+        trace = mdl._trace
+    finally:
+        mdl._noise_hook, mdl._noise_hook_takes_uuid, mdl._trace, mdl._on_call = None, False, None, None
+    assert not errs, errs
+    by_uuid = {}
+    for t in trace:
+        by_uuid.setdefault(t[4], []).append(t)
+    assert len(by_uuid) == len(calls)
+    hop = 25
+    assert sorted(uuid_of) == list(range(len(calls)))
+    for i in range(len(calls)):
+        tr = by_uuid[uuid_of[i]]
+        n_tok = tr[-1][0].shape[2] // 2
+        assert sum(c.shape[1] for c in out[i]) == 960 * n_tok and len(out[i]) == len(tr)
+        P = 255 if calls[i][1] == 'fr' else 310
+        pad = int(np.ceil(P / hop) * hop - P)
+        offs = [t[1] for t in tr]
+        assert offs[0] == 0 and (len(offs) == 1 or offs[1] == hop + pad) and all(b - a == hop for a, b in zip(offs[1:-1], offs[2:]))
+        assert [t[2] for t in tr] == [False] * (len(tr) - 1) + [True]
+        assert len(tr) >= 3, 'the run must cross several chunk boundaries'
+        ref = restate(tr)
+        a_chunks, a_trace = alone[calls[i]]
+        assert len(a_chunks) == len(out[i])
+        for c, (got, want) in enumerate(zip(out[i], ref)):
+            assert got.shape == want.shape, f'stream {i} chunk {c}: {got.shape} vs {want.shape}'
+            err = (got - want).abs().max().item()
+            assert err < 1e-3, f'stream {i} ({calls[i]}) chunk {c}: max abs err {err:.3e}'
+            m_alone, m_conc = a_trace[c][0], tr[c][0]
+            assert m_alone.shape == m_conc.shape and rel(m_conc, m_alone) < 3e-2, f'stream {i} chunk {c}: flow mel differs from the solo run'
+    assert sorted(mdl._slot_free) == list(range(mdl.max_batch)) and not mdl._active_slots and not mdl.hift_cache_dict and not mdl._hift_pin
+
+
+def test_one_failing_request_does_not_poison_its_batch(dev):
+    """SURVEY.md §5 / evaluation/cosyvoice_synthesizer.py:265-297: of four coalesced calls, the one whose sampler exhausts its 100
+    EOS re-draws (llm.py:242-250) gets the RuntimeError; the other three get their audio."""
+    from cv2amd import synth
+    from cosyvoice.cli.model import CosyVoice2Model
+    sd = synth.make_llm(layers=2)
+    sd['llm_decoder.bias'] = sd['llm_decoder.bias'].clone()
+    sd['llm_decoder.bias'][6561] = 1e4                              # EOS always wins: fatal only while a request is below its min_len
+    mdl = CosyVoice2Model(sd, synth.make_flow(), synth.make_hift(), max_batch=4, coalesce_ms=200.0, max_text=64, max_prompt_tokens=64, max_new_tokens=256)
+    inp = synth.synthetic_inputs(prompt_len=20, prompt_text_len=3)
+    base = dict(flow_embedding=inp['embedding'], llm_embedding=inp['embedding'], prompt_text=inp['prompt_text'],
+                llm_prompt_speech_token=inp['prompt_token'], flow_prompt_speech_token=inp['prompt_token'], prompt_speech_feat=inp['prompt_feat'])
+    texts = [torch.zeros(1, 0, dtype=torch.int32)] * 3 + [inp['text'][:, :5]]      # min_len = 2 x text length: 0, 0, 0, 10
+    res, errs = [None] * 4, [None] * 4
+
+    def work(i):
+        try:
+            res[i] = list(mdl.tts(text=texts[i], **base))[0]['tts_speech']
+        except Exception as e:      # noqa: BLE001
+            errs[i] = e
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ths]
+    [t.join(300) for t in ths]
+    assert max(mdl.batch_sizes) == 4, mdl.batch_sizes
+    assert isinstance(errs[3], RuntimeError) and 'max_trials' in str(errs[3]) and res[3] is None
+    for i in range(3):
+        assert errs[i] is None and res[i] is not None and res[i].shape[1] == 960 and torch.isfinite(res[i]).all()

@@ -227,3 +227,26 @@ def test_streaming_chunk_arithmetic():
         pad = int(np.ceil(P / hop) * hop - P)
         assert hop + pad + la == first
         assert (P + hop + pad) % hop == 0
+
+
+def test_bench_gpus2_spawns_ranks_and_gathers(tmp_path):
+    """`python bench.py --gpus 2` without a launcher must spawn 2 ranks itself (torch.distributed.run as a child), run the sharded
+    configuration through shard.synthesize_sharded and print ONE JSON line with n_gpus == 2.  CPU plumbing run: gloo + a fake
+    synthesiser (CV2_BENCH_FAKE_SYNTH) whose waveform lengths follow the forced-length rule, so the gather is checked too."""
+    import json
+    import subprocess
+    env = dict(os.environ, CV2_BENCH_BACKEND='gloo', CV2_BENCH_FAKE_SYNTH='1', CV2_BENCH_PER_GPU='5', MASTER_PORT=str(_free_port()))
+    env.pop('RANK', None)
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1 and out['scaling'] == 'weak' and out['value'] > 0
+    assert out['config']['batch_per_gpu'] == 5 and 'configs[3]' in out['config']['workload'] and out['data'].startswith('FAKE')
+    # a launcher / flag mismatch fails loudly instead of reporting a 1-GPU number as N = 2's line
+    env2 = dict(env, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env2, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)

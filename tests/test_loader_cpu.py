@@ -1,0 +1,156 @@
+"""Host-side loading path on CPU: cosyvoice2.yaml reader, strict checkpoint validation, text normalisation / splitting.
+The text golden (tests/golden/split_paragraph.json) holds the outputs of the reference's own functions."""
+import json
+import os
+
+import pytest
+import torch
+
+from cv2amd import checkpoint as CK
+from cv2amd import config as CFG
+from cv2amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+YAML = """
+__set_seed1: !apply:random.seed [1986]
+sample_rate: 24000
+spk_embed_dim: 192
+qwen_pretrain_path: ''
+token_frame_rate: 25
+token_mel_ratio: 2
+chunk_size: 25
+num_decoding_left_chunks: -1
+llm: !new:cosyvoice.llm.llm.Qwen2LM
+    llm_input_size: 0
+    speech_token_size: 6561
+    mix_ratio: [5, 15]
+    llm: !new:cosyvoice.llm.llm.HFBackbone
+        pretrain_path: !ref <qwen_pretrain_path>
+    sampling: !name:cosyvoice.utils.common.ras_sampling
+        top_p: {top_p}
+        top_k: {top_k}
+        win_size: 10
+        tau_r: 0.1
+flow: !new:cosyvoice.flow.flow.CausalMaskedDiffWithXvec
+    input_size: 512
+    spk_embed_dim: !ref <spk_embed_dim>
+    input_frame_rate: !ref <token_frame_rate>
+    token_mel_ratio: !ref <token_mel_ratio>
+    pre_lookahead_len: 3
+    encoder: !new:cosyvoice.transformer.upsample_encoder.UpsampleConformerEncoder
+        num_blocks: {num_blocks}
+        static_chunk_size: !ref <chunk_size>
+    decoder: !new:cosyvoice.flow.flow_matching.CausalConditionalCFM
+        cfm_params: !new:omegaconf.DictConfig
+            content:
+                t_scheduler: 'cosine'
+                inference_cfg_rate: {cfg}
+        estimator: !new:cosyvoice.flow.decoder.CausalConditionalDecoder
+            num_mid_blocks: 12
+            static_chunk_size: !ref <chunk_size> * <token_mel_ratio>
+            num_decoding_left_chunks: !ref <num_decoding_left_chunks>
+hift: !new:cosyvoice.hifigan.generator.HiFTGenerator
+    sampling_rate: !ref <sample_rate>
+    upsample_rates: [8, 5, 3]
+    audio_limit: 0.99
+get_tokenizer: !name:cosyvoice.tokenizer.tokenizer.get_qwen_tokenizer
+    token_path: !ref <qwen_pretrain_path>
+allowed_special: 'all'
+"""
+
+
+def test_yaml_reader_resolves_refs_and_reads_runtime_constants():
+    d = CFG.parse(YAML.format(top_p=0.7, top_k=20, num_blocks=6, cfg=0.5), {'qwen_pretrain_path': '/m/CosyVoice-BlankEN'})
+    assert d['llm']['llm']['pretrain_path'] == '/m/CosyVoice-BlankEN' and d['get_tokenizer']['token_path'] == '/m/CosyVoice-BlankEN'
+    assert d['flow']['decoder']['estimator']['static_chunk_size'] == 50 and d['flow']['encoder']['static_chunk_size'] == 25
+    c = CFG.Config.from_dict(d)
+    assert c.sampling == dict(top_p=0.7, top_k=20, win_size=10, tau_r=0.1)
+    assert c.inference_cfg_rate == 0.5 and c.pre_lookahead_len == 3 and c.token_mel_ratio == 2 and c.input_frame_rate == 25
+    assert c.sample_rate == 24000 and c.qwen_pretrain_path == '/m/CosyVoice-BlankEN'
+
+
+def test_yaml_reader_refuses_another_architecture_or_sampler():
+    with pytest.raises(ValueError, match='flow.encoder.num_blocks'):
+        CFG.Config.from_dict(CFG.parse(YAML.format(top_p=0.8, top_k=25, num_blocks=8, cfg=0.7)))
+    with pytest.raises(ValueError, match='sampler constants'):
+        CFG.Config.from_dict(CFG.parse(YAML.format(top_p=0.8, top_k=50, num_blocks=6, cfg=0.7)))
+
+
+def test_checkpoint_schema_counts_match_appendix_a():
+    # flow.pt 1121 tensors, hift.pt 328 tensors
+    assert len(CK.schema('flow')) == 1121 and len(CK.schema('hift')) == 328
+    s = CK.schema('llm')
+    assert s['llm.model.model.layers.23.mlp.down_proj.weight'] == (896, 4864) and s['llm_decoder.weight'] == (6564, 896)
+    assert s['speech_embedding.weight'] == (6564, 896) and s['llm_embedding.weight'] == (2, 896)
+
+
+def test_flow_checkpoint_with_attention_bias_is_refused():
+    sd = synth.make_flow(meta=True)
+    CK.check(sd, 'flow')
+    sd['decoder.estimator.mid_blocks.3.1.2.attn1.to_q.bias'] = torch.empty(512, device='meta')
+    with pytest.raises(RuntimeError, match=r'Unexpected key\(s\) in state_dict: "decoder.estimator.mid_blocks.3.1.2.attn1.to_q.bias"'):
+        CK.check(sd, 'flow')
+    sd = synth.make_flow(meta=True)
+    del sd['encoder.after_norm.bias']
+    with pytest.raises(RuntimeError, match='Missing key'):
+        CK.check(sd, 'flow')
+    sd = synth.make_hift(meta=True)
+    sd['conv_post.bias'] = torch.empty(17, device='meta')
+    with pytest.raises(RuntimeError, match='size mismatch for conv_post.bias'):
+        CK.check(sd, 'hift')
+
+
+def test_validate_strips_prefix_and_metadata_and_llm_fallback():
+    llm = synth.make_llm(layers=2, meta=True)
+    flow, hift = synth.make_flow(meta=True), synth.make_hift(meta=True)
+    llm_ck = dict(llm, epoch=3, step=1200)
+    flow_ck = dict(flow, epoch=3, step=1200)
+    hift_ck = {'generator.' + k: v for k, v in hift.items()}
+    a, b, c = CK.validate(llm_ck, flow_ck, hift_ck)
+    assert set(a) == set(llm) and set(b) == set(flow) and set(c) == set(hift)
+    # LLM strict=False fallback (cli/model.py:67-82): the unused tied lm_head may be missing; surplus keys are dropped with a warning
+    llm2 = dict(llm)
+    del llm2['llm.model.lm_head.weight']
+    llm2['llm.model.model.rotary_emb.inv_freq'] = torch.empty(32, device='meta')
+    a, _, _ = CK.validate(llm2, flow, hift)
+    assert 'llm.model.model.rotary_emb.inv_freq' not in a
+    llm3 = dict(llm)
+    del llm3['llm_decoder.bias']
+    with pytest.raises(RuntimeError, match='llm_decoder.bias'):
+        CK.validate(llm3, flow, hift)
+    # an unexpected key alone is NOT a reason for the fallback in the reference (only missing keys / size mismatch are): strict error
+    llm4 = dict(llm)
+    llm4['extra.weight'] = torch.empty(1, device='meta')
+    with pytest.raises(RuntimeError, match='Unexpected key'):
+        CK.validate(llm4, flow, hift)
+
+
+def test_split_paragraph_matches_reference_outputs():
+    from cosyvoice.utils import frontend_utils as U
+    g = json.load(open(os.path.join(GOLDEN, 'split_paragraph.json')))
+    tok = lambda t: t.split()      # noqa: E731
+    for c in g['cases']:
+        try:
+            out = U.split_paragraph(c['text'], tok, c['lang'], **c['kw'])
+        except IndexError:
+            out = 'IndexError'
+        assert out == c['out'], (c['lang'], c['kw'], c['text'][:40])
+    texts = [c['text'] for c in g['cases'][::4]]
+    assert [U.split_sentences(t) for t in texts] == g['sentences']
+    assert all(U.is_only_punctuation(k) == v for k, v in g['punct'].items())
+    assert all(U.contains_french(k) == v for k, v in g['french'].items())
+
+
+def test_text_normalize_splits_long_text_and_passes_generators_through():
+    from cosyvoice.cli.frontend import PrecomputedFrontEnd
+    fe = PrecomputedFrontEnd(lambda t: t.split())
+    long_text = ' '.join('Phrase numéro {} avec quelques mots de plus pour la longueur.'.format(i) for i in range(30))
+    segs = fe.text_normalize(long_text, split=True, text_frontend=True)
+    assert len(segs) > 1 and all(len(s.split()) <= 80 + 12 for s in segs)        # ~80-token budget, cut at sentence ends
+    assert ''.join(segs).replace(' ', '') == long_text.replace(' ', '')
+    assert fe.text_normalize(long_text, split=True, text_frontend=False) == [long_text]
+    assert fe.text_normalize('', split=True) == [''] and fe.text_normalize('...', split=True) == []
+    gen = (t for t in ['a', 'b'])
+    assert fe.text_normalize(gen, split=True) == [gen]
+    assert fe.text_normalize('Bonjour tout le monde', split=False) == 'Bonjour tout le monde.'
