@@ -124,6 +124,11 @@ class CosyVoice2:
             model_input = self.frontend.frontend_cross_lingual(i, prompt_speech_16k, self.sample_rate, zero_shot_spk_id)
             yield from self._run(model_input, stream, speed, i)
 
+    def inference_vc(self, source_speech_16k, prompt_speech_16k, stream=False, speed=1.0):
+        """cli/cosyvoice.py:132-139: voice conversion = the source utterance's speech tokens through flow + HiFT with the prompt's voice."""
+        model_input = self.frontend.frontend_vc(source_speech_16k, prompt_speech_16k, self.sample_rate)
+        yield from self._run(model_input, stream, speed, 'vc')
+
     def inference_instruct(self, *args, **kwargs):
         raise NotImplementedError('inference_instruct is not implemented for CosyVoice2!')
 

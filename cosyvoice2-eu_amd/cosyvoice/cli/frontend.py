@@ -110,6 +110,21 @@ class PrecomputedFrontEnd:
         return model_input
 
 
+    def frontend_vc(self, source_speech_16k, prompt_speech_16k, resample_rate):
+        """frontend.py:539-549.  Without the ONNX speech tokenizer the two arguments name pre-extracted entries: `source_speech_16k`
+        = a [1, n] tensor of source speech tokens (or a key of spk2info whose flow_prompt_speech_token is used), `prompt_speech_16k`
+        = a key of spk2info holding the prompt's tokens / mel / embedding."""
+        if not isinstance(prompt_speech_16k, str):
+            raise FrontEndUnavailable('frontend_vc on raw audio needs onnxruntime + whisper + the model_dir ONNX files')
+        p = self.spk2info[prompt_speech_16k]
+        src = self.spk2info[source_speech_16k]['flow_prompt_speech_token'] if isinstance(source_speech_16k, str) else source_speech_16k
+        src = src.reshape(1, -1).to(torch.int32)
+        return {'source_speech_token': src, 'source_speech_token_len': torch.tensor([src.shape[1]], dtype=torch.int32),
+                'flow_prompt_speech_token': p['flow_prompt_speech_token'], 'flow_prompt_speech_token_len': p['flow_prompt_speech_token_len'],
+                'prompt_speech_feat': p['prompt_speech_feat'], 'prompt_speech_feat_len': p['prompt_speech_feat_len'],
+                'flow_embedding': p['flow_embedding']}
+
+
 class CosyVoiceFrontEnd(PrecomputedFrontEnd):
     """The reference's frontend on its own third-party stack (frontend.py:38-127).  Raises FrontEndUnavailable at construction
     when that stack (onnxruntime, whisper, transformers tokenizer files) is not installed."""
@@ -155,6 +170,15 @@ class CosyVoiceFrontEnd(PrecomputedFrontEnd):
         feat = feat - feat.mean(dim=0, keepdim=True)
         emb = self.campplus_session.run(None, {self.campplus_session.get_inputs()[0].name: feat.unsqueeze(0).cpu().numpy()})[0].flatten().tolist()
         return torch.tensor([emb])
+
+    def frontend_vc(self, source_speech_16k, prompt_speech_16k, resample_rate):
+        if isinstance(prompt_speech_16k, str):
+            return super().frontend_vc(source_speech_16k, prompt_speech_16k, resample_rate)
+        z = self.frontend_zero_shot('', '', prompt_speech_16k, resample_rate, '')
+        src, src_len = self._extract_speech_token(source_speech_16k)
+        return {'source_speech_token': src, 'source_speech_token_len': src_len,
+                'flow_prompt_speech_token': z['flow_prompt_speech_token'], 'flow_prompt_speech_token_len': z['flow_prompt_speech_token_len'],
+                'prompt_speech_feat': z['prompt_speech_feat'], 'prompt_speech_feat_len': z['prompt_speech_feat_len'], 'flow_embedding': z['flow_embedding']}
 
     def frontend_zero_shot(self, tts_text, prompt_text, prompt_speech_16k, resample_rate, zero_shot_spk_id):
         if zero_shot_spk_id != '':

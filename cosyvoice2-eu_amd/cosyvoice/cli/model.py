@@ -432,6 +432,75 @@ class CosyVoice2Model:
             raise p.exc
         return p.speech
 
+    def _tts_pulled(self, text, prompt_text, llm_ptok, source_speech_token, fpt, feat, femb, this_uuid, stream, speed, vc):
+        """tts() for the two token sources that are not the batched unistream LLM: voice conversion (vc_job, model.py:141-143: the
+        speech tokens of the source utterance ARE the tokens) and generator text (inference_bistream on one LLM slot, llm.py:721-834).
+        Tokens are pulled from the source exactly as far as the next chunk needs; the chunk arithmetic is model.py:351-394."""
+        hop, la = self.token_hop_len, self.flow.pre_lookahead_len
+        slot = None if vc else self._enter_shared()
+        toks = self.tts_speech_token_dict[this_uuid]
+        try:
+            if vc:
+                toks.extend(source_speech_token.flatten().tolist())
+                src = iter(())
+            else:
+                def on_device(fn):
+                    with self.run_lock:
+                        with torch.cuda.stream(self.llm_stream):
+                            r = fn()
+                        self.llm_stream.synchronize()
+                        return r
+
+                def n_seqs():
+                    with self._mode:
+                        return max(self._active_slots) + 1
+                self.seed += 1
+                src = self.llm.bistream(slot, text, prompt_text.to(self.device), llm_ptok.to(self.device), mode=self.sampling_mode,
+                                        seed=self.seed, n_seqs=n_seqs, on_device=on_device)
+            ended = vc
+
+            def pull(n_total):
+                nonlocal ended
+                while len(toks) < n_total and not ended:
+                    try:
+                        toks.append(next(src))
+                    except StopIteration:
+                        ended = True
+                        self.llm_end_dict[this_uuid] = True
+            if stream is True:
+                token_offset = 0
+                prompt_token_pad = int(np.ceil(fpt.shape[1] / hop) * hop - fpt.shape[1])
+                while True:
+                    this_hop = hop + prompt_token_pad if token_offset == 0 else hop
+                    pull(token_offset + this_hop + la)
+                    if len(toks) - token_offset < this_hop + la:
+                        break
+                    this_tok = torch.tensor(toks[:token_offset + this_hop + la], dtype=torch.int32).unsqueeze(0)
+                    speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, True, False)
+                    token_offset += this_hop
+                    yield {'tts_speech': speech}
+                pull(1 << 30)
+                this_tok = torch.tensor(toks, dtype=torch.int32).unsqueeze(0)
+                yield {'tts_speech': self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, False, True)}
+            else:
+                pull(1 << 30)
+                with self.run_lock:
+                    this_tok = torch.tensor(toks, dtype=torch.int32).unsqueeze(0)
+                    speech = self.token2wav(this_tok, fpt, feat, femb, 0, this_uuid, finalize=True, speed=speed).cpu()
+                yield {'tts_speech': speech}
+        finally:
+            if slot is not None:
+                with self.run_lock:
+                    with torch.cuda.stream(self.llm_stream):
+                        self.llm.park(slot)
+                    self.llm_stream.synchronize()
+                self._exit_shared(slot)
+            with self.lock:
+                self.tts_speech_token_dict.pop(this_uuid, None)
+                self.llm_end_dict.pop(this_uuid, None)
+                self.hift_cache_dict.pop(this_uuid, None)
+                self._hift_pin.pop(this_uuid, None)
+
     # ---- model.py:336-401 -------------------------------------------------------------------------------------
     def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192), llm_embedding=torch.zeros(0, 192),
             prompt_text=torch.zeros(1, 0, dtype=torch.int32),
@@ -441,10 +510,11 @@ class CosyVoice2Model:
             force_len=None, **kwargs):
         """force_len (an extension; the reference swallows unknown keywords in **kwargs): synthetic-weights mode of SURVEY.md §8(d) —
         exactly that many speech tokens, EOS and fill ids never drawn — so that benchmark work is deterministic without a checkpoint."""
-        if source_speech_token.shape[1] != 0:
-            raise NotImplementedError('voice conversion (vc_job, model.py:141-143) is outside the zero-shot hot path')
-        if isinstance(text, torch.Tensor) is False:
-            raise NotImplementedError('generator text input (inference_bistream, llm.py:721-834) is not supported yet')
+        from collections.abc import Generator
+        vc = source_speech_token.shape[1] != 0                   # vc_job (model.py:141-143): the tokens are given, no LLM
+        bistream = isinstance(text, Generator)                    # llm_job's bistream branch (model.py:120-128)
+        if not vc and not bistream and not isinstance(text, torch.Tensor):
+            raise TypeError('text must be a tensor of token ids or a generator of such tensors')
         this_uuid = str(uuid.uuid1())
         if self._on_call is not None:
             self._on_call(this_uuid)
@@ -455,6 +525,10 @@ class CosyVoice2Model:
         fpt = flow_prompt_speech_token.to(dev)
         feat = prompt_speech_feat.to(dev)
         femb = flow_embedding.to(dev)
+        if vc or bistream:
+            yield from self._tts_pulled(text, prompt_text, llm_prompt_speech_token, source_speech_token, fpt, feat, femb, this_uuid,
+                                        stream, speed, vc)
+            return
         if stream is not True and self.max_batch > 1 and self._noise_hook is None and self._trace is None:
             p = self._Pending()
             p.text, p.prompt_text, p.llm_ptok = text.to(dev), prompt_text.to(dev), llm_prompt_speech_token.to(dev)

@@ -386,6 +386,7 @@ struct SampleArgs {
     int* state; int* out_tokens; int max_out;
     const float* speech_emb; float* x_next; int hidden;
     int vocab, eos, max_pos;
+    int bi_speech;                              // bistream: speech tokens per text block (mix_ratio[1] = 15)
     float top_p; int top_k, win; float rep_thr; // ras_sampling constants (conf/cosyvoice2.yaml:33-37): nucleus mass / size, repetition window, win_size * tau_r
     int prefill_seq, row, prefill_pos;          // prefill: one block, reads logits row `row`, updates slot prefill_seq,
 };                                              // whose next KV position becomes prefill_pos (= prompt length)
@@ -500,16 +501,22 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
     const int nhist = min(sv[CV2_ST_NOUT], a.max_out);                      // (nout never passes max_out: the slot finishes there)
     int hv = -1;
     if (tid < a.win && nhist - a.win + tid >= 0) hv = a.out_tokens[(size_t)seq * a.max_out + nhist - a.win + tid];
-    if (!done) {
-        const bool ignore_eos = step < sv[CV2_ST_MINLEN];
+    // bistream (inference_bistream, llm.py:721-834): bimode 1 = text still expected (EOS always re-drawn, the fill id eos + 2 stops
+    // the slot until the host has fed the next text block and is FORCED every n_speech + 1 entries once it has appeared), 2 = final
+    // decode (EOS ends the request); out_tokens then holds every drawn id incl. fill / EOS, as the reference's list does
+    const int bimode = sv[CV2_ST_BIMODE];
+    const bool forced_fill = !done && bimode == 1 && sv[CV2_ST_NEXTFILL] != -1 && sv[CV2_ST_NOUT] == sv[CV2_ST_NEXTFILL];
+    if (forced_fill && tid == 0) s_top = a.eos + 2;
+    if (!done && !forced_fill) {
+        const bool ignore_eos = bimode == 1 ? true : (bimode == 2 ? false : step < sv[CV2_ST_MINLEN]);
         const bool force = sv[CV2_ST_FORCE] != 0;
         const int mode = sv[CV2_ST_MODE];
         // masks on logits == masks on logp (log_softmax is monotone):
-        //   step 0 never EOS (llm.py:693-694); forced-length mode never draws ids >= eos
+        //   step 0 never EOS (inference_wrapper only, llm.py:693-694); forced-length mode never draws ids >= eos
 #pragma unroll
         for (int e = 0; e < SM_NE; e++) {
             const int i = tid + e * SM_T;
-            if (i >= V || (step == 0 && i == a.eos) || (force && i >= a.eos)) lv[e] = -INFINITY;
+            if (i >= V || (bimode == 0 && step == 0 && i == a.eos) || (force && i >= a.eos)) lv[e] = -INFINITY;
         }
         if (mode == 0) {
             // greedy: argmax with EOS excluded while ignore_eos; ties -> lowest id
@@ -748,20 +755,33 @@ sample_done:
     if (tid == 0 && !done) {
         int nout = sv[CV2_ST_NOUT];
         int fin = 0;
+        const int nstep = step + 1;
+        if (bimode != 0) {
+            const int fill = a.eos + 2;
+            if (top == fill) st[CV2_ST_NEXTFILL] = nout + a.bi_speech + 1;                // llm.py:802-804 (also what the forced entry advances to)
+            if (nout < a.max_out) a.out_tokens[(size_t)seq * a.max_out + nout] = top;     // out_tokens.append(top_ids), fill and EOS included
+            nout++;
+            if (top >= a.eos) {
+                fin = 1;
+                if (bimode == 1 && top == fill) st[CV2_ST_WAIT] = 1;                     // llm.py:807-808: wait for text
+                else if (!(bimode == 2 && top == a.eos)) st[CV2_ST_ERR] = 2;             // llm.py:809-810, 829-831: ValueError
+            }
+        } else {
         if (top == a.eos) fin = 1;                                        // llm.py:707-708
         else if (top < a.eos) {                                           // normal token: emit
             if (nout < a.max_out) a.out_tokens[(size_t)seq * a.max_out + nout] = top;
             nout++;
         }                                                                 // top > eos: fed back, not emitted (llm.py:712-714)
-        const int nstep = step + 1;
         if (nstep >= sv[CV2_ST_MAXLEN]) fin = 1;                          // for i in range(max_len)
+        }
         if (nout >= a.max_out) fin = 1;                                   // output buffer full (the host clamps max_len to max_out, so
                                                                           // this only guards a state record written behind its back)
         if (st[CV2_ST_ERR]) fin = 1;                                      // (may have been raised above: read back)
         const int pos = a.prefill_seq >= 0 ? a.prefill_pos : sv[CV2_ST_POS] + 1;
         if (pos + 1 >= a.max_pos) fin = 1;
         st[CV2_ST_NOUT] = nout; st[CV2_ST_STEP] = nstep; st[CV2_ST_LAST] = top; st[CV2_ST_DONE] = fin;
-        if (!fin || a.prefill_seq >= 0) st[CV2_ST_POS] = pos;    // a finished slot idles on its last position
+        // a finished slot idles on its last position; a slot waiting for text (fill) moves on: the text block goes to the next one
+        if (!fin || a.prefill_seq >= 0 || (bimode == 1 && st[CV2_ST_WAIT])) st[CV2_ST_POS] = pos;
     }
     SK_STAMP(6);
     SK_STAMP_FLUSH;
@@ -1211,7 +1231,7 @@ static int init_attrs_once() {
 static int launch_sample(cv2_llm* h, int nblocks, int prefill_seq, int row, int prefill_pos, hipStream_t s) {
     const cv2_llm_dims& d = h->d;
     SampleArgs a{h->io.logits, d.vocab_pad, h->io.state, h->io.out_tokens, d.max_out, h->w.speech_emb, h->xnext,
-                 d.hidden, d.vocab, d.eos, d.max_pos, d.top_p, d.top_k, d.win_size, (float)d.win_size * d.tau_r, prefill_seq, row, prefill_pos};
+                 d.hidden, d.vocab, d.eos, d.max_pos, 15, d.top_p, d.top_k, d.win_size, (float)d.win_size * d.tau_r, prefill_seq, row, prefill_pos};
     hipLaunchKernelGGL(k_sample, dim3(nblocks), dim3(SM_T), 0, s, a);
     CV2_LAUNCH_CHECK();
     return 0;
@@ -1232,6 +1252,23 @@ extern "C" int cv2_llm_prefill(cv2_llm* h, int32_t seq, const float* embeds, int
     }
     // draw step 0 from the last row's logits; the slot's next KV position becomes len
     return launch_sample(h, 1, seq, (len - 1) % 32, len, s);
+}
+
+// Continue slot `seq` with `len` more input rows at positions pos0 .. pos0 + len - 1 (bistream: the next text block, or the final
+// [pending input, remaining text, task id]), then draw from the last row under the slot's state (bimode, next fill index).
+extern "C" int cv2_llm_extend(cv2_llm* h, int32_t seq, const float* embeds, int32_t len, int32_t pos0, void* stream) {
+    CV2_CHECK(h && embeds, "cv2_llm_extend: null argument");
+    CV2_CHECK(seq >= 0 && seq < h->d.max_seqs, "cv2_llm_extend: bad slot %d", seq);
+    CV2_CHECK(len >= 1 && pos0 >= 0 && pos0 + len + 1 < h->d.max_pos, "cv2_llm_extend: rows [%d, %d) do not fit max_pos %d", pos0, pos0 + len, h->d.max_pos);
+    if (init_attrs_once()) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    for (int p0 = 0; p0 < len; p0 += 32) {
+        const int rows = len - p0 < 32 ? len - p0 : 32;
+        RowMap rm{h->io.state, 1, seq, pos0 + p0};
+        int rc = rows <= 16 ? run_layers<1>(h, rows, embeds + (size_t)p0 * h->d.hidden, rm, s) : run_layers_pre(h, rows, embeds + (size_t)p0 * h->d.hidden, rm, s);
+        if (rc) return rc;
+    }
+    return launch_sample(h, 1, seq, (len - 1) % 32, pos0 + len, s);
 }
 
 // Step 0 of inference_wrapper for several slots at once: embeds = the prompts' rows concatenated [sum(lens)][hidden] fp32

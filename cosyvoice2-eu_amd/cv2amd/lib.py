@@ -10,7 +10,8 @@ LIB_PATH = os.environ.get('CV2_AMD_LIB') or os.path.join(_HERE, 'libcv2amd.so') 
 _lib = None
 
 STATE_STRIDE = 16
-ST_POS, ST_STEP, ST_NOUT, ST_DONE, ST_MINLEN, ST_MAXLEN, ST_MODE, ST_FORCE, ST_SEED_LO, ST_SEED_HI, ST_ERR, ST_LAST = range(12)
+(ST_POS, ST_STEP, ST_NOUT, ST_DONE, ST_MINLEN, ST_MAXLEN, ST_MODE, ST_FORCE, ST_SEED_LO, ST_SEED_HI, ST_ERR, ST_LAST, ST_BIMODE, ST_NEXTFILL,
+ ST_WAIT) = range(15)
 
 
 class Cv2Error(RuntimeError):
@@ -51,6 +52,7 @@ def lib():
         L.cv2_llm_destroy.argtypes = [C.c_void_p]
         L.cv2_llm_prefill.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         L.cv2_llm_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.cv2_llm_extend.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.cv2_llm_prefill_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]
         L.cv2_skinny_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_void_p]
@@ -77,7 +79,7 @@ def ptr(t):
 
 
 EXPORTS = ['cv2_last_error', 'cv2_version', 'cv2_llm_workspace_bytes', 'cv2_llm_create', 'cv2_llm_destroy',
-           'cv2_llm_prefill', 'cv2_llm_prefill_batch', 'cv2_llm_decode', 'cv2_skinny_gemm', 'cv2_gemm_bf16',
+           'cv2_llm_prefill', 'cv2_llm_prefill_batch', 'cv2_llm_extend', 'cv2_llm_decode', 'cv2_skinny_gemm', 'cv2_gemm_bf16',
            'cv2_flow_workspace_bytes', 'cv2_flow_create', 'cv2_flow_destroy', 'cv2_flow_inference', 'cv2_flow_estimator',
            'cv2_flow_encoder', 'cv2_hift_workspace_bytes', 'cv2_hift_create', 'cv2_hift_destroy', 'cv2_hift_inference',
            'cv2_fade_in_out']

@@ -201,6 +201,96 @@ class LLMEngine:
             to_max = max(int(st[b, L.ST_MAXLEN]) - int(st[b, L.ST_STEP]) for b in live)
             self.step(n, max(1, min(max(sync_every, to_min), to_max)))
 
+    # ---- llm.py:721-834 ------------------------------------------------------------------------------------------
+    def bistream(self, slot, text, prompt_text, prompt_speech_token, mode=MODE_GREEDY, seed=0, mix_ratio=(5, 15), burst=16,
+                 n_seqs=None, on_device=None):
+        """Qwen2LM.inference_bistream on slot `slot`: `text` is an iterable of int tensors [1, n] arriving over time; yields speech
+        token ids as the reference generator does.  The LM input interleaves mix_ratio[0] text tokens with mix_ratio[1] speech
+        tokens; the device stops the slot on the fill id (k_sample, CV2_ST_WAIT) and this loop feeds the next text block with
+        cv2_llm_extend, exactly where the reference breaks out of its inner `while True` (llm.py:807-808).
+
+        Same bookkeeping as the reference, including its quirks: the stale `lm_input` is replaced by the text block after a fill
+        but fed again in front of the remaining text + task id at the end (llm.py:817).  `on_device(fn)` runs fn() under the
+        caller's device lock / stream (the scheduler passes one); `n_seqs` = slots covered by a decode step (default slot + 1)."""
+        n_text, n_speech = mix_ratio
+        dev = self.device
+        run = on_device or (lambda fn: fn())          # every device operation below goes through run()
+        S = {'pos': 0, 'n_read': 0, 'started': False}     # KV rows fed so far / entries of the device's out_tokens already seen
+        outs = []                                     # the reference's out_tokens (fill / EOS included)
+
+        def emb(ids):
+            return self.text_emb[ids.reshape(-1).to(dev).long()]
+
+        def feed(rows, final=False):
+            rows = rows.contiguous()
+            if not S['started']:
+                self.state[slot, L.ST_BIMODE], self.state[slot, L.ST_NEXTFILL] = 1, -1
+                S['started'] = True
+            self.state[slot, L.ST_DONE], self.state[slot, L.ST_WAIT], self.state[slot, L.ST_BIMODE] = 0, 0, (2 if final else 1)
+            L.check(self.lib.cv2_llm_extend(self.handle, slot, L.ptr(rows), rows.shape[0], S['pos'], L.stream_ptr()))
+            self._keep_rows = rows                    # keep the rows alive until the stream has consumed them
+
+        def poll():
+            st = self.state[slot].cpu()
+            n = min(int(st[L.ST_NOUT]), self.max_out)
+            new = self.out_tokens[slot, S['n_read']:n].cpu().tolist()
+            S['n_read'], S['pos'] = n, int(st[L.ST_POS])
+            return new, bool(st[L.ST_DONE]), int(st[L.ST_ERR])
+
+        def init():
+            self._init_state(slot, 0, self.max_out, mode, seed, False)
+            return (self.speech_emb[prompt_speech_token.reshape(-1).to(dev).long()], self.llm_emb[0:1], emb(prompt_text))
+        sp_left, lm_input, text_cache = run(init)
+
+        def decode_until_stop():
+            """the inner `while True` of llm.py:787-811 / 819-832: yields emitted ids until fill (mid) or EOS (final)."""
+            nonlocal lm_input
+            while True:
+                new, done, err = run(poll)
+                for t in new:
+                    outs.append(t)
+                    if t < EOS:
+                        yield t
+                if err == 1:
+                    raise RuntimeError(self.ERR_MSG)
+                if err == 2:
+                    raise ValueError('should not get token {}'.format(outs[-1]))
+                real = [t for t in new if t < EOS]
+                if real:                              # lm_input = speech_embedding[last emitted id] (llm.py:811)
+                    last = real[-1]
+                    lm_input = run(lambda: self.speech_emb[last:last + 1])
+                if done:
+                    return
+                run(lambda: self.step((n_seqs() if callable(n_seqs) else n_seqs) or slot + 1, burst))
+
+        for this_text in text:
+            def block():
+                nonlocal sp_left, lm_input, text_cache
+                text_cache = torch.cat([text_cache, emb(this_text)], dim=0)
+                while sp_left.shape[0] != 0:                               # llm.py:766-774
+                    if text_cache.shape[0] >= n_text:
+                        lm_input = torch.cat([lm_input, text_cache[:n_text], sp_left[:n_speech]], dim=0)
+                        text_cache, sp_left = text_cache[n_text:], sp_left[n_speech:]
+                    else:
+                        break
+                if sp_left.shape[0] != 0:
+                    return False
+                last_fill = len(outs) != 0 and outs[-1] == EOS + 2         # llm.py:776-786
+                if last_fill or (len(outs) == 0 and lm_input.shape[0] == 1):
+                    if text_cache.shape[0] < n_text:
+                        return False
+                    lm_input = text_cache[:n_text] if last_fill else torch.cat([lm_input, text_cache[:n_text]], dim=0)
+                    text_cache = text_cache[n_text:]
+                feed(lm_input)
+                return True
+            if run(block):
+                yield from decode_until_stop()
+
+        def final():
+            feed(torch.cat([lm_input, text_cache, self.llm_emb[1:2]], dim=0), final=True)     # llm.py:817
+        run(final)
+        yield from decode_until_stop()
+
     def generate_fixed(self, requests, n_tokens, mode=MODE_RAS, seed=0):
         """Synthetic-weights mode: exactly n_tokens per request, EOS never drawn, no host sync inside the
         decode loop.  Returns (list of token lists, (start, end) torch events bracketing the n_tokens-1 decode steps)."""

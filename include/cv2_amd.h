@@ -89,8 +89,12 @@ enum {
     CV2_ST_FORCE = 7,    /* 1: synthetic-weights mode, ids >= eos never drawn (fixed decode length) */
     CV2_ST_SEED_LO = 8,
     CV2_ST_SEED_HI = 9,
-    CV2_ST_ERR = 10,     /* 1: sampler exhausted 100 EOS re-draws (RuntimeError in llm.py:249) */
+    CV2_ST_ERR = 10,     /* 1: sampler exhausted 100 EOS re-draws (RuntimeError in llm.py:249); 2: bistream drew a special id it must
+                          * not ("should not get token", ValueError in llm.py:809, 829) */
     CV2_ST_LAST = 11,    /* last drawn id */
+    CV2_ST_BIMODE = 12,  /* inference_bistream (llm.py:721-834): 0 unistream, 1 text still expected, 2 final decode */
+    CV2_ST_NEXTFILL = 13,/* next_fill_index of llm.py:783 (-1: none yet); counts entries of out_tokens incl. fill ids */
+    CV2_ST_WAIT = 14,    /* 1: the slot stopped on the fill id (eos + 2) and waits for cv2_llm_extend with the next text block */
     CV2_LLM_STATE_STRIDE = 16
 };
 
@@ -112,6 +116,10 @@ int cv2_llm_prefill(cv2_llm* h, int32_t seq, const float* prompt_embeds, int32_t
  * concatenated, fp32 [sum(lens)][hidden] on the device; slots / lens are HOST arrays of n entries.  state[slot] must be
  * initialised like for cv2_llm_prefill.  Weights are streamed once for all rows. */
 int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int32_t* lens, const float* embeds, void* stream);
+/* inference_bistream (llm.py:787-811, 817-832): `len` further input rows for slot `seq` at KV positions pos0 .. pos0 + len - 1
+ * (embeds fp32 [len][hidden], device), then one draw from the last row under state[seq] (CV2_ST_BIMODE, CV2_ST_NEXTFILL).  In
+ * bistream modes out_tokens receives EVERY drawn id (fill and EOS included), as the reference's out_tokens list does. */
+int cv2_llm_extend(cv2_llm* h, int32_t seq, const float* embeds, int32_t len, int32_t pos0, void* stream);
 /* n_steps iterations of the decode loop for slots 0..n_seqs-1 in lock step (one hipGraph replay per step);
  * finished slots idle.  No host synchronisation inside. */
 int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream);

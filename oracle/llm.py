@@ -196,3 +196,89 @@ def inference(sd, text, prompt_text, prompt_speech_token, mode='greedy', uniform
             continue
         out.append(top)
     return (out, logps) if return_logp else out
+
+
+FILL_TOKEN = SPEECH_TOKEN_SIZE + 2     # "need more text" (llm/llm.py:412)
+
+
+def inference_bistream(sd, text_chunks, prompt_text, prompt_speech_token, mode='greedy', uniforms=None, mix_ratio=(5, 15),
+                       max_steps=100000):
+    """Qwen2LM.inference_bistream (llm/llm.py:721-834) restated: text arrives in pieces; the LM input interleaves mix_ratio[0]
+    text tokens with mix_ratio[1] speech tokens; id 6563 (fill) asks for the next text block and is forced every
+    mix_ratio[1] + 1 emitted entries once it has appeared.  Yields nothing: returns (emitted ids, out_tokens incl. fill / EOS).
+
+    Kept exactly, including what looks accidental in the reference: `out_tokens` (the sampler's repetition window) contains the
+    fill tokens; after a fill the stale `lm_input` (the last fed embedding) is REPLACED by the next text block, but at the end of
+    the text it is fed AGAIN in front of the remaining text and the task id (llm.py:817); EOS is only re-drawn (never masked)
+    while text is still expected; an id >= 6561 other than fill (mid) / EOS (final) raises ValueError (llm.py:809, 829).
+    `max_steps` bounds the loop for synthetic weights (the reference has no bound here)."""
+    d = LLMDims(sd)
+    emb = sd['llm.model.model.embed_tokens.weight']
+    sp = sd['speech_embedding.weight']
+    n_text, n_speech = mix_ratio
+    prompt_speech = sp[prompt_speech_token.reshape(-1).long()]          # remaining prompt speech embeddings [P, H]
+    lm_input = sd['llm_embedding.weight'][0:1]                          # sos
+    task = sd['llm_embedding.weight'][1:2]
+    text_cache = emb[prompt_text.reshape(-1).long()]
+    cache = [None] * d.layers
+    out_tokens, emitted = [], []
+    next_fill = -1
+    step = 0
+
+    def draw(logp, ignore_eos):
+        nonlocal step
+        top = sampling_ids(logp, out_tokens, ignore_eos, mode, uniforms, step)
+        step += 1
+        return top
+
+    for this_text in text_chunks:
+        text_cache = torch.cat([text_cache, emb[this_text.reshape(-1).long()]], dim=0)
+        while prompt_speech.shape[0] != 0:                              # llm.py:766-774
+            if text_cache.shape[0] >= n_text:
+                lm_input = torch.cat([lm_input, text_cache[:n_text], prompt_speech[:n_speech]], dim=0)
+                text_cache, prompt_speech = text_cache[n_text:], prompt_speech[n_speech:]
+            else:
+                break
+        if prompt_speech.shape[0] == 0:                                 # llm.py:776-811
+            last_fill = len(out_tokens) != 0 and out_tokens[-1] == FILL_TOKEN
+            if last_fill or (len(out_tokens) == 0 and lm_input.shape[0] == 1):
+                if text_cache.shape[0] >= n_text:
+                    lm_input = text_cache[:n_text] if last_fill else torch.cat([lm_input, text_cache[:n_text]], dim=0)
+                    text_cache = text_cache[n_text:]
+                else:
+                    continue
+            while True:
+                y = qwen2_step(sd, d, lm_input, cache)
+                logp = F.linear(y[-1], sd['llm_decoder.weight'], sd['llm_decoder.bias']).log_softmax(dim=-1)
+                if next_fill != -1 and len(out_tokens) == next_fill:
+                    top = FILL_TOKEN
+                    next_fill += n_speech + 1
+                    step += 1                                           # the forced entry consumes a step index (no draw)
+                else:
+                    top = draw(logp, True)
+                if top == FILL_TOKEN:
+                    next_fill = len(out_tokens) + n_speech + 1
+                out_tokens.append(top)
+                if top >= SPEECH_TOKEN_SIZE:
+                    if top == FILL_TOKEN:
+                        break
+                    raise ValueError('should not get token {}'.format(top))
+                emitted.append(top)
+                lm_input = sp[top:top + 1]
+                if len(out_tokens) > max_steps:
+                    raise RuntimeError('bistream: max_steps exceeded')
+    lm_input = torch.cat([lm_input, text_cache, task], dim=0)           # llm.py:817
+    while True:
+        y = qwen2_step(sd, d, lm_input, cache)
+        logp = F.linear(y[-1], sd['llm_decoder.weight'], sd['llm_decoder.bias']).log_softmax(dim=-1)
+        top = draw(logp, False)
+        out_tokens.append(top)
+        if top >= SPEECH_TOKEN_SIZE:
+            if top == SPEECH_TOKEN_SIZE:
+                break
+            raise ValueError('should not get token {}'.format(top))
+        emitted.append(top)
+        lm_input = sp[top:top + 1]
+        if len(out_tokens) > max_steps:
+            raise RuntimeError('bistream: max_steps exceeded')
+    return emitted, out_tokens

@@ -226,6 +226,39 @@ def build_llm(num_layers=24, sampling=None):
                    length_normalized_loss=True, lsm_weight=0, mix_ratio=[5, 15]).eval()
 
 
+class _CacheView:
+    """What `inference_bistream` needs from the KV cache of transformers 4.40.1 (a tuple of (k, v) per layer): `cache[0][0].size(2)`
+    = cached length (llm/llm.py:794, 820).  transformers 5 returns a DynamicCache without that indexing; this view answers the one
+    question and hands the real object back to the model."""
+
+    def __init__(self, inner):
+        self.inner = inner
+
+    class _Len:
+        def __init__(self, n):
+            self.n = n
+
+        def size(self, dim):
+            assert dim == 2
+            return self.n
+
+    def __getitem__(self, i):
+        return (self._Len(self.inner.get_seq_length()),)
+
+
+def enable_bistream(llm):
+    """Make Qwen2LM.inference_bistream of the reference runnable under the installed transformers: forward_one_step keeps its
+    signature and arithmetic, only the cache object is wrapped in _CacheView on the way out and unwrapped on the way in."""
+    bb = llm.llm
+    orig = bb.forward_one_step
+
+    def forward_one_step(xs, masks, cache=None):
+        y, new = orig(xs, masks, cache.inner if isinstance(cache, _CacheView) else cache)
+        return y, _CacheView(new)
+    bb.forward_one_step = forward_one_step
+    return llm
+
+
 def greedy_sampling_ids(self, weighted_scores, decoded_tokens, sampling, ignore_eos=True):
     """Harness-defined greedy: what `sampling_ids` (llm/llm.py:235-250) converges to with a deterministic
     sampler -- argmax with EOS (speech_token_size) excluded while ignore_eos, instead of 100 identical re-draws."""

@@ -11,6 +11,7 @@ What is pinned (reference symbol -> file):
   UpsampleConformerEncoder.forward (upsample_encoder.py:243) flow_encoder.npz    (T_tok = 28, 53; full/chunk/context)
   Qwen2LM.inference greedy (llm.py:575-719)                  llm_greedy.npz      (24 layers; zero-shot and cross-lingual)
                                                              llm_greedy_bf16w.npz (same, GEMM weights rounded to bf16 first)
+  Qwen2LM.inference_bistream greedy (llm.py:721-834)          llm_bistream.npz    (24 layers; via the cache view of oracle/ref_harness.py)
   flow.inference at T=1010 + HiFTGenerator.inference on 500 frames     fullsize.npz        (BASELINE configs[1] shapes)
   nucleus_sampling candidate set (common.py:120-134)         sampler.npz
 Each block also asserts that oracle/ reproduces the reference before writing.
@@ -153,6 +154,47 @@ def gen_llm(rounded=False):
     save('llm_greedy_bf16w.npz' if rounded else 'llm_greedy.npz', text_len=6, prompt_len=12, prompt_text_len=4, **out)
 
 
+BISTREAM = dict(fill_bias=6.0, eos_bias=14.0, text_len=23, prompt_len=31, prompt_text_len=6, cuts=(0, 3, 10, 15, 23), seeds=(1, 3))
+
+
+def bistream_sd(layers=24):
+    """Synthetic checkpoint on which bistream decoding terminates: the fill id (6563) and EOS get a decoder bias so that they win some
+    argmaxes, 6562 can never win (the reference raises ValueError for it, llm.py:809)."""
+    from cv2amd import weights as W
+    sd = W.round_llm_sd(synth.make_llm(layers=layers))
+    b = sd['llm_decoder.bias'].clone()
+    b[6563] += BISTREAM['fill_bias']
+    b[6561] += BISTREAM['eos_bias']
+    b[6562] = -30.0
+    sd['llm_decoder.bias'] = b
+    return sd
+
+
+def gen_bistream():
+    """Qwen2LM.inference_bistream (llm.py:721-834) of the reference itself, greedy harness sampler, 24 layers, text delivered in four
+    pieces of 3 / 7 / 5 / 8 tokens, with and without prompt speech tokens."""
+    l = R.enable_bistream(R.build_llm(num_layers=24))
+    sd = bistream_sd()
+    l.load_state_dict(sd, strict=True)
+    l.sampling_ids = types.MethodType(R.greedy_sampling_ids, l)
+    out = {}
+    c = BISTREAM['cuts']
+    for seed in BISTREAM['seeds']:
+        inp = synth.synthetic_inputs(seed=seed, text_len=BISTREAM['text_len'], prompt_len=BISTREAM['prompt_len'], prompt_text_len=BISTREAM['prompt_text_len'])
+        e0 = torch.zeros(1, 0, dtype=torch.int32)
+        for tag, ptok in (('prompt', inp['prompt_token']), ('noprompt', e0)):
+            chunks = [inp['text'][:, a:b] for a, b in zip(c[:-1], c[1:])]
+            with torch.inference_mode():
+                ref = list(l.inference_bistream(text=(t for t in chunks), prompt_text=inp['prompt_text'], prompt_text_len=torch.tensor([inp['prompt_text'].shape[1]]),
+                                                prompt_speech_token=ptok, prompt_speech_token_len=torch.tensor([ptok.shape[1]]), embedding=inp['embedding']))
+            ids, outs = OL.inference_bistream(sd, chunks, inp['prompt_text'], ptok)
+            assert ids == ref, 'oracle != reference (bistream ids)'
+            out[f'ids_{tag}_{seed}'] = np.asarray(ref, dtype=np.int32)
+            out[f'out_tokens_{tag}_{seed}'] = np.asarray(outs, dtype=np.int32)
+            print(tag, seed, len(ref), 'emitted,', outs.count(6563), 'fills')
+    save('llm_bistream.npz', **{k: v for k, v in BISTREAM.items() if k != 'cuts'}, cuts=np.asarray(c), **out)
+
+
 def gen_llm_bf16w():
     gen_llm(rounded=True)
 
@@ -252,6 +294,6 @@ def gen_sampler():
 if __name__ == '__main__':
     assert R.available(), 'needs /root/reference'
     R.activate()
-    which = sys.argv[1:] or ['hift', 'flow', 'llm', 'llm_bf16w', 'fullsize', 'text', 'sampler']
+    which = sys.argv[1:] or ['hift', 'flow', 'llm', 'llm_bf16w', 'bistream', 'fullsize', 'text', 'sampler']
     for w in which:
         globals()['gen_' + w]()

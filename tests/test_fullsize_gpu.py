@@ -233,7 +233,7 @@ def cv_from_disk(tmp_path_factory, llm_sd):
     torch.save(synth.make_flow(), d / 'flow.pt')
     torch.save({'generator.' + k: v for k, v in synth.make_hift().items()}, d / 'hift.pt')
     (d / 'cosyvoice2.yaml').write_text(YAML)
-    fe = PrecomputedFrontEnd(lambda t: TEXTS[t.rstrip('.')], {'fr': _spk(255, 1986), 'de': _spk(310, 1987)})
+    fe = PrecomputedFrontEnd(lambda t: TEXTS.get(t.rstrip('.'), [1, 2, 3]), {'fr': _spk(255, 1986), 'de': _spk(310, 1987)})
     m = CosyVoice2(str(d), final=True, frontend=fe)
     m.model.sampling_mode = 0                     # harness-defined greedy: deterministic tokens
     m.model.max_token_text_ratio = 5              # 150-180 tokens per utterance keep the streaming runs short
@@ -373,3 +373,69 @@ def test_one_failing_request_does_not_poison_its_batch(dev):
     assert isinstance(errs[3], RuntimeError) and 'max_trials' in str(errs[3]) and res[3] is None
     for i in range(3):
         assert errs[i] is None and res[i] is not None and res[i].shape[1] == 960 and torch.isfinite(res[i]).all()
+
+
+# ------------------------------------------------------------------------------------------------ bistream (configs[4] names it)
+def _bistream_sd(layers):
+    """the checkpoint of tests/golden/make_golden.py:bistream_sd (fill / EOS decoder biases so that bistream decoding terminates)."""
+    from cv2amd import synth
+    sd = synth.make_llm(layers=layers)
+    b = sd['llm_decoder.bias'].clone()
+    b[6563] += 6.0
+    b[6561] += 14.0
+    b[6562] = -30.0
+    sd['llm_decoder.bias'] = b
+    return sd
+
+
+def test_bistream_24_layers_vs_reference_golden(golden, dev):
+    """Qwen2LM.inference_bistream of the REFERENCE (tests/golden/llm_bistream.npz: greedy harness, 24 layers, text arriving in four
+    pieces, with and without prompt speech tokens): the device state machine (fill id stops the slot, forced fill every 16 entries,
+    final decode) + cv2_llm_extend must emit the same ids AND the same out_tokens list (fill / EOS entries included)."""
+    from cv2amd import synth
+    from cv2amd.llm import LLMEngine
+    gd = golden('llm_bistream.npz')
+    eng = LLMEngine(_bistream_sd(24), dev, max_seqs=2, max_pos=1024, max_out=512)
+    cuts = gd['cuts'].tolist()
+    for seed in gd['seeds'].tolist():
+        inp = synth.synthetic_inputs(seed=seed, text_len=int(gd['text_len']), prompt_len=int(gd['prompt_len']), prompt_text_len=int(gd['prompt_text_len']))
+        for tag, ptok in (('prompt', inp['prompt_token']), ('noprompt', torch.zeros(1, 0, dtype=torch.int32))):
+            chunks = (inp['text'][:, a:b] for a, b in zip(cuts[:-1], cuts[1:]))
+            got = list(eng.bistream(1, chunks, inp['prompt_text'], ptok))
+            assert got == gd[f'ids_{tag}_{seed}'].tolist(), f'{tag} seed {seed}'
+            n = int(eng.state[1, 2])
+            assert eng.out_tokens[1, :n].cpu().tolist() == gd[f'out_tokens_{tag}_{seed}'].tolist()
+    eng.park()
+
+
+def test_generator_text_and_vc_through_the_scheduler(dev):
+    """tts() with a text GENERATOR (llm_job's bistream branch, model.py:120-128) streaming and non-streaming, and voice conversion
+    (vc_job, model.py:141-143): chunk boundaries follow model.py:351-381, token counts equal the oracle's bistream ids."""
+    from cv2amd import synth, weights as W
+    from cosyvoice.cli.model import CosyVoice2Model
+    from oracle import llm as OL
+    sd = _bistream_sd(2)
+    mdl = CosyVoice2Model(sd, synth.make_flow(), synth.make_hift(), max_batch=2, max_text=64, max_prompt_tokens=64, max_new_tokens=512, sampling='greedy')
+    inp = synth.synthetic_inputs(seed=1, text_len=23, prompt_len=31, prompt_text_len=6)
+    cuts = (0, 3, 10, 15, 23)
+    pieces = lambda: (inp['text'][:, a:b] for a, b in zip(cuts[:-1], cuts[1:]))      # noqa: E731
+    want, _ = OL.inference_bistream(W.round_llm_sd(sd), list(pieces()), inp['prompt_text'], inp['prompt_token'])
+    kw = dict(flow_embedding=inp['embedding'], llm_embedding=inp['embedding'], prompt_text=inp['prompt_text'],
+              llm_prompt_speech_token=inp['prompt_token'], flow_prompt_speech_token=inp['prompt_token'], prompt_speech_feat=inp['prompt_feat'])
+    whole = list(mdl.tts(text=pieces(), stream=False, **kw))
+    assert len(whole) == 1 and whole[0]['tts_speech'].shape[1] == 960 * len(want)
+    chunks = [o['tts_speech'] for o in mdl.tts(text=pieces(), stream=True, **kw)]
+    assert sum(c.shape[1] for c in chunks) == 960 * len(want) and all(torch.isfinite(c).all() for c in chunks)
+    pad = int(np.ceil(31 / 25) * 25 - 31)
+    if len(want) >= 25 + pad + 3:
+        assert len(chunks) >= 2 and chunks[0].shape[1] == 960 * (25 + pad) - 3840      # first chunk minus the cross-fade tail kept back
+    # voice conversion: the source tokens go straight to the flow
+    g = torch.Generator().manual_seed(4)
+    src = torch.randint(0, 6561, (1, 70), generator=g, dtype=torch.int32)
+    vc = list(mdl.tts(source_speech_token=src, flow_prompt_speech_token=inp['prompt_token'], prompt_speech_feat=inp['prompt_feat'],
+                      flow_embedding=inp['embedding'], stream=False))
+    assert len(vc) == 1 and vc[0]['tts_speech'].shape[1] == 960 * 70 and torch.isfinite(vc[0]['tts_speech']).all()
+    vcs = [o['tts_speech'] for o in mdl.tts(source_speech_token=src, flow_prompt_speech_token=inp['prompt_token'], prompt_speech_feat=inp['prompt_feat'],
+                                            flow_embedding=inp['embedding'], stream=True)]
+    assert len(vcs) >= 2 and sum(c.shape[1] for c in vcs) == 960 * 70
+    assert sorted(mdl._slot_free) == [0, 1] and not mdl.tts_speech_token_dict

@@ -110,3 +110,24 @@ def test_ras_repetition_and_eos_guard():
     logp[OL.SPEECH_TOKEN_SIZE] = 0.0
     with pytest.raises(RuntimeError):
         OL.sampling_ids(logp.log_softmax(0), [], True, 'ras', lambda s, t: (0.5, 0.5), 0)
+
+
+def test_llm_bistream_ids(golden):
+    """oracle.llm.inference_bistream vs the reference's Qwen2LM.inference_bistream (llm.py:721-834) run under the cache view of
+    oracle/ref_harness.py: emitted ids and the out_tokens list (fill / EOS entries included).  One of the four stored cases keeps
+    the CPU suite short; the GPU parity test consumes all four."""
+    from cv2amd import weights as W
+    gd = golden('llm_bistream.npz')
+    sd = W.round_llm_sd(synth.make_llm(layers=24))
+    b = sd['llm_decoder.bias'].clone()
+    b[6563] += float(gd['fill_bias'])
+    b[6561] += float(gd['eos_bias'])
+    b[6562] = -30.0
+    sd['llm_decoder.bias'] = b
+    seed = 3
+    inp = synth.synthetic_inputs(seed=seed, text_len=int(gd['text_len']), prompt_len=int(gd['prompt_len']), prompt_text_len=int(gd['prompt_text_len']))
+    cuts = gd['cuts'].tolist()
+    chunks = [inp['text'][:, a:b2] for a, b2 in zip(cuts[:-1], cuts[1:])]
+    ids, outs = OL.inference_bistream(sd, chunks, inp['prompt_text'], inp['prompt_token'])
+    assert ids == gd[f'ids_prompt_{seed}'].tolist() and outs == gd[f'out_tokens_prompt_{seed}'].tolist()
+    assert outs.count(OL.FILL_TOKEN) == 3 and outs[-1] == OL.SPEECH_TOKEN_SIZE
