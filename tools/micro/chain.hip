@@ -8,7 +8,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __global__ void k_empty(float* p) { if (p && threadIdx.x == 9999) p[0] = 1.f; }
 // stream `bytes` once (16 B per lane, all loads of a thread in flight), reduce, one store per block
 template <int NLD>
-__global__ __launch_bounds__(512) void k_stream(const u32x4* w, long n16_per_block, const float* dep, float* out) {
+__global__ __launch_bounds__(1024) void k_stream(const u32x4* w, long n16_per_block, const float* dep, float* out) {
     const u32x4* p = w + (long)blockIdx.x * n16_per_block + threadIdx.x;
     u32x4 v[NLD];
 #pragma unroll
@@ -17,12 +17,12 @@ __global__ __launch_bounds__(512) void k_stream(const u32x4* w, long n16_per_blo
     unsigned acc = 0;
 #pragma unroll
     for (int i = 0; i < NLD; i++) acc ^= v[i][0] ^ v[i][1] ^ v[i][2] ^ v[i][3];
-    __shared__ float red[8];
+    __shared__ float red[16];
     float s = x + (float)(acc & 1);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7];
+    if (threadIdx.x == 0) { float t = 0.f; for (int i = 0; i < (int)blockDim.x / 64; i++) t += red[i]; out[blockIdx.x] = t; }
 }
 int main() {
     const int NK = 120, REP = 50;
@@ -56,5 +56,16 @@ int main() {
             hipLaunchKernelGGL((k_stream<14>), dim3(152), dim3(512), 0, s, w + (size_t)(i % 24) * (18 << 16), 14L * 512, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
     if (run("stream  1.6 MB, 56 blocks x 256", [&](int i) {
             hipLaunchKernelGGL((k_stream<7>), dim3(56), dim3(256), 0, s, w + (size_t)(i % 24) * (18 << 16), 7L * 256, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
+    // fat blocks: what can ONE workgroup pull when only a few run (fused per-head attention + O-slice block: 230-690 KB per block)?
+    if (run("stream 344 KB per block, 14 blocks x 1024 (21 loads per thread)", [&](int i) {
+            hipLaunchKernelGGL((k_stream<21>), dim3(14), dim3(1024), 0, s, w + (size_t)(i % 24) * (18 << 16), 21L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
+    if (run("stream 229 KB per block, 28 blocks x 1024 (14 loads per thread)", [&](int i) {
+            hipLaunchKernelGGL((k_stream<14>), dim3(28), dim3(1024), 0, s, w + (size_t)(i % 24) * (18 << 16), 14L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
+    if (run("stream 688 KB per block, 14 blocks x 1024 (42 loads per thread)", [&](int i) {
+            hipLaunchKernelGGL((k_stream<42>), dim3(14), dim3(1024), 0, s, w + (size_t)(i % 24) * (18 << 16), 42L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
+    if (run("stream 459 KB per block, 42 blocks x 1024 (28 loads per thread)", [&](int i) {
+            hipLaunchKernelGGL((k_stream<28>), dim3(42), dim3(1024), 0, s, w + (size_t)(i % 24) * (18 << 16), 28L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
+    if (run("stream 344 KB per block, 76 blocks x 1024 (21 loads per thread, 26 MB)", [&](int i) {
+            hipLaunchKernelGGL((k_stream<21>), dim3(76), dim3(1024), 0, s, w + (size_t)(i % 12) * (36 << 16), 21L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
     return 0;
 }

@@ -21,7 +21,7 @@ struct Args { u64* bufs[NPH]; int bsize[NPH]; Phase ph[NPH]; int layers; unsigne
 __device__ __forceinline__ u64 ld_g(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_g(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int WL>
+template <int WL, bool SENT>
 __global__ __launch_bounds__(256, 1) void k_chain(Args a) {
     __shared__ float red[4];
     __shared__ int fail;
@@ -44,6 +44,21 @@ __global__ __launch_bounds__(256, 1) void k_chain(Args a) {
             const u64* src = a.bufs[ph.gbuf] + (size_t)l * a.bsize[ph.gbuf] + (ph.gshared ? 0 : (size_t)ci * ph.gper);
             float s = 0.f;
             bool ok = false;
+            if (SENT) {      // wave 0 polls ONE granule (the last of the region) with s_sleep, the other waves wait at the barrier
+                if (tid < 64) {
+                    for (unsigned spin = 0;; spin++) {
+                        const u64 g = ld_g(src + ph.gper - 1);
+                        if ((unsigned)(g >> 32) == a.epoch) break;
+                        if ((spin & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t_start > 20000000ull || ld_g((const u64*)a.abort_flag) != 0)) {
+                            if (tid == 0) { atomicExch(a.abort_flag, 1u + p); fail = 1; }
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                __syncthreads();
+                if (fail) return;
+            }
             for (unsigned spin = 0; !ok; spin++) {
                 s = 0.f;
                 bool all = true;
@@ -115,19 +130,23 @@ int main() {
     a.ph[3] = Phase{92, 244,  3, 896, 1,                  4, 32};     // G: 152 units read x_mid, write 32 of h each
     a.ph[4] = Phase{0, 92,    4, 3648, 1,                 0, 48};     // D: 92 blocks (2-3 units each) read 3 x 1216 of h, write 48 (92 x 48 = 4416 of 4480)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto run = [&](const char* name, int wl) -> int {
+    unsigned epoch_ctr = 100;
+    bool small = false;
+    auto run = [&](const char* name, int wl, bool sent) -> int {
         float best = 1e9f;
         for (int rep = 0; rep < 6; rep++) {
-            a.epoch = 100 + rep + wl * 16;
+            a.epoch = ++epoch_ctr;
             CK(hipMemsetAsync(a.abort_flag, 0, 64, s));
             hipLaunchKernelGGL(k_fill, dim3((4480 + 255) / 256), dim3(256), 0, s, a.bufs[0], 4480, a.epoch);       // layer 0 input
             // the D phase writes only 4416 of 4480: pre-fill the tail of every layer's x buffer
             for (int l = 1; l <= layers; l++) hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, s, a.bufs[0] + (size_t)l * 4480 + 4416, 64, a.epoch);
+            (void)small;
             a.wloads = wl;
             CK(hipEventRecord(e0, s));
-            if (wl == 0) hipLaunchKernelGGL(k_chain<0>, dim3(G), dim3(256), 0, s, a);
-            else if (wl == 8) hipLaunchKernelGGL(k_chain<8>, dim3(G), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(k_chain<28>, dim3(G), dim3(256), 0, s, a);
+            if (wl == 0 && !sent) hipLaunchKernelGGL((k_chain<0, false>), dim3(G), dim3(256), 0, s, a);
+            else if (wl == 0) hipLaunchKernelGGL((k_chain<0, true>), dim3(G), dim3(256), 0, s, a);
+            else if (wl == 28 && !sent) hipLaunchKernelGGL((k_chain<28, false>), dim3(G), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_chain<28, true>), dim3(G), dim3(256), 0, s, a);
             CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             unsigned ab; CK(hipMemcpy(&ab, a.abort_flag, 4, hipMemcpyDeviceToHost));
@@ -137,8 +156,16 @@ int main() {
         printf("%-70s %8.1f us per launch = %6.2f us per layer (%d layers)\n", name, best * 1e3, best * 1e3 / layers, layers);
         return 0;
     };
-    if (run("chain only (5 hand-offs per layer)", 0)) return 1;
-    if (run("chain + 8 x 4 KB weight loads per block per phase visit", 8)) return 1;
-    if (run("chain + 28 x 4 KB weight loads per block per phase visit (~29 MB/layer)", 28)) return 1;
+    if (run("chain only, every waiting CU sweeps its whole region", 0, false)) return 1;
+    if (run("chain only, sentinel poll (one granule, s_sleep) then sweep", 0, true)) return 1;
+    if (run("chain + ~29 MB/layer weight prefetch, full sweeps", 28, false)) return 1;
+    if (run("chain + ~29 MB/layer weight prefetch, sentinel", 28, true)) return 1;
+    // latency floor: the same chain with tiny regions (64 granules gathered, 1-2 published per consumer)
+    const Phase keep[NPH] = {a.ph[0], a.ph[1], a.ph[2], a.ph[3], a.ph[4]};
+    for (int i = 0; i < NPH; i++) { a.ph[i].gper = 64; }
+    a.ph[0].pper = 2; a.ph[1].pper = 8; a.ph[2].pper = 2; a.ph[3].pper = 1; a.ph[4].pper = 1;      // 36x2=72>=64, 8x8=64, 56x2, 152x1, 92x1
+    small = true;
+    if (run("tiny regions (64 granules), sentinel: latency floor of 5 hops", 0, true)) return 1;
+    for (int i = 0; i < NPH; i++) a.ph[i] = keep[i];
     return 0;
 }
