@@ -11,6 +11,7 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'cosyvoice2-eu_amd')
 
 
 def _header_functions():
@@ -250,3 +251,72 @@ def test_bench_gpus2_spawns_ranks_and_gathers(tmp_path):
     env2 = dict(env, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env2, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_serving_wire_formats_match_protobuf_and_pcm():
+    """runtime/python/wire.py against google.protobuf on the schema of runtime/python/grpc/cosyvoice.proto:8-42, the int16 PCM rule of
+    the servers (fastapi/server.py:40-43), and one gRPC round trip through the generic handler with a fake model."""
+    sys.path.insert(0, os.path.join(PKG, 'runtime', 'python'))
+    import wire
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name='cosyvoice_test.proto', package='cosyvoice', syntax='proto3')
+
+    def msg(name, fields):
+        m = fd.message_type.add(name=name)
+        for i, (fname, ftype) in enumerate(fields, 1):
+            m.field.add(name=fname, number=i, type=ftype, label=1)
+        return m
+    S, B = 9, 12
+    msg('sftRequest', [('spk_id', S), ('tts_text', S)])
+    msg('zeroshotRequest', [('tts_text', S), ('prompt_text', S), ('prompt_audio', B)])
+    msg('crosslingualRequest', [('tts_text', S), ('prompt_audio', B)])
+    msg('instructRequest', [('tts_text', S), ('spk_id', S), ('instruct_text', S)])
+    req = fd.message_type.add(name='Request')
+    req.oneof_decl.add(name='RequestPayload')
+    for i, (n, t) in enumerate((('sft_request', 'sftRequest'), ('zero_shot_request', 'zeroshotRequest'),
+                                ('cross_lingual_request', 'crosslingualRequest'), ('instruct_request', 'instructRequest')), 1):
+        req.field.add(name=n, number=i, type=11, label=1, type_name='.cosyvoice.' + t, oneof_index=0)
+    msg('Response', [('tts_audio', B)])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    Request = message_factory.GetMessageClass(pool.FindMessageTypeByName('cosyvoice.Request'))
+    Response = message_factory.GetMessageClass(pool.FindMessageTypeByName('cosyvoice.Response'))
+    audio = np.arange(-300, 300, dtype=np.int16).tobytes()
+    r = Request()
+    r.zero_shot_request.tts_text = 'Bonjour à tous'
+    r.zero_shot_request.prompt_text = 'salut'
+    r.zero_shot_request.prompt_audio = audio
+    assert wire.decode_request(r.SerializeToString()) == ('zero_shot_request', {'tts_text': 'Bonjour à tous', 'prompt_text': 'salut', 'prompt_audio': audio})
+    assert wire.encode_request('zero_shot_request', tts_text='Bonjour à tous', prompt_text='salut', prompt_audio=audio) == r.SerializeToString()
+    r = Request()
+    r.instruct_request.tts_text, r.instruct_request.spk_id = 'x', 'fr'
+    assert wire.decode_request(r.SerializeToString()) == ('instruct_request', {'tts_text': 'x', 'spk_id': 'fr', 'instruct_text': ''})
+    assert wire.encode_request('cross_lingual_request', tts_text='hé', prompt_audio=audio) == \
+        Request(cross_lingual_request=dict(tts_text='hé', prompt_audio=audio)).SerializeToString()
+    assert wire.encode_response(audio) == Response(tts_audio=audio).SerializeToString() and wire.decode_response(Response(tts_audio=audio).SerializeToString()) == audio
+    w = torch.tensor([[0.0, 0.5, -0.5, 0.999]])
+    assert np.frombuffer(wire.pcm16(w), dtype=np.int16).tolist() == [0, 16384, -16384, 32735]
+    assert np.allclose(wire.pcm16_to_float(wire.pcm16(w)), w.numpy(), atol=2 ** -15)
+
+    # one streamed rpc through the generic handler, fake model yielding two chunks
+    import grpc
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('cv2_grpc_server', os.path.join(PKG, 'runtime', 'python', 'grpc', 'server.py'))
+    srv_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(srv_mod)
+
+    class Fake:
+        def inference_cross_lingual(self, text, prompt):
+            assert text == 'hé' and prompt.shape == (1, 600)
+            yield {'tts_speech': torch.full((1, 4), 0.25)}
+            yield {'tts_speech': torch.full((1, 2), -0.25)}
+    server, port = srv_mod.make_server(Fake(), 0)
+    server.start()
+    try:
+        ch = grpc.insecure_channel('127.0.0.1:{}'.format(port))
+        call = ch.unary_stream('/cosyvoice.CosyVoice/Inference', request_serializer=lambda kw: wire.encode_request(**kw),
+                               response_deserializer=wire.decode_response)
+        chunks = list(call(dict(kind='cross_lingual_request', tts_text='hé', prompt_audio=audio), timeout=30))
+        assert [np.frombuffer(c, dtype=np.int16).tolist() for c in chunks] == [[8192] * 4, [-8192] * 2]
+    finally:
+        server.stop(0)
