@@ -25,6 +25,37 @@ import torch.nn.functional as F
 
 _NOISE = {}
 
+# Rounded-operand mode: every matrix-product operand (activations AND weights of Linear / Conv1d, q / k / v and the softmax
+# probabilities of attention) is rounded to bf16 before the fp32 product, which is where the HIP path rounds (bf16 MFMA operands,
+# fp32 accumulation, fp32 LayerNorm / softmax / residual stream).  With it the HIP-vs-oracle comparison separates operand
+# rounding (modelled) from everything else (accumulation order, exp / erf approximations), so the GPU tests can hold a ~10x
+# tighter bar than against the fp32 oracle.  Off by default: the golden vectors of the reference are fp32.
+ROUND = {'on': False}
+
+
+class rounded_operands:
+    def __enter__(self):
+        self.prev, ROUND['on'] = ROUND['on'], True
+
+    def __exit__(self, *a):
+        ROUND['on'] = self.prev
+
+
+def _r(x):
+    return x.to(torch.bfloat16).to(torch.float32) if ROUND['on'] else x
+
+
+def _linear(x, w, b=None):
+    return F.linear(_r(x), _r(w), b)
+
+
+def _conv1d(x, w, b=None):
+    return F.conv1d(_r(x), _r(w), b)
+
+
+def _matmul(a, b):
+    return torch.matmul(_r(a), _r(b))
+
 
 def rand_noise():
     """flow_matching.py:197-198 — set_all_random_seed(0); randn([1, 80, 15000]) on the CPU generator."""
@@ -36,7 +67,7 @@ def rand_noise():
 
 
 def lin(sd, name, x):
-    return F.linear(x, sd[name + '.weight'], sd.get(name + '.bias'))
+    return _linear(x, sd[name + '.weight'], sd.get(name + '.bias'))
 
 
 def ln(sd, name, x, eps):
@@ -80,16 +111,16 @@ def rel_attention(sd, p, x, mask, pos_emb, heads=8):
     q = lin(sd, p + '.linear_q', x).view(B, T, heads, dk)
     k = lin(sd, p + '.linear_k', x).view(B, T, heads, dk).transpose(1, 2)
     v = lin(sd, p + '.linear_v', x).view(B, T, heads, dk).transpose(1, 2)
-    pp = F.linear(pos_emb, sd[p + '.linear_pos.weight']).view(1, -1, heads, dk).transpose(1, 2)
+    pp = _linear(pos_emb, sd[p + '.linear_pos.weight']).view(1, -1, heads, dk).transpose(1, 2)
     qu = (q + sd[p + '.pos_bias_u']).transpose(1, 2)
     qv = (q + sd[p + '.pos_bias_v']).transpose(1, 2)
-    ac = torch.matmul(qu, k.transpose(-2, -1))
-    bd = rel_shift(torch.matmul(qv, pp.transpose(-2, -1)))
+    ac = _matmul(qu, k.transpose(-2, -1))
+    bd = rel_shift(_matmul(qv, pp.transpose(-2, -1)))
     s = (ac + bd) / math.sqrt(dk)
     m = mask.unsqueeze(1).eq(0)
     s = s.masked_fill(m, float('-inf'))
     a = torch.softmax(s, dim=-1).masked_fill(m, 0.0)
-    o = torch.matmul(a, v).transpose(1, 2).contiguous().view(B, T, D)
+    o = _matmul(a, v).transpose(1, 2).contiguous().view(B, T, D)
     return lin(sd, p + '.linear_out', o)
 
 
@@ -108,9 +139,9 @@ def pre_lookahead(sd, x, context):
     else:
         assert context.shape[1] == 3
         o = torch.cat([o, context.transpose(1, 2)], dim=2)
-    o = F.leaky_relu(F.conv1d(o, sd['encoder.pre_lookahead_layer.conv1.weight'], sd['encoder.pre_lookahead_layer.conv1.bias']))
+    o = F.leaky_relu(_conv1d(o, sd['encoder.pre_lookahead_layer.conv1.weight'], sd['encoder.pre_lookahead_layer.conv1.bias']))
     o = F.pad(o, (2, 0))
-    o = F.conv1d(o, sd['encoder.pre_lookahead_layer.conv2.weight'], sd['encoder.pre_lookahead_layer.conv2.bias'])
+    o = _conv1d(o, sd['encoder.pre_lookahead_layer.conv2.weight'], sd['encoder.pre_lookahead_layer.conv2.bias'])
     return o.transpose(1, 2) + x
 
 
@@ -130,7 +161,7 @@ def encoder(sd, xs, context=None, streaming=False, n_enc=None, n_up=None):
         i += 1
     # Upsample1D: nearest x2, left pad 4, conv k=5
     o = F.interpolate(xs.transpose(1, 2), scale_factor=2.0, mode='nearest')
-    o = F.conv1d(F.pad(o, (4, 0)), sd['encoder.up_layer.conv.weight'], sd['encoder.up_layer.conv.bias'])
+    o = _conv1d(F.pad(o, (4, 0)), sd['encoder.up_layer.conv.weight'], sd['encoder.up_layer.conv.bias'])
     xs = o.transpose(1, 2)
     T2 = xs.shape[1]
     masks = torch.ones(B, 1, T2, dtype=torch.bool)
@@ -156,7 +187,7 @@ def sinusoidal_pos_emb(t, dim=320, scale=1000):
 
 def causal_conv(sd, name, x):
     k = sd[name + '.weight'].shape[-1]
-    return F.conv1d(F.pad(x, (k - 1, 0)), sd[name + '.weight'], sd[name + '.bias'])
+    return _conv1d(F.pad(x, (k - 1, 0)), sd[name + '.weight'], sd[name + '.bias'])
 
 
 def causal_block(sd, p, x, mask):
@@ -171,18 +202,18 @@ def resnet(sd, p, x, mask, temb):
     h = causal_block(sd, p + '.block1', x, mask)
     h = h + lin(sd, p + '.mlp.1', F.mish(temb)).unsqueeze(-1)
     h = causal_block(sd, p + '.block2', h, mask)
-    return h + F.conv1d(x * mask, sd[p + '.res_conv.weight'], sd[p + '.res_conv.bias'])
+    return h + _conv1d(x * mask, sd[p + '.res_conv.weight'], sd[p + '.res_conv.bias'])
 
 
 def transformer_block(sd, p, x, bias, heads=8):
     # matcha transformer.py:243-316 (self-attn + FF only; dropout 0)
     B, T, C = x.shape
     h = ln(sd, p + '.norm1', x, 1e-5)
-    q = F.linear(h, sd[p + '.attn1.to_q.weight']).view(B, T, heads, -1).transpose(1, 2)
-    k = F.linear(h, sd[p + '.attn1.to_k.weight']).view(B, T, heads, -1).transpose(1, 2)
-    v = F.linear(h, sd[p + '.attn1.to_v.weight']).view(B, T, heads, -1).transpose(1, 2)
-    s = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(q.shape[-1]) + bias.unsqueeze(1)
-    o = torch.matmul(torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(B, T, -1)
+    q = _linear(h, sd[p + '.attn1.to_q.weight']).view(B, T, heads, -1).transpose(1, 2)
+    k = _linear(h, sd[p + '.attn1.to_k.weight']).view(B, T, heads, -1).transpose(1, 2)
+    v = _linear(h, sd[p + '.attn1.to_v.weight']).view(B, T, heads, -1).transpose(1, 2)
+    s = _matmul(q, k.transpose(-2, -1)) / math.sqrt(q.shape[-1]) + bias.unsqueeze(1)
+    o = _matmul(torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(B, T, -1)
     x = x + lin(sd, p + '.attn1.to_out.0', o)
     h = ln(sd, p + '.norm3', x, 1e-5)
     return x + lin(sd, p + '.ff.net.2', F.gelu(lin(sd, p + '.ff.net.0.proj', h)))
@@ -232,7 +263,7 @@ def estimator(sd, x, mask, mu, t, spks, cond, streaming=False):
     h = tblocks(P + '.up_blocks.0', h)
     h = causal_conv(sd, P + '.up_blocks.0.2', h * mask)
     h = causal_block(sd, P + '.final_block', h, mask)
-    o = F.conv1d(h * mask, sd[P + '.final_proj.weight'], sd[P + '.final_proj.bias'])
+    o = _conv1d(h * mask, sd[P + '.final_proj.weight'], sd[P + '.final_proj.bias'])
     return o * mask
 
 

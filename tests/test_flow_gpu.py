@@ -170,3 +170,53 @@ def test_oracle_full_size_estimator_random(eng, dev, flow_sd):
     torch.cuda.synchronize()
     ref = OF.estimator(flow_sd, x, torch.ones(2, 1, T), mu, t, spks, cond, False)
     assert rel(y.cpu(), ref) < 4e-2
+
+
+def _record(name, **vals):
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'flow_rounded_operand_errors.jsonl'), 'a') as f:
+        f.write(json.dumps(dict(test=name, **vals)) + '\n')
+
+
+@pytest.mark.parametrize('streaming', [False, True])
+def test_estimator_vs_rounded_operand_oracle(eng, dev, flow_sd, streaming):
+    """against the fp32 oracle the bar has to be 4e-2 (bf16 operand rounding through 56 blocks), which could hide
+    a small bug.  The oracle's rounded-operand mode rounds every matrix-product operand to bf16 exactly where the HIP path does, so
+    what is left is accumulation order, the exp / erf / Mish approximations and rounding flips of near-ties: an order of magnitude
+    less.  Both errors are recorded in gpurun_out/flow_rounded_operand_errors.jsonl."""
+    from oracle import flow as OF
+    T = 150
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 80, T, generator=g)
+    mu = torch.randn(2, 80, T, generator=g)
+    cond = torch.randn(2, 80, T, generator=g)
+    spks = torch.randn(2, 80, generator=g)
+    t = torch.full((2,), 0.62)
+    y = eng.forward_estimator(x.to(dev).contiguous(), torch.ones(2, 1, T, device=dev), mu.to(dev), t.to(dev), spks.to(dev), cond.to(dev), streaming).cpu()
+    ref32 = OF.estimator(flow_sd, x, torch.ones(2, 1, T), mu, t, spks, cond, streaming)
+    with OF.rounded_operands():
+        refr = OF.estimator(flow_sd, x, torch.ones(2, 1, T), mu, t, spks, cond, streaming)
+    e32, er = rel(y, ref32), rel(y, refr)
+    mr = ((y - refr).abs().mean() / refr.abs().mean()).item()
+    _record('estimator_T150_' + ('chunk' if streaming else 'full'), rel_max_vs_fp32=e32, rel_max_vs_rounded=er, mean_rel_vs_rounded=mr)
+    assert er < 8e-3 and mr < 2e-3, f'vs rounded-operand oracle: rel max {er:.3e}, mean rel {mr:.3e} (vs fp32 oracle {e32:.3e})'
+
+
+def test_flow_inference_vs_rounded_operand_oracle(golden, eng, flow_sd):
+    from cv2amd import synth
+    from oracle import flow as OF
+    gd = golden('flow_e2e.npz')
+    inp = synth.synthetic_inputs(prompt_len=int(gd['prompt_len']))
+    tok = torch.from_numpy(gd['token'])
+    mel, _ = eng.inference(tok, None, inp['prompt_token'], None, inp['prompt_feat'], None, inp['embedding'], False, True)
+    got = mel.cpu()
+    with OF.rounded_operands():
+        refr = OF.inference(flow_sd, tok, inp['prompt_token'], inp['prompt_feat'], inp['embedding'], False, True)
+    ref32 = torch.from_numpy(gd['mel_full'])
+    er, e32 = rel(got, refr), rel(got, ref32)
+    mr = ((got - refr).abs().mean() / refr.abs().mean()).item()
+    _record('flow_e2e_full', rel_max_vs_fp32=e32, rel_max_vs_rounded=er, mean_rel_vs_rounded=mr)
+    assert er < 1e-2 and mr < 3e-3, f'vs rounded-operand oracle: rel max {er:.3e}, mean rel {mr:.3e} (vs the reference golden {e32:.3e})'

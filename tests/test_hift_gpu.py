@@ -102,3 +102,31 @@ def test_fade_in_out(eng, dev):
     got = eng.fade_in_out(a.to(dev).clone(), b.to(dev), win.to(dev))
     torch.cuda.synchronize()
     assert torch.allclose(got.cpu(), ref, atol=1e-6)
+
+
+def test_decoder_at_real_checkpoint_ranges(dev):
+    """the device Snake uses __sinf, ELU / exp use __expf; on unit-variance synthetic weights their arguments stay
+    small.  Here the checkpoint is pushed to the ranges a trained HiFT reaches: Snake alpha log-uniform in [0.05, 20] (a trained
+    alpha spans about that), conv_pre scaled so that the activations entering the resblocks are ~30x larger (|alpha x| up to ~1e3,
+    where a fast sine loses absolute accuracy first).  Decoder alone (oracle source injected), bar relative to the waveform range."""
+    from cv2amd import synth
+    from cv2amd.hift import HiftEngine
+    from oracle import hift as OH
+    sd = dict(synth.make_hift())
+    g = torch.Generator().manual_seed(42)
+    for k in list(sd):
+        if k.endswith('.alpha'):
+            sd[k] = torch.exp(torch.empty_like(sd[k]).uniform_(np.log(0.05), np.log(20.0), generator=g))
+    sd['conv_pre.parametrizations.weight.original0'] = sd['conv_pre.parametrizations.weight.original0'] * 30.0
+    sd['conv_post.parametrizations.weight.original0'] = sd['conv_post.parametrizations.weight.original0'] / 30.0     # keep exp(magnitude) finite
+    eng = HiftEngine(sd, dev, max_frames=128)
+    T = 40
+    mel = (torch.randn(1, 80, T, generator=g) * 2 - 4).clamp(-11.5, 2)
+    ri, nz = _noise(78, T)
+    wo, so = OH.inference(sd, mel, torch.zeros(1, 1, 0), ri, nz)
+    wav, src = eng.inference(mel.to(dev), so, noise=nz)             # decoder only: the oracle's source injected
+    torch.cuda.synchronize()
+    assert torch.isfinite(wav).all()
+    rng = max(wo.abs().max().item(), 1e-3)
+    err = (wav.cpu() - wo).abs().max().item()
+    assert err < 2e-3 * rng + 2e-5, f'decoder at real-checkpoint ranges: max abs err {err:.3e} (waveform range {rng:.3f})'
