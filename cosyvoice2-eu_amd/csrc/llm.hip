@@ -290,132 +290,6 @@ static void launch_attn(const AttnArgs& a, int rows, hipStream_t s) {
     else hipLaunchKernelGGL(k_attn<1>, grid, dim3(256), 0, s, a);
 }
 
-// ------------------------------------------------------------------ k_attn_o: one-row decode attention + O projection per head
-// Batch-1 decode is bound by its chain of dependent launches, not by bytes.  Attention and the O projection are
-// "tensor-parallel over heads": head h's attention output multiplies only columns [64 h, 64 h + 64) of W_o, so ONE launch can do both
-// per head and leave P = W_o[:, head h] . o_unnormalised (a full hidden-size vector) plus the softmax statistics; k_gateup's FOLD
-// prologue combines the 14 x 2 vectors (split-softmax weights are scalars, so they commute with the projection) while its weights
-// stream.  Block = (head, key split): 512 threads; the two splits take the 64-key tiles alternately, 4 tiles (256 keys) per block
-// and round, every load (q, K rows, V rows, the head's 112 KiB slice of W_o) requested at kernel entry.
-struct AttnOArgs {
-    const float* q; const float* kc; const float* vc; const uint16_t* wo;
-    float* parts;             // [n_q * 2][hidden]  P vectors
-    float* ml;                // [n_q * 2][2]       (max, sum)
-    const int* state;
-    int n_q, n_kv, rep, max_pos, hidden, KSO;   // KSO = k-steps of W_o = n_q * 64 / 32
-};
-#define AO_MAXT 7             // 16-row tiles of W_o per wave (hidden <= 8 waves x 7 x 16 = 896)
-__global__ __launch_bounds__(512) void k_attn_o(AttnOArgs a) {
-    __shared__ __attribute__((aligned(16))) float qs[64];
-    __shared__ __attribute__((aligned(16))) float ps[256];
-    __shared__ __attribute__((aligned(16))) float po[32 * 64];
-    __shared__ __attribute__((aligned(16))) uint16_t ob[2][64];      // o as hi / lo bf16
-    __shared__ float wred[8];
-    const int h = blockIdx.x, sp = blockIdx.y, g = h / a.rep;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kl = tid >> 1, hf = tid & 1;                 // scores: thread = (local key 0..255, 32-dim half)
-    const int d4 = tid & 15, kg = tid >> 4;                // PV: thread = (4 dims, 8 local keys)
-    // local key c (0..255) of round rd is key 64 * (2 * (4 rd + (c >> 6)) + sp) + (c & 63)
-    auto key_of = [&](int rd, int c) { return 64 * (2 * (4 * rd + (c >> 6)) + sp) + (c & 63); };
-    const float qv = a.q[h * 64 + (tid & 63)];
-    const int pos = a.state[CV2_ST_POS];
-    const float* K = a.kc + (size_t)g * a.max_pos * 64;
-    const float* V = a.vc + (size_t)g * a.max_pos * 64;
-    f32x4 kk[8], vv[8];
-    auto load_kv = [&](int rd) {
-        const int jr = min(key_of(rd, kl), a.max_pos - 1);
-#pragma unroll
-        for (int i = 0; i < 8; i++) kk[i] = *reinterpret_cast<const f32x4*>(K + (size_t)jr * 64 + hf * 32 + 4 * i);
-#pragma unroll
-        for (int k = 0; k < 8; k++) vv[k] = *reinterpret_cast<const f32x4*>(V + (size_t)min(key_of(rd, kg * 8 + k), a.max_pos - 1) * 64 + d4 * 4);
-    };
-    load_kv(0);
-    // this wave's tiles of W_o: wave, wave + 8, ...; the head's columns are k-steps 2 h and 2 h + 1 of every tile
-    const int ntile = a.hidden / 16;
-    s16x8 wf[AO_MAXT][2];
-#pragma unroll
-    for (int i = 0; i < AO_MAXT; i++) {
-        const int t = min(wave + 8 * i, ntile - 1);
-        const char* base = reinterpret_cast<const char*>(a.wo) + ((size_t)t * a.KSO + 2 * h) * 1024 + lane * 16;
-        wf[i][0] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(base));
-        wf[i][1] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(base + 1024));
-    }
-    if (tid < 64) qs[tid] = qv;
-    const int L = pos + 1;
-    const int rounds = (L + 511) / 512;
-    float run_m = -INFINITY, run_l = 0.f;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    for (int rd = 0; rd < rounds; rd++) {
-        if (rd > 0) load_kv(rd);
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const f32x4 q4 = *reinterpret_cast<const f32x4*>(&qs[hf * 32 + 4 * i]);
-            acc += kk[i][0] * q4[0] + kk[i][1] * q4[1] + kk[i][2] * q4[2] + kk[i][3] * q4[3];
-        }
-        acc += dpp_mov_f32<0xB1, 0xf>(0.f, acc);          // the two halves of a key sit in neighbouring lanes
-        const float sc = key_of(rd, kl) < L ? acc * 0.125f : -INFINITY;
-        // block maximum: wave max, then 8 values through LDS
-        const float wm = wave_max(sc);
-        if (lane == 0) wred[wave] = wm;
-        __syncthreads();
-        float mt = wred[0];
-#pragma unroll
-        for (int w = 1; w < 8; w++) mt = fmaxf(mt, wred[w]);
-        const float mn = fmaxf(run_m, mt);                 // -inf only if no key at all so far (an empty split)
-        const float p = mn == -INFINITY ? 0.f : __expf(sc - mn);
-        __syncthreads();                                   // wred read by everyone before it is reused
-        if (hf == 0) ps[kl] = p;
-        const float ws = wave_sum(hf == 0 ? p : 0.f);
-        if (lane == 0) wred[wave] = ws;
-        __syncthreads();
-        float lt = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; w++) lt += wred[w];
-        const float scale = mn == -INFINITY ? 1.f : __expf(run_m - mn);     // 0 on the first round with keys (run_m = -inf)
-        run_l = run_l * scale + lt;
-        run_m = mn;
-        o *= scale;
-#pragma unroll
-        for (int k4 = 0; k4 < 2; k4++) {
-            const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[kg * 8 + 4 * k4]);
-#pragma unroll
-            for (int e = 0; e < 4; e++)                    // rows past the length may hold anything (NaN bit patterns included): select, never multiply
-                o += key_of(rd, kg * 8 + 4 * k4 + e) < L ? pa[e] * vv[4 * k4 + e] : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();                                   // ps / wred are rewritten by the next round
-    }
-    *reinterpret_cast<f32x4*>(&po[kg * 64 + d4 * 4]) = o;
-    __syncthreads();
-    if (tid < 64) {
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; k++) sum += po[k * 64 + tid];
-        uint16_t hi, lo;
-        split_bf16(sum, hi, lo);
-        ob[0][tid] = hi; ob[1][tid] = lo;
-    }
-    if (tid == 0) { a.ml[(h * 2 + sp) * 2] = run_m; a.ml[(h * 2 + sp) * 2 + 1] = run_l; }
-    __syncthreads();
-    // P = W_o[:, 64 h .. 64 h + 64) . o : B column 0 = hi, column 1 = lo of o, two k-steps
-    const uint16_t* obs = (lane & 15) == 1 ? ob[1] : ob[0];
-    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(obs + 8 * (lane >> 4));
-    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(obs + 32 + 8 * (lane >> 4));
-    float* out = a.parts + (size_t)(h * 2 + sp) * a.hidden;
-#pragma unroll
-    for (int i = 0; i < AO_MAXT; i++) {
-        const int t = wave + 8 * i;
-        f32x4 r = {0.f, 0.f, 0.f, 0.f};
-        r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][0]), b0, r, 0, 0, 0);
-        r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][1]), b1, r, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; e++) r[e] += dpp_mov_f32<0xB1, 0xf>(0.f, r[e]);      // column 0 (hi) + column 1 (lo)
-        if (t < ntile && (lane & 15) == 0) *reinterpret_cast<f32x4*>(out + t * 16 + 4 * (lane >> 4)) = r;
-    }
-}
-
 // split combine as its own pass (used when many rows share a launch: inside the O-projection every block would redo it)
 struct CombArgs { const float* part_o; const float* part_ml; const int* part_cnt; float* out; int K; int nsplit; };
 __global__ __launch_bounds__(128) void k_attn_combine(CombArgs a) {
@@ -467,11 +341,11 @@ extern "C" int cv2_debug_stamps(unsigned long long* out_host) {
 #define STAMP_SET(v) do { } while (0)
 #define STAMP_SET_ON(st_, v) do { } while (0)
 #endif
-template <int NB, bool PRE = false, bool FOLD = false>
+template <int NB, bool PRE = false>
 __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wr = (threadIdx.x >> 6) % 2;
-    float* res = skinny_core<NB, 2, 4, 8, false, PRE, SkNoHook, FOLD>(a.W, blockIdx.x * 2 + wr, a.KS, a.rows, a.K, a.X, smem);   // rows 0-15 gate, 16-31 up
+    float* res = skinny_core<NB, 2, 4, 8, false, PRE>(a.W, blockIdx.x * 2 + wr, a.KS, a.rows, a.K, a.X, smem);   // rows 0-15 gate, 16-31 up
     const int ld = NB * 16 + 1;
     for (int e = threadIdx.x; e < a.rows * 16; e += blockDim.x) {
         const int r = e >> 4, i = e & 15;
@@ -1107,7 +981,6 @@ struct cv2_llm {
     float *pf_x, *pf_qkv, *pf_q, *pf_gu, *pf_last;
     uint16_t *pf_hi, *pf_lo;
     int* pf_int;               // row_seq[pf_rows], row_pos[pf_rows], seq tables 5 x 32
-    bool fuse_ao;              // one-row decode: k_attn_o + FOLD gate/up instead of k_attn, k_store(o), gate/up
     std::map<int, hipGraphExec_t> graphs;
     hipStream_t cap_stream;    // private stream used only to capture the decode-step graph (the caller's may be the null stream)
 };
@@ -1173,10 +1046,6 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
     h->keys_per_split = AT_KB;
     while ((d->max_pos + h->keys_per_split - 1) / h->keys_per_split > SK_MAXSPLIT) h->keys_per_split *= 2;
     h->nsplit = (d->max_pos + h->keys_per_split - 1) / h->keys_per_split;
-    {
-        const char* env = getenv("CV2_LLM_FUSED_AO");
-        h->fuse_ao = !(env && env[0] == '0') && d->hidden % 16 == 0 && d->hidden <= 8 * AO_MAXT * 16 && 2 * d->n_q <= SK_FOLDMAX && d->hidden <= 1024;
-    }
     h->cap_stream = nullptr;
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -1220,20 +1089,12 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             hipLaunchKernelGGL(k_qkv<NB>, dim3(2 * (d.n_q + 2 * d.n_kv), 1), dim3(512), sm, s, a);
             STAMP_SET(-1);
         }
-        if (rows == 1 && !rm.prefill && h->fuse_ao) {        // one row: attention + O projection per head in one launch
-            AttnOArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, L.wo, h->att, h->att_ml, h->io.state, d.n_q, d.n_kv, d.n_q / d.n_kv, d.max_pos, H,
-                        d.n_q * 64 / 32};
-            hipLaunchKernelGGL(k_attn_o, dim3(d.n_q, 2), dim3(512), 0, s, a);
-            STAMP_SET(-1);
-        } else {
+        {
             AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm, d.n_q / d.n_kv};
             launch_attn(a, rows, s);
             STAMP_SET(-1);
         }
-        const bool fused_ao = rows == 1 && !rm.prefill && h->fuse_ao;
-        if (fused_ao) {
-            // attention and O projection already ran as ONE launch (k_attn_o above); the gate/up prologue folds its partial vectors
-        } else if (rows <= 4) {     // few rows: combine the key splits while loading the O-projection operand (saves a launch)
+        if (rows <= 4) {     // few rows: combine the key splits while loading the O-projection operand (saves a launch)
             StoreArgs a{};
             a.W = L.wo; a.bias = nullptr;
             a.X = SkinnyX{nullptr, h->att, h->nsplit, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt};
@@ -1258,12 +1119,7 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             a.X = SkinnyX{x1, h->o, 1, L.ln2, d.rms_eps, x2};   // o is one "partial" laid out [SK_ROWS_CAP][H]
             a.KS = KSH; a.rows = rows; a.K = H; a.inter = d.inter; a.h = h->hbuf;
             const size_t sm = skinny_smem_bytes<NB, 2, 4>(KSH);
-            if (fused_ao) {      // x_mid = x1 + sum over (head, split) of w P: folded in the prologue
-                a.X.parts = h->att; a.X.np = 2 * d.n_q; a.X.att_ml = h->att_ml; a.X.fold_heads = d.n_q;
-                hipLaunchKernelGGL((k_gateup<1, false, true>), dim3(d.inter / 16, 1), dim3(512), sm, s, a);
-            } else {
-                hipLaunchKernelGGL(k_gateup<NB>, dim3(d.inter / 16, 1), dim3(512), sm, s, a);
-            }
+            hipLaunchKernelGGL(k_gateup<NB>, dim3(d.inter / 16, 1), dim3(512), sm, s, a);
             STAMP_SET(-1);
         }
         {
@@ -1363,7 +1219,7 @@ static int init_attrs_once() {
     static bool done = false;
     if (done) return 0;
     const size_t big = 160 * 1024;
-    if (set_smem(k_qkv<1>, big) || set_smem(k_qkv<2>, big) || set_smem(k_gateup<1>, big) || set_smem((k_gateup<1, false, true>), big) || set_smem(k_gateup<2>, big) ||
+    if (set_smem(k_qkv<1>, big) || set_smem(k_qkv<2>, big) || set_smem(k_gateup<1>, big) || set_smem(k_gateup<2>, big) ||
         set_smem((k_store<1, 8>), big) || set_smem((k_store<2, 8>), big) || set_smem((k_store<1, 8, true>), big) || set_smem((k_store<2, 8, true>), big) || set_smem((k_store<1, 10>), big) ||
         set_smem((k_store<2, 10>), big) || set_smem((k_qkv<2, true>), big) || set_smem((k_gateup<2, true>), big) ||
         set_smem((k_store<2, 8, false, true>), big) || set_smem((k_store<2, 10, false, true>), big))

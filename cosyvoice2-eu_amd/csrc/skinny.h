@@ -35,11 +35,7 @@ struct SkinnyX {
     // PRE kernels: the operand already folded / normalised / split by k_prep, in LDS B-operand order
     // [K/32][NB=2][hi, lo][1 KiB]; the prologue is a straight copy of the block's K slice
     const uint16_t* pre;
-    // FOLD kernels (one row): x = base + sum_i w_i P_i, P_i = parts[i][K] the O-projected partial output of (head, key split) i as
-    // left by k_attn_o, w_i = exp(m_i - M_h) / sum_s exp(m_s - M_h) l_s from att_ml[i][2] = (max, sum); np = fold_heads * 2 vectors
-    int fold_heads;
 };
-#define SK_FOLDMAX 28     // (head, split) partial vectors a FOLD consumer can combine
 
 __device__ __forceinline__ void split8(const f32x8 v, bf16x8& hi, bf16x8& lo) {
     hi = __builtin_convertvector(v, bf16x8);                       // v_cvt_pk_bf16_f32, RNE
@@ -157,7 +153,7 @@ __device__ __host__ constexpr int sk_xstage_bytes(int nks) { return nks * NB * 2
 // `tile` = this wave's 16-feature row tile of W.
 // `issued` runs right after the last weight load has been issued and before anything is consumed: the place for a caller's
 // dependent loads (k_qkv: position -> RoPE table) that must not delay the stream.
-template <int NB, int NWR, int NWK, int MAXKS, bool ATT = false, bool PRE = false, class HOOK = SkNoHook, bool FOLD = false>
+template <int NB, int NWR, int NWK, int MAXKS, bool ATT = false, bool PRE = false, class HOOK = SkNoHook>
 __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, int tile, int KS, int rows, int K,
                                                const SkinnyX& X, char* smem, HOOK issued = HOOK()) {
     const int tid = threadIdx.x;
@@ -205,24 +201,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     if (ATT && half_fold) {
         if (htid < nitems) sk_issue_att_half(X, 0, K, ks0 * 32 + htid * 8, hgrp * SK_HALFSPLIT, rawh);
     }
-    // FOLD (one row, every thread takes two columns): all partial vectors of the thread's column pair are requested together
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    f32x2_t fb = {0.f, 0.f}, fg = {0.f, 0.f}, fp[SK_FOLDMAX];
-    float fm[2] = {0.f, 0.f}, fl[2] = {1.f, 1.f};
-    const int fc = tid * 2;
-    const bool fown = FOLD && fc < K;
-    if (FOLD) {
-        const unsigned fo = fown ? fc : 0;
-        fb = *reinterpret_cast<const f32x2_t*>(X.base + fo);
-        fg = *reinterpret_cast<const f32x2_t*>(X.norm_w + fo);
-#pragma unroll
-        for (int i = 0; i < SK_FOLDMAX; i++)
-            if (i < X.np) fp[i] = *reinterpret_cast<const f32x2_t*>(X.parts + (size_t)i * K + fo);
-        const int fh = min(tid, X.fold_heads - 1);
-#pragma unroll
-        for (int sp = 0; sp < 2; sp++) { const float2 mlv = *reinterpret_cast<const float2*>(X.att_ml + (fh * 2 + sp) * 2); fm[sp] = mlv.x; fl[sp] = mlv.y; }
-    }
-    const bool has0 = !PRE && !FOLD && !half_fold && tid < nitems;
+    const bool has0 = !PRE && !half_fold && tid < nitems;
     const int r0 = row_of(tid), c0 = ks0 * 32 + (tid - r0 * k8n) * 8;
     f32x8 g0;                                                     // RMSNorm weight of the item (unused without norm)
     if (has0) {
@@ -268,42 +247,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         // (no second barrier: the area becomes the reduction buffer of step 4 only after the staging barrier below)
     }
 
-  if (FOLD) {
-    float* fw = reinterpret_cast<float*>(smem + sk_xstage_bytes<NB>(nks) + 32 * sizeof(float));      // [np] (the reduction area is still unused)
-    float* fsq = reinterpret_cast<float*>(smem + sk_xstage_bytes<NB>(nks));                          // [8] per-wave sums of squares
-    if (tid < X.fold_heads) {                                     // split-softmax weights of this head's two key splits (an empty split has max = -inf)
-        const float M = fmaxf(fm[0], fm[1]);
-        const float e0 = __expf(fm[0] - M), e1 = __expf(fm[1] - M);
-        const float inv = 1.f / (e0 * fl[0] + e1 * fl[1]);
-        fw[tid * 2] = e0 * inv; fw[tid * 2 + 1] = e1 * inv;
-    }
-    __syncthreads();
-    f32x2_t x = fb;
-#pragma unroll
-    for (int i = 0; i < SK_FOLDMAX; i++)
-        if (i < X.np) x += fw[i] * fp[i];                         // fixed order
-    if (!fown) x = (f32x2_t){0.f, 0.f};
-    if (X.x_out && blockIdx.x == 0 && fown) *reinterpret_cast<f32x2_t*>(X.x_out + fc) = x;
-    float sq = x[0] * x[0] + x[1] * x[1];
-    sq = wave_sum(sq);
-    if (lane == 0) fsq[wave] = sq;
-    if (fown) {                                                   // g . x as hi / lo into the B operand (row 0); the row statistic scales the outputs
-        const float g0_ = fg[0] * x[0], g1_ = fg[1] * x[1];
-        const uint16_t h0 = f2bf(g0_), h1 = f2bf(g1_);
-        const uint16_t l0 = f2bf(g0_ - bf2f(h0)), l1 = f2bf(g1_ - bf2f(h1));
-        const int k8 = fc >> 3;
-        char* dst = smem + ((size_t)((k8 >> 2) * NB) * 2) * 1024 + ((k8 & 3) * 16) * 16 + (fc & 7) * 2;
-        *reinterpret_cast<uint32_t*>(dst) = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        *reinterpret_cast<uint32_t*>(dst + 1024) = (uint32_t)l0 | ((uint32_t)l1 << 16);
-    }
-    __syncthreads();
-    {
-        float t = 0.f;
-#pragma unroll
-        for (int w_ = 0; w_ < NWR * NWK; w_++) t += fsq[w_];
-        rs_def = rsqrtf(t / (float)K + X.eps);
-    }
-  } else if (PRE) {
+  if (PRE) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   } else {

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(1024) void k_stream(const u32x4* w, long n16_per_bl
     if (threadIdx.x == 0) { float t = 0.f; for (int i = 0; i < (int)blockDim.x / 64; i++) t += red[i]; out[blockIdx.x] = t; }
 }
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     const int NK = 120, REP = 50;
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     const size_t big = (size_t)24 * 18 * 1024 * 1024;          // 24 "layers" x 18 MB: larger than the 256 MiB Infinity Cache
@@ -58,14 +59,14 @@ int main() {
             hipLaunchKernelGGL((k_stream<7>), dim3(56), dim3(256), 0, s, w + (size_t)(i % 24) * (18 << 16), 7L * 256, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
     // fat blocks: what can ONE workgroup pull when only a few run (fused per-head attention + O-slice block: 230-690 KB per block)?
     if (run("stream 344 KB per block, 14 blocks x 1024 (21 loads per thread)", [&](int i) {
-            hipLaunchKernelGGL((k_stream<21>), dim3(14), dim3(1024), 0, s, w + (size_t)(i % 24) * (18 << 16), 21L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
+            hipLaunchKernelGGL((k_stream<21>), dim3(14), dim3(1024), 0, s, w + (size_t)(i % 16) * (18 << 16), 21L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
     if (run("stream 229 KB per block, 28 blocks x 1024 (14 loads per thread)", [&](int i) {
-            hipLaunchKernelGGL((k_stream<14>), dim3(28), dim3(1024), 0, s, w + (size_t)(i % 24) * (18 << 16), 14L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
+            hipLaunchKernelGGL((k_stream<14>), dim3(28), dim3(1024), 0, s, w + (size_t)(i % 16) * (18 << 16), 14L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
     if (run("stream 688 KB per block, 14 blocks x 1024 (42 loads per thread)", [&](int i) {
-            hipLaunchKernelGGL((k_stream<42>), dim3(14), dim3(1024), 0, s, w + (size_t)(i % 24) * (18 << 16), 42L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
+            hipLaunchKernelGGL((k_stream<42>), dim3(14), dim3(1024), 0, s, w + (size_t)(i % 16) * (18 << 16), 42L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
     if (run("stream 459 KB per block, 42 blocks x 1024 (28 loads per thread)", [&](int i) {
-            hipLaunchKernelGGL((k_stream<28>), dim3(42), dim3(1024), 0, s, w + (size_t)(i % 24) * (18 << 16), 28L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
+            hipLaunchKernelGGL((k_stream<28>), dim3(42), dim3(1024), 0, s, w + (size_t)(i % 16) * (18 << 16), 28L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
     if (run("stream 344 KB per block, 76 blocks x 1024 (21 loads per thread, 26 MB)", [&](int i) {
-            hipLaunchKernelGGL((k_stream<21>), dim3(76), dim3(1024), 0, s, w + (size_t)(i % 12) * (36 << 16), 21L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
+            hipLaunchKernelGGL((k_stream<21>), dim3(76), dim3(1024), 0, s, w + (size_t)(i % 8) * (36 << 16), 21L * 1024, (i & 1) ? a : b, (i & 1) ? b : a); })) return 1;
     return 0;
 }
