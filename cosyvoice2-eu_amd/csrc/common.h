@@ -1,6 +1,7 @@
 // Shared device/host helpers for the cv2amd HIP library (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>

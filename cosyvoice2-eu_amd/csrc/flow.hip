@@ -741,8 +741,10 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(M / 64, 8), dim3(256), 0, c.s, a);
         else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(M / 32, 8), dim3(256), 0, c.s, a);       // one utterance: split keys over two wave groups
     }
-    if ((long)(M / 64) < 200) {
-        // one utterance: O-projection, norm3, feed-forward and the next block's norm1 are row-local -> one launch per 16-row panel
+    static const bool tail_rows_off = getenv("CV2_FLOW_TAIL_ROWS") && getenv("CV2_FLOW_TAIL_ROWS")[0] == '0';     // A/B switch (diagnostics)
+    if ((long)(M / 64) < 200 || !tail_rows_off) {
+        // O-projection, norm3, feed-forward and the next block's norm1 are row-local -> one launch per row panel: 16-row panels at one
+        // utterance (128 blocks), 64-row blocks for batches (every weight fragment then feeds four MFMAs)
         TailArgs t{};
         t.att = GB(h->att, 512); t.lda = 512;
         t.Wo = tb.out.w; t.bo = tb.out.b; t.g3 = tb.norm3.g; t.b3 = tb.norm3.b; t.eps3 = 1e-5f;
@@ -750,7 +752,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         t.gn = next_ln ? next_ln->g : nullptr; t.bn = next_ln ? next_ln->b : nullptr; t.epsn = 1e-5f;
         t.xf = h->xf; t.out_ln = GB(h->lnb, 256); t.ldo_ln = 256; t.out_x = xout; t.ldo_x = ldx;
         t.seq = c.L->tab(); t.M_valid = M;
-        return tail_panel_go(t, M, c.s);
+        return (long)(M / 64) < 200 ? tail_panel_go(t, M, c.s) : tail_rows_go(t, M, c.s);
     }
     {
         GemmArgs a = gemm_args(GB(h->att, 512), 512, 0, tb.out.w, M, 256, 512);

@@ -614,6 +614,180 @@ __global__ __launch_bounds__(1024) void k_tail_panel(TailArgs a) {
 }
 constexpr size_t tail_panel_smem() { return (size_t)(17 + 8 + 32 + 6) * 1024; }
 
+// The same chain for MANY rows (batched utterances): RT row tiles of 16 rows per block, so that every weight fragment fetched from
+// L2 (1.25 MB per block) feeds RT MFMAs instead of one: at RT = 4 a block's 84 MFLOP take about as long on the CU's matrix cores as its
+// weights take through the CU's 64 B/clk vector-memory path, where the three separate GEMM launches it replaces ran at ~12 % of the MFMA
+// roof (N = 256 / K <= 1024 tiles, fp32 activations through HBM between them).  The 1024-wide hidden activations are produced and
+// consumed in four quarters of 256 columns (LDS: attention panel 16 RT KiB | x panel 8 RT | hidden quarter 8 RT), the FF2
+// accumulators stay in registers across the quarters.  Wave w owns output columns [16 w, 16 w + 16) of the N = 256 GEMMs and hidden
+// columns [16 w, 16 w + 16) of each quarter; rows: wave w finishes rows w, w + 16, ... (tile i, row w) in the row epilogues.
+template <int RT>
+__global__ __launch_bounds__(1024) void k_tail_rows(TailArgs a) {
+    constexpr int LDC = 260, KS0 = 16, KS1 = 8, KS2 = 32, CH = 8, QK = 8;      // QK = k-steps of one hidden quarter
+    constexpr size_t C_BYTES = (size_t)RT * 16 * LDC * 4, ATT_BYTES = (size_t)KS0 * RT * 1024;
+    constexpr size_t X_OFF = ((C_BYTES > ATT_BYTES ? C_BYTES : ATT_BYTES) + 1023) / 1024 * 1024, H_OFF = X_OFF + (size_t)KS1 * RT * 1024,
+                     PAR_OFF = H_OFF + (size_t)QK * RT * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xs = smem + X_OFF;
+    char* hs = smem + H_OFF;
+    float* par = reinterpret_cast<float*>(smem + PAR_OFF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * (16 * RT), n = lane * 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    {   // attention panel: piece (kb, rt) = 16 rows x 32 k; wave w fetches k-step w of every row tile
+        const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 5) << 1);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const uint16_t* src = a.att + (long)(m0 + rt * 16 + srow) * a.lda + wave * 32 + schunk * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + (size_t)(wave * RT + rt) * 1024), 16, 0, 0);
+        }
+    }
+    if (wave < 6) {                                          // per-column vectors: bo, g3, b3, b2, gn, bn
+        const float* src = wave == 0 ? a.bo : wave == 1 ? a.g3 : wave == 2 ? a.b3 : wave == 3 ? a.b2 : wave == 4 ? a.gn : a.bn;
+        if (src)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(par) + wave * 1024), 16, 0, 0);
+    }
+    f32x4 xrow[RT];                                           // residual rows of this wave: row wave of every tile
+#pragma unroll
+    for (int i = 0; i < RT; i++) xrow[i] = *reinterpret_cast<const f32x4*>(a.xf + (size_t)(m0 + 16 * i + wave) * 256 + n);
+    __builtin_amdgcn_s_barrier();
+    const s16x8* wop = reinterpret_cast<const s16x8*>(a.Wo) + ((size_t)wave * KS0) * 64 + lane;
+    s16x8 wr[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) wr[i] = wop[(size_t)i * 64];
+    int ep_start = 0, ep_len = a.M_valid;
+    if (a.seq.tile_seq) {
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) i32x4_t k_i32x4;
+        const i32x4_t ti = *reinterpret_cast<k_i32x4*>(reinterpret_cast<uintptr_t>(a.seq.tile_info + (m0 >> 6)));
+        ep_start = ti.y; ep_len = ti.z;
+    }
+    vmcnt_wait<CH>();
+    __builtin_amdgcn_s_barrier();
+    const int a_off = subtile_off(lane & 15, lane >> 4);
+    const f32x4* pv = reinterpret_cast<const f32x4*>(par) + lane;
+    float* C = reinterpret_cast<float*>(smem);
+    // ---- GEMM 0: O-projection
+    f32x4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) acc[rt] = z4;
+#pragma unroll
+    for (int kb = 0; kb < KS0; kb++) {
+        const bf16x8 wf = __builtin_bit_cast(bf16x8, wr[kb % CH]);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(smem + (size_t)(kb * RT + rt) * 1024 + a_off);
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[rt], 0, 0, 0);
+        }
+        if (kb + CH < KS0) wr[kb % CH] = wop[(size_t)(kb + CH) * 64];
+    }
+    // W1 fragments of the first hidden quarter: they fly during the epilogue below
+    s16x8 w1[KS1], w2[QK];
+    {
+        const s16x8* w1p = reinterpret_cast<const s16x8*>(a.W1) + ((size_t)wave * KS1) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KS1; i++) w1[i] = w1p[(size_t)i * 64];
+    }
+    __syncthreads();                                         // attention panel fully read: its LDS becomes the C tile
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) *reinterpret_cast<f32x4*>(&C[(rt * 16 + (lane & 15)) * LDC + wave * 16 + 4 * (lane >> 4)]) = acc[rt];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RT; i++) {   // x += o + bo ; y = LN3(x) -> x panel (bf16, operand layout of GEMM 1: tile i, row = wave)
+        const bool valid = (m0 + 16 * i + wave - ep_start) < ep_len;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&C[(16 * i + wave) * LDC + n]) + pv[0] + xrow[i];
+        if (!valid) v = z4;
+        xrow[i] = v;
+        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256);
+        const f32x4 d = v - mean;
+        const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256);
+        f32x4 y = d * rsqrtf(var + a.eps3) * pv[64] + pv[128];
+        if (!valid) y = z4;
+        char* dst = xs + (size_t)((n >> 5) * RT + i) * 1024 + subtile_off(wave, (n & 31) >> 3) + (n & 7) * 2;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+    }
+    __syncthreads();
+    // ---- feed-forward, one hidden quarter at a time; FF2 accumulates over the quarters
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) acc[rt] = z4;
+#pragma unroll
+    for (int hq = 0; hq < 4; hq++) {
+        // GEMM 1 quarter: hidden columns 256 hq + [16 w, 16 w + 16), bias + GELU -> hidden panel (operand layout of GEMM 2)
+        f32x4 a1[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) a1[rt] = z4;
+#pragma unroll
+        for (int kb = 0; kb < KS1; kb++) {
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, w1[kb]);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const bf16x8 xf_ = *reinterpret_cast<const bf16x8*>(xs + (size_t)(kb * RT + rt) * 1024 + a_off);
+                a1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf_, a1[rt], 0, 0, 0);
+            }
+        }
+        {   // this quarter's W2 fragments (k-steps 8 hq .. 8 hq + 7 of output tile `wave`), then the next quarter's W1
+            const s16x8* w2p = reinterpret_cast<const s16x8*>(a.W2) + ((size_t)wave * KS2 + hq * QK) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < QK; i++) w2[i] = w2p[(size_t)i * 64];
+        }
+        const int cq = wave * 16 + 4 * (lane >> 4);                      // column inside the quarter
+        const f32x4 b1v = *reinterpret_cast<const f32x4*>(a.b1 + hq * 256 + cq);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            f32x4 v = a1[rt] + b1v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = act_apply(v[e], ACT_GELU, 0.f);
+            char* d = hs + (size_t)((cq >> 5) * RT + rt) * 1024 + subtile_off(lane & 15, (cq & 31) >> 3) + (cq & 7) * 2;
+            *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+        if (hq + 1 < 4) {
+            const s16x8* w1p = reinterpret_cast<const s16x8*>(a.W1) + ((size_t)((hq + 1) * 16 + wave) * KS1) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < KS1; i++) w1[i] = w1p[(size_t)i * 64];
+        }
+        __syncthreads();                                     // hidden quarter complete
+#pragma unroll
+        for (int kb = 0; kb < QK; kb++) {
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, w2[kb]);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (size_t)(kb * RT + rt) * 1024 + a_off);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hf, acc[rt], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                     // hidden panel consumed: the next quarter may overwrite it
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) *reinterpret_cast<f32x4*>(&C[(rt * 16 + (lane & 15)) * LDC + wave * 16 + 4 * (lane >> 4)]) = acc[rt];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RT; i++) {   // x += ff + b2 ; stores
+        const int m = m0 + 16 * i + wave;
+        const bool valid = (m - ep_start) < ep_len;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&C[(16 * i + wave) * LDC + n]) + pv[192] + xrow[i];
+        if (!valid) v = z4;
+        if (a.gn) {
+            *reinterpret_cast<f32x4*>(a.xf + (size_t)m * 256 + n) = v;
+            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256);
+            const f32x4 d = v - mean;
+            const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256);
+            f32x4 y = d * rsqrtf(var + a.epsn) * pv[256] + pv[320];
+            if (!valid) y = z4;
+            *reinterpret_cast<uint2*>(a.out_ln + (size_t)m * a.ldo_ln + n) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+        } else {
+            *reinterpret_cast<uint2*>(a.out_x + (size_t)m * a.ldo_x + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+    }
+}
+template <int RT>
+constexpr size_t tail_rows_smem() {
+    constexpr size_t c = (size_t)RT * 16 * 260 * 4, att = (size_t)16 * RT * 1024;
+    return ((c > att ? c : att) + 1023) / 1024 * 1024 + (size_t)(8 + 8) * RT * 1024 + 6 * 1024;
+}
+
 template <int BM, int BN, bool SPLITA = false, int NSTAGE = 2>
 constexpr size_t gemm_smem_bytes() {
     constexpr size_t stages = NSTAGE * (size_t)(((SPLITA ? 2 : 1) * BM + BN) / 16 * 2) * 1024;

@@ -7,11 +7,11 @@ static int gemm_go(const GemmArgs& a, int batch, bool packed, hipStream_t s) {
     constexpr size_t sm = gemm_smem_bytes<BM, BN, SPLITA, NSTAGE>();
     dim3 grid(a.N / BN, a.M / BM, batch), block(WM * WN * 64);
     if (packed) {
-        static bool once = false;
+        static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
         if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, true, SPLITA, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
         hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true, SPLITA, NSTAGE>), grid, block, sm, s, a);
     } else if (!SPLITA) {
-        static bool once = false;
+        static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
         if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, false, false, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
         hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false, false, NSTAGE>), grid, block, sm, s, a);
     } else {
@@ -26,7 +26,7 @@ static int gemm_go_panel_k(const GemmArgs& a, int batch, hipStream_t s) {
     constexpr int CH = 8;
     constexpr size_t panel = (size_t)KS_T * 1024, ctile = (size_t)16 * (256 + 4) * 4;
     constexpr size_t sm = (panel > ctile ? panel : ctile) + 5 * 1024;      // + the five epilogue vectors
-    static bool once = false;
+    static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
     if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_panel<CH, KS_T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
     hipLaunchKernelGGL((k_gemm_panel<CH, KS_T>), dim3(a.N / 256, a.M / 16, batch), dim3(1024), sm, s, a);
     CV2_LAUNCH_CHECK();
@@ -44,9 +44,18 @@ static int gemm_go_panel(const GemmArgs& a, int batch, hipStream_t s) {
     }
 }
 
+// many rows: 64-row blocks (M is a multiple of 128)
+static int tail_rows_go(const TailArgs& a, int M, hipStream_t s) {
+    constexpr size_t sm = tail_rows_smem<4>();
+    static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
+    if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_rows<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
+    hipLaunchKernelGGL(k_tail_rows<4>, dim3(1, M / 64, 1), dim3(1024), sm, s, a);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
 static int tail_panel_go(const TailArgs& a, int M, hipStream_t s) {
     constexpr size_t sm = tail_panel_smem();
-    static bool once = false;
+    static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
     if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_panel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
     hipLaunchKernelGGL(k_tail_panel<0>, dim3(1, M / 16, 1), dim3(1024), sm, s, a);
     CV2_LAUNCH_CHECK();

@@ -365,7 +365,7 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
     cv2_hift* h = new cv2_hift();
     h->d = *d; h->w = *w;
     hift_carve(*d, h, (char*)ws);
-    static bool once = false;
+    static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
     if (!once) {
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;

@@ -1216,7 +1216,7 @@ static int set_smem(F f, size_t bytes) {
     return 0;
 }
 static int init_attrs_once() {
-    static bool done = false;
+    static std::atomic<bool> done{false};   // idempotent: a concurrent first call repeats the attribute calls rather than launch before they are in place
     if (done) return 0;
     const size_t big = 160 * 1024;
     if (set_smem(k_qkv<1>, big) || set_smem(k_qkv<2>, big) || set_smem(k_gateup<1>, big) || set_smem(k_gateup<2>, big) ||
@@ -1276,7 +1276,7 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
     CV2_CHECK(h && slots && lens && embeds && n >= 1 && n <= 32, "cv2_llm_prefill_batch: bad argument");
     CV2_CHECK(h->pf_rows > 0, "cv2_llm_prefill_batch: created with max_prefill_rows == 0");
     if (init_attrs_once()) return -1;
-    static bool once = false;
+    static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
     if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_prefill), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
     const cv2_llm_dims& d = h->d;
     hipStream_t s = (hipStream_t)stream;
