@@ -446,7 +446,7 @@ def run_sharded(args):
                                       f'gather waveforms over {"RCCL" if backend == "nccl" else backend} inside the timed region; every rank runs its shard as '
                                       f'one coalesced batch through CosyVoice2Model.tts()', 'batch_per_gpu': per,
                           'audio_s_per_step_total': round(audio_per_step, 2),
-                          'scaling_reference': "per-GPU work is fixed at 32 utterances: compare with N x the N=1 line's extra.batch32.value"}}
+                          'scaling_reference': f"per-GPU work is fixed at {per} utterances: compare with N x the N=1 line's extra.batch32.value (32 per GPU there)"}}
         if st is not None:
             sync()
             dec_ms, dec_steps = st.result()

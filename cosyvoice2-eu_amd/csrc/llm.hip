@@ -305,8 +305,13 @@ struct StoreArgs {
     const uint16_t* W; const float* bias;       // bias may be null
     SkinnyX X; int KS, rows, K, N;
     float* out;                                 // gridDim.y == 1: [rows][N]; else partials [gridDim.y][SK_ROWS_CAP][N]
+    // NEXT epilogue (many-row O projection): the block finishes the residual stream for its 16 columns and PREPARES the next kernel's
+    // operand, so that no k_prep launch is needed between the O projection and gate/up: x_mid = resid + out -> x_out (fp32), the hi / lo
+    // planes of next_g . x_mid in the layout the PRE kernels copy, and this block's share of every row's sum of squares (the consumer
+    // sums the N / 16 shares in a fixed order and scales its OUTPUTS by the row's rstd: W (g . x) rstd = W (g . x rstd))
+    const float* resid; const float* next_g; float* x_out; uint16_t* next_pre; float* next_sq;
 };
-template <int NB, int MAXKS, bool ATT = false, bool PRE = false>
+template <int NB, int MAXKS, bool ATT = false, bool PRE = false, bool NEXT = false>
 __global__ __launch_bounds__(256) void k_store(StoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* res = skinny_core<NB, 1, 4, MAXKS, ATT, PRE>(a.W, blockIdx.x, a.KS, a.rows, a.K, a.X, smem);
@@ -317,7 +322,24 @@ __global__ __launch_bounds__(256) void k_store(StoreArgs a) {
         const int r = e >> 4, i = e & 15;
         float v = res[i * ld + r];
         if (a.bias && blockIdx.y == 0) v += a.bias[n0 + i];
-        out[(size_t)r * a.N + n0 + i] = v;
+        if (NEXT) {
+            const int c = n0 + i;
+            v += a.resid[(size_t)r * a.N + c];
+            a.x_out[(size_t)r * a.N + c] = v;
+            const float gx = a.next_g[c] * v;
+            uint16_t* d = a.next_pre + ((size_t)((c >> 5) * 2 + (r >> 4)) * 2) * 512 + (((c >> 3) & 3) * 16 + (r & 15)) * 8 + (c & 7);
+            const uint16_t hb = f2bf(gx);
+            d[0] = hb;
+            d[512] = f2bf(gx - bf2f(hb));
+            float sq = v * v;                                 // the row's 16 columns sit in 16 consecutive lanes
+            sq += dpp_mov_f32<0xB1, 0xf>(0.f, sq);            // quad_perm [1,0,3,2]
+            sq += dpp_mov_f32<0x4E, 0xf>(0.f, sq);            // quad_perm [2,3,0,1]
+            sq += __shfl_xor(sq, 4);
+            sq += __shfl_xor(sq, 8);
+            if (i == 0) a.next_sq[(size_t)r * gridDim.x + blockIdx.x] = sq;
+        } else {
+            out[(size_t)r * a.N + n0 + i] = v;
+        }
     }
 }
 
@@ -326,6 +348,7 @@ struct GateUpArgs {
     const uint16_t* W; SkinnyX X; int KS, rows, K, inter;
     float* h;                                   // [rows][inter]
     uint16_t* hpre;                             // PRE kernels: h written as prepared hi/lo planes for the down projection instead
+    const float* sq; int nsq; float eps;        // PRE operand left un-normalised by k_store<.., NEXT>: rstd[r] = rsqrt(sum_b sq[r][b] / K + eps)
 };
 #ifdef CV2_STAMPS
 __global__ void k_stamp_set(int v) { if (threadIdx.x == 0) g_stamp_slot = v < 0 ? g_stamp_slot + 1 : v; }
@@ -349,7 +372,17 @@ __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
     const int ld = NB * 16 + 1;
     for (int e = threadIdx.x; e < a.rows * 16; e += blockDim.x) {
         const int r = e >> 4, i = e & 15;
-        const float g = res[i * ld + r], u = res[(16 + i) * ld + r];
+        float rs = 1.f;
+        if (PRE && a.sq) {                       // the row's statistic from the producers' shares: the 16 threads of a row sum them in a fixed order
+            float t = 0.f;
+            for (int b = i; b < a.nsq; b += 16) t += a.sq[(size_t)r * a.nsq + b];
+            t += dpp_mov_f32<0xB1, 0xf>(0.f, t);
+            t += dpp_mov_f32<0x4E, 0xf>(0.f, t);
+            t += __shfl_xor(t, 4);
+            t += __shfl_xor(t, 8);
+            rs = rsqrtf(t / (float)a.K + a.eps);
+        }
+        const float g = res[i * ld + r] * rs, u = res[(16 + i) * ld + r] * rs;
         const float hv = (g / (1.f + __expf(-g))) * u;
         if (PRE && a.hpre) {                     // LDS B-operand order of skinny.h: [k-block][row tile][hi, lo][quarter][row][8]
             const int c = blockIdx.x * 16 + i;
@@ -972,6 +1005,8 @@ struct cv2_llm {
     float *att_ml;             // [nsplit][32][n_q][2]
     int *att_cnt;              // [32] non-empty splits per row
     float *attc;               // [32][n_q*64] combined attention output (many-row path)
+    uint16_t *xp2;             // prepared gate/up operand written by the O projection's epilogue (xp is still being read by that launch)
+    float *sqp;                // [32][hidden / 16] shares of the rows' sums of squares
     uint16_t *xp, *xp_h;       // prepared operand planes [K/32][2][hi, lo][512]: k_prep output; SwiGLU output of k_gateup<2, true>
     int nsplit, keys_per_split;
     float *hbuf;               // [32][inter]
@@ -1003,6 +1038,8 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     p = take((size_t)32 * d.n_q * 64 * 4); if (h) h->attc = (float*)p;
     p = take((size_t)(d.inter / 32) * 2 * 2 * 1024); if (h) h->xp = (uint16_t*)p;
     p = take((size_t)(d.inter / 32) * 2 * 2 * 1024); if (h) h->xp_h = (uint16_t*)p;
+    p = take((size_t)(d.inter / 32) * 2 * 2 * 1024); if (h) h->xp2 = (uint16_t*)p;
+    p = take((size_t)32 * (d.hidden / 16) * 4); if (h) h->sqp = (float*)p;
     p = take((size_t)32 * d.hidden * 4); if (h) h->o = (float*)p;
     p = take((size_t)32 * d.inter * 4); if (h) h->hbuf = (float*)p;
     p = take((size_t)SK_MAXNP * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
@@ -1177,16 +1214,19 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
             launch_attn(a, rows, s);
         }
         prep(SkinnyX{nullptr, h->att, h->nsplit, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt}, NQ, true);
-        {
+        float* x2 = (x1 == h->xa) ? h->xb : h->xa;
+        {   // O projection; its epilogue adds the residual and prepares the gate/up operand (no k_prep launch in between)
             StoreArgs a{};
             a.W = L.wo; a.X = pre; a.KS = NQ / 32; a.rows = rows; a.K = NQ; a.N = H; a.out = h->o;
-            { const size_t sm = skinny_smem_bytes<2, 1, 4>(a.KS); hipLaunchKernelGGL((k_store<2, 8, false, true>), dim3(H / 16, 1), dim3(256), sm, s, a); }
+            a.resid = x1; a.next_g = L.ln2; a.x_out = x2; a.next_pre = h->xp2; a.next_sq = h->sqp;
+            { const size_t sm = skinny_smem_bytes<2, 1, 4>(a.KS); hipLaunchKernelGGL((k_store<2, 8, false, true, true>), dim3(H / 16, 1), dim3(256), sm, s, a); }
         }
-        float* x2 = (x1 == h->xa) ? h->xb : h->xa;
-        prep(SkinnyX{x1, h->o, 1, L.ln2, d.rms_eps, x2}, H, false);
         {
             GateUpArgs a{};
-            a.W = L.wgu; a.X = pre; a.KS = KSH; a.rows = rows; a.K = H; a.inter = d.inter; a.h = h->hbuf; a.hpre = h->xp_h;
+            SkinnyX pre2{};
+            pre2.pre = h->xp2;
+            a.W = L.wgu; a.X = pre2; a.KS = KSH; a.rows = rows; a.K = H; a.inter = d.inter; a.h = h->hbuf; a.hpre = h->xp_h;
+            a.sq = h->sqp; a.nsq = H / 16; a.eps = d.rms_eps;
             { const size_t sm = skinny_smem_bytes<2, 2, 4>(KSH); hipLaunchKernelGGL((k_gateup<2, true>), dim3(d.inter / 16, 1), dim3(512), sm, s, a); }
         }
         {
@@ -1222,7 +1262,7 @@ static int init_attrs_once() {
     if (set_smem(k_qkv<1>, big) || set_smem(k_qkv<2>, big) || set_smem(k_gateup<1>, big) || set_smem(k_gateup<2>, big) ||
         set_smem((k_store<1, 8>), big) || set_smem((k_store<2, 8>), big) || set_smem((k_store<1, 8, true>), big) || set_smem((k_store<2, 8, true>), big) || set_smem((k_store<1, 10>), big) ||
         set_smem((k_store<2, 10>), big) || set_smem((k_qkv<2, true>), big) || set_smem((k_gateup<2, true>), big) ||
-        set_smem((k_store<2, 8, false, true>), big) || set_smem((k_store<2, 10, false, true>), big))
+        set_smem((k_store<2, 8, false, true>), big) || set_smem((k_store<2, 8, false, true, true>), big) || set_smem((k_store<2, 10, false, true>), big))
         return -1;
     done = true;
     return 0;
