@@ -742,6 +742,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(M / 32, 8), dim3(256), 0, c.s, a);       // one utterance: split keys over two wave groups
     }
     static const bool tail_rows_off = getenv("CV2_FLOW_TAIL_ROWS") && getenv("CV2_FLOW_TAIL_ROWS")[0] == '0';     // A/B switch (diagnostics)
+    static const long tail_rows_min = getenv("CV2_FLOW_TAIL_ROWS_MIN") ? atol(getenv("CV2_FLOW_TAIL_ROWS_MIN")) : 96;    // 64-row tiles from which the 64-row blocks are used (8 streaming chunks: 192 -> 184 ms first chunk)
     if ((long)(M / 64) < 200 || !tail_rows_off) {
         // O-projection, norm3, feed-forward and the next block's norm1 are row-local -> one launch per row panel: 16-row panels at one
         // utterance (128 blocks), 64-row blocks for batches (every weight fragment then feeds four MFMAs)
@@ -752,7 +753,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         t.gn = next_ln ? next_ln->g : nullptr; t.bn = next_ln ? next_ln->b : nullptr; t.epsn = 1e-5f;
         t.xf = h->xf; t.out_ln = GB(h->lnb, 256); t.ldo_ln = 256; t.out_x = xout; t.ldo_x = ldx;
         t.seq = c.L->tab(); t.M_valid = M;
-        return (long)(M / 64) < 200 ? tail_panel_go(t, M, c.s) : tail_rows_go(t, M, c.s);
+        return (long)(M / 64) < tail_rows_min ? tail_panel_go(t, M, c.s) : tail_rows_go(t, M, c.s);
     }
     {
         GemmArgs a = gemm_args(GB(h->att, 512), 512, 0, tb.out.w, M, 256, 512);
