@@ -87,7 +87,7 @@ class CosyVoice2Model:
         self.llm_end_dict = {}
         self.hift_cache_dict = {}
         self._hift_pin, self._pin_rr = {}, -1  # uuid -> index of the HiftPool engine / HIP stream serving that call's chunks
-        self.llm_stream = torch.cuda.Stream(self.device)
+        self.llm_stream = torch.cuda.Stream(self.device)   # (torch.cuda.Stream.priority_range() is (0, -1) here: no priority below the default exists)
         self.sampling_mode = MODE_RAS if sampling == 'ras' else MODE_GREEDY
         self.seed = seed
         self._limits = (max_text, max_prompt_tokens, max_new_tokens)

@@ -21,6 +21,7 @@
 // [frame][phase][channel] output IS the time-major upsampled signal.
 // Roofline: fp32 MFMA (157 TFLOP/s); HBM traffic per conv is one read + one write of the activation.
 #include "common.h"
+#include <map>
 #include "../../include/cv2_amd.h"
 #include <math.h>
 #include <vector>
@@ -228,6 +229,7 @@ struct SrcArgs {
     const float* f0; const float* phase; int T;
     const float* noise;                  // [480 T][9] or null
     uint32_t seed_lo, seed_hi;
+    const uint32_t* seed_dev;            // != null: the seed is read from here (graph replays: kernel arguments are frozen)
     const float* lw; const float* lb;    // m_source.l_linear
     const float* cache; int n_cache;     // cache_source overwrite (generator.py:579-580)
     float* s;                            // [480 T]
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void k_source(SrcArgs a) {
         uint32_t r[4];
 #pragma unroll
         for (int q = 0; q < 3; q++) {          // 3 x (2 Box-Muller pairs) -> 12 normals, 9 used
-            philox4((uint32_t)n, (uint32_t)(n >> 32), (uint32_t)q, 0x48694654u, a.seed_lo, a.seed_hi, r);
+            philox4((uint32_t)n, (uint32_t)(n >> 32), (uint32_t)q, 0x48694654u, a.seed_dev ? a.seed_dev[0] : a.seed_lo, a.seed_dev ? a.seed_dev[1] : a.seed_hi, r);
             const float u0 = ((r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = (r[1] >> 8) * (1.0f / 16777216.0f);
             const float u2 = ((r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = (r[3] >> 8) * (1.0f / 16777216.0f);
             const float ra = sqrtf(-2.f * logf(u0)), rb = sqrtf(-2.f * logf(u2));
@@ -338,7 +340,14 @@ struct cv2_hift {
     cv2_hift_weights w;
     // workspace
     float *melT, *f0a, *f0b, *f0, *phase, *s, *sstft, *xpre, *x, *xt, *ra, *sum, *sd, *post, *frames;
+    // short calls (streaming chunks) are host-launch-bound: ~330 launches for a few ms of GPU work.  They replay a hipGraph captured per
+    // (frames, cache length) over engine-owned staging buffers; the caller's tensors are copied in / out around the replay.
+    float *g_mel, *g_cs, *g_wav, *g_src; uint32_t* g_seed;
+    std::map<long, hipGraphExec_t> graphs;
+    hipStream_t cap_stream = nullptr;
 };
+#define HG_MAX_T 160          // longest call that goes through a graph (frames)
+#define HG_MAX_GRAPHS 24
 
 struct HCarver {
     char* base; size_t off = 0;
@@ -354,6 +363,9 @@ static size_t hift_carve(const cv2_hift_dims& d, cv2_hift* h, char* base) {
     const size_t big = L3 * 64 + 64;                                 // every stage is C * L = 7680 T (+ the reflect row)
     f.x = c.take(big); f.xt = c.take(big); f.ra = c.take(big); f.sum = c.take(big); f.sd = c.take(big);
     f.post = c.take(L3 * 18); f.frames = c.take(L3 * 16);
+    const size_t GT = T < HG_MAX_T ? T : HG_MAX_T;
+    f.g_mel = c.take(GT * 80); f.g_cs = c.take(480 * GT); f.g_wav = c.take(480 * GT); f.g_src = c.take(480 * GT);
+    f.g_seed = reinterpret_cast<uint32_t*>(c.take(64));
     return c.off;
 }
 extern "C" size_t cv2_hift_workspace_bytes(const cv2_hift_dims* d) { return hift_carve(*d, nullptr, nullptr); }
@@ -370,10 +382,17 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
+    if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) h->cap_stream = nullptr;      // no graphs then
     *out = h;
     return 0;
 }
-extern "C" int cv2_hift_destroy(cv2_hift* h) { delete h; return 0; }
+extern "C" int cv2_hift_destroy(cv2_hift* h) {
+    if (!h) return 0;
+    for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.second);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    delete h;
+    return 0;
+}
 // test hook: device pointers of intermediate buffers (0 melT, 1 f0, 2 s_stft, 3 conv_pre out, 4 x (last stage out), 5 conv_post out)
 extern "C" const float* cv2_hift_debug_buffer(cv2_hift* h, int32_t which) {
     switch (which) { case 0: return h->melT; case 1: return h->f0; case 2: return h->sstft; case 3: return h->xpre; case 4: return h->sum; case 5: return h->post; default: return nullptr; }
@@ -403,12 +422,50 @@ static int resblock(cv2_hift* h, const cv2_resblock& rb, const float* x, int L, 
     return 0;
 }
 
+__global__ void k_set_seed(uint32_t* p, uint32_t lo, uint32_t hi) { if (threadIdx.x == 0) { p[0] = lo; p[1] = hi; } }
+
+static int hift_run(cv2_hift* h, const float* mel, int32_t T, const float* cache_source, int32_t n_cache, const float* noise, uint64_t seed,
+                    const uint32_t* seed_dev, float* wav, float* source, hipStream_t s);
+
 extern "C" int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, const float* cache_source, int32_t n_cache,
                                   const float* noise, uint64_t seed, float* wav, float* source, void* stream) {
     CV2_CHECK(h && mel && wav && source, "cv2_hift_inference: null argument");
     CV2_CHECK(T >= 2 && T <= h->d.max_frames, "cv2_hift_inference: T=%d out of range (max %d)", T, h->d.max_frames);
     CV2_CHECK(n_cache >= 0 && n_cache <= 480 * T && (n_cache == 0 || cache_source), "cv2_hift_inference: bad cache_source");
     hipStream_t s = (hipStream_t)stream;
+    static const bool graphs_off = getenv("CV2_HIFT_GRAPH") && getenv("CV2_HIFT_GRAPH")[0] == '0';
+    if (noise || T > HG_MAX_T || graphs_off || !h->cap_stream) return hift_run(h, mel, T, cache_source, n_cache, noise, seed, nullptr, wav, source, s);
+    // ---- graph path
+    const long key = ((long)T << 32) | (long)n_cache;
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        if ((int)h->graphs.size() >= HG_MAX_GRAPHS) {                 // bounded: drop one (chunk shapes of a serving process are few)
+            (void)hipGraphExecDestroy(h->graphs.begin()->second);
+            h->graphs.erase(h->graphs.begin());
+        }
+        hipGraph_t g;
+        CV2_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = hift_run(h, h->g_mel, T, n_cache ? h->g_cs : nullptr, n_cache, nullptr, 0, h->g_seed, h->g_wav, h->g_src, h->cap_stream);
+        const hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+        if (rc) return rc;
+        CV2_HIP(e);
+        hipGraphExec_t ge;
+        CV2_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CV2_HIP(hipGraphDestroy(g));
+        it = h->graphs.emplace(key, ge).first;
+    }
+    CV2_HIP(hipMemcpyAsync(h->g_mel, mel, (size_t)T * 80 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (n_cache) CV2_HIP(hipMemcpyAsync(h->g_cs, cache_source, (size_t)n_cache * sizeof(float), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_set_seed, dim3(1), dim3(64), 0, s, h->g_seed, (uint32_t)seed, (uint32_t)(seed >> 32));
+    CV2_HIP(hipGraphLaunch(it->second, s));
+    CV2_HIP(hipMemcpyAsync(wav, h->g_wav, (size_t)480 * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CV2_HIP(hipMemcpyAsync(source, h->g_src, (size_t)480 * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+static int hift_run(cv2_hift* h, const float* mel, int32_t T, const float* cache_source, int32_t n_cache, const float* noise, uint64_t seed,
+                    const uint32_t* seed_dev, float* wav, float* source, hipStream_t s) {
     const cv2_hift_weights& w = h->w;
     const int Ls = 480 * T, F = Ls / 4 + 1;
     hipLaunchKernelGGL(k_mel_tm, dim3((T * 80 + 255) / 256), dim3(256), 0, s, mel, h->melT, (int)T);
@@ -424,7 +481,7 @@ extern "C" int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, cons
     // source
     hipLaunchKernelGGL(k_phase, dim3(1), dim3(64), 0, s, (const float*)h->f0, h->phase, (int)T);
     {
-        SrcArgs a{h->f0, h->phase, T, noise, (uint32_t)seed, (uint32_t)(seed >> 32), w.src_w, w.src_b, cache_source, n_cache, source};
+        SrcArgs a{h->f0, h->phase, T, noise, (uint32_t)seed, (uint32_t)(seed >> 32), seed_dev, w.src_w, w.src_b, cache_source, n_cache, source};
         hipLaunchKernelGGL(k_source, dim3((Ls + 255) / 256), dim3(256), 0, s, a);
     }
     hipLaunchKernelGGL(k_stft, dim3(((long)F * 9 + 255) / 256), dim3(256), 0, s, (const float*)source, Ls, h->sstft, F);
