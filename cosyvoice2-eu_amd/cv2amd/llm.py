@@ -133,7 +133,7 @@ class LLMEngine:
         L24 = self.dims.layers
         if n_seqs <= 16:
             return f'LLM decode step = one hipGraph replay ({L24} x {{k_qkv, k_attn, k_store(o), k_gateup, k_store(down)}} + head + k_sample), {n_seqs} row(s)'
-        return (f'LLM decode step = one hipGraph replay ({L24} x {{k_prep, k_qkv, k_attn, k_prep, k_store(o), k_prep, k_gateup, k_store(down)}} + head + '
+        return (f'LLM decode step = one hipGraph replay ({L24} x {{k_prep, k_qkv, k_attn, k_prep, k_store(o)+norm2, k_gateup, k_store(down)}} + head + '
                 f'k_sample), {n_seqs} rows')
 
     def step(self, n_seqs, n_steps=1):
