@@ -160,15 +160,18 @@ def request(seed, prompt_len, text_len, dev, prompt_text_len=PROMPT_TEXT_LEN):
                 flow_embedding=inp['embedding'].to(d), llm_embedding=inp['embedding'].to(d))
 
 
-def run_calls(model, reqs, forces, stream=False):
+def run_calls(model, reqs, forces, stream=False, chunk_times=None):
     """The evaluation harness pattern (evaluation/cosyvoice_synthesizer.py:219,260): one thread per utterance calling tts() on ONE
-    model.  Returns (list of waveforms [1, n] CPU, list of first-yield times relative to the common start)."""
+    model.  Returns (list of waveforms [1, n] CPU, list of first-yield times relative to the common start); chunk_times (a list of n
+    lists) receives the yield time of every chunk."""
     n = len(reqs)
     if n == 1:
         t0 = time.perf_counter()
         outs, first = [], None
         for o in model.tts(**reqs[0], stream=stream, force_len=forces[0]):
             first = first if first is not None else time.perf_counter() - t0
+            if chunk_times is not None:
+                chunk_times[0].append(time.perf_counter() - t0)
             outs.append(o['tts_speech'])
         import torch
         return [outs[0] if len(outs) == 1 else torch.cat(outs, 1)], [first]
@@ -182,6 +185,8 @@ def run_calls(model, reqs, forces, stream=False):
             for o in model.tts(**reqs[i], stream=stream, force_len=forces[i]):
                 if first[i] is None:
                     first[i] = time.perf_counter() - t0
+                if chunk_times is not None:
+                    chunk_times[i].append(time.perf_counter() - t0)
                 outs.append(o['tts_speech'])
             wavs[i] = outs[0] if len(outs) == 1 else torch.cat(outs, 1)
         except Exception as e:      # noqa: BLE001
@@ -361,7 +366,25 @@ def extras(model, st, flow_t, hift_t, dev):
         firsts.sort()
         out[n] = {'first_chunk_ms_p50': round(firsts[len(firsts) // 2] * 1e3, 1), 'first_chunk_ms_max': round(firsts[-1] * 1e3, 1),
                   'audio_s_per_s': round(audio / dts, 1)}
-    ex['streaming'] = {'workload': 'configs[4]: streaming (hop 25, look-ahead 3), P=255: the first chunk needs prefill + 48 tokens, chunk-masked flow at '
+    # the same with 250 forced tokens (10 s of audio, 9 chunks of 25 tokens after the first + the final call): time between chunks
+    for n in (1, 8):
+        run_calls(model, [sreq] * n, [250] * n, stream=True)
+        gaps_early, gaps_late, audio, dts = [], [], 0.0, 0.0
+        for _ in range(2):
+            ct = [[] for _ in range(n)]
+            t0 = time.perf_counter()
+            wavs, _ = run_calls(model, [sreq] * n, [250] * n, stream=True, chunk_times=ct)
+            dts += time.perf_counter() - t0
+            audio += sum(w.shape[1] for w in wavs) / 24000.0
+            for c in ct:                                   # chunk k arrives c[k]; non-final chunks are c[0..8], the final call c[9]
+                g = [b - a for a, b in zip(c[:-2], c[1:-1])]
+                gaps_early += g[:3]
+                gaps_late += g[-3:]
+        gaps_early.sort(); gaps_late.sort()
+        out[n].update({'forced250_audio_s_per_s': round(audio / dts, 1),
+                       'chunk_gap_ms_p50_chunks_2_4': round(gaps_early[len(gaps_early) // 2] * 1e3, 1),
+                       'chunk_gap_ms_p50_chunks_8_10': round(gaps_late[len(gaps_late) // 2] * 1e3, 1)})
+    ex['streaming'] = {'flow_cache': bool(getattr(model, 'flow_cache', False)), 'workload': 'configs[4]: streaming (hop 25, look-ahead 3), P=255: the first chunk needs prefill + 48 tokens, chunk-masked flow at '
                                    'T=600, HiFT on 90 frames; time from the tts() call to its first yielded chunk, 3 rounds',
                        'streams_1': out[1], 'streams_8': out[8]}
     return ex

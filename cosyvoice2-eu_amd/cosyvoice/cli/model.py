@@ -25,6 +25,7 @@ What is different, by design:
         all of them, the flow runs over the packed ragged batch, HiFT on a pool of streams);
       - the two kinds exclude each other (a batch uses slots 0..n-1): streams hold the model in shared mode, a batch in exclusive mode.
 """
+import os
 import threading
 import time
 import uuid
@@ -102,6 +103,10 @@ class CosyVoice2Model:
         self._noise_hook_takes_uuid = False    # tests with concurrent calls: callable(T, uuid)
         self._on_call = None                   # tests: callable(uuid), invoked in the caller's thread when a tts() call starts
         self._trace = None                     # tests: list receiving (flow mel, token_offset, finalize, noise) per token2wav call
+        # non-final chunks of streaming calls keep a per-call flow cache (cv2_flow_inference_chunk): a chunk costs its own 50 frames
+        # instead of the whole prefix the reference re-runs (model.py:351-381).  CV2_FLOW_CACHE=0: recompute like the reference.
+        self.flow_cache = os.environ.get('CV2_FLOW_CACHE', '1') != '0'
+        self._flow_caches = {}                 # uuid -> cv2amd.flow.FlowCache, touched under run_lock only
         if llm_sd is not None:
             self.load_state_dicts(llm_sd, flow_sd, hift_sd)
 
@@ -146,11 +151,15 @@ class CosyVoice2Model:
                                          finalize=finalize)
         return self._mel2wav(tts_mel, token_offset, uuid, finalize, speed)
 
-    def _mel2wav(self, tts_mel, token_offset, uuid, finalize, speed, hift=None):
-        """model.py:311-334: everything of token2wav after the flow (slice, mel / source / speech caches, HiFT, cross-fade)."""
+    def _mel2wav(self, tts_mel, token_offset, uuid, finalize, speed, hift=None, mel_first=0):
+        """model.py:311-334: everything of token2wav after the flow (slice, mel / source / speech caches, HiFT, cross-fade).
+        mel_first: index of tts_mel's first frame in the mel flow.inference would have returned (cached chunks hold only the tail)."""
         hift = hift or self.hift
         flow_mel = tts_mel
-        tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio:]
+        if mel_first and self._trace is not None:                              # tests slice the traced mel themselves: full-length view
+            flow_mel = torch.cat([tts_mel.new_zeros(1, tts_mel.shape[1], mel_first), tts_mel], dim=2)
+        assert token_offset * self.flow.token_mel_ratio >= mel_first
+        tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio - mel_first:]
         cache = self.hift_cache_dict[uuid]
         if cache is not None:
             tts_mel = torch.concat([cache['mel'], tts_mel], dim=2)
@@ -182,7 +191,25 @@ class CosyVoice2Model:
 
     # ---- chunks of concurrent streams: one ragged flow batch for every chunk that is ready -------------------------------
     class _Chunk:
-        __slots__ = ('token', 'fpt', 'feat', 'femb', 'offset', 'uuid', 'stream', 'finalize', 'done', 'speech', 'exc')
+        __slots__ = ('token', 'fpt', 'feat', 'femb', 'offset', 'uuid', 'stream', 'finalize', 'done', 'speech', 'exc', 'cap_hint')
+
+    def _flow_cache_for(self, c):
+        """The call's flow cache, large enough for this chunk.  Capacity: the caller's estimate of the utterance (frames), at least
+        twice what this chunk needs; a cache that turns out too small is replaced by a larger empty one, which makes this chunk a
+        recompute of the whole prefix (what the reference does for every chunk)."""
+        need = self.flow.token_mel_ratio * (c.fpt.shape[1] + c.token.shape[1] - self.flow.pre_lookahead_len)
+        fc = self._flow_caches.get(c.uuid)
+        if fc is None or fc.frames < need:
+            cap = min(max(c.cap_hint or 0, need + need // 2), self.flow.max_len)
+            fc = self._flow_caches[c.uuid] = self.flow.new_cache(max(cap, need))
+        return fc
+
+    def _flow_batch(self, grp, streaming, finalize):
+        """[(mel, first frame index)] of one group of chunks; cached for the non-final chunks of streaming calls."""
+        utts = [dict(token=c.token, prompt_token=c.fpt, prompt_feat=c.feat, embedding=c.femb) for c in grp]
+        if streaming and not finalize and self.flow_cache:
+            return self.flow.inference_chunk_batch(utts, [self._flow_cache_for(c) for c in grp], finalize=False)
+        return [(m, 0) for m in self.flow.inference_batch(utts, streaming=streaming, finalize=finalize)]
 
     def _run_chunks(self, batch):
         """One round of ready chunks.  A failure is delivered only to the call it belongs to (an utterance failure must not poison its
@@ -192,17 +219,18 @@ class CosyVoice2Model:
             for key in sorted({(c.stream, c.finalize) for c in batch}):
                 grp = [c for c in batch if (c.stream, c.finalize) == key]
                 try:
-                    mels = self.flow.inference_batch([dict(token=c.token, prompt_token=c.fpt, prompt_feat=c.feat, embedding=c.femb) for c in grp],
-                                                     streaming=key[0], finalize=key[1])
-                except Exception:                                              # find the offender: run the chunks one by one
-                    mels = []
+                    mels = self._flow_batch(grp, key[0], key[1])
+                except Exception:                                              # find the offender: run the chunks one by one (a failed
+                    mels = []                                                  # cached call left its caches where they were)
                     for c in grp:
                         try:
-                            mels.append(self.flow.inference_batch([dict(token=c.token, prompt_token=c.fpt, prompt_feat=c.feat, embedding=c.femb)],
-                                                                  streaming=key[0], finalize=key[1])[0])
+                            mels.append(self._flow_batch([c], key[0], key[1])[0])
                         except Exception as e:
                             c.exc = e
                             mels.append(None)
+                if key[1]:                                                     # the final chunk is a full-context recompute (model.py:374-380
+                    for c in grp:                                              # passes no `stream`): the call's cache is not needed any more
+                        self._flow_caches.pop(c.uuid, None)
                 # HiFT (and the cache / cross-fade bookkeeping) of a chunk always runs on the pool engine + HIP stream its call was pinned
                 # to at its first chunk: the per-uuid caches are then allocated, read and freed on ONE stream (a cache block freed on
                 # stream A while stream B still reads it could be handed out again by the caching allocator), joined before anything is read
@@ -216,9 +244,10 @@ class CosyVoice2Model:
                         continue
                     k = self._hift_pin[c.uuid]
                     try:
+                        mel, first = mel
                         with torch.cuda.stream(pool.streams[k]):
                             mel.record_stream(pool.streams[k])                 # produced on the main stream, consumed on the pinned one
-                            sp.append(self._mel2wav(mel, c.offset, c.uuid, c.finalize, 1.0, hift=pool.engines[k]))
+                            sp.append(self._mel2wav(mel, c.offset, c.uuid, c.finalize, 1.0, hift=pool.engines[k], mel_first=first))
                     except Exception as e:
                         c.exc = e
                         sp.append(None)
@@ -240,12 +269,12 @@ class CosyVoice2Model:
         self._pin_rr = (self._pin_rr + 1) % len(self.hift_pool.engines)
         return self._pin_rr
 
-    def _chunk_submit(self, token, fpt, feat, femb, offset, this_uuid, stream, finalize):
+    def _chunk_submit(self, token, fpt, feat, femb, offset, this_uuid, stream, finalize, cap_hint=None):
         """token2wav for one chunk of a streaming call.  The chunk is queued; whoever gets the device next runs the flow over ALL
         queued chunks as one ragged batch (streams that share decode steps become ready together), then HiFT per chunk."""
         c = self._Chunk()
         c.token, c.fpt, c.feat, c.femb, c.offset, c.uuid, c.stream, c.finalize = token, fpt, feat, femb, offset, this_uuid, stream, finalize
-        c.done, c.speech, c.exc = False, None, None
+        c.done, c.speech, c.exc, c.cap_hint = False, None, None, cap_hint
         with self.lock:
             self._chunk_q.append(c)
         with self.run_lock:
@@ -500,6 +529,7 @@ class CosyVoice2Model:
                 self.llm_end_dict.pop(this_uuid, None)
                 self.hift_cache_dict.pop(this_uuid, None)
                 self._hift_pin.pop(this_uuid, None)
+                self._flow_caches.pop(this_uuid, None)
 
     # ---- model.py:336-401 -------------------------------------------------------------------------------------
     def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192), llm_embedding=torch.zeros(0, 192),
@@ -542,6 +572,7 @@ class CosyVoice2Model:
                     self.llm_end_dict.pop(this_uuid, None)
                     self.hift_cache_dict.pop(this_uuid, None)
                 self._hift_pin.pop(this_uuid, None)
+                self._flow_caches.pop(this_uuid, None)
             return
         slot = self._enter_shared()
         hop, la = self.token_hop_len, self.flow.pre_lookahead_len
@@ -550,6 +581,9 @@ class CosyVoice2Model:
             if stream is True:
                 token_offset = 0
                 prompt_token_pad = int(np.ceil(fpt.shape[1] / hop) * hop - fpt.shape[1])
+                # flow-cache capacity in frames: the forced length, else a typical 8 speech tokens per text token (grown when exceeded)
+                n_guess = force_len if force_len is not None else min(self._limits[2], 8 * int(text.shape[1]) + 64)
+                cap_hint = self.flow.token_mel_ratio * (fpt.shape[1] + n_guess)
                 self._llm_start(slot, text_d, ptext_d, lptok_d, force_len)     # prefill draws token 0; the first pass of the loop below
                 while True:                                                    # requests the rest of the first chunk's tokens
                     this_tok, finished = None, False
@@ -567,7 +601,7 @@ class CosyVoice2Model:
                         else:
                             self._llm_advance(this_token_hop_len + la - have)  # fill tokens skipped (ids > eos)
                     if this_tok is not None:
-                        speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, True, False)
+                        speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, True, False, cap_hint)
                         token_offset += this_token_hop_len
                         yield {'tts_speech': speech}
                     if finished:
@@ -604,3 +638,4 @@ class CosyVoice2Model:
                 self.llm_end_dict.pop(this_uuid, None)
                 self.hift_cache_dict.pop(this_uuid, None)
                 self._hift_pin.pop(this_uuid, None)
+                self._flow_caches.pop(this_uuid, None)

@@ -194,6 +194,10 @@ struct PackArgs {
     SeqTable seq;                // estimator table (2U sequences)
     int RU, U;
     uint16_t* a0;                // [2RU][320]
+    // cached streaming: the rows are the NEW frames of every stream; frame t of sequence s sits at position pos0[s] + t of its
+    // utterance (noise, prompt mel) and its mu row is mu_start[s] + pos0[s] + t.  twin = row distance to the uncond twin; rows
+    // below `lead` belong to no sequence (their twin rows do not exist).
+    const int* pos0; const int* mu_start; int twin, lead;
 };
 __global__ __launch_bounds__(256) void k_euler_pack(PackArgs a) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -206,22 +210,29 @@ __global__ __launch_bounds__(256) void k_euler_pack(PackArgs a) {
         const int t = row - a.seq.seq_start[s];
         valid = t < a.seq.seq_len[s];
         if (valid) {
-            if (a.noise) x = *reinterpret_cast<const f32x4*>(a.noise + (size_t)t * 80 + c);
+            const int pt = (a.pos0 ? a.pos0[s] : 0) + t;               // frame index within the utterance
+            if (a.noise) x = *reinterpret_cast<const f32x4*>(a.noise + (size_t)pt * 80 + c);
             else {
                 x = *reinterpret_cast<const f32x4*>(a.x + (size_t)row * 80 + c);
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(a.v + (size_t)row * 80 + c);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(a.v + (size_t)(row + a.RU) * 80 + c);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(a.v + (size_t)(row + a.twin) * 80 + c);
                 x = x + a.dt * ((1.0f + a.cfg) * v0 - a.cfg * v1);
             }
-            mu = *reinterpret_cast<const f32x4*>(a.mu + (size_t)row * 80 + c);
+            const size_t mrow = a.mu_start ? (size_t)a.mu_start[s] + pt : (size_t)row;
+            mu = *reinterpret_cast<const f32x4*>(a.mu + mrow * 80 + c);
             sp = *reinterpret_cast<const f32x4*>(a.spk + (size_t)s * 80 + c);
-            if (t < a.n_prompt[s]) cd = *reinterpret_cast<const f32x4*>(a.prompt[s] + (size_t)t * 80 + c);
+            if (pt < a.n_prompt[s]) cd = *reinterpret_cast<const f32x4*>(a.prompt[s] + (size_t)pt * 80 + c);
         }
     }
     *reinterpret_cast<f32x4*>(a.x + (size_t)row * 80 + c) = x;
     const uint2 xb = make_uint2(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]));
     uint16_t* r0 = a.a0 + (size_t)row * 320 + c;
-    uint16_t* r1 = a.a0 + (size_t)(row + a.RU) * 320 + c;
+    uint16_t* r1 = a.a0 + (size_t)(row + a.twin) * 320 + c;
+    if (row < a.lead) {                                              // lead rows: no twin
+        *reinterpret_cast<uint2*>(r0) = make_uint2(0u, 0u); *reinterpret_cast<uint2*>(r0 + 80) = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(r0 + 160) = make_uint2(0u, 0u); *reinterpret_cast<uint2*>(r0 + 240) = make_uint2(0u, 0u);
+        return;
+    }
     *reinterpret_cast<uint2*>(r0) = xb;
     *reinterpret_cast<uint2*>(r0 + 80) = make_uint2(pack_bf16x2(mu[0], mu[1]), pack_bf16x2(mu[2], mu[3]));
     *reinterpret_cast<uint2*>(r0 + 160) = make_uint2(pack_bf16x2(sp[0], sp[1]), pack_bf16x2(sp[2], sp[3]));
@@ -242,6 +253,60 @@ __global__ __launch_bounds__(256) void k_mel_out(MelOutArgs a) {
     if (idx >= (long)n2 * 80) return;
     const int c = idx / n2, t = idx % n2;
     a.out[s][(size_t)c * n2 + t] = a.x[(size_t)(start + p + t) * 80 + c];
+}
+
+// ---- cached streaming (cv2_flow_inference_chunk) ------------------------------------------------------------------------------
+// The estimator of a streaming call is chunk-causal (decoder.py:439-441 masks, causal convolutions), so the frames of finished
+// chunks never change and the reference's recompute of the whole prefix per chunk (cli/model.py:351-381) can be replaced by a
+// per-stream cache: for every (CFG branch, Euler step, transformer block) the keys / values of all frames so far, and for every
+// causal convolution the last two input rows.
+#define INC_LEAD 128            // rows in front of the first sequence: its conv tails are written there (never into the zero guard)
+#define INC_TBLOCKS 56
+#define INC_CONVS 31
+struct IncTabs {
+    uint16_t* const* kv;        // [2U] cache base of (stream, branch): [n_steps][56] slots of K [frames][512] + V^T [512][frames]
+    const int* kv_frames;       // [2U]
+    const int* pos0;            // [2U] frames cached before this call
+    uint16_t* const* tails;     // [2U] conv tails of (stream, branch): [2 generations][n_steps][31][2 rows][512]
+    const int* gen;             // [2U] generation to READ (the call writes the other one: a failed call can be repeated)
+};
+// keys / values of the call's new rows -> cache slot
+struct KvAppendArgs { const uint16_t* qk; const uint16_t* vt; long R; SeqTable seq; IncTabs inc; long slot; };
+__global__ __launch_bounds__(256) void k_kv_append(KvAppendArgs a) {
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int s = a.seq.tile_seq[tile];
+    if (s < 0) return;
+    const int start = a.seq.seq_start[s], len = a.seq.seq_len[s], p0 = a.inc.pos0[s];
+    const int t0 = tile * 64 - start, n = min(64, len - t0);
+    if (n <= 0) return;
+    const long fr = a.inc.kv_frames[s];
+    uint16_t* kb = a.inc.kv[s] + a.slot * fr * 1024;
+    uint16_t* vb = kb + fr * 512;
+    for (int i = tid; i < n * 64; i += 256) {                  // K rows: 64 x 16 B per frame
+        const int r = i >> 6, ch = (i & 63) * 8;
+        *reinterpret_cast<uint4*>(kb + (size_t)(p0 + t0 + r) * 512 + ch) =
+            *reinterpret_cast<const uint4*>(a.qk + (size_t)(tile * 64 + r) * 1024 + 512 + ch);
+    }
+    for (int i = tid; i < 512 * 64; i += 256) {                // V^T: 512 channels x n frames
+        const int ch = i >> 6, r = i & 63;
+        if (r < n) vb[(size_t)ch * fr + p0 + t0 + r] = a.vt[(size_t)ch * a.R + tile * 64 + r];
+    }
+}
+// before a causal k=3 convolution reads `buf`: rows [start-2, start) <- the cached last two input rows of the previous call,
+// and the last two input rows of this call -> cache (other generation)
+struct ConvTailArgs { uint16_t* buf; int C; SeqTable seq; IncTabs inc; int rd_slot, wr_slot; };     // slot = (gen * n_steps + step) * 31 + conv
+__global__ __launch_bounds__(256) void k_conv_tail(ConvTailArgs a) {
+    const int s = blockIdx.x;
+    const int start = a.seq.seq_start[s], len = a.seq.seq_len[s], p0 = a.inc.pos0[s], g = a.inc.gen[s] & 1;
+    const uint16_t* tr = a.inc.tails[s] + (size_t)(g ? a.wr_slot : a.rd_slot) * 1024;       // slots are given for gen = 0; swapped for gen = 1
+    uint16_t* tw = a.inc.tails[s] + (size_t)(g ? a.rd_slot : a.wr_slot) * 1024;
+    for (int e = threadIdx.x; e < 2 * a.C; e += 256) {
+        const int j = e / a.C, c = e - j * a.C;
+        const uint16_t o0 = p0 > 0 ? tr[c] : (uint16_t)0, o1 = p0 > 0 ? tr[512 + c] : (uint16_t)0;
+        a.buf[(long)(start - 2 + j) * a.C + c] = j ? o1 : o0;
+        const int pos = len - 2 + j;
+        tw[j * 512 + c] = pos >= 0 ? a.buf[(long)(start + pos) * a.C + c] : (pos == -1 ? o1 : o0);
+    }
 }
 
 // TensorRT-seam pack / unpack (flow_matching.py:125-150): channel-major (2,80,T) tensors <-> packed rows
@@ -289,6 +354,12 @@ struct AttnEstArgs {
     const uint16_t* vt;   // [512][R]
     uint16_t* out;        // [R][512]
     SeqTable seq; int chunk; long R;
+    // cached streaming (cv2_flow_inference_chunk): keys / values of sequence s come from its cache slot, which already holds the
+    // rows of this call; the queries are the call's new frames at positions pos0[s] + t
+    uint16_t* const* kv;  // [S] -> cache base of the sequence's CFG branch (null: keys from qk / vt)
+    const int* kv_frames; // [S] capacity in frames of that cache
+    const int* pos0;      // [S] frames already cached before this call
+    long slot;            // (Euler step * 56 + transformer block): slot s of a cache = K [frames][512] then V^T [512][frames]
 };
 #define AK_LD 72    // K tile row stride (bf16 elements): 64 + 8
 #define AV_LD 68    // V^T tile row stride: 64 + 4
@@ -395,13 +466,25 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
     }
     const int start = a.seq.seq_start[s], len = a.seq.seq_len[s];
     const int t0 = m0 - start;
+    // key source: the packed rows of this call, or the sequence's cache slot (keys 0 .. p0 + len)
+    const int p0 = a.kv ? a.pos0[s] : 0;
+    const int klen = p0 + len;
+    const uint16_t* kbase; const uint16_t* vbase; long kld, vld;
+    if (a.kv) {
+        const long fr = a.kv_frames[s];
+        kbase = a.kv[s] + a.slot * fr * 1024 + h * 64; kld = 512;
+        vbase = a.kv[s] + a.slot * fr * 1024 + fr * 512 + (long)h * 64 * fr; vld = fr;
+    } else {
+        kbase = a.qk + (size_t)start * 1024 + 512 + h * 64; kld = 1024;
+        vbase = a.vt + (size_t)h * 64 * a.R + start; vld = a.R;
+    }
     int tq[QS], kmax_q[QS];
 #pragma unroll
     for (int u = 0; u < QS; u++) {
         tq[u] = t0 + RB * u + 16 * w + q16;                          // this lane's query frames
-        kmax_q[u] = a.chunk > 0 ? min(len, (tq[u] / a.chunk + 1) * a.chunk) : len;
+        kmax_q[u] = a.chunk > 0 ? min(klen, ((p0 + tq[u]) / a.chunk + 1) * a.chunk) : klen;
     }
-    const int kmax_blk = a.chunk > 0 ? min(len, ((t0 + RB * QS - 1) / a.chunk + 1) * a.chunk) : len;
+    const int kmax_blk = a.chunk > 0 ? min(klen, ((p0 + t0 + RB * QS - 1) / a.chunk + 1) * a.chunk) : klen;
     const int ntiles = (kmax_blk + 63) / 64;
 
     bf16x8 qf[QS][2];
@@ -422,10 +505,10 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
 #define ATT_GLOAD1(S, C, KROW)                                                                                               \
     if (NCH > C) {                                                                                                           \
         const int idx = tid + 64 * NW * C, kr = idx >> 3, kc = idx & 7;                                                       \
-        kreg##S##C = *reinterpret_cast<const uint4*>(a.qk + (size_t)((KROW) + kr) * 1024 + 512 + h * 64 + kc * 8);            \
-        vreg##S##C = *reinterpret_cast<const uint4*>(a.vt + (size_t)(h * 64 + kr) * a.R + (KROW) + kc * 8);                   \
+        kreg##S##C = *reinterpret_cast<const uint4*>(kbase + ((KROW) + kr) * kld + kc * 8);                                   \
+        vreg##S##C = *reinterpret_cast<const uint4*>(vbase + kr * vld + (KROW) + kc * 8);                                     \
     }
-#define ATT_GLOAD(S, KT) { const long krow_ = (long)start + (KT) * 64; ATT_GLOAD1(S, 0, krow_) ATT_GLOAD1(S, 1, krow_) ATT_GLOAD1(S, 2, krow_) ATT_GLOAD1(S, 3, krow_) }
+#define ATT_GLOAD(S, KT) { const long krow_ = (long)(KT) * 64; ATT_GLOAD1(S, 0, krow_) ATT_GLOAD1(S, 1, krow_) ATT_GLOAD1(S, 2, krow_) ATT_GLOAD1(S, 3, krow_) }
 #define ATT_LSTORE1(S, C, BUF)                                                                                               \
     if (NCH > C) {                                                                                                           \
         const int idx = tid + 64 * NW * C, kr = idx >> 3, kc = idx & 7;                                                       \
@@ -591,7 +674,7 @@ static size_t flow_carve(const cv2_flow_dims& d, cv2_flow* h, char* base) {
     f.e_a = c.take<uint16_t>(RG * 512); f.e_b = c.take<uint16_t>(RG * 512); f.e_ln = c.take<uint16_t>(RG * 512);
     f.e_qkv = c.take<uint16_t>(RG * 1536); f.e_vt = c.take<uint16_t>((size_t)(512 + 64) * RG); f.e_att = c.take<uint16_t>(RG * 512);
     f.e_ff = c.take<uint16_t>(RG * 2048); f.e_x = c.take<float>(R * 512); f.e_tmp = c.take<float>(R * 512);
-    f.itab = c.take<int>((size_t)6 * itab_per(R, d.max_seqs));
+    f.itab = c.take<int>((size_t)8 * itab_per(R, d.max_seqs));      // layouts 0-3, ints 4; cached streaming: layouts 5-6, ints 7
     f.ptab = c.take<void*>((size_t)8 * d.max_seqs + 64);
     return c.off;
 }
@@ -632,10 +715,10 @@ static int upload_layout(cv2_flow* h, Layout& L, int slot, hipStream_t s) {
     return 0;
 }
 
-static Layout make_layout(const std::vector<int>& lens) {
+static Layout make_layout(const std::vector<int>& lens, int lead = 0) {
     Layout L;
     L.S = (int)lens.size();
-    int r = 0;
+    int r = lead;                               // rows [0, lead) belong to no sequence
     for (int l : lens) { L.start.push_back(r); L.len.push_back(l); L.ext.push_back(pad_rows(l)); r += pad_rows(l); }
     L.rows = r;
     return L;
@@ -694,7 +777,18 @@ extern "C" int cv2_flow_create(const cv2_flow_dims* d, const cv2_flow_weights* w
 extern "C" int cv2_flow_destroy(cv2_flow* h) { delete h; return 0; }
 
 // ------------------------------------------------------------------ estimator core
-struct EstCtx { cv2_flow* h; const Layout* L; const float* temb; int chunk; hipStream_t s; };
+struct EstCtx { cv2_flow* h; const Layout* L; const float* temb; int chunk; hipStream_t s;
+                const IncTabs* inc = nullptr; int step = 0, conv_i = 0, tb_i = 0; };      // cached streaming: tables, Euler step, site counters
+
+// cached streaming: hand the conv at this site its left context and keep this call's last two input rows
+static int est_conv_tail(EstCtx& c, uint16_t* buf, int C) {
+    if (!c.inc) return 0;
+    const int nst = c.h->d.n_timesteps, ci = c.conv_i++;
+    CV2_CHECK(ci < INC_CONVS, "flow: conv site counter overflow");
+    ConvTailArgs a{buf, C, c.L->tab(), *c.inc, (0 * nst + c.step) * INC_CONVS + ci, (1 * nst + c.step) * INC_CONVS + ci};
+    hipLaunchKernelGGL(k_conv_tail, dim3(c.L->S), dim3(256), 0, c.s, a);
+    return 0;
+}
 
 static int est_gemm(EstCtx& c, GemmArgs a, int cfg) {
     a.seq = c.L->tab(); a.mask = 1;
@@ -702,8 +796,9 @@ static int est_gemm(EstCtx& c, GemmArgs a, int cfg) {
 }
 
 // resnet: A = bf16 input (guard-offset pointer) with C_in channels; leaves x (fp32, xf) and LN'd bf16 (lnb) for the first tblock
-static int est_resnet(EstCtx& c, const cv2_resnet& rn, int ridx, const uint16_t* A, int cin, const cv2_ln& next_ln) {
+static int est_resnet(EstCtx& c, const cv2_resnet& rn, int ridx, uint16_t* A, int cin, const cv2_ln& next_ln) {
     cv2_flow* h = c.h; const int M = c.L->rows;
+    if (est_conv_tail(c, A, cin)) return -1;
     {   // res_conv 1x1
         GemmArgs a = gemm_args(A, cin, 0, rn.res.w, M, 256, cin);
         a.bias = rn.res.b; a.out_f32 = h->rf; a.ldo = 256;
@@ -716,6 +811,7 @@ static int est_resnet(EstCtx& c, const cv2_resnet& rn, int ridx, const uint16_t*
         a.out_bf16 = GB(h->hb, 256); a.ldo16 = 256;
         if (est_gemm(c, a, 1)) return -1;
     }
+    if (est_conv_tail(c, GB(h->hb, 256), 256)) return -1;
     {   // block2 + residual; second LN = norm1 of the first transformer block
         GemmArgs a = gemm_args(GB(h->hb, 256), 256, -2, rn.conv2.w, M, 256, 768);
         a.bias = rn.conv2.b; a.ln1_g = rn.ln2.g; a.ln1_b = rn.ln2.b; a.ln1_eps = 1e-5f; a.act = ACT_MISH;
@@ -736,7 +832,14 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         if (est_gemm(c, a, 0)) return -1;
     }
     {
-        AttnEstArgs a{GB(h->qk, 1024), h->vt + GUARD, GB(h->att, 512), c.L->tab(), c.chunk, (long)(h->R + GUARD + 8)};
+        AttnEstArgs a{GB(h->qk, 1024), h->vt + GUARD, GB(h->att, 512), c.L->tab(), c.chunk, (long)(h->R + GUARD + 8), nullptr, nullptr, nullptr, 0};
+        if (c.inc) {                 // cached streaming: this call's keys / values join the cache, the attention reads all of it
+            const int bi = c.tb_i++;
+            CV2_CHECK(bi < INC_TBLOCKS, "flow: transformer block counter overflow");
+            a.kv = c.inc->kv; a.kv_frames = c.inc->kv_frames; a.pos0 = c.inc->pos0; a.slot = (long)c.step * INC_TBLOCKS + bi;
+            KvAppendArgs k{GB(h->qk, 1024), h->vt + GUARD, a.R, c.L->tab(), *c.inc, a.slot};
+            hipLaunchKernelGGL(k_kv_append, dim3(M / 64), dim3(256), 0, c.s, k);
+        }
         if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(M / 128, 8), dim3(256), 0, c.s, a);   // enough blocks to fill the chip twice
         else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(M / 64, 8), dim3(256), 0, c.s, a);
         else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(M / 32, 8), dim3(256), 0, c.s, a);       // one utterance: split keys over two wave groups
@@ -778,7 +881,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
     return 0;
 }
 
-static int est_block(EstCtx& c, const cv2_unet_block& b, int ridx, const uint16_t* A, int cin, uint16_t* xout, long ldx) {
+static int est_block(EstCtx& c, const cv2_unet_block& b, int ridx, uint16_t* A, int cin, uint16_t* xout, long ldx) {
     if (est_resnet(c, b.rn, ridx, A, cin, b.tb[0].norm1)) return -1;
     for (int j = 0; j < 4; j++)
         if (est_tblock(c, b.tb[j], j < 3 ? &b.tb[j + 1].norm1 : nullptr, xout, ldx)) return -1;
@@ -789,25 +892,29 @@ static int est_block(EstCtx& c, const cv2_unet_block& b, int ridx, const uint16_
 static int estimator_core(EstCtx& c) {
     cv2_flow* h = c.h; const int M = c.L->rows;
     const cv2_flow_weights& w = h->w;
+    c.conv_i = 0; c.tb_i = 0;
     if (est_block(c, w.down, 0, GB(h->a0, 320), 320, GB(h->xa, 256), 256)) return -1;
     // skip connection: xa -> cat[:, 256:512]
     CV2_HIP(hipMemcpy2DAsync(GB(h->cat, 512) + 256, 512 * 2, GB(h->xa, 256), 256 * 2, 256 * 2, M, hipMemcpyDeviceToDevice, c.s));
+    if (est_conv_tail(c, GB(h->xa, 256), 256)) return -1;
     {   // downsample tail: CausalConv1d(256,256,3)
         GemmArgs a = gemm_args(GB(h->xa, 256), 256, -2, w.down.tail.w, M, 256, 768);
         a.bias = w.down.tail.b; a.out_bf16 = GB(h->xbuf, 256); a.ldo16 = 256;
         if (est_gemm(c, a, 1)) return -1;
     }
     for (int i = 0; i < 12; i++) {
-        const uint16_t* A = i == 0 ? GB(h->xbuf, 256) : GB(h->xa, 256);
+        uint16_t* A = i == 0 ? GB(h->xbuf, 256) : GB(h->xa, 256);
         uint16_t* xo = i == 11 ? GB(h->cat, 512) : GB(h->xa, 256);
         if (est_block(c, w.mid[i], 1 + i, A, 256, xo, i == 11 ? 512 : 256)) return -1;
     }
     if (est_block(c, w.up_blk, 13, GB(h->cat, 512), 512, GB(h->xa, 256), 256)) return -1;
+    if (est_conv_tail(c, GB(h->xa, 256), 256)) return -1;
     {   // upsample tail
         GemmArgs a = gemm_args(GB(h->xa, 256), 256, -2, w.up_blk.tail.w, M, 256, 768);
         a.bias = w.up_blk.tail.b; a.out_bf16 = GB(h->xbuf, 256); a.ldo16 = 256;
         if (est_gemm(c, a, 1)) return -1;
     }
+    if (est_conv_tail(c, GB(h->xbuf, 256), 256)) return -1;
     {   // final_block: conv -> LN -> Mish
         GemmArgs a = gemm_args(GB(h->xbuf, 256), 256, -2, w.final_conv.w, M, 256, 768);
         a.bias = w.final_conv.b; a.ln1_g = w.final_ln.g; a.ln1_b = w.final_ln.b; a.ln1_eps = 1e-5f; a.act = ACT_MISH;
@@ -1037,7 +1144,8 @@ extern "C" int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t
         EstCtx c{h, &LE, nullptr, streaming ? 50 : 0, s};
         for (int st = 0; st < h->d.n_timesteps; st++) {
             PackArgs p{h->xs, h->mu, h->spk, (const float* const*)(dp + U), ibase, st == 0 ? h->w.rand_noise : nullptr,
-                       st == 0 ? nullptr : h->vf, st == 0 ? 0.f : h->dt_host[st - 1], h->d.cfg_rate, L2.tab(), RU, U, GB(h->a0, 320)};
+                       st == 0 ? nullptr : h->vf, st == 0 ? 0.f : h->dt_host[st - 1], h->d.cfg_rate, L2.tab(), RU, U, GB(h->a0, 320),
+                       nullptr, nullptr, RU, 0};
             hipLaunchKernelGGL(k_euler_pack, dim3(((long)RU * 20 + 255) / 256), dim3(256), 0, s, p);
             c.temb = h->temb_tab + (size_t)st * 14 * 256;
             if (estimator_core(c)) return -1;
@@ -1045,7 +1153,7 @@ extern "C" int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t
         {   // last update without a following pack: reuse k_euler_pack (a0 is scratch now)
             const int st = h->d.n_timesteps;
             PackArgs p{h->xs, h->mu, h->spk, (const float* const*)(dp + U), ibase, nullptr, h->vf, h->dt_host[st - 1], h->d.cfg_rate,
-                       L2.tab(), RU, U, GB(h->a0, 320)};
+                       L2.tab(), RU, U, GB(h->a0, 320), nullptr, nullptr, RU, 0};
             hipLaunchKernelGGL(k_euler_pack, dim3(((long)RU * 20 + 255) / 256), dim3(256), 0, s, p);
         }
         int maxn2 = 1;
@@ -1053,6 +1161,98 @@ extern "C" int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t
         MelOutArgs mo{h->xs, (float* const*)(dp + 2 * U), ibase, L2.tab()};
         hipLaunchKernelGGL(k_mel_out, dim3(((long)maxn2 * 80 + 255) / 256, U), dim3(256), 0, s, mo);
     }
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ cached streaming
+static size_t inc_kv_elems(const cv2_flow* h, long frames) { return (size_t)2 * h->d.n_timesteps * INC_TBLOCKS * frames * 1024; }
+static size_t inc_tail_elems(const cv2_flow* h) { return (size_t)2 * 2 * h->d.n_timesteps * INC_CONVS * 1024; }
+
+extern "C" size_t cv2_flow_cache_bytes(const cv2_flow* h, int32_t frames) {
+    if (!h || frames < 64 || frames % 64) return 0;
+    return (inc_kv_elems(h, frames) + inc_tail_elems(h)) * sizeof(uint16_t);
+}
+
+extern "C" int cv2_flow_inference_chunk(cv2_flow* h, const cv2_flow_utt* utts, const cv2_flow_cache_ref* refs, int32_t U, int32_t finalize,
+                                        void* stream) {
+    CV2_CHECK(h && utts && refs && U >= 1, "cv2_flow_inference_chunk: bad argument");
+    CV2_CHECK(2 * U <= h->d.max_seqs, "cv2_flow_inference_chunk: %d utterances exceed max_seqs/2", U);
+    hipStream_t s = (hipStream_t)stream;
+    const int la = finalize ? 0 : 3;
+    std::vector<int> lensT, lens2, lensN, lensNE;
+    for (int u = 0; u < U; u++) {
+        const int T = utts[u].n_tok - la, nc = refs[u].n_cached;
+        CV2_CHECK(T >= 1, "cv2_flow_inference_chunk: utterance %d has no tokens", u);
+        CV2_CHECK(utts[u].n_prompt_feat >= 0 && utts[u].n_prompt_feat <= 2 * T, "cv2_flow_inference_chunk: prompt_feat longer than the mel (%d > %d)", utts[u].n_prompt_feat, 2 * T);
+        CV2_CHECK(refs[u].cache && refs[u].cache_frames >= 64 && refs[u].cache_frames % 64 == 0, "cv2_flow_inference_chunk: utterance %d: cache of %d frames (need a multiple of 64)", u, refs[u].cache_frames);
+        CV2_CHECK(nc >= 0 && nc % 50 == 0 && nc < 2 * T, "cv2_flow_inference_chunk: utterance %d: %d cached frames must be whole chunks of 50 and fewer than the %d frames of this call", u, nc, 2 * T);
+        CV2_CHECK(2 * T <= refs[u].cache_frames, "cv2_flow_inference_chunk: utterance %d: %d frames exceed the cache capacity %d", u, 2 * T, refs[u].cache_frames);
+        CV2_CHECK(finalize || (2 * T) % 50 == 0, "cv2_flow_inference_chunk: utterance %d: a non-final call must end on a chunk boundary (%d frames)", u, 2 * T);
+        lensT.push_back(T); lens2.push_back(2 * T); lensN.push_back(2 * T - nc);
+    }
+    Layout LT = make_layout(lensT), L2 = make_layout(lens2);
+    Layout LA = LT;
+    for (int u = 0; u < U; u++) LA.len[u] += la;
+    Layout LI = make_layout(lensN, INC_LEAD);
+    lensNE = lensN; lensNE.insert(lensNE.end(), lensN.begin(), lensN.end());
+    Layout LIE = make_layout(lensNE, INC_LEAD);
+    if (check_rows(h, L2, "cv2_flow_inference_chunk") || check_rows(h, LIE, "cv2_flow_inference_chunk")) return -1;
+    const int RI = LI.rows, twin = RI - INC_LEAD;
+    if (upload_layout(h, LA, 0, s) || upload_layout(h, LT, 1, s) || upload_layout(h, L2, 2, s) || upload_layout(h, LI, 5, s) ||
+        upload_layout(h, LIE, 6, s)) return -1;
+    const size_t per = itab_per(h->R, h->d.max_seqs);
+    CV2_CHECK((size_t)12 * U + 16 <= per, "cv2_flow_inference_chunk: int table overflow");
+    // pointer tables: [emb U][prompt U][mel_out U][tokens U][kv 2U][tails 2U]; int tables: [n_prompt U][skip U][mu_start U][pos0 2U][frames 2U][gen 2U]
+    std::vector<const void*> ptrs(8 * U);
+    std::vector<int> ints(9 * U);
+    int maxn2 = 1;
+    for (int u = 0; u < U; u++) {
+        ptrs[u] = utts[u].embedding; ptrs[U + u] = utts[u].prompt_feat; ptrs[2 * U + u] = utts[u].mel_out; ptrs[3 * U + u] = utts[u].tokens;
+        const long fr = refs[u].cache_frames;
+        uint16_t* base = (uint16_t*)refs[u].cache;
+        uint16_t* tails = base + inc_kv_elems(h, fr);
+        ptrs[4 * U + u] = base; ptrs[5 * U + u] = base + inc_kv_elems(h, fr) / 2;
+        ptrs[6 * U + u] = tails; ptrs[7 * U + u] = tails + inc_tail_elems(h) / 2;
+        const int nc = refs[u].n_cached, skip = std::max(utts[u].n_prompt_feat - nc, 0);
+        ints[u] = utts[u].n_prompt_feat; ints[U + u] = skip; ints[2 * U + u] = L2.start[u];
+        ints[3 * U + u] = ints[4 * U + u] = nc;
+        ints[5 * U + u] = ints[6 * U + u] = (int)fr;
+        ints[7 * U + u] = ints[8 * U + u] = refs[u].gen;
+        maxn2 = std::max(maxn2, lensN[u] - skip);
+    }
+    CV2_HIP(hipMemcpyAsync(h->ptab, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, s));
+    int* ibase = h->itab + (size_t)7 * per;
+    CV2_HIP(hipMemcpyAsync(ibase, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    CV2_HIP(hipStreamSynchronize(s));
+    const void* const* dp = (const void* const*)h->ptab;
+    IncTabs tabs{(uint16_t* const*)(dp + 4 * U), ibase + 5 * U, ibase + 3 * U, (uint16_t* const*)(dp + 6 * U), ibase + 7 * U};
+    // encoder over the whole prefix (2 % of the flow's work; its chunk masks make the rows of finished chunks reproduce exactly)
+    SpkArgs sp{(const float* const*)dp, h->w.spk_w, h->w.spk_b, h->spk};
+    hipLaunchKernelGGL(k_spk, dim3(U), dim3(128), 0, s, sp);
+    EmbedPtrArgs ea{(const int* const*)(dp + 3 * U), h->w.input_embedding, LA.tab(), LA.rows, GB(h->e_a, 512)};
+    hipLaunchKernelGGL(k_embed_tokens_ptr, dim3((LA.rows + 1) / 2), dim3(256), 0, s, ea);
+    if (encoder_core(h, LA, LT, L2, 1, nullptr, s)) return -1;
+    {
+        GemmArgs a = gemm_args(GB(h->e_ln, 512), 512, 0, h->w.enc_proj.w, L2.rows, 128, 512);
+        a.bias = h->w.enc_proj.b; a.out_f32 = h->mu; a.ldo = 80; a.n_store = 80; a.seq = L2.tab(); a.mask = 1;
+        if (gemm_launch_cfg(a, 0, 1, true, s)) return -1;
+    }
+    // Euler loop over the new frames only
+    EstCtx c{h, &LIE, nullptr, 50, s};
+    c.inc = &tabs;
+    for (int st = 0; st <= h->d.n_timesteps; st++) {
+        PackArgs p{h->xs, h->mu, h->spk, (const float* const*)(dp + U), ibase, st == 0 ? h->w.rand_noise : nullptr,
+                   st == 0 ? nullptr : h->vf, st == 0 ? 0.f : h->dt_host[st - 1], h->d.cfg_rate, LI.tab(), RI, U, GB(h->a0, 320),
+                   ibase + 3 * U, ibase + 2 * U, twin, INC_LEAD};
+        hipLaunchKernelGGL(k_euler_pack, dim3(((long)RI * 20 + 255) / 256), dim3(256), 0, s, p);
+        if (st == h->d.n_timesteps) break;                       // last update: no estimator call follows
+        c.temb = h->temb_tab + (size_t)st * 14 * 256;
+        c.step = st;
+        if (estimator_core(c)) return -1;
+    }
+    MelOutArgs mo{h->xs, (float* const*)(dp + 2 * U), ibase + U, LI.tab()};
+    hipLaunchKernelGGL(k_mel_out, dim3(((long)maxn2 * 80 + 255) / 256, U), dim3(256), 0, s, mo);
     CV2_LAUNCH_CHECK();
     return 0;
 }

@@ -56,6 +56,23 @@ class FlowUtt(C.Structure):
                 ('embedding', C.c_void_p), ('mel_out', C.c_void_p)]
 
 
+class FlowCacheRef(C.Structure):
+    _fields_ = [('cache', C.c_void_p), ('cache_frames', C.c_int32), ('n_cached', C.c_int32), ('gen', C.c_int32)]
+
+
+class FlowCache:
+    """Per-stream state of cv2_flow_inference_chunk: the device buffer (zero-initialised) plus what the next call needs to know."""
+    __slots__ = ('buf', 'frames', 'n_cached', 'gen')
+
+    def __init__(self, engine, max_frames):
+        self.frames = (int(max_frames) + 63) // 64 * 64
+        nbytes = engine.lib.cv2_flow_cache_bytes(engine.handle, self.frames)
+        if nbytes == 0:
+            raise ValueError(f'flow cache: bad capacity {self.frames}')
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=engine.device)
+        self.n_cached, self.gen = 0, 0
+
+
 def _bind(lib):
     if getattr(lib, '_flow_bound', False):
         return
@@ -65,6 +82,9 @@ def _bind(lib):
                                     C.POINTER(C.c_void_p)]
     lib.cv2_flow_destroy.argtypes = [C.c_void_p]
     lib.cv2_flow_inference.argtypes = [C.c_void_p, C.POINTER(FlowUtt), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.cv2_flow_cache_bytes.restype = C.c_size_t
+    lib.cv2_flow_cache_bytes.argtypes = [C.c_void_p, C.c_int32]
+    lib.cv2_flow_inference_chunk.argtypes = [C.c_void_p, C.POINTER(FlowUtt), C.POINTER(FlowCacheRef), C.c_int32, C.c_int32, C.c_void_p]
     lib.cv2_flow_estimator.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p]
     lib.cv2_flow_encoder.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.cv2_gemm_bf16.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
@@ -207,6 +227,40 @@ class FlowEngine:
             outs.append(out)
             arr[i] = FlowUtt(tok.data_ptr(), tok.numel(), pf.data_ptr(), pf.shape[0], emb.data_ptr(), out.data_ptr())
         L.check(self.lib.cv2_flow_inference(self.handle, arr, len(utts), int(streaming), int(finalize), L.stream_ptr()))
+        self._last_keep = keep
+        return outs
+
+    # ---- the same call for streams that keep a cache: only the frames after the cached ones are computed and returned --------
+    def new_cache(self, max_frames):
+        return FlowCache(self, max_frames)
+
+    def inference_chunk_batch(self, utts, caches, finalize):
+        """utts as for inference_batch (token = the whole prefix so far), caches[i] = the stream's FlowCache.  Returns
+        [(mel [1, 80, n] fp32, first) ...]: the frames from index `first` of the mel the recompute would return (flow.py:281).
+        The caches advance only when the whole call succeeded."""
+        assert 1 <= len(utts) <= self.max_utts and len(caches) == len(utts)
+        dev = self.device
+        arr, refs = (FlowUtt * len(utts))(), (FlowCacheRef * len(utts))()
+        outs, keep, ends = [], [], []
+        la = 0 if finalize else self.pre_lookahead_len
+        for i, (u, c) in enumerate(zip(utts, caches)):
+            tok = torch.cat([u['prompt_token'].reshape(-1).to(dev), u['token'].reshape(-1).to(dev)]).to(dtype=torch.int32).contiguous()
+            pf = u['prompt_feat'].reshape(-1, 80).to(device=dev, dtype=torch.float32).contiguous()
+            emb = u['embedding'].reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+            t2 = 2 * (tok.numel() - la)
+            first = max(c.n_cached, pf.shape[0])
+            n = t2 - first
+            if n < 0 or t2 <= c.n_cached:
+                raise ValueError(f'flow cache: the call ends at frame {t2} but {c.n_cached} frames are cached')
+            out = torch.empty(1, 80, n, dtype=torch.float32, device=dev)
+            keep += [tok, pf, emb]
+            outs.append((out, first - pf.shape[0]))
+            ends.append(t2)
+            arr[i] = FlowUtt(tok.data_ptr(), tok.numel(), pf.data_ptr(), pf.shape[0], emb.data_ptr(), out.data_ptr())
+            refs[i] = FlowCacheRef(c.buf.data_ptr(), c.frames, c.n_cached, c.gen)
+        L.check(self.lib.cv2_flow_inference_chunk(self.handle, arr, refs, len(utts), int(finalize), L.stream_ptr()))
+        for c, t2 in zip(caches, ends):
+            c.n_cached, c.gen = t2, c.gen + 1
         self._last_keep = keep
         return outs
 

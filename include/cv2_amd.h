@@ -230,6 +230,24 @@ typedef struct {
 } cv2_flow_utt;
 int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t n_utts, int32_t streaming, int32_t finalize, void* stream);
 
+/* Streaming calls with a per-stream cache.  The reference's token2wav re-runs flow.inference over the WHOLE prefix for every chunk
+ * (cli/model.py:351-381, 300-311) and keeps mel[token_offset * 2:].  With streaming masks the estimator is chunk-causal (flow/decoder.py:
+ * 439-441: static chunk of 50 frames; every convolution is causal), so the frames of finished chunks never change: this entry point
+ * computes only the frames the cache does not hold yet and returns exactly those the recompute would have produced for them.
+ *   cache         device memory of cv2_flow_cache_bytes(h, cache_frames) bytes, ZERO-initialised by the caller before the first call of a
+ *                 stream, owned by the caller (one per stream); cache_frames = a multiple of 64 >= the longest prefix in frames
+ *   n_cached      frames the cache holds = 2 * (n_tok - 3) of the stream's previous (non-final) call, 0 on the first call; a multiple of 50
+ *   gen           0 on the first call, +1 after every SUCCESSFUL call (the convolution tails are double-buffered on it, so a failed
+ *                 call can be repeated)
+ * utts[u] as for cv2_flow_inference (tokens = the whole prefix), except
+ *   mel_out[u]    fp32 [80][n] with n = 2 * (n_tok - 3 * !finalize) - max(n_cached, n_prompt_feat): the frames after the cached ones
+ * A non-final call must end on a chunk boundary (2 * (n_tok - 3) % 50 == 0), as the reference's hop alignment guarantees
+ * (cli/model.py:357-360). */
+typedef struct { void* cache; int32_t cache_frames; int32_t n_cached; int32_t gen; } cv2_flow_cache_ref;
+size_t cv2_flow_cache_bytes(const cv2_flow* h, int32_t cache_frames);
+int cv2_flow_inference_chunk(cv2_flow* h, const cv2_flow_utt* utts, const cv2_flow_cache_ref* refs, int32_t n_utts, int32_t finalize,
+                             void* stream);
+
 /* The estimator alone behind the reference's TensorRT seam (flow_matching.py:125-150): six contiguous device
  * tensors x(2,80,T) mask(2,1,T) mu(2,80,T) t(2,) spks(2,80) cond(2,80,T), result written in place into x. */
 int cv2_flow_estimator(cv2_flow* h, float* x, const float* mask, const float* mu, const float* t, const float* spks,

@@ -228,3 +228,92 @@ def test_flow_inference_error_is_explained_by_operand_rounding(golden, eng, flow
             hip_vs_rounded_max=rel(got, refr), hip_vs_rounded_mean=_mrel(got, refr))
     assert hip_mean < 1.25 * rnd_mean and hip_max < 1.25 * rnd_max, \
         f'HIP vs reference (max {hip_max:.3e}, mean {hip_mean:.3e}) exceeds what bf16 operand rounding explains (max {rnd_max:.3e}, mean {rnd_mean:.3e})'
+
+
+def _stream_calls(P, N, hop=25, la=3):
+    """Token counts of the flow calls of one streaming utterance (cli/model.py:351-381): (n_tokens_given, token_offset, finalize)."""
+    pad = -(-P // hop) * hop - P
+    calls, off = [], 0
+    while True:
+        this = hop + pad if off == 0 else hop
+        if N - off >= this + la:
+            calls.append((off + this + la, off, False))
+            off += this
+        else:
+            break
+    calls.append((N, off, True))
+    return calls
+
+
+def test_cached_chunks_equal_the_recompute_of_the_whole_prefix(eng):
+    """cv2_flow_inference_chunk (per-stream K/V + conv-tail cache) against the reference's scheme, which re-runs flow.inference over the
+    whole prefix for every chunk and keeps mel[:, :, token_offset*2:] (cli/model.py:300-311).  Same kernels and arithmetic class, other
+    row counts (so other tile shapes / summation orders): agreement to bf16 round-off, the bound of the batch-vs-single test above."""
+    from cv2amd import synth
+    P, N = 37, 150
+    inp = synth.synthetic_inputs(seed=91, prompt_len=P)
+    tok = torch.randint(0, 6561, (1, N), generator=torch.Generator().manual_seed(5), dtype=torch.int32)
+    calls = _stream_calls(P, N)
+    assert len(calls) >= 5 and calls[-1][2]
+    cache = eng.new_cache(2 * (P + N))
+    worst = 0.0
+    for n, off, fin in calls:
+        u = dict(token=tok[:, :n], prompt_token=inp['prompt_token'], prompt_feat=inp['prompt_feat'], embedding=inp['embedding'])
+        ref = eng.inference_batch([u], streaming=True, finalize=fin)[0][:, :, 2 * off:].clone()
+        (got, first), = eng.inference_chunk_batch([u], [cache], finalize=fin)
+        torch.cuda.synchronize()
+        assert first == 2 * off, (first, off)
+        assert got.shape == ref.shape and torch.isfinite(got).all()
+        worst = max(worst, rel(got.cpu(), ref.cpu()))
+        assert rel(got.cpu(), ref.cpu()) < 3e-2, f'call at offset {off}: {rel(got.cpu(), ref.cpu()):.3e}'
+    assert cache.n_cached == 2 * (P + N) and cache.gen == len(calls)
+    _record('cached_chunks_vs_recompute', worst_rel=worst, calls=len(calls))
+
+
+def test_cached_chunks_of_streams_in_different_phases_share_a_batch(eng):
+    """Three streams whose calls are batched although one is at its first chunk, one in the middle and one just started later: every
+    stream gets what it gets alone; a repeated call (same gen, as after a failure elsewhere in the batch) reproduces the result."""
+    from cv2amd import synth
+    specs = [(20, 120, 61), (44, 95, 62), (25, 140, 63)]
+    streams = []
+    for P, N, seed in specs:
+        inp = synth.synthetic_inputs(seed=seed, prompt_len=P)
+        tok = torch.randint(0, 6561, (1, N), generator=torch.Generator().manual_seed(seed), dtype=torch.int32)
+        streams.append(dict(inp=inp, tok=tok, calls=_stream_calls(P, N), P=P, N=N))
+
+    def utt(st, n):
+        return dict(token=st['tok'][:, :n], prompt_token=st['inp']['prompt_token'], prompt_feat=st['inp']['prompt_feat'],
+                    embedding=st['inp']['embedding'])
+    # alone
+    alone = []
+    for st in streams:
+        c = eng.new_cache(2 * (st['P'] + st['N']))
+        outs = []
+        for n, off, fin in st['calls']:
+            (m, first), = eng.inference_chunk_batch([utt(st, n)], [c], finalize=fin)
+            outs.append(m.clone())
+        alone.append(outs)
+    # batched, stream k starts k rounds late; non-final calls only share a batch with non-final calls
+    caches = [eng.new_cache(2 * (st['P'] + st['N'])) for st in streams]
+    pos = [0, 0, 0]
+    rnd = 0
+    while any(p < len(st['calls']) for p, st in zip(pos, streams)):
+        ready = [k for k, st in enumerate(streams) if rnd >= k and pos[k] < len(st['calls'])]
+        for fin in (False, True):
+            grp = [k for k in ready if streams[k]['calls'][pos[k]][2] == fin]
+            if not grp:
+                continue
+            us = [utt(streams[k], streams[k]['calls'][pos[k]][0]) for k in grp]
+            if rnd == 2 and not fin:                                          # a repeated call must be harmless
+                saved = [(caches[k].n_cached, caches[k].gen) for k in grp]
+                eng.inference_chunk_batch(us, [caches[k] for k in grp], finalize=fin)
+                for k, (nc, g) in zip(grp, saved):
+                    caches[k].n_cached, caches[k].gen = nc, g
+            outs = eng.inference_chunk_batch(us, [caches[k] for k in grp], finalize=fin)
+            torch.cuda.synchronize()
+            for k, (m, first) in zip(grp, outs):
+                ref = alone[k][pos[k]]
+                assert m.shape == ref.shape
+                assert rel(m.cpu(), ref.cpu()) < 3e-2, f'stream {k} call {pos[k]}: {rel(m.cpu(), ref.cpu()):.3e}'
+                pos[k] += 1
+        rnd += 1

@@ -301,6 +301,24 @@ def test_config4_eight_streams_every_chunk_vs_reference_logic(cv_from_disk):
             chunks = [o['tts_speech'] for o in cv.inference_zero_shot(text, 'salut', None, zero_shot_spk_id=spk, stream=True)]
             alone[(text, spk)] = (chunks, mdl._trace)
             cnt.clear()
+        # the per-call flow cache (non-final chunks compute only their own frames) against the reference's scheme, the recompute of the
+        # whole prefix for every chunk (model.py:351-381): same frames kept, same values to bf16 round-off
+        assert mdl.flow_cache
+        mdl.flow_cache, mdl._trace = False, []
+        try:
+            text, spk = calls[0]
+            r_chunks = [o['tts_speech'] for o in cv.inference_zero_shot(text, 'salut', None, zero_shot_spk_id=spk, stream=True)]
+            r_trace = mdl._trace
+        finally:
+            mdl.flow_cache = True
+        cnt.clear()
+        c_chunks, c_trace = alone[calls[0]]
+        assert len(r_trace) == len(c_trace) >= 3
+        for k, (tc, tr_) in enumerate(zip(c_trace, r_trace)):
+            assert tc[1] == tr_[1] and tc[2] == tr_[2] and tc[0].shape == tr_[0].shape
+            a, b = tc[0][:, :, 2 * tc[1]:], tr_[0][:, :, 2 * tr_[1]:]
+            assert rel(a, b) < 3e-2, f'chunk {k}: cached flow differs from the recompute: {rel(a, b):.3e}'
+            assert c_chunks[k].shape == r_chunks[k].shape
         mdl._trace = []
         out, errs, uuid_of, tl = [None] * len(calls), [], {}, threading.local()
         mdl._on_call = lambda u: uuid_of.__setitem__(tl.i, u)
