@@ -84,6 +84,7 @@ class CosyVoice2Model:
         self._mode = threading.Condition()     # shared (streams, one LLM slot each) / exclusive (a batch) use of the engines
         self._n_shared, self._excl, self._excl_waiting = 0, False, 0
         self._slot_free, self._active_slots = [], set()
+        self._bursts, self._enq, self._slot_ready = [], {}, {}      # events of enqueued decode bursts; tokens per slot once they have run; prefill events
         self.tts_speech_token_dict = {}
         self.llm_end_dict = {}
         self.hift_cache_dict = {}
@@ -107,6 +108,7 @@ class CosyVoice2Model:
         # instead of the whole prefix the reference re-runs (model.py:351-381).  CV2_FLOW_CACHE=0: recompute like the reference.
         self.flow_cache = os.environ.get('CV2_FLOW_CACHE', '1') != '0'
         self._flow_caches = {}                 # uuid -> cv2amd.flow.FlowCache, touched under run_lock only
+        self.flow_cache_min_group, self.flow_cache_min_frames = 2, 1500
         if llm_sd is not None:
             self.load_state_dicts(llm_sd, flow_sd, hift_sd)
 
@@ -205,11 +207,28 @@ class CosyVoice2Model:
         return fc
 
     def _flow_batch(self, grp, streaming, finalize):
-        """[(mel, first frame index)] of one group of chunks; cached for the non-final chunks of streaming calls."""
+        """[(mel, first frame index)] of one group of chunks.  Non-final chunks of streaming calls go through the per-call flow cache
+        when that pays: never a call's first chunk (its latency is the one that is felt; the second chunk fills the cache instead),
+        and only when at least `flow_cache_min_group` chunks share the round or a prefix is long — one short stream alone is
+        latency-bound either way (measured: 45 ms per chunk cached, 37 ms recomputed; 8 streams: 87 ms against 127 ms per round).  A
+        cache that sat out some rounds is still valid for the frames it holds: the next cached call computes everything after them."""
         utts = [dict(token=c.token, prompt_token=c.fpt, prompt_feat=c.feat, embedding=c.femb) for c in grp]
+        outs, cached = [None] * len(grp), []
         if streaming and not finalize and self.flow_cache:
-            return self.flow.inference_chunk_batch(utts, [self._flow_cache_for(c) for c in grp], finalize=False)
-        return [(m, 0) for m in self.flow.inference_batch(utts, streaming=streaming, finalize=finalize)]
+            cached = [i for i, c in enumerate(grp) if c.offset > 0]
+            frames = [self.flow.token_mel_ratio * (grp[i].fpt.shape[1] + grp[i].token.shape[1]) for i in cached]
+            if len(cached) < self.flow_cache_min_group and not any(f >= self.flow_cache_min_frames for f in frames):
+                cached = []
+        if cached:
+            res = self.flow.inference_chunk_batch([utts[i] for i in cached], [self._flow_cache_for(grp[i]) for i in cached], finalize=False)
+            for i, r in zip(cached, res):
+                outs[i] = r
+        rest = [i for i in range(len(grp)) if outs[i] is None]
+        if rest:
+            res = self.flow.inference_batch([utts[i] for i in rest], streaming=streaming, finalize=finalize)
+            for i, m in zip(rest, res):
+                outs[i] = (m, 0)
+        return outs
 
     def _run_chunks(self, batch):
         """One round of ready chunks.  A failure is delivered only to the call it belongs to (an utterance failure must not poison its
@@ -301,6 +320,8 @@ class CosyVoice2Model:
     def _exit_shared(self, slot):
         with self._mode:
             self._active_slots.discard(slot)
+            self._enq.pop(slot, None)
+            self._slot_ready.pop(slot, None)
             self._slot_free.append(slot)
             self._slot_free.sort()
             self._n_shared -= 1
@@ -350,6 +371,10 @@ class CosyVoice2Model:
                             else:
                                 for b, x, mm in zip(grp, gx, gm):
                                     self.llm.add_requests([b.slot], [x], [mm], self.sampling_mode, self.seed, forced)
+                        ev = torch.cuda.Event()
+                        ev.record(self.llm_stream)
+                    for b in batch:
+                        self._slot_ready[b.slot], self._enq[b.slot] = ev, 1          # the prefill draws token 0
                 except BaseException as e:
                     for b in batch:
                         b.exc = e
@@ -361,18 +386,40 @@ class CosyVoice2Model:
 
     # the helpers below run under self.run_lock
     def _llm_advance(self, n_steps):
-        """n_steps decode steps for EVERY active slot (slots 0..highest active; parked slots in between idle)."""
+        """n_steps decode steps for EVERY active slot (slots 0..highest active; parked slots in between idle), enqueued on the LLM
+        stream; `_enq[slot]` = the tokens a live slot holds at most once everything enqueued so far has run."""
         if n_steps <= 0:
             return
         with self._mode:
-            hi = max(self._active_slots) + 1
+            act = sorted(self._active_slots)
         with torch.cuda.stream(self.llm_stream):
-            self.llm.step(hi, n_steps)
+            self.llm.step(act[-1] + 1, n_steps)
+            ev = torch.cuda.Event()
+            ev.record(self.llm_stream)
+        while self._bursts and self._bursts[0].query():                       # finished bursts nobody had to wait for
+            self._bursts.pop(0)
+        self._bursts.append(ev)
+        for sl in act:
+            self._enq[sl] = self._enq.get(sl, 0) + n_steps
 
-    def _llm_poll(self, this_uuid, slot):
-        """Wait for the enqueued LLM work, publish the tokens so far (the reference's thread appends to the same list)."""
-        self.llm_stream.synchronize()
-        st, toks = self.llm.read_slot(slot)
+    def _llm_poll(self, this_uuid, slot, need=None):
+        """Publish the tokens of the slot so far (the reference's thread appends to the same list).  need = None: wait for all the
+        enqueued LLM work.  Otherwise wait only until the slot holds `need` tokens: the burst that another stream's next chunk asked
+        for keeps running on the LLM stream BESIDE this chunk's flow and HiFT (a full synchronize here would put every decode burst in
+        front of the chunk round: 24 + 58 ms per round of 8 streams instead of max(24, 58))."""
+        ready = self._slot_ready.pop(slot, None)
+        if ready is not None:
+            ready.synchronize()                                               # the slot's prefill: before it the state row is the previous call's
+        if need is None:
+            self.llm_stream.synchronize()
+            del self._bursts[:]
+        while True:
+            st, toks = self.llm.read_slot(slot)
+            if need is None or len(toks) >= need or bool(st[L.ST_DONE]) or not self._bursts:
+                break
+            self._bursts.pop(0).synchronize()
+        if not self._bursts:
+            self._enq[slot] = len(toks)                                       # nothing in flight: the count is exact (ids above EOS are steps without a token)
         self.tts_speech_token_dict[this_uuid] = toks
         self.llm_end_dict[this_uuid] = bool(st[L.ST_DONE])
         return toks
@@ -588,18 +635,18 @@ class CosyVoice2Model:
                 while True:                                                    # requests the rest of the first chunk's tokens
                     this_tok, finished = None, False
                     with self.run_lock:
-                        toks = self._llm_poll(this_uuid, slot)
-                        ended = self.llm_end_dict[this_uuid]
                         this_token_hop_len = hop + prompt_token_pad if token_offset == 0 else hop
-                        have = len(toks) - token_offset
-                        if have >= this_token_hop_len + la:
-                            if not ended:                                      # the next chunk's missing tokens: their burst overlaps this
-                                self._llm_advance(this_token_hop_len + hop + la - have)   # chunk's flow + HiFT (other streams ride along)
-                            this_tok = torch.tensor(toks[:token_offset + this_token_hop_len + la], dtype=torch.int32).unsqueeze(0)
+                        need = token_offset + this_token_hop_len + la
+                        toks = self._llm_poll(this_uuid, slot, need)
+                        ended = self.llm_end_dict[this_uuid]
+                        if len(toks) >= need:
+                            if not ended:                                      # the next chunk's tokens beyond what is already enqueued (by this
+                                self._llm_advance(need + hop - max(len(toks), self._enq.get(slot, 0)))    # or another stream): the burst
+                            this_tok = torch.tensor(toks[:need], dtype=torch.int32).unsqueeze(0)          # overlaps this chunk's flow + HiFT
                         elif ended:
                             finished = True
                         else:
-                            self._llm_advance(this_token_hop_len + la - have)  # fill tokens skipped (ids > eos)
+                            self._llm_advance(need - len(toks))                # nothing in flight any more (ids above EOS are steps without a token)
                     if this_tok is not None:
                         speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, True, False, cap_hint)
                         token_offset += this_token_hop_len

@@ -272,8 +272,8 @@ struct IncTabs {
 };
 // keys / values of the call's new rows -> cache slot
 struct KvAppendArgs { const uint16_t* qk; const uint16_t* vt; long R; SeqTable seq; IncTabs inc; long slot; };
-__global__ __launch_bounds__(256) void k_kv_append(KvAppendArgs a) {
-    const int tile = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_kv_append(KvAppendArgs a) {      // grid (64-row tiles, 8 heads)
+    const int tile = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
     const int s = a.seq.tile_seq[tile];
     if (s < 0) return;
     const int start = a.seq.seq_start[s], len = a.seq.seq_len[s], p0 = a.inc.pos0[s];
@@ -282,14 +282,21 @@ __global__ __launch_bounds__(256) void k_kv_append(KvAppendArgs a) {
     const long fr = a.inc.kv_frames[s];
     uint16_t* kb = a.inc.kv[s] + a.slot * fr * 1024;
     uint16_t* vb = kb + fr * 512;
-    for (int i = tid; i < n * 64; i += 256) {                  // K rows: 64 x 16 B per frame
-        const int r = i >> 6, ch = (i & 63) * 8;
+    // K: this head's 64 channels of every frame (8 x 16 B per frame)
+    for (int i = tid; i < n * 8; i += 256) {
+        const int r = i >> 3, ch = hd * 64 + (i & 7) * 8;
         *reinterpret_cast<uint4*>(kb + (size_t)(p0 + t0 + r) * 512 + ch) =
             *reinterpret_cast<const uint4*>(a.qk + (size_t)(tile * 64 + r) * 1024 + 512 + ch);
     }
-    for (int i = tid; i < 512 * 64; i += 256) {                // V^T: 512 channels x n frames
-        const int ch = i >> 6, r = i & 63;
-        if (r < n) vb[(size_t)ch * fr + p0 + t0 + r] = a.vt[(size_t)ch * a.R + tile * 64 + r];
+    // V^T: 64 channels x n frames, two frames (4 B) per access: p0 and t0 are even
+    const int np = (n + 1) >> 1;
+    for (int i = tid; i < 64 * 32; i += 256) {
+        const int ch = hd * 64 + (i >> 5), pr = i & 31;
+        if (pr >= np) continue;
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(a.vt + (size_t)ch * a.R + tile * 64 + 2 * pr);
+        uint16_t* d = vb + (size_t)ch * fr + p0 + t0 + 2 * pr;
+        if (2 * pr + 1 < n) *reinterpret_cast<uint32_t*>(d) = v;
+        else *d = (uint16_t)(v & 0xffffu);
     }
 }
 // before a causal k=3 convolution reads `buf`: rows [start-2, start) <- the cached last two input rows of the previous call,
@@ -466,6 +473,13 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
     }
     const int start = a.seq.seq_start[s], len = a.seq.seq_len[s];
     const int t0 = m0 - start;
+    if (t0 >= len) {                                   // padding rows of the sequence's last tile(s): zeros, as for a padding tile
+#pragma unroll
+        for (int u = 0; u < QS; u++)
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) *reinterpret_cast<uint2*>(orow[u] + 16 * dt) = make_uint2(0u, 0u);
+        return;
+    }
     // key source: the packed rows of this call, or the sequence's cache slot (keys 0 .. p0 + len)
     const int p0 = a.kv ? a.pos0[s] : 0;
     const int klen = p0 + len;
@@ -838,7 +852,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
             CV2_CHECK(bi < INC_TBLOCKS, "flow: transformer block counter overflow");
             a.kv = c.inc->kv; a.kv_frames = c.inc->kv_frames; a.pos0 = c.inc->pos0; a.slot = (long)c.step * INC_TBLOCKS + bi;
             KvAppendArgs k{GB(h->qk, 1024), h->vt + GUARD, a.R, c.L->tab(), *c.inc, a.slot};
-            hipLaunchKernelGGL(k_kv_append, dim3(M / 64), dim3(256), 0, c.s, k);
+            hipLaunchKernelGGL(k_kv_append, dim3(M / 64, 8), dim3(256), 0, c.s, k);
         }
         if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(M / 128, 8), dim3(256), 0, c.s, a);   // enough blocks to fill the chip twice
         else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(M / 64, 8), dim3(256), 0, c.s, a);

@@ -267,6 +267,19 @@ def test_cached_chunks_equal_the_recompute_of_the_whole_prefix(eng):
         worst = max(worst, rel(got.cpu(), ref.cpu()))
         assert rel(got.cpu(), ref.cpu()) < 3e-2, f'call at offset {off}: {rel(got.cpu(), ref.cpu()):.3e}'
     assert cache.n_cached == 2 * (P + N) and cache.gen == len(calls)
+    # a cache that sits out some calls (the scheduler only uses it when that pays) stays valid for the frames it holds: the next
+    # cached call computes everything after them
+    lazy = eng.new_cache(2 * (P + N))
+    for k, (n, off, fin) in enumerate(calls[:-1]):
+        if k not in (1, 4):
+            continue
+        u = dict(token=tok[:, :n], prompt_token=inp['prompt_token'], prompt_feat=inp['prompt_feat'], embedding=inp['embedding'])
+        full = eng.inference_batch([u], streaming=True, finalize=fin)[0].clone()
+        before = lazy.n_cached
+        (got, first), = eng.inference_chunk_batch([u], [lazy], finalize=fin)
+        torch.cuda.synchronize()
+        assert first == max(before - 2 * P, 0) and first <= 2 * off and got.shape[2] == full.shape[2] - first
+        assert rel(got.cpu(), full[:, :, first:].cpu()) < 3e-2
     _record('cached_chunks_vs_recompute', worst_rel=worst, calls=len(calls))
 
 

@@ -294,6 +294,8 @@ def test_config4_eight_streams_every_chunk_vs_reference_logic(cv_from_disk):
                 speech = speech[:, :-3840]
             ref.append(speech)
         return ref
+    old_group = mdl.flow_cache_min_group
+    mdl.flow_cache_min_group = 1                    # a stream alone uses its flow cache too (by default only from two chunks per round on)
     try:
         alone = {}
         for text, spk in calls[:2]:
@@ -335,6 +337,7 @@ def test_config4_eight_streams_every_chunk_vs_reference_logic(cv_from_disk):
         trace = mdl._trace
     finally:
         mdl._noise_hook, mdl._noise_hook_takes_uuid, mdl._trace, mdl._on_call = None, False, None, None
+        mdl.flow_cache_min_group = old_group
     assert not errs, errs
     by_uuid = {}
     for t in trace:
@@ -362,6 +365,7 @@ def test_config4_eight_streams_every_chunk_vs_reference_logic(cv_from_disk):
             m_alone, m_conc = a_trace[c][0], tr[c][0]
             assert m_alone.shape == m_conc.shape and rel(m_conc, m_alone) < 3e-2, f'stream {i} chunk {c}: flow mel differs from the solo run'
     assert sorted(mdl._slot_free) == list(range(mdl.max_batch)) and not mdl._active_slots and not mdl.hift_cache_dict and not mdl._hift_pin
+    assert not mdl._flow_caches
 
 
 def test_one_failing_request_does_not_poison_its_batch(dev):
