@@ -1270,3 +1270,16 @@ extern "C" int cv2_flow_inference_chunk(cv2_flow* h, const cv2_flow_utt* utts, c
     CV2_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------ test hook: the epilogue activations as the GEMM kernels evaluate them
+__global__ void k_dbg_act(const float* x, float* out, int n, int act, float slope) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = act_apply(x[i], act, slope);
+}
+extern "C" int cv2_dbg_act(const float* x, float* out, int64_t n, int32_t act, float slope, void* stream) {
+    CV2_CHECK(x && out && n > 0 && n < (1ll << 30), "cv2_dbg_act: bad argument");
+    hipLaunchKernelGGL(k_dbg_act, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, (int)n, (int)act, slope);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+

@@ -529,3 +529,16 @@ extern "C" int cv2_fade_in_out(float* fade_in, const float* old_tail, const floa
     CV2_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------ test hook: the conv pre-activations (Snake / leaky ReLU) as k_conv evaluates them
+__global__ void k_dbg_pre(const float* x, float* out, int n, int pre, float alpha, float slope) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = pre_apply(x[i], pre, alpha, slope);
+}
+extern "C" int cv2_dbg_pre(const float* x, float* out, int64_t n, int32_t pre, float alpha, float slope, void* stream) {
+    CV2_CHECK(x && out && n > 0 && n < (1ll << 30), "cv2_dbg_pre: bad argument");
+    hipLaunchKernelGGL(k_dbg_pre, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, (int)n, (int)pre, alpha, slope);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+

@@ -303,6 +303,13 @@ int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, const float* ca
  * win fp32 [2w] (np.hamming(2w)), old_tail points at the last w samples of the previous chunk. */
 int cv2_fade_in_out(float* fade_in, const float* old_tail, const float* window, int32_t w, void* stream);
 
+/* Test hooks: the element-wise functions exactly as the kernels evaluate them (fast-math exp / sin / reciprocal), so that their
+ * error against libm can be swept over the input ranges of the real checkpoint (tests/test_math_gpu.py).
+ *   act: 1 exact-erf GELU (diffusers GELU, matcha transformer.py FeedForward), 2 SiLU, 3 Mish, 4 leaky ReLU (slope)
+ *   pre: 1 Snake x + sin^2(alpha x) / (alpha + 1e-9) (hifigan/generator.py ResBlock activations), 2 leaky ReLU (slope) */
+int cv2_dbg_act(const float* x, float* out, int64_t n, int32_t act, float slope, void* stream);
+int cv2_dbg_pre(const float* x, float* out, int64_t n, int32_t pre, float alpha, float slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
