@@ -109,6 +109,7 @@ class CosyVoice2Model:
         self.flow_cache = os.environ.get('CV2_FLOW_CACHE', '1') != '0'
         self._flow_caches = {}                 # uuid -> cv2amd.flow.FlowCache, touched under run_lock only
         self.flow_cache_min_group, self.flow_cache_min_frames = 2, 1500
+        self.flow_cache_headroom = 0.5         # capacity beyond the chunk at hand when the caller's estimate is smaller
         if llm_sd is not None:
             self.load_state_dicts(llm_sd, flow_sd, hift_sd)
 
@@ -202,7 +203,7 @@ class CosyVoice2Model:
         need = self.flow.token_mel_ratio * (c.fpt.shape[1] + c.token.shape[1] - self.flow.pre_lookahead_len)
         fc = self._flow_caches.get(c.uuid)
         if fc is None or fc.frames < need:
-            cap = min(max(c.cap_hint or 0, need + need // 2), self.flow.max_len)
+            cap = min(max(c.cap_hint or 0, need + int(need * self.flow_cache_headroom)), self.flow.max_len)
             fc = self._flow_caches[c.uuid] = self.flow.new_cache(max(cap, need))
         return fc
 

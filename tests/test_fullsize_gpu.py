@@ -461,3 +461,49 @@ def test_generator_text_and_vc_through_the_scheduler(dev):
                                             flow_embedding=inp['embedding'], stream=True)]
     assert len(vcs) >= 2 and sum(c.shape[1] for c in vcs) == 960 * 70
     assert sorted(mdl._slot_free) == [0, 1] and not mdl.tts_speech_token_dict
+
+
+def test_flow_cache_policy_and_regrowth(cv_from_disk):
+    """The scheduler's use of the per-call flow cache: (1) by default one stream alone recomputes (no cache is allocated) — the cache
+    only pays from two chunks per round on; (2) forced on with a capacity hint that is far too small, the cache is replaced by a
+    larger empty one when a chunk does not fit, which turns that chunk into a recompute of the prefix: same number of chunks, same
+    chunk boundaries, mels equal to the recompute run to bf16 round-off."""
+    cv = cv_from_disk
+    mdl = cv.model
+    made = []
+    orig = mdl.flow.new_cache
+
+    def spy(frames):
+        made.append(frames)
+        return orig(frames)
+    mdl.flow.new_cache = spy
+    try:
+        mdl._trace = []
+        ref_chunks = [o['tts_speech'] for o in cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr', stream=True)]
+        ref_trace = mdl._trace
+        assert not made and len(ref_trace) >= 3
+        mdl.flow_cache_min_group, mdl.flow_cache_headroom, mdl._trace = 1, 0.0, []
+        real_submit = mdl._chunk_submit
+
+        def tiny_hint(*a, **k):
+            a = list(a)
+            if len(a) >= 9:
+                a[8] = 64
+            elif 'cap_hint' in k:
+                k['cap_hint'] = 64
+            return real_submit(*a, **k)
+        mdl._chunk_submit = tiny_hint
+        chunks = [o['tts_speech'] for o in cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr', stream=True)]
+        trace = mdl._trace
+    finally:
+        mdl.flow.new_cache = orig
+        mdl.flow_cache_min_group, mdl.flow_cache_headroom, mdl._trace = 2, 0.5, None
+        if '_chunk_submit' in mdl.__dict__:
+            del mdl.__dict__['_chunk_submit']
+    assert len(made) >= 2 and all(a < b for a, b in zip(made, made[1:])), made        # too small at least once: replaced by a larger one
+    assert len(chunks) == len(ref_chunks) and [c.shape for c in chunks] == [c.shape for c in ref_chunks]
+    for k, (a, b) in enumerate(zip(trace, ref_trace)):
+        assert a[1] == b[1] and a[2] == b[2]
+        assert rel(a[0][:, :, 2 * a[1]:], b[0][:, :, 2 * b[1]:]) < 3e-2, f'chunk {k}'
+    assert not mdl._flow_caches
+
