@@ -448,7 +448,7 @@ __device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t*
 // KSP = 2: a second group of NW waves works on the odd key tiles of the same queries (own LDS tiles, own register sets) and the two
 // (max, sum, O) states are merged through LDS at the end.  One utterance gives only one wave per SIMD otherwise, and every LDS /
 // MFMA / transcendental latency of the tile body is then exposed (phase stamps: ~1400 cycles of compute per 64-key tile).
-template <int QS, int NW, int KSP = 1>
+template <int QS, int NW, int KSP = 1, bool CACHE = false>
 __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t Ks_[KSP][2][64 * AK_LD];
     __shared__ __attribute__((aligned(16))) uint16_t Vs_[KSP][2][64 * AV_LD];
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
     }
     const int start = a.seq.seq_start[s], len = a.seq.seq_len[s];
     const int t0 = m0 - start;
-    if (t0 >= len) {                                   // padding rows of the sequence's last tile(s): zeros, as for a padding tile
+    if (CACHE && t0 >= len) {                          // padding rows of the sequence's last tile(s): zeros, as for a padding tile
 #pragma unroll
         for (int u = 0; u < QS; u++)
 #pragma unroll
@@ -481,16 +481,13 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
         return;
     }
     // key source: the packed rows of this call, or the sequence's cache slot (keys 0 .. p0 + len)
-    const int p0 = a.kv ? a.pos0[s] : 0;
+    const int p0 = CACHE ? a.pos0[s] : 0;
     const int klen = p0 + len;
-    const uint16_t* kbase; const uint16_t* vbase; long kld, vld;
-    if (a.kv) {
+    const uint16_t* kbase = nullptr; const uint16_t* vbase = nullptr; long vld = 0;      // CACHE only; the packed-row form below is the round-1 code
+    if (CACHE) {
         const long fr = a.kv_frames[s];
-        kbase = a.kv[s] + a.slot * fr * 1024 + h * 64; kld = 512;
+        kbase = a.kv[s] + a.slot * fr * 1024 + h * 64;
         vbase = a.kv[s] + a.slot * fr * 1024 + fr * 512 + (long)h * 64 * fr; vld = fr;
-    } else {
-        kbase = a.qk + (size_t)start * 1024 + 512 + h * 64; kld = 1024;
-        vbase = a.vt + (size_t)h * 64 * a.R + start; vld = a.R;
     }
     int tq[QS], kmax_q[QS];
 #pragma unroll
@@ -519,10 +516,15 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
 #define ATT_GLOAD1(S, C, KROW)                                                                                               \
     if (NCH > C) {                                                                                                           \
         const int idx = tid + 64 * NW * C, kr = idx >> 3, kc = idx & 7;                                                       \
-        kreg##S##C = *reinterpret_cast<const uint4*>(kbase + ((KROW) + kr) * kld + kc * 8);                                   \
-        vreg##S##C = *reinterpret_cast<const uint4*>(vbase + kr * vld + (KROW) + kc * 8);                                     \
+        if (CACHE) {                                                                                                          \
+            kreg##S##C = *reinterpret_cast<const uint4*>(kbase + ((KROW) - start + kr) * 512 + kc * 8);                       \
+            vreg##S##C = *reinterpret_cast<const uint4*>(vbase + kr * vld + ((KROW) - start) + kc * 8);                       \
+        } else {                                                                                                              \
+            kreg##S##C = *reinterpret_cast<const uint4*>(a.qk + (size_t)((KROW) + kr) * 1024 + 512 + h * 64 + kc * 8);        \
+            vreg##S##C = *reinterpret_cast<const uint4*>(a.vt + (size_t)(h * 64 + kr) * a.R + (KROW) + kc * 8);               \
+        }                                                                                                                     \
     }
-#define ATT_GLOAD(S, KT) { const long krow_ = (long)(KT) * 64; ATT_GLOAD1(S, 0, krow_) ATT_GLOAD1(S, 1, krow_) ATT_GLOAD1(S, 2, krow_) ATT_GLOAD1(S, 3, krow_) }
+#define ATT_GLOAD(S, KT) { const long krow_ = (long)start + (KT) * 64; ATT_GLOAD1(S, 0, krow_) ATT_GLOAD1(S, 1, krow_) ATT_GLOAD1(S, 2, krow_) ATT_GLOAD1(S, 3, krow_) }
 #define ATT_LSTORE1(S, C, BUF)                                                                                               \
     if (NCH > C) {                                                                                                           \
         const int idx = tid + 64 * NW * C, kr = idx >> 3, kc = idx & 7;                                                       \
@@ -854,7 +856,12 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
             KvAppendArgs k{GB(h->qk, 1024), h->vt + GUARD, a.R, c.L->tab(), *c.inc, a.slot};
             hipLaunchKernelGGL(k_kv_append, dim3(M / 64, 8), dim3(256), 0, c.s, k);
         }
-        if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(M / 128, 8), dim3(256), 0, c.s, a);   // enough blocks to fill the chip twice
+        if (c.inc) {
+            if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4, 1, true>), dim3(M / 128, 8), dim3(256), 0, c.s, a);
+            else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4, 1, true>), dim3(M / 64, 8), dim3(256), 0, c.s, a);
+            else hipLaunchKernelGGL((k_attn_est<1, 2, 2, true>), dim3(M / 32, 8), dim3(256), 0, c.s, a);
+        }
+        else if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(M / 128, 8), dim3(256), 0, c.s, a);   // enough blocks to fill the chip twice
         else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(M / 64, 8), dim3(256), 0, c.s, a);
         else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(M / 32, 8), dim3(256), 0, c.s, a);       // one utterance: split keys over two wave groups
     }
