@@ -273,7 +273,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
             rs_one = rsqrtf((rstd[0] + rstd[1]) / (float)K + X.eps);
         }
         SK_STAMP(2);                                             // operand arrived
-    } else if (X.norm_w) {
+    } else if (X.norm_w && !DEFER) {                             // (DEFER: the sums of squares are taken in the staging pass below: each item is folded once)
         for (int it = tid; it < nitems; it += nthreads) {
             f32x8 v = v0;
             if (it != tid) { const int r = row_of(it), k8 = it - r * k8n; v = sk_load_x<ATT>(X, r, K, ks0 * 32 + k8 * 8); }
@@ -296,6 +296,8 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
         f32x8 v = v0, g = g0;
         if (it != tid) { v = sk_load_x<ATT>(X, r, K, k); if (X.norm_w) g = *reinterpret_cast<const f32x8*>(X.norm_w + k); }
         if (X.x_out && blockIdx.x == 0) *reinterpret_cast<f32x8*>(X.x_out + (unsigned)(r * K + k)) = v;
+        if (DEFER && X.norm_w && !one_row)
+            isq[it] = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
         if (X.norm_w) v = DEFER ? g * v : g * (v * (one_row ? rs_one : rstd[r]));
         bf16x8 hi, lo;
         split8(v, hi, lo);
