@@ -13,38 +13,6 @@ class FrontEndUnavailable(RuntimeError):
     pass
 
 
-def _mel_24k(speech_24k):
-    """matcha.utils.audio.mel_spectrogram with the cosyvoice2.yaml feat_extractor settings (n_fft 1920, hop 480, win 1920,
-    80 mels, fmin 0, fmax 8000, center False; matcha/utils/audio.py:45-82): reflect-pad (n_fft-hop)/2, hann STFT, slaney mel
-    filterbank, log(clamp(.., 1e-5))."""
-    import numpy as np
-    n_fft, hop, n_mels, sr, fmax = 1920, 480, 80, 24000, 8000
-
-    def hz_to_mel(f):
-        f = np.asarray(f, dtype=np.float64)
-        mel = f / (200.0 / 3)
-        lin = f >= 1000.0
-        return np.where(lin, 15.0 + np.log(np.maximum(f, 1e-9) / 1000.0) / (np.log(6.4) / 27.0), mel)
-
-    def mel_to_hz(m):
-        m = np.asarray(m, dtype=np.float64)
-        return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), m * (200.0 / 3))
-
-    fftfreqs = np.linspace(0, sr / 2, n_fft // 2 + 1)
-    mel_f = mel_to_hz(np.linspace(hz_to_mel(0.0), hz_to_mel(fmax), n_mels + 2))
-    fdiff = np.diff(mel_f)
-    ramps = mel_f[:, None] - fftfreqs[None, :]
-    lower = -ramps[:-2] / fdiff[:-1, None]
-    upper = ramps[2:] / fdiff[1:, None]
-    fb = np.maximum(0, np.minimum(lower, upper)) * (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
-    fb = torch.from_numpy(fb.astype(np.float32))
-    y = torch.nn.functional.pad(speech_24k.unsqueeze(1), ((n_fft - hop) // 2, (n_fft - hop) // 2), mode='reflect').squeeze(1)
-    spec = torch.view_as_real(torch.stft(y, n_fft, hop_length=hop, win_length=n_fft, window=torch.hann_window(n_fft), center=False,
-                                         pad_mode='reflect', normalized=False, onesided=True, return_complex=True))
-    spec = torch.sqrt(spec.pow(2).sum(-1) + 1e-9)
-    return torch.log(torch.clamp(torch.matmul(fb, spec), min=1e-5))
-
-
 class PrecomputedFrontEnd:
     """Frontend over pre-extracted prompts: spk2info[id] holds the dict frontend_zero_shot would build (prompt_text tokens,
     speech tokens, prompt mel, embeddings).  Text -> ids goes through `tokenize` (any callable str -> list[int])."""
@@ -145,6 +113,7 @@ class CosyVoiceFrontEnd(PrecomputedFrontEnd):
                                                  '[hissing]', '[sigh]', '[vocalized-noise]', '[lipsmack]', '[mn]']}
         self._tok.add_special_tokens(special)                                   # tokenizer/tokenizer.py:244-265
         super().__init__(lambda t: self._tok([t], return_tensors='pt')['input_ids'][0].tolist())
+        self._prompt, self._prompt_rate = None, None                             # cv2amd.prompt.PromptFeatures, built on first use
         opt = onnxruntime.SessionOptions()
         opt.graph_optimization_level = onnxruntime.GraphOptimizationLevel.ORT_ENABLE_ALL
         opt.intra_op_num_threads = 1
@@ -183,11 +152,13 @@ class CosyVoiceFrontEnd(PrecomputedFrontEnd):
     def frontend_zero_shot(self, tts_text, prompt_text, prompt_speech_16k, resample_rate, zero_shot_spk_id):
         if zero_shot_spk_id != '':
             return super().frontend_zero_shot(tts_text, prompt_text, prompt_speech_16k, resample_rate, zero_shot_spk_id)
-        import torchaudio
         text, text_len = self._extract_text_token(tts_text)
         ptext, ptext_len = self._extract_text_token(prompt_text)
-        rs = torchaudio.transforms.Resample(orig_freq=16000, new_freq=resample_rate)(prompt_speech_16k)
-        feat = _mel_24k(rs).squeeze(0).transpose(0, 1).unsqueeze(0)
+        # frontend.py:497-498: Resample(16000, resample_rate) + feat_extractor, both on the device (cv2_resample, cv2_melspec)
+        if self._prompt is None or self._prompt_rate != resample_rate:
+            from cv2amd.prompt import PromptFeatures
+            self._prompt, self._prompt_rate = PromptFeatures(sr=resample_rate), resample_rate
+        feat = self._prompt.prompt_feat(prompt_speech_16k).cpu()
         tok, tok_len = self._extract_speech_token(prompt_speech_16k)
         n = min(int(feat.shape[1] / 2), tok.shape[1])                            # frontend.py:498-502: force feat = 2 x token
         feat, tok = feat[:, :2 * n], tok[:, :n]

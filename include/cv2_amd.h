@@ -303,6 +303,28 @@ int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, const float* ca
  * win fp32 [2w] (np.hamming(2w)), old_tail points at the last w samples of the previous chunk. */
 int cv2_fade_in_out(float* fade_in, const float* old_tail, const float* window, int32_t w, void* stream);
 
+/* =====================================================================================================================
+ * Prompt features (the extractor that feeds this path): replaces the reference's
+ *   feat_extractor = matcha.utils.audio.mel_spectrogram(n_fft 1920, num_mels 80, sampling_rate 24000, hop_size 480, win_size 1920,
+ *                    fmin 0, fmax 8000, center False)          conf/cosyvoice2.yaml:152-160, third_party/Matcha-TTS/matcha/utils/audio.py:45-82
+ *   torchaudio.transforms.Resample(16000, 24000)               cli/frontend.py:497 (torchaudio 2.3.1, functional.py _apply_sinc_resample_kernel)
+ * Table-driven: the host computes window, twiddles, mel filterbank and the polyphase kernel (cv2amd/prompt.py), all DEVICE pointers.
+ * cv2_melspec: wav fp32 [n]; out fp32 [n_frames][n_mels] time-major (= prompt_speech_feat[0]); reflect padding (n_fft - hop) / 2 on both
+ *   sides, frames of n_fft at stride hop, |DFT| = sqrt(re^2 + im^2 + 1e-9), out = log(max(mel_fb @ |DFT|, clamp_min));
+ *   n_frames = 1 + (n + (n_fft - hop) - n_fft) / hop.
+ * cv2_resample: out[i * up + p] = sum_j kernel[p][j] * xpad[i * down + j], xpad = zeros(pad_left) ++ in ++ zeros; n_out <= ceil(n_in * up / down). */
+typedef struct {
+    int32_t n_fft, hop, n_mels, n_bins;          /* n_bins = n_fft / 2 + 1 */
+    const double* window;                        /* [n_fft] fp64 */
+    const double* twiddle;                       /* [n_fft][2] fp64: cos, sin of 2 pi j / n_fft */
+    const float* mel_fb;                         /* [n_mels][n_bins] */
+    const int32_t* fb_lo; const int32_t* fb_hi;  /* [n_mels]: filter m is zero outside bins [fb_lo[m], fb_hi[m]) */
+    float clamp_min;
+} cv2_melspec_cfg;
+int cv2_melspec(const cv2_melspec_cfg* cfg, const float* wav, int64_t n, float* out, int32_t n_frames, void* stream);
+int cv2_resample(const float* in, int64_t n_in, const float* kernel, int32_t up, int32_t down, int32_t klen, int32_t pad_left,
+                 float* out, int64_t n_out, void* stream);
+
 /* Test hooks: the element-wise functions exactly as the kernels evaluate them (fast-math exp / sin / reciprocal), so that their
  * error against libm can be swept over the input ranges of the real checkpoint (tests/test_math_gpu.py).
  *   act: 1 exact-erf GELU (diffusers GELU, matcha transformer.py FeedForward), 2 SiLU, 3 Mish, 4 leaky ReLU (slope)

@@ -211,14 +211,33 @@ def test_load_wav_mono_and_resample(tmp_path):
     assert (y[0, 200:-200] - ref[200:-200]).abs().max() < 2e-3
 
 
-def test_frontend_mel_matches_reference_formula():
-    """_mel_24k against a direct restatement of matcha.utils.audio.mel_spectrogram's pieces it does not share (DFT by matmul)."""
-    from cosyvoice.cli.frontend import _mel_24k
+def test_prompt_feature_oracle_conventions():
+    """oracle/frontend.py, the CPU restatement of the prompt feature path (matcha/utils/audio.py:45-82 behind cosyvoice2.yaml:152-160,
+    torchaudio's Resample(16000, 24000) of cli/frontend.py:497).  The STFT half is pinned by torch.stft itself (the reference's call)
+    against the DFT by definition in float64; the Slaney filterbank and the sinc kernel are third-party algorithms (librosa,
+    torchaudio: absent here) checked through their structural properties only."""
+    from oracle import frontend as OF
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(1, 24000, generator=g) * 0.1
-    m = _mel_24k(x)
-    assert m.shape == (1, 80, 50)            # 24000 / 480 frames
-    assert torch.isfinite(m).all() and m.min() >= np.log(1e-5) - 1e-6
+    x = torch.randn(1, 24000 + 137, generator=g) * 0.1
+    a, b = OF.stft_mag(x), OF.stft_mag_direct(x)
+    assert a.shape == b.shape == (1, 961, 50)
+    assert (a - b).abs().max().item() < 2e-4 * a.abs().max().item()
+    m = OF.mel_spectrogram(x)
+    assert m.shape == (1, 80, 50) and torch.isfinite(m).all() and m.min() >= np.log(1e-5) - 1e-6
+    fb = OF.mel_filterbank()
+    assert fb.shape == (80, 961) and (fb >= 0).all()
+    area = fb.sum(1) * 12.5                               # bin spacing 24000 / 1920 Hz; Slaney norm: unit-area triangles
+    assert np.all(np.abs(area[2:] - 1.0) < 0.08), area
+    peaks = fb.argmax(1)
+    assert np.all(np.diff(peaks) > 0) and peaks[-1] * 12.5 < 8000.0
+    k, width, orig, new = OF.resample_kernel()
+    assert (orig, new, width) == (2, 3, 7) and tuple(k.shape) == (3, 16)
+    assert np.allclose(k.sum(1).numpy(), 1.0, atol=2e-2)                      # every output phase passes DC
+    t16 = torch.arange(16000, dtype=torch.float64) / 16000
+    y = OF.resample(torch.sin(2 * np.pi * 440 * t16).float()[None])
+    assert y.shape == (1, 24000)
+    t24 = torch.arange(24000, dtype=torch.float64) / 24000
+    assert (y[0, 50:-50] - torch.sin(2 * np.pi * 440 * t24).float()[50:-50]).abs().max().item() < 2e-3
 
 
 def test_streaming_chunk_arithmetic():
