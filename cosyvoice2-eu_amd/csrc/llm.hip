@@ -364,12 +364,16 @@ extern "C" int cv2_debug_stamps(unsigned long long* out_host) {
 #define STAMP_SET(v) do { } while (0)
 #define STAMP_SET_ON(st_, v) do { } while (0)
 #endif
-template <int NB, bool PRE = false>
+// FT feature tiles per block (PRE only): the 112 KB operand of a 32-row launch leaves room for ONE block per CU, and inter / 16 = 304
+// blocks then run in two rounds on 256 CUs; 152 blocks stage the operand once and stream two tiles' weights past it.
+template <int NB, bool PRE = false, int FT = 1>
 __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wr = (threadIdx.x >> 6) % 2;
-    float* res = skinny_core<NB, 2, 4, 8, false, PRE>(a.W, blockIdx.x * 2 + wr, a.KS, a.rows, a.K, a.X, smem);   // rows 0-15 gate, 16-31 up
     const int ld = NB * 16 + 1;
+  for (int ft = 0; ft < FT; ft++) {
+    const int ftile = blockIdx.x * FT + ft;
+    float* res = skinny_core<NB, 2, 4, 8, false, PRE, SkNoHook, (FT > 1)>(a.W, ftile * 2 + wr, a.KS, a.rows, a.K, a.X, smem, SkNoHook(), ft > 0);   // rows 0-15 gate, 16-31 up
     for (int e = threadIdx.x; e < a.rows * 16; e += blockDim.x) {
         const int r = e >> 4, i = e & 15;
         float rs = 1.f;
@@ -385,15 +389,17 @@ __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
         const float g = res[i * ld + r] * rs, u = res[(16 + i) * ld + r] * rs;
         const float hv = (g / (1.f + __expf(-g))) * u;
         if (PRE && a.hpre) {                     // LDS B-operand order of skinny.h: [k-block][row tile][hi, lo][quarter][row][8]
-            const int c = blockIdx.x * 16 + i;
+            const int c = ftile * 16 + i;
             uint16_t* d = a.hpre + ((size_t)((c >> 5) * 2 + (r >> 4)) * 2) * 512 + (((c >> 3) & 3) * 16 + (r & 15)) * 8 + (c & 7);
             const uint16_t hb = f2bf(hv);
             d[0] = hb;
             d[512] = f2bf(hv - bf2f(hb));
         } else {
-            a.h[(size_t)r * a.inter + blockIdx.x * 16 + i] = hv;
+            a.h[(size_t)r * a.inter + ftile * 16 + i] = hv;
         }
     }
+    if (ft + 1 < FT) __syncthreads();            // the tile is consumed: the next call reuses the reduction buffers
+  }
 }
 
 // ------------------------------------------------------------------ k_sample
@@ -1227,7 +1233,10 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
             pre2.pre = h->xp2;
             a.W = L.wgu; a.X = pre2; a.KS = KSH; a.rows = rows; a.K = H; a.inter = d.inter; a.h = h->hbuf; a.hpre = h->xp_h;
             a.sq = h->sqp; a.nsq = H / 16; a.eps = d.rms_eps;
-            { const size_t sm = skinny_smem_bytes<2, 2, 4>(KSH); hipLaunchKernelGGL((k_gateup<2, true>), dim3(d.inter / 16, 1), dim3(512), sm, s, a); }
+            if ((d.inter / 16) % 2 == 0 && d.inter / 16 > 256) {     // more tiles than CUs: two per block, one round
+                const size_t sm = skinny_smem_bytes_keep<2, 2, 4>(KSH);
+                hipLaunchKernelGGL((k_gateup<2, true, 2>), dim3(d.inter / 32, 1), dim3(512), sm, s, a);
+            } else { const size_t sm = skinny_smem_bytes<2, 2, 4>(KSH); hipLaunchKernelGGL((k_gateup<2, true>), dim3(d.inter / 16, 1), dim3(512), sm, s, a); }
         }
         {
             StoreArgs a{};
@@ -1261,7 +1270,7 @@ static int init_attrs_once() {
     const size_t big = 160 * 1024;
     if (set_smem(k_qkv<1>, big) || set_smem(k_qkv<2>, big) || set_smem(k_gateup<1>, big) || set_smem(k_gateup<2>, big) ||
         set_smem((k_store<1, 8>), big) || set_smem((k_store<2, 8>), big) || set_smem((k_store<1, 8, true>), big) || set_smem((k_store<2, 8, true>), big) || set_smem((k_store<1, 10>), big) ||
-        set_smem((k_store<2, 10>), big) || set_smem((k_qkv<2, true>), big) || set_smem((k_gateup<2, true>), big) ||
+        set_smem((k_store<2, 10>), big) || set_smem((k_qkv<2, true>), big) || set_smem((k_gateup<2, true>), big) || set_smem((k_gateup<2, true, 2>), big) ||
         set_smem((k_store<2, 8, false, true>), big) || set_smem((k_store<2, 8, false, true, true>), big) || set_smem((k_store<2, 10, false, true>), big))
         return -1;
     done = true;

@@ -153,9 +153,11 @@ __device__ __host__ constexpr int sk_xstage_bytes(int nks) { return nks * NB * 2
 // `tile` = this wave's 16-feature row tile of W.
 // `issued` runs right after the last weight load has been issued and before anything is consumed: the place for a caller's
 // dependent loads (k_qkv: position -> RoPE table) that must not delay the stream.
-template <int NB, int NWR, int NWK, int MAXKS, bool ATT = false, bool PRE = false, class HOOK = SkNoHook>
+// KEEP (PRE kernels that run several feature tiles per block): the reduction buffers sit behind the x stage also for 32 rows, so the
+// staged operand survives the call; `staged` = the operand of an earlier call is still there (no DMA, no wait for it).
+template <int NB, int NWR, int NWK, int MAXKS, bool ATT = false, bool PRE = false, class HOOK = SkNoHook, bool KEEP = false>
 __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, int tile, int KS, int rows, int K,
-                                               const SkinnyX& X, char* smem, HOOK issued = HOOK()) {
+                                               const SkinnyX& X, char* smem, HOOK issued = HOOK(), bool staged = false) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     // wave-uniform values are made provably uniform (readfirstlane): the weight addresses then live in scalar registers and the
@@ -174,7 +176,7 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
 
     // 0. (PRE) the operand prepared by k_prep goes global -> LDS by DMA, issued BEFORE the weight stream so that the two are in
     //    flight together and no VGPR / ds_write work is spent on it: this block's K slice [ks0, ks1) of the hi / lo planes
-    if (PRE) {
+    if (PRE && !staged) {
         const char* src = reinterpret_cast<const char*>(X.pre) + (size_t)ks0 * NB * 2 * 1024 + lane * 16;
         for (int pc = wave; pc < nks * NB * 2; pc += NWR * NWK)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)pc * 1024),
@@ -248,8 +250,10 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     }
 
   if (PRE) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!staged) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
   } else {
     // 2. fold / normalise / split the block's x slice [ks0*32, ks1*32) into LDS (B-operand order)
     //    item = (row r, group of 8 columns); the first item of every thread stays in registers.
@@ -342,8 +346,8 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     SK_STAMP(4);                                                 // weights arrived, MFMAs issued
     // 4. reduce the NWK K-slices through LDS, leave the tile in res[feature][row].  The reduction buffers sit BEHIND the x
     //    stage (not on top of it) for up to 16 rows, so no barrier is needed between the MFMAs and the partial-sum writes.
-    if (NB > 1) __syncthreads();                                  // 32-row stage is too large to keep: reuse it (x stage fully read)
-    char* rbase = NB > 1 ? smem : smem + sk_xstage_bytes<NB>(nks) + 32 * sizeof(float);
+    if (NB > 1 && !KEEP) __syncthreads();                         // 32-row stage is too large to keep: reuse it (x stage fully read)
+    char* rbase = (NB > 1 && !KEEP) ? smem : smem + sk_xstage_bytes<NB>(nks) + 32 * sizeof(float);
     f32x4* red = reinterpret_cast<f32x4*>(rbase);                                   // [NWK][NWR][NB][64]
     float* res = reinterpret_cast<float*>(rbase + NWK * NWR * NB * 1024);           // [NWR*16][NB*16+1]
 #pragma unroll
@@ -402,6 +406,10 @@ __global__ __launch_bounds__(256) void k_prep(SkinnyX X, int K, uint16_t* pre) {
     }
 }
 
+template <int NB, int NWR, int NWK>
+static inline size_t skinny_smem_bytes_keep(int nks_block) {      // KEEP layout: x stage, then the reduction buffers
+    return (size_t)nks_block * NB * 2 * 1024 + 32 * sizeof(float) + (size_t)NWK * NWR * NB * 1024 + (size_t)NWR * 16 * (NB * 16 + 1) * sizeof(float);
+}
 template <int NB, int NWR, int NWK>
 static inline size_t skinny_smem_bytes(int nks_block) {
     const size_t xs = (size_t)nks_block * NB * 2 * 1024 + 32 * sizeof(float);
