@@ -294,7 +294,7 @@ def run_single(args):
         'config': {'workload': f'configs[{1 if B == 1 else 2}]: zero-shot FR{"+DE" if B > 1 else ""}, batch={B}, non-streaming, through CosyVoice2Model.tts() '
                                f'(scheduler + D2H of the waveform inside the timed region), P=255{"/310" if B > 1 else ""} prompt tokens, '
                                f'{TEXT_LEN} text tokens, {"250" if B == 1 else "U{150..500}"} generated tokens (forced), 10 Euler steps + CFG, RAS sampler; '
-                               f'LLM bf16 weights / fp32 KV, flow bf16 MFMA, HiFT fp32 MFMA', 'batch_per_gpu': B,
+                               f'LLM bf16 weights / fp32 KV, flow bf16 MFMA, HiFT fp32 data with three-plane bf16 MFMA products (fp32-equivalent) and fp32 MFMA for the f0 predictor', 'batch_per_gpu': B,
                    'audio_s_per_step_per_gpu': round(audio_per_step, 3)},
         'roofline': {'bound': 'hbm', 'kernel': model.llm.decode_kernel_desc(B),
                      'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
@@ -303,7 +303,8 @@ def run_single(args):
                                    'hift': round(hift_t.ms() / args.steps, 3),
                                    'rest (prefill, scheduler, D2H)': round((dt * 1e3 - dec_ms - flow_t.ms() - hift_t.ms()) / args.steps, 3)},
                    'flow_mfma': {'achieved': round(flow_tf, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(flow_tf / MFMA_BF16_PEAK, 4)},
-                   'hift_fp32_mfma': {'achieved': round(hift_tf, 2), 'peak': FP32_MFMA_PEAK, 'unit': 'TFLOP/s', 'frac': round(hift_tf / FP32_MFMA_PEAK, 4)}},
+                   'hift_fp32_mfma': {'achieved': round(hift_tf, 2), 'peak': FP32_MFMA_PEAK, 'unit': 'TFLOP/s', 'frac': round(hift_tf / FP32_MFMA_PEAK, 4),
+                                      'note': 'algorithmic (fp32-equivalent) FLOP/s against the fp32 matrix roof; k_conv6 issues 6 bf16 MFMAs per term'}},
     }
     if not args.no_extra and B == 1:
         out['extra'] = extras(model, st, flow_t, hift_t, dev)

@@ -2,8 +2,9 @@
 // decode :520-552, _stft/_istft :504-518, ResBlock :94-101, SineGen2 :256-339, SourceModuleHnNSF2 :375-389,
 // ConvRNNF0Predictor f0_predictor.py:55-58, Snake transformer/activation.py:73-84).
 //
-// Layout: every activation is fp32, TIME-MAJOR [L][C].  All arithmetic is fp32 (the reference computes this stage in
-// fp32 and the waveform is exp()/sin() of the last conv, so bf16 products would not hold a tight tolerance).
+// Layout: every activation is fp32, TIME-MAJOR [L][C].  All arithmetic is fp32 or fp32-equivalent (the reference computes this
+// stage in fp32 and the waveform is exp()/sin() of the last conv, so plain bf16 products would not hold a tight tolerance): k_conv
+// multiplies on the fp32 matrix cores, k_conv6 forms every product from three bf16 planes per operand (see there).
 //
 // k_conv: Conv1d as an LDS line-buffered implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, bit-exact
 // fp32 FMA chains at the vector-FMA peak rate, leaving the VALU to the activation and address work):
@@ -33,6 +34,7 @@ enum { ACC_STORE = 0, ACC_ADD = 1, ACC_ADD_DIV3 = 2 };
 struct ConvArgs {
     const float* x; int L_in, Cin;          // input frames, channels (row stride Cin)
     const float* wp; const float* bias;     // packed weights [taps][CinP/2][CoutP/32][64], bias [CoutP]
+    const uint16_t* w3;                     // k_conv6: three bf16 planes of the weights, [taps][CinP/16][CoutP/32][3][64 lanes][8]
     int CinP, CoutP, Cout_store;            // padded sizes (CinP % 64 == 0, CoutP % 64 == 0)
     int taps, dil, pad_left;
     int pre; const float* alpha; float slope;
@@ -134,6 +136,148 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #undef CV_MMA
     }
     // epilogue: lane holds channel co (li) of its output tile and 16 frames of each of its two frame tiles
+#pragma unroll
+    for (int tile = 0; tile < 2; tile++) {
+        const int co = co0 + cw * 32 + li;
+        if (co >= a.Cout_store) continue;
+        const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int t = t0 + fw * 64 + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (t >= a.L_out) continue;
+            float v = (tile == 0 ? acc0[r] : acc1[r]) + b;
+            if (a.res) v += a.res[(size_t)t * a.ldres + co];
+            if (a.post == POST_ELU) v = v > 0.f ? v : expm1f(v);
+            float* o = a.out + (size_t)t * a.ldo + a.out_off + co;
+            if (a.acc == ACC_ADD) v = *o + v;
+            else if (a.acc == ACC_ADD_DIV3) v = (*o + v) / 3.0f;
+            *o = v;
+        }
+    }
+}
+
+// k_conv6: the same convolution on the bf16 matrix cores at fp32 accuracy.  Both operands are split into three bf16 planes
+// (x = x0 + x1 + x2, each the leading bf16 of what the previous ones left: 24 mantissa bits) and the six products of weight >= 2^-16
+// (x0 w0, x0 w1, x1 w0, x0 w2, x1 w1, x2 w0) are accumulated in the MFMA's fp32 accumulators; what is dropped (x1 w2, x2 w1, x2 w2)
+// is below 2^-23 of the term, i.e. the size of an fp32 rounding.  Six 32x32x16 bf16 MFMAs (32 cycles each) replace the eight
+// 32x32x2 fp32 MFMAs (64 cycles each) of a 16-channel step: 192 against 512 matrix-core cycles per tile.  Same block shape,
+// staging, epilogue and argument struct as k_conv; the line buffer holds the three planes of the pre-activated input.
+#define C6_G 4                                        // 16-channel steps per weight register set (4 = one tap of the 64-channel chunk)
+#define C6_LD 72                                      // bf16 elements per line-buffer row (64 + 8: 144-B stride, conflict-free ds_read_b128)
+// x = h0 + h1 + h2 EXACTLY, each the top 16 bits (sign, exponent, 7 mantissa bits) of what the previous ones left: truncation instead
+// of rounding makes the three-plane form lossless for a 24-bit mantissa and costs two ANDs and two subtractions per element
+// (round-to-nearest planes cost ~20 VALU operations per element, and this staging is VALU-bound: it runs once per block and chunk)
+__device__ __forceinline__ void split3t(float v, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
+    h0 = __builtin_bit_cast(uint32_t, v) & 0xFFFF0000u;
+    const float r1 = v - __builtin_bit_cast(float, h0);
+    h1 = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, h1);
+    h2 = __builtin_bit_cast(uint32_t, r2);               // <= 8 significant bits left: its low half is zero
+}
+// two planes' high halves -> one dword (element a low, element b high)
+__device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * CV_BT, co0 = blockIdx.y * 64;
+    const int span = (a.taps - 1) * a.dil;
+    const int rows = CV_BT + span;
+    uint16_t* xp[3];
+    xp[0] = reinterpret_cast<uint16_t*>(smem); xp[1] = xp[0] + (size_t)rows * C6_LD; xp[2] = xp[1] + (size_t)rows * C6_LD;
+    const int ntile = a.CoutP / 32;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const int li = lane & 31, lk = lane >> 5;
+    const int fw = wave >> 1, cw = wave & 1;                        // frame half (64 frames), 32-channel output tile
+    const size_t kbstride = (size_t)ntile * 3 * 512;                // elements between consecutive 16-channel blocks of one tap
+    for (int c0 = 0; c0 < a.CinP; c0 += CV_CK) {
+        __syncthreads();
+        for (int it0 = tid; it0 < rows * 16; it0 += 256 * 4) {
+            f32x4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int it = it0 + 256 * u;
+                const int r = it >> 4, c = c0 + (it & 15) * 4, t = t0 - a.pad_left + r;
+                q[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (it < rows * 16 && t >= 0 && t < a.L_in) {
+                    const float* src = a.x + (size_t)t * a.Cin + c;
+                    if (c + 3 < a.Cin) q[u] = *reinterpret_cast<const f32x4*>(src);
+                    else for (int e = 0; e < 4; e++) if (c + e < a.Cin) q[u][e] = src[e];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int it = it0 + 256 * u;
+                if (it >= rows * 16) break;
+                const int r = it >> 4, c4 = (it & 15) * 4, c = c0 + c4, t = t0 - a.pad_left + r;
+                f32x4 v = q[u];
+                if (a.pre != PRE_NONE && t >= 0 && t < a.L_in)
+                    for (int e = 0; e < 4; e++)
+                        if (c + e < a.Cin) v[e] = pre_apply(v[e], a.pre, a.pre == PRE_SNAKE ? a.alpha[c + e] : 0.f, a.slope);
+                uint32_t h0[4], h1[4], h2[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) split3t(v[e], h0[e], h1[e], h2[e]);
+                const size_t o = (size_t)r * C6_LD + c4;
+                *reinterpret_cast<uint2*>(xp[0] + o) = make_uint2(pack_hi(h0[0], h0[1]), pack_hi(h0[2], h0[3]));
+                *reinterpret_cast<uint2*>(xp[1] + o) = make_uint2(pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3]));
+                *reinterpret_cast<uint2*>(xp[2] + o) = make_uint2(pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3]));
+            }
+        }
+        __syncthreads();
+        // one 16-channel step = weight fragments of the three planes (3 x 16 B per lane, global / L2) + the two frame tiles' activation
+        // fragments of the three planes (LDS) + 12 MFMAs; the next step's weights are requested before the current step's MFMAs
+        const uint16_t* wb = a.w3 + ((size_t)(c0 / 16) * ntile + co0 / 32 + cw) * 3 * 512 + (size_t)lane * 8;
+        const size_t tapstride = (size_t)(a.CinP / 16) * kbstride;
+        // register sets of C6_G steps (3 C6_G fragments): while one set's 12 C6_G MFMAs run, the other set's loads are in flight
+        // (one step = 384 matrix-core cycles is less than an L2 round trip: with one step per set the loop ran at the weights' latency)
+        bf16x8 wA[3 * C6_G], wB[3 * C6_G];
+#define C6_LOAD(SET, GI)                                                                                            \
+        _Pragma("unroll") for (int g_ = 0; g_ < C6_G; g_++) {                                                         \
+            const int si_ = (GI) * C6_G + g_;                                                                         \
+            const uint16_t* wn_ = wb + (si_ >> 2) * tapstride + (size_t)(si_ & 3) * kbstride;                         \
+            _Pragma("unroll") for (int p = 0; p < 3; p++) SET[g_ * 3 + p] = *reinterpret_cast<const bf16x8*>(wn_ + p * 512); \
+        }
+#define C6_MMA(SET, GI)                                                                                             \
+        _Pragma("unroll") for (int g_ = 0; g_ < C6_G; g_++) {                                                         \
+            const int si_ = (GI) * C6_G + g_;                                                                         \
+            const size_t xo_ = (size_t)(fw * 64 + li + (si_ >> 2) * a.dil) * C6_LD + (si_ & 3) * 16 + lk * 8;         \
+            bf16x8 x0[3], x1[3];                                                                                      \
+            _Pragma("unroll") for (int p = 0; p < 3; p++) {                                                           \
+                x0[p] = *reinterpret_cast<const bf16x8*>(xp[p] + xo_);                                                \
+                x1[p] = *reinterpret_cast<const bf16x8*>(xp[p] + xo_ + 32 * C6_LD);                                   \
+            }                                                                                                       \
+            const bf16x8 w0_ = SET[g_ * 3], w1_ = SET[g_ * 3 + 1], w2_ = SET[g_ * 3 + 2];                             \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[2], w0_, acc0, 0, 0, 0);                                \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[2], w0_, acc1, 0, 0, 0);                                \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[1], w1_, acc0, 0, 0, 0);                                \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[1], w1_, acc1, 0, 0, 0);                                \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[0], w2_, acc0, 0, 0, 0);                                \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w2_, acc1, 0, 0, 0);                                \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[1], w0_, acc0, 0, 0, 0);                                \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[1], w0_, acc1, 0, 0, 0);                                \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[0], w1_, acc0, 0, 0, 0);                                \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w1_, acc1, 0, 0, 0);                                \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[0], w0_, acc0, 0, 0, 0);                                \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w0_, acc1, 0, 0, 0);                                \
+        }
+        static_assert(4 % C6_G == 0, "a register set must not straddle taps");
+        const int ngroups = a.taps * 4 / C6_G;
+        C6_LOAD(wA, 0)
+        for (int gi = 0; gi < ngroups; gi += 2) {
+            if (gi + 1 < ngroups) C6_LOAD(wB, gi + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            C6_MMA(wA, gi)
+            __builtin_amdgcn_sched_barrier(0);
+            if (gi + 2 < ngroups) C6_LOAD(wA, gi + 2)
+            __builtin_amdgcn_sched_barrier(0);
+            if (gi + 1 < ngroups) C6_MMA(wB, gi + 1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef C6_LOAD
+#undef C6_MMA
+    }
+    // epilogue: identical to k_conv
 #pragma unroll
     for (int tile = 0; tile < 2; tile++) {
         const int co = co0 + cw * 32 + li;
@@ -380,6 +524,7 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
     static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
     if (!once) {
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) h->cap_stream = nullptr;      // no graphs then
@@ -405,6 +550,14 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
     a.Cout_store = cw.cout; a.taps = cw.taps; a.dil = cw.dil; a.pad_left = cw.pad_left; a.pre = pre; a.alpha = alpha; a.slope = slope;
     a.L_out = L_out; a.out = out; a.ldo = ldo; a.out_off = out_off; a.res = res; a.ldres = ldres; a.post = post; a.acc = acc;
     CV2_CHECK(cw.cin_pad % 64 == 0 && cw.cout_pad % 64 == 0 && cw.w, "hift conv: bad packed weight (cin_pad %d cout_pad %d)", cw.cin_pad, cw.cout_pad);
+    static const bool fp32_only = getenv("CV2_HIFT_FP32") && getenv("CV2_HIFT_FP32")[0] == '1';      // A/B switch: the fp32 matrix-core kernel everywhere
+    if (cw.w3 && !fp32_only) {
+        a.w3 = cw.w3;
+        const size_t sm = (size_t)(CV_BT + (cw.taps - 1) * cw.dil) * C6_LD * 2 * 3;
+        hipLaunchKernelGGL(k_conv6, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64), dim3(256), sm, s, a);
+        CV2_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t sm = (size_t)(CV_BT + (cw.taps - 1) * cw.dil) * CV_LD * 4;
     hipLaunchKernelGGL(k_conv, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64), dim3(256), sm, s, a);
     CV2_LAUNCH_CHECK();

@@ -15,7 +15,7 @@ from . import lib as L
 
 class Conv(C.Structure):
     _fields_ = [('w', C.c_void_p), ('b', C.c_void_p)] + [(n, C.c_int32) for n in
-                                                          ('cin', 'cout', 'cin_pad', 'cout_pad', 'taps', 'dil', 'pad_left')]
+                                                          ('cin', 'cout', 'cin_pad', 'cout_pad', 'taps', 'dil', 'pad_left')] + [('w3', C.c_void_p)]
 
 
 class ResBlock(C.Structure):
@@ -67,6 +67,24 @@ def pack_conv_f32(w):
     return wp.view(k, cip // 2, 2, cop // 32, 32).permute(0, 1, 3, 2, 4).contiguous().reshape(-1), cip, cop
 
 
+def pack_conv_split3(w):
+    """[C_out][C_in][k] fp32 -> three bf16 planes (w = w0 + w1 + w2, each the bf16 rounding of what is left) in the MFMA 32x32x16
+    B-operand order [k][cin_pad/16][cout_pad/32][3][64 lanes][8]: lane = ((c_in % 16) // 8) * 32 + (c_out & 31), element = c_in % 8.
+    Returned as an int16 tensor of bf16 bit patterns."""
+    co, ci, k = w.shape
+    cip, cop = _pad64(ci), _pad64(co)
+    wp = w.new_zeros(k, cip, cop)
+    wp[:, :ci, :co] = w.permute(2, 1, 0)
+    wp = wp.view(k, cip // 16, 2, 8, cop // 32, 32).permute(0, 1, 4, 2, 5, 3).contiguous()          # [k][kb][nt][khalf][n][j]
+    planes, rest = [], wp
+    for _ in range(3):
+        b = rest.to(torch.bfloat16)
+        planes.append(b)
+        rest = rest - b.float()
+    out = torch.stack(planes, 3)                                                                       # [k][kb][nt][3][khalf][n][j]
+    return out.contiguous().view(torch.int16).reshape(-1)
+
+
 def polyphase(wt, u, pad):
     """ConvTranspose1d weight [C_in][C_out][k] -> equivalent Conv1d weight [u*C_out][C_in][3] over input taps q-1, q, q+1."""
     ci, co, k = wt.shape
@@ -80,9 +98,10 @@ def polyphase(wt, u, pad):
 
 
 class HiftEngine:
-    def __init__(self, sd, device='cuda:0', max_frames=2048, share_weights_with=None):
+    def __init__(self, sd, device='cuda:0', max_frames=2048, share_weights_with=None, split_products=True):
         """share_weights_with: another HiftEngine whose packed weights are reused (several engines = several workspaces, so
-        independent utterances can run on different HIP streams at once)."""
+        independent utterances can run on different HIP streams at once).  split_products=False: every convolution on the fp32
+        matrix cores (k_conv) instead of the three-plane bf16 products (k_conv6); the reference path of the A/B test."""
         sd = {k[len('generator.'):] if k.startswith('generator.') else k: v for k, v in sd.items()}     # cli/model.py:88
         self.device = dev = torch.device(device)
         self.lib = L.lib()
@@ -94,12 +113,18 @@ class HiftEngine:
             keep.append(t)
             return t.data_ptr()
 
-        def conv(w, bias, dil, pad_left):
+        def conv(w, bias, dil, pad_left, split=True):
+            """split: also pack the three-plane bf16 form (k_conv6); False keeps the convolution on the fp32 matrix cores."""
             co, ci, k = w.shape
             wp, cip, cop = pack_conv_f32(w.float())
             b = torch.zeros(cop)
             b[:co] = bias.float()
-            return Conv(f32(wp), f32(b), ci, co, cip, cop, k, dil, pad_left)
+            w3 = None
+            if split and split_products:
+                t3 = pack_conv_split3(w.float()).to(dev)
+                keep.append(t3)
+                w3 = t3.data_ptr()
+            return Conv(f32(wp), f32(b), ci, co, cip, cop, k, dil, pad_left, w3)
 
         def resblock(p, k, dils=(1, 3, 5)):
             rb = ResBlock()
@@ -130,7 +155,8 @@ class HiftEngine:
     def _pack(sd, conv, resblock, f32):
         w = HiftWeights()
         for n, i in enumerate((0, 2, 4, 6, 8)):
-            w.f0_conv[n] = conv(weight_norm(sd, f'f0_predictor.condnet.{i}'), sd[f'f0_predictor.condnet.{i}.bias'], 1, 1)
+            # the f0 predictor stays on the fp32 matrix cores: its output is integrated into a phase of ~1e5 rad (k_phase)
+            w.f0_conv[n] = conv(weight_norm(sd, f'f0_predictor.condnet.{i}'), sd[f'f0_predictor.condnet.{i}.bias'], 1, 1, split=False)
         w.f0_w, w.f0_b = f32(sd['f0_predictor.classifier.weight'].reshape(-1)), f32(sd['f0_predictor.classifier.bias'])
         w.src_w, w.src_b = f32(sd['m_source.l_linear.weight'].reshape(-1)), f32(sd['m_source.l_linear.bias'])
         w.conv_pre = conv(weight_norm(sd, 'conv_pre'), sd['conv_pre.bias'], 1, 3)

@@ -260,7 +260,7 @@ int cv2_flow_encoder(cv2_flow* h, const float* xs, int32_t T, const float* conte
 /* ------------------------------------------------------------------------------------------------
  * Stage 3 — HiFT vocoder (replaces HiFTGenerator.inference, cosyvoice/hifigan/generator.py:570-582, and decode :520-552,
  * _stft/_istft :504-518, ResBlock :94-101, SourceModuleHnNSF2 :375-389, SineGen2 :256-339, ConvRNNF0Predictor
- * f0_predictor.py:55-58).  All fp32.
+ * f0_predictor.py:55-58).  fp32 storage and accumulation throughout.
  *
  * Conv weights (weight-norm already folded, w = g v / ||v||) are fp32 in the MFMA 32x32x2 B-operand order
  * [tap][c_in/2][c_out/32][64 lanes], lane = (c_in & 1) * 32 + (c_out & 31), both channel counts zero-padded to 64.
@@ -272,6 +272,12 @@ typedef struct cv2_hift cv2_hift;
 typedef struct {
     const float* w; const float* b;     /* packed weight, bias [cout_pad] */
     int32_t cin, cout, cin_pad, cout_pad, taps, dil, pad_left;
+    const uint16_t* w3;                 /* optional: the same weight as three bf16 planes (w = w0 + w1 + w2, each the bf16 rounding of the
+                                           remainder) in the MFMA 32x32x16 B-operand order [tap][c_in/16][c_out/32][plane][64 lanes][8],
+                                           lane = ((c_in % 16) / 8) * 32 + (c_out & 31), element = c_in % 8.  When given, the convolution runs
+                                           on the bf16 matrix cores with six products per term (fp32-equivalent accuracy, csrc/hift.hip k_conv6);
+                                           NULL: fp32 matrix cores (exact fp32 FMA chains; kept for the f0 predictor, whose output is integrated
+                                           into a 1e5-rad phase) */
 } cv2_conv;
 typedef struct {                          /* ResBlock: convs1 (dilated), convs2, Snake alphas */
     cv2_conv c1[3], c2[3];
