@@ -309,9 +309,9 @@ __global__ __launch_bounds__(256) void k_source_down(SdArgs a) {
         const int f = t * a.stride - a.pad + j;
         if (f < 0 || f >= a.F) continue;
         const float* xr = a.x + (size_t)f * 18;
-        const float* wr = a.w + ((size_t)co * a.k + j) * 18;         // packed [C][k][18]
+        const float* wr = a.w + (size_t)j * 18 * a.C + co;           // packed [k][18][C]: the threads of a wave (consecutive co) read consecutive words
 #pragma unroll
-        for (int c = 0; c < 18; c++) acc += wr[c] * xr[c];
+        for (int c = 0; c < 18; c++) acc += wr[(size_t)c * a.C] * xr[c];
     }
     a.out[(size_t)t * a.C + co] = acc + a.b[co];
 }

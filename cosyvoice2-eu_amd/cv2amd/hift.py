@@ -164,7 +164,7 @@ class HiftEngine:
             wt = weight_norm(sd, f'ups.{i}')
             b = sd[f'ups.{i}.bias'].float()
             w.ups[i] = conv(polyphase(wt, u, (k - u) // 2), b.repeat(u), 1, 1)
-            w.sd_w[i] = f32(sd[f'source_downs.{i}.weight'].float().permute(0, 2, 1))
+            w.sd_w[i] = f32(sd[f'source_downs.{i}.weight'].float().permute(2, 1, 0))      # [C][18][k] -> [k][18][C]
             w.sd_b[i] = f32(sd[f'source_downs.{i}.bias'])
             w.src_rb[i] = resblock(f'source_resblocks.{i}', (7, 7, 11)[i])
             for j, k2 in enumerate((3, 7, 11)):

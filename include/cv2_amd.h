@@ -289,7 +289,7 @@ typedef struct {
     const float* src_w; const float* src_b; /* m_source.l_linear [9], [1] */
     cv2_conv conv_pre;
     cv2_conv ups[3];
-    const float* sd_w[3]; const float* sd_b[3];  /* source_downs weights re-ordered [C][k][18] */
+    const float* sd_w[3]; const float* sd_b[3];  /* source_downs weights re-ordered [k][18][C] */
     cv2_resblock src_rb[3];
     cv2_resblock rb[9];
     cv2_conv conv_post;
