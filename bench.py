@@ -367,6 +367,20 @@ def extras(model, st, flow_t, hift_t, dev):
         firsts.sort()
         out[n] = {'first_chunk_ms_p50': round(firsts[len(firsts) // 2] * 1e3, 1), 'first_chunk_ms_max': round(firsts[-1] * 1e3, 1),
                   'audio_s_per_s': round(audio / dts, 1)}
+    # first chunk when the prompt has NOT been seen before (no prompt flow cache to start from): the number a new voice gets
+    if hasattr(model, '_prompt_caches'):
+        keep_max = model.prompt_cache_max
+        model.prompt_cache_max = 0
+        model._prompt_caches.clear()
+        try:
+            firsts = []
+            for _ in range(2):
+                _, first = run_calls(model, [sreq] * 8, [None] * 8, stream=True)
+                firsts += first
+            firsts.sort()
+            out[8]['first_chunk_ms_p50_new_prompt'] = round(firsts[len(firsts) // 2] * 1e3, 1)
+        finally:
+            model.prompt_cache_max = keep_max
     # the same with 250 forced tokens (10 s of audio, 9 chunks of 25 tokens after the first + the final call): time between chunks
     for n in (1, 8):
         run_calls(model, [sreq] * n, [250] * n, stream=True)
@@ -385,7 +399,10 @@ def extras(model, st, flow_t, hift_t, dev):
         out[n].update({'forced250_audio_s_per_s': round(audio / dts, 1),
                        'chunk_gap_ms_p50_chunks_2_4': round(gaps_early[len(gaps_early) // 2] * 1e3, 1),
                        'chunk_gap_ms_p50_chunks_8_10': round(gaps_late[len(gaps_late) // 2] * 1e3, 1)})
-    ex['streaming'] = {'flow_cache': bool(getattr(model, 'flow_cache', False)), 'workload': 'configs[4]: streaming (hop 25, look-ahead 3), P=255: the first chunk needs prefill + 48 tokens, chunk-masked flow at '
+    ex['streaming'] = {'flow_cache': bool(getattr(model, 'flow_cache', False)),
+                       'prompt_cache': 'the streams share a prompt the model has served before: its whole chunks come from the prompt flow cache '
+                                       '(first_chunk_ms_p50_new_prompt: without it)' if getattr(model, 'prompt_cache_max', 0) > 0 else 'off',
+                       'workload': 'configs[4]: streaming (hop 25, look-ahead 3), P=255: the first chunk needs prefill + 48 tokens, chunk-masked flow at '
                                    'T=600, HiFT on 90 frames; time from the tts() call to its first yielded chunk, 3 rounds',
                        'streams_1': out[1], 'streams_8': out[8]}
     return ex

@@ -109,6 +109,10 @@ class CosyVoice2Model:
         self.flow_cache = os.environ.get('CV2_FLOW_CACHE', '1') != '0'
         self._flow_caches = {}                 # uuid -> cv2amd.flow.FlowCache, touched under run_lock only
         self.flow_cache_min_group, self.flow_cache_min_frames = 2, 1500
+        import collections
+        self._prompt_caches = collections.OrderedDict()    # prompt key -> FlowCache of the prompt alone (LRU), touched under run_lock
+        self._prompt_building = set()
+        self.prompt_cache_max = int(os.environ.get('CV2_PROMPT_CACHES', '4'))       # 1.15 GB per 10 s prompt; 0 disables
         self.flow_cache_headroom = 0.5         # capacity beyond the chunk at hand when the caller's estimate is smaller
         if llm_sd is not None:
             self.load_state_dicts(llm_sd, flow_sd, hift_sd)
@@ -194,7 +198,7 @@ class CosyVoice2Model:
 
     # ---- chunks of concurrent streams: one ragged flow batch for every chunk that is ready -------------------------------
     class _Chunk:
-        __slots__ = ('token', 'fpt', 'feat', 'femb', 'offset', 'uuid', 'stream', 'finalize', 'done', 'speech', 'exc', 'cap_hint')
+        __slots__ = ('token', 'fpt', 'feat', 'femb', 'offset', 'uuid', 'stream', 'finalize', 'done', 'speech', 'exc', 'cap_hint', 'pkey')
 
     def _flow_cache_for(self, c):
         """The call's flow cache, large enough for this chunk.  Capacity: the caller's estimate of the utterance (frames), at least
@@ -203,9 +207,31 @@ class CosyVoice2Model:
         need = self.flow.token_mel_ratio * (c.fpt.shape[1] + c.token.shape[1] - self.flow.pre_lookahead_len)
         fc = self._flow_caches.get(c.uuid)
         if fc is None or fc.frames < need:
-            cap = min(max(c.cap_hint or 0, need + int(need * self.flow_cache_headroom)), self.flow.max_len)
-            fc = self._flow_caches[c.uuid] = self.flow.new_cache(max(cap, need))
+            cap = max(min(max(c.cap_hint or 0, need + int(need * self.flow_cache_headroom)), self.flow.max_len), need)
+            pc = self._prompt_caches.get(c.pkey) if (fc is None and c.offset == 0) else None
+            if pc is not None:                                                 # a prompt this model has run before: start from its frames
+                self._prompt_caches.move_to_end(c.pkey)
+                fc = self._flow_caches[c.uuid] = self.flow.clone_cache(pc, cap)
+            else:
+                fc = self._flow_caches[c.uuid] = self.flow.new_cache(cap)
         return fc
+
+    def _build_prompt_cache(self, pkey, fpt, feat, femb):
+        """Background: the flow cache of a prompt alone (its whole chunks), kept for later calls with the same prompt — their first
+        chunk then computes ~100 frames instead of the prompt's ~500 + its own.  At most `prompt_cache_max` prompts are kept (LRU)."""
+        try:
+            with self.run_lock:
+                if pkey not in self._prompt_caches:
+                    pc = self.flow.prompt_cache(fpt, feat, femb, hop=self.token_hop_len)
+                    torch.cuda.current_stream().synchronize()
+                    if pc is not None:
+                        self._prompt_caches[pkey] = pc
+                        while len(self._prompt_caches) > self.prompt_cache_max:
+                            self._prompt_caches.popitem(last=False)
+        except Exception:                                                      # an optimisation only: the calls go on without it
+            pass
+        finally:
+            self._prompt_building.discard(pkey)
 
     def _flow_batch(self, grp, streaming, finalize):
         """[(mel, first frame index)] of one group of chunks.  Non-final chunks of streaming calls go through the per-call flow cache
@@ -216,10 +242,16 @@ class CosyVoice2Model:
         utts = [dict(token=c.token, prompt_token=c.fpt, prompt_feat=c.feat, embedding=c.femb) for c in grp]
         outs, cached = [None] * len(grp), []
         if streaming and not finalize and self.flow_cache:
-            cached = [i for i, c in enumerate(grp) if c.offset > 0]
+            # first chunks join only when their prompt's cache exists already (a voice used before)
+            cached = [i for i, c in enumerate(grp) if c.offset > 0 or (c.pkey is not None and c.pkey in self._prompt_caches)]
             frames = [self.flow.token_mel_ratio * (grp[i].fpt.shape[1] + grp[i].token.shape[1]) for i in cached]
             if len(cached) < self.flow_cache_min_group and not any(f >= self.flow_cache_min_frames for f in frames):
                 cached = []
+            if len(grp) >= self.flow_cache_min_group and self.prompt_cache_max > 0:
+                for c in grp:                                                  # several streams at once and a prompt not seen before:
+                    if c.offset == 0 and c.pkey is not None and c.pkey not in self._prompt_caches and c.pkey not in self._prompt_building:
+                        self._prompt_building.add(c.pkey)                      # prepare it for the calls to come (after this round)
+                        threading.Thread(target=self._build_prompt_cache, args=(c.pkey, c.fpt, c.feat, c.femb), daemon=True).start()
         if cached:
             res = self.flow.inference_chunk_batch([utts[i] for i in cached], [self._flow_cache_for(grp[i]) for i in cached], finalize=False)
             for i, r in zip(cached, res):
@@ -289,12 +321,12 @@ class CosyVoice2Model:
         self._pin_rr = (self._pin_rr + 1) % len(self.hift_pool.engines)
         return self._pin_rr
 
-    def _chunk_submit(self, token, fpt, feat, femb, offset, this_uuid, stream, finalize, cap_hint=None):
+    def _chunk_submit(self, token, fpt, feat, femb, offset, this_uuid, stream, finalize, cap_hint=None, pkey=None):
         """token2wav for one chunk of a streaming call.  The chunk is queued; whoever gets the device next runs the flow over ALL
         queued chunks as one ragged batch (streams that share decode steps become ready together), then HiFT per chunk."""
         c = self._Chunk()
         c.token, c.fpt, c.feat, c.femb, c.offset, c.uuid, c.stream, c.finalize = token, fpt, feat, femb, offset, this_uuid, stream, finalize
-        c.done, c.speech, c.exc, c.cap_hint = False, None, None, cap_hint
+        c.done, c.speech, c.exc, c.cap_hint, c.pkey = False, None, None, cap_hint, pkey
         with self.lock:
             self._chunk_q.append(c)
         with self.run_lock:
@@ -632,6 +664,10 @@ class CosyVoice2Model:
                 # flow-cache capacity in frames: the forced length, else a typical 8 speech tokens per text token (grown when exceeded)
                 n_guess = force_len if force_len is not None else min(self._limits[2], 8 * int(text.shape[1]) + 64)
                 cap_hint = self.flow.token_mel_ratio * (fpt.shape[1] + n_guess)
+                pkey = None
+                if self.flow_cache and self.prompt_cache_max > 0:              # identity of the prompt: tokens + checksums of mel and embedding
+                    pkey = (tuple(flow_prompt_speech_token.flatten().tolist()), float(prompt_speech_feat.double().sum()),
+                            float(flow_embedding.double().sum()))
                 self._llm_start(slot, text_d, ptext_d, lptok_d, force_len)     # prefill draws token 0; the first pass of the loop below
                 while True:                                                    # requests the rest of the first chunk's tokens
                     this_tok, finished = None, False
@@ -649,7 +685,7 @@ class CosyVoice2Model:
                         else:
                             self._llm_advance(need - len(toks))                # nothing in flight any more (ids above EOS are steps without a token)
                     if this_tok is not None:
-                        speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, True, False, cap_hint)
+                        speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, True, False, cap_hint, pkey)
                         token_offset += this_token_hop_len
                         yield {'tts_speech': speech}
                     if finished:

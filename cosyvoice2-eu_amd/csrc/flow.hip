@@ -1195,6 +1195,44 @@ extern "C" size_t cv2_flow_cache_bytes(const cv2_flow* h, int32_t frames) {
     return (inc_kv_elems(h, frames) + inc_tail_elems(h)) * sizeof(uint16_t);
 }
 
+// first n frames of every slot (and the convolution tails) of one cache -> another cache of a different capacity: a stream that
+// starts from a prompt another call has already run (same prompt tokens, prompt mel, speaker embedding) begins with that prefix
+struct CacheCopyArgs { const uint16_t* src; uint16_t* dst; long sfr, dfr; int n; };
+__global__ __launch_bounds__(256) void k_cache_copy(CacheCopyArgs a) {      // grid (slots, 2 * 8): y < 8: K rows, y >= 8: V^T rows, 64 channels each
+    const long slot = blockIdx.x;
+    const int part = blockIdx.y >> 3, hd = blockIdx.y & 7, tid = threadIdx.x;
+    const uint16_t* s = a.src + slot * a.sfr * 1024;
+    uint16_t* d = a.dst + slot * a.dfr * 1024;
+    if (part == 0) {                                               // K [frames][512]: 8 x 16 B of this head per frame
+        for (long i = tid; i < (long)a.n * 8; i += 256) {
+            const long r = i >> 3; const int ch = hd * 64 + (int)(i & 7) * 8;
+            *reinterpret_cast<uint4*>(d + r * 512 + ch) = *reinterpret_cast<const uint4*>(s + r * 512 + ch);
+        }
+    } else {                                                       // V^T [512][frames]: n is even (whole chunks of 50)
+        const int np = a.n >> 1;
+        for (long i = tid; i < (long)64 * np; i += 256) {
+            const long ch = hd * 64 + i / np, pr = i % np;
+            *reinterpret_cast<uint32_t*>(d + a.dfr * 512 + ch * a.dfr + 2 * pr) = *reinterpret_cast<const uint32_t*>(s + a.sfr * 512 + ch * a.sfr + 2 * pr);
+        }
+    }
+}
+extern "C" int cv2_flow_cache_copy(const cv2_flow* h, const void* src, int32_t src_frames, void* dst, int32_t dst_frames, int32_t n_frames,
+                                   void* stream) {
+    CV2_CHECK(h && src && dst && src != dst, "cv2_flow_cache_copy: bad argument");
+    CV2_CHECK(src_frames >= 64 && src_frames % 64 == 0 && dst_frames >= 64 && dst_frames % 64 == 0, "cv2_flow_cache_copy: capacities must be multiples of 64");
+    CV2_CHECK(n_frames >= 0 && n_frames % 50 == 0 && n_frames <= src_frames && n_frames <= dst_frames, "cv2_flow_cache_copy: %d frames (whole chunks of 50, within both capacities)", n_frames);
+    hipStream_t s = (hipStream_t)stream;
+    const int slots = 2 * h->d.n_timesteps * INC_TBLOCKS;
+    if (n_frames > 0) {
+        CacheCopyArgs a{(const uint16_t*)src, (uint16_t*)dst, (long)src_frames, (long)dst_frames, (int)n_frames};
+        hipLaunchKernelGGL(k_cache_copy, dim3(slots, 16), dim3(256), 0, s, a);
+    }
+    CV2_HIP(hipMemcpyAsync((uint16_t*)dst + inc_kv_elems(h, dst_frames), (const uint16_t*)src + inc_kv_elems(h, src_frames),
+                           inc_tail_elems(h) * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int cv2_flow_inference_chunk(cv2_flow* h, const cv2_flow_utt* utts, const cv2_flow_cache_ref* refs, int32_t U, int32_t finalize,
                                         void* stream) {
     CV2_CHECK(h && utts && refs && U >= 1, "cv2_flow_inference_chunk: bad argument");

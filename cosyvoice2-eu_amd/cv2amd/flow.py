@@ -84,6 +84,7 @@ def _bind(lib):
     lib.cv2_flow_inference.argtypes = [C.c_void_p, C.POINTER(FlowUtt), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.cv2_flow_cache_bytes.restype = C.c_size_t
     lib.cv2_flow_cache_bytes.argtypes = [C.c_void_p, C.c_int32]
+    lib.cv2_flow_cache_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.cv2_flow_inference_chunk.argtypes = [C.c_void_p, C.POINTER(FlowUtt), C.POINTER(FlowCacheRef), C.c_int32, C.c_int32, C.c_void_p]
     lib.cv2_flow_estimator.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p]
     lib.cv2_flow_encoder.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -233,6 +234,27 @@ class FlowEngine:
     # ---- the same call for streams that keep a cache: only the frames after the cached ones are computed and returned --------
     def new_cache(self, max_frames):
         return FlowCache(self, max_frames)
+
+    def clone_cache(self, src, max_frames):
+        """A new cache of capacity >= max_frames that starts with everything `src` holds (a prompt another call has already run)."""
+        dst = FlowCache(self, max(max_frames, src.n_cached))
+        L.check(self.lib.cv2_flow_cache_copy(self.handle, src.buf.data_ptr(), src.frames, dst.buf.data_ptr(), dst.frames, src.n_cached,
+                                             L.stream_ptr()))
+        dst.n_cached, dst.gen = src.n_cached, src.gen
+        return dst
+
+    def prompt_cache(self, prompt_token, prompt_feat, embedding, hop=25):
+        """The cache of a prompt alone: the whole chunks of the prompt whose look-ahead lies inside the prompt (flow.py:260-263 needs
+        pre_lookahead_len tokens after the last one).  None when the prompt is shorter than one chunk plus the look-ahead."""
+        P = int(prompt_token.numel())
+        n_full = (P - self.pre_lookahead_len) // hop * hop
+        if n_full <= 0:
+            return None
+        c = FlowCache(self, self.token_mel_ratio * n_full)
+        u = dict(token=prompt_token.reshape(1, -1)[:, :0], prompt_token=prompt_token.reshape(1, -1)[:, :n_full + self.pre_lookahead_len],
+                 prompt_feat=prompt_feat.reshape(1, -1, 80)[:, :self.token_mel_ratio * n_full], embedding=embedding)
+        self.inference_chunk_batch([u], [c], finalize=False)
+        return c
 
     def inference_chunk_batch(self, utts, caches, finalize):
         """utts as for inference_batch (token = the whole prefix so far), caches[i] = the stream's FlowCache.  Returns

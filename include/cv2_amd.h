@@ -247,6 +247,10 @@ typedef struct { void* cache; int32_t cache_frames; int32_t n_cached; int32_t ge
 size_t cv2_flow_cache_bytes(const cv2_flow* h, int32_t cache_frames);
 int cv2_flow_inference_chunk(cv2_flow* h, const cv2_flow_utt* utts, const cv2_flow_cache_ref* refs, int32_t n_utts, int32_t finalize,
                              void* stream);
+/* The first n_frames (whole chunks of 50) of one cache and its convolution tails into another cache (other capacity allowed): a stream
+ * whose prompt (tokens, mel, speaker embedding) another call has already run starts from that call's cache — n_cached = n_frames and the
+ * same `gen` as the source.  The source must hold exactly n_frames (its tails belong to that position). */
+int cv2_flow_cache_copy(const cv2_flow* h, const void* src, int32_t src_frames, void* dst, int32_t dst_frames, int32_t n_frames, void* stream);
 
 /* The estimator alone behind the reference's TensorRT seam (flow_matching.py:125-150): six contiguous device
  * tensors x(2,80,T) mask(2,1,T) mu(2,80,T) t(2,) spks(2,80) cond(2,80,T), result written in place into x. */

@@ -330,3 +330,29 @@ def test_cached_chunks_of_streams_in_different_phases_share_a_batch(eng):
                 assert rel(m.cpu(), ref.cpu()) < 3e-2, f'stream {k} call {pos[k]}: {rel(m.cpu(), ref.cpu()):.3e}'
                 pos[k] += 1
         rnd += 1
+
+
+def test_stream_started_from_a_prompt_cache(eng):
+    """A prompt that another call has already run: its whole chunks (those whose look-ahead lies inside the prompt) are computed once
+    (`prompt_cache`), copied into the new stream's cache of another capacity (`clone_cache` -> cv2_flow_cache_copy), and the stream's
+    first chunk computes only the frames after them.  Every chunk equals the stream that started from an empty cache."""
+    from cv2amd import synth
+    P, N = 87, 120                                        # 87 - 3 = 84 -> 75 prompt tokens = 150 frames come from the prompt cache
+    inp = synth.synthetic_inputs(seed=93, prompt_len=P)
+    tok = torch.randint(0, 6561, (1, N), generator=torch.Generator().manual_seed(8), dtype=torch.int32)
+    calls = _stream_calls(P, N)[:-1]
+    pc = eng.prompt_cache(inp['prompt_token'], inp['prompt_feat'], inp['embedding'])
+    assert pc is not None and pc.n_cached == 150 and pc.gen == 1
+    a = eng.new_cache(2 * (P + N))
+    b = eng.clone_cache(pc, 2 * (P + N) + 64)
+    assert b.n_cached == 150 and b.frames != pc.frames
+    for n, off, fin in calls:
+        u = dict(token=tok[:, :n], prompt_token=inp['prompt_token'], prompt_feat=inp['prompt_feat'], embedding=inp['embedding'])
+        (ma, fa), = eng.inference_chunk_batch([u], [a], finalize=False)
+        ma = ma.clone()
+        (mb, fb), = eng.inference_chunk_batch([u], [b], finalize=False)
+        torch.cuda.synchronize()
+        assert fa == fb and ma.shape == mb.shape
+        assert rel(mb.cpu(), ma.cpu()) < 3e-2, f'offset {off}: {rel(mb.cpu(), ma.cpu()):.3e}'
+    assert a.n_cached == b.n_cached
+    assert eng.prompt_cache(inp['prompt_token'][:, :20], inp['prompt_feat'][:, :40], inp['embedding']) is None

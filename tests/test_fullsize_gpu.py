@@ -362,7 +362,7 @@ def test_config4_eight_streams_every_chunk_vs_reference_logic(cv_from_disk):
             assert got.shape == want.shape, f'stream {i} chunk {c}: {got.shape} vs {want.shape}'
             err = (got - want).abs().max().item()
             assert err < 1e-3, f'stream {i} ({calls[i]}) chunk {c}: max abs err {err:.3e}'
-            m_alone, m_conc = a_trace[c][0], tr[c][0]
+            m_alone, m_conc = a_trace[c][0][:, :, 2 * tr[c][1]:], tr[c][0][:, :, 2 * tr[c][1]:]     # the frames token2wav keeps (what lies before them depends on which frames the call's flow cache held)
             assert m_alone.shape == m_conc.shape and rel(m_conc, m_alone) < 3e-2, f'stream {i} chunk {c}: flow mel differs from the solo run'
     assert sorted(mdl._slot_free) == list(range(mdl.max_batch)) and not mdl._active_slots and not mdl.hift_cache_dict and not mdl._hift_pin
     assert not mdl._flow_caches
@@ -507,3 +507,60 @@ def test_flow_cache_policy_and_regrowth(cv_from_disk):
         assert rel(a[0][:, :, 2 * a[1]:], b[0][:, :, 2 * b[1]:]) < 3e-2, f'chunk {k}'
     assert not mdl._flow_caches
 
+
+
+def test_second_wave_of_streams_starts_from_the_prompt_cache(cv_from_disk):
+    """Two concurrent streams with a prompt the model has not served yet: first chunks are recomputed and the prompt's flow cache is
+    built in the background; a second wave with the same prompt starts from it (clone_cache called, first chunk computes only the
+    frames after the prompt's whole chunks).  Chunk boundaries and the kept mel frames of the two waves agree."""
+    import time
+    cv = cv_from_disk
+    mdl = cv.model
+    mdl._prompt_caches.clear()
+    mdl.flow_cache_min_group = 1                    # chunks that happen to run alone in their round count too (deterministic test)
+    clones = []
+    orig = mdl.flow.clone_cache
+
+    def spy(src, max_frames):
+        clones.append(src.n_cached)
+        return orig(src, max_frames)
+    mdl.flow.clone_cache = spy
+
+    def wave():
+        mdl._trace = []
+        outs, errs = [None, None], []
+
+        def work(i):
+            try:
+                outs[i] = [o['tts_speech'] for o in cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr', stream=True)]
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [t.start() for t in ths]
+        [t.join(600) for t in ths]
+        assert not errs, errs
+        tr = mdl._trace
+        by = {}
+        for t in tr:
+            by.setdefault(t[4], []).append(t)
+        return outs, list(by.values())
+    try:
+        o1, t1 = wave()
+        assert not clones
+        for _ in range(200):                                       # the background build takes the device after the wave
+            if mdl._prompt_caches and not mdl._prompt_building:
+                break
+            time.sleep(0.05)
+        assert len(mdl._prompt_caches) == 1
+        pc = next(iter(mdl._prompt_caches.values()))
+        assert pc.n_cached == 2 * ((255 - 3) // 25 * 25)           # 500 frames of the P=255 prompt
+        o2, t2 = wave()
+        assert clones == [pc.n_cached, pc.n_cached]
+    finally:
+        mdl.flow.clone_cache = orig
+        mdl._trace, mdl.flow_cache_min_group = None, 2
+    assert [len(x) for x in o1] == [len(x) for x in o2]
+    for a, b in zip(t1[0], t2[0]):                                 # greedy tokens: every call of a wave sees the same chunks
+        assert a[1] == b[1] and a[2] == b[2] and a[0].shape == b[0].shape
+        assert rel(b[0][:, :, 2 * b[1]:], a[0][:, :, 2 * a[1]:]) < 3e-2
+    assert not mdl._flow_caches
