@@ -1,8 +1,9 @@
 """cosyvoice/utils/file_utils.py:44-50 — load_wav(wav, target_sr): mono, resampled down to target_sr, float32 [1, n].
 
 The reference uses torchaudio (soundfile backend + sinc resampler).  torchaudio is optional here: it is used when present,
-otherwise 16-bit / 32-bit PCM and float WAV files are read with the standard library and resampled with
-scipy.signal.resample_poly (a polyphase Kaiser low-pass; numerically close to, not bit-identical with, torchaudio's).
+otherwise 16-bit / 32-bit PCM and float WAV files are read with the standard library and resampled with the same windowed-sinc
+polyphase kernel torchaudio's Resample builds (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99; cv2amd/prompt.py:_sinc_kernel,
+the table the device resampler uses), applied as a strided convolution.
 """
 import logging
 import wave
@@ -49,8 +50,10 @@ def load_wav(wav, target_sr):
     speech = speech.mean(dim=0, keepdim=True)
     if sample_rate != target_sr:
         assert sample_rate > target_sr, 'wav sample rate {} must be greater than {}'.format(sample_rate, target_sr)
-        from math import gcd
-        from scipy.signal import resample_poly
-        g = gcd(int(sample_rate), int(target_sr))
-        speech = torch.from_numpy(resample_poly(speech.numpy(), target_sr // g, sample_rate // g, axis=1).astype(np.float32))
+        from cv2amd.prompt import _sinc_kernel
+        kern, width, orig, new = _sinc_kernel(int(sample_rate), int(target_sr))
+        n = speech.shape[1]
+        xp = torch.nn.functional.pad(speech, (width, width + orig))
+        y = torch.nn.functional.conv1d(xp[:, None], torch.from_numpy(kern)[:, None], stride=orig)
+        speech = y.transpose(1, 2).reshape(1, -1)[:, :-(-new * n // orig)].contiguous()
     return speech
