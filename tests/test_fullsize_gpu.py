@@ -546,7 +546,8 @@ def test_second_wave_of_streams_starts_from_the_prompt_cache(cv_from_disk):
         return outs, list(by.values())
     try:
         o1, t1 = wave()
-        assert not clones
+        n1 = len(clones)                                           # 0, or 1 when the second stream's first chunk came after the build
+        assert n1 <= 1
         for _ in range(200):                                       # the background build takes the device after the wave
             if mdl._prompt_caches and not mdl._prompt_building:
                 break
@@ -555,7 +556,7 @@ def test_second_wave_of_streams_starts_from_the_prompt_cache(cv_from_disk):
         pc = next(iter(mdl._prompt_caches.values()))
         assert pc.n_cached == 2 * ((255 - 3) // 25 * 25)           # 500 frames of the P=255 prompt
         o2, t2 = wave()
-        assert clones == [pc.n_cached, pc.n_cached]
+        assert clones[n1:] == [pc.n_cached, pc.n_cached]
     finally:
         mdl.flow.clone_cache = orig
         mdl._trace, mdl.flow_cache_min_group = None, 2
