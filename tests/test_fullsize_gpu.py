@@ -516,6 +516,10 @@ def test_second_wave_of_streams_starts_from_the_prompt_cache(cv_from_disk):
     import time
     cv = cv_from_disk
     mdl = cv.model
+    for _ in range(200):                            # background builds started by earlier tests
+        if not mdl._prompt_building:
+            break
+        time.sleep(0.05)
     mdl._prompt_caches.clear()
     mdl.flow_cache_min_group = 1                    # chunks that happen to run alone in their round count too (deterministic test)
     clones = []
