@@ -108,7 +108,7 @@ class CosyVoice2Model:
         # instead of the whole prefix the reference re-runs (model.py:351-381).  CV2_FLOW_CACHE=0: recompute like the reference.
         self.flow_cache = os.environ.get('CV2_FLOW_CACHE', '1') != '0'
         self._flow_caches = {}                 # uuid -> cv2amd.flow.FlowCache, touched under run_lock only
-        self.flow_cache_min_group, self.flow_cache_min_frames = 2, 1500
+        self.flow_cache_min_group, self.flow_cache_min_frames, self.flow_cache_min_first = 2, 1500, 4
         import collections
         self._prompt_caches = collections.OrderedDict()    # prompt key -> FlowCache of the prompt alone (LRU), touched under run_lock
         self._prompt_building = set()
@@ -243,7 +243,10 @@ class CosyVoice2Model:
         outs, cached = [None] * len(grp), []
         if streaming and not finalize and self.flow_cache:
             # first chunks join only when their prompt's cache exists already (a voice used before)
-            cached = [i for i, c in enumerate(grp) if c.offset > 0 or (c.pkey is not None and c.pkey in self._prompt_caches)]
+            firsts = [i for i, c in enumerate(grp) if c.offset == 0 and c.pkey is not None and c.pkey in self._prompt_caches]
+            if len(firsts) < self.flow_cache_min_first:                        # a cached call costs ~40 ms whatever it holds, a recomputed
+                firsts = []                                                    # first chunk ~19 + 5.5 ms per stream: worth it from 4 on
+            cached = sorted([i for i, c in enumerate(grp) if c.offset > 0] + firsts)
             frames = [self.flow.token_mel_ratio * (grp[i].fpt.shape[1] + grp[i].token.shape[1]) for i in cached]
             if len(cached) < self.flow_cache_min_group and not any(f >= self.flow_cache_min_frames for f in frames):
                 cached = []

@@ -521,7 +521,7 @@ def test_second_wave_of_streams_starts_from_the_prompt_cache(cv_from_disk):
             break
         time.sleep(0.05)
     mdl._prompt_caches.clear()
-    mdl.flow_cache_min_group = 1                    # chunks that happen to run alone in their round count too (deterministic test)
+    mdl.flow_cache_min_group = mdl.flow_cache_min_first = 1      # chunks that happen to run alone in their round count too (deterministic test)
     clones = []
     orig = mdl.flow.clone_cache
 
@@ -563,7 +563,7 @@ def test_second_wave_of_streams_starts_from_the_prompt_cache(cv_from_disk):
         assert clones[n1:] == [pc.n_cached, pc.n_cached]
     finally:
         mdl.flow.clone_cache = orig
-        mdl._trace, mdl.flow_cache_min_group = None, 2
+        mdl._trace, mdl.flow_cache_min_group, mdl.flow_cache_min_first = None, 2, 4
     assert [len(x) for x in o1] == [len(x) for x in o2]
     for a, b in zip(t1[0], t2[0]):                                 # greedy tokens: every call of a wave sees the same chunks
         assert a[1] == b[1] and a[2] == b[2] and a[0].shape == b[0].shape
