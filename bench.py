@@ -370,11 +370,10 @@ def extras(model, st, flow_t, hift_t, dev):
     # first chunk when the prompt has NOT been seen before (no prompt flow cache to start from): the number a new voice gets
     if hasattr(model, '_prompt_caches'):
         keep_max = model.prompt_cache_max
-        model.prompt_cache_max = 0
-        model._prompt_caches.clear()
         try:
             firsts = []
-            for _ in range(2):
+            for _ in range(3):
+                model._prompt_caches.clear()                      # the model has never seen this prompt
                 _, first = run_calls(model, [sreq] * 8, [None] * 8, stream=True)
                 firsts += first
             firsts.sort()
