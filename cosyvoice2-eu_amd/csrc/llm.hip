@@ -12,10 +12,17 @@
 // All are HBM-bound weight streams (skinny.h); the per-step algorithmic traffic is the bf16 weights once
 // (727.6 MB at the real dims) plus the KV read.
 #include "skinny.h"
+#ifdef CV2_STAMPS
+extern __device__ unsigned long long g_chain_t[1024][4];
+#define R1_T_OPERAND do { if (op.dbg && threadIdx.x == 0) g_chain_t[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
+#include "chain.h"
 #include "skinny_launch.h"
 #include "gemm_launch.h"
 #include "../../include/cv2_amd.h"
+#include <algorithm>
 #include <map>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <vector>
 
@@ -402,6 +409,70 @@ __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ k_chain (one row: O projection -> gate/up -> down, chain.h)
+struct ChainArgs {
+    const uint16_t* wo; const uint16_t* wgu; const uint16_t* wdown;
+    SkinnyX Xatt;                               // attention partials (split-key combine)
+    const float* resid;                         // x1 [hidden]: residual stream entering the attention block
+    const float* ln2; float eps;
+    float* x_out;                               // x_mid [hidden] for the next layer's residual (written by gate/up block 0)
+    float* parts;                               // down-projection split-K partials [SK_MAXNP][SK_ROWS_CAP][hidden]
+    u64* xgran; u64* hgran;                     // this layer's hand-off granules: x_mid [hidden], h [inter]
+    const unsigned* epoch; int* err;
+    int H, NQ, inter;
+    int dbg;
+};
+// blocks [0, H/16): O projection tiles; then inter/16 gate/up tiles; then SK_MAXNP x H/16 down tiles (split-major)
+#ifdef CV2_STAMPS
+__device__ unsigned long long g_chain_t[1024][4] = {};      // per block of layer 1's k_chain: start, operand ready, published (100 MHz ticks)
+#define CH_T(i) do { if (a.dbg && threadIdx.x == 0) g_chain_t[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int cv2_debug_chain(unsigned long long* out_host) {
+    CV2_HIP(hipDeviceSynchronize());
+    CV2_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_chain_t), sizeof(unsigned long long) * 1024 * 4));
+    return 0;
+}
+#else
+#define CH_T(i) do { } while (0)
+#endif
+__global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    CH_T(0);
+    const unsigned epoch = *a.epoch;
+    const int nO = a.H / 16, nGU = a.inter / 16;
+    int b = blockIdx.x;
+    if (b < nO) {
+        const float rv = a.resid[b * 16 + (tid & 15)];          // requested before anything else; needed last
+        OpAtt op{a.Xatt, a.NQ, a.dbg != 0};
+        const float o = row1_core<1, 4, 8, false>(a.wo, b, a.NQ / 32, a.NQ, 0, a.NQ / 32, op, nullptr, 0.f, nullptr, smem);
+        CH_T(1);
+        if (tid < 16) gran_store(a.xgran + b * 16 + tid, epoch, rv + o);
+        CH_T(2);
+        return;
+    }
+    b -= nO;
+    if (b < nGU) {
+        OpGran op{a.xgran, epoch, a.err, a.xgran + a.H - 1, nullptr, true, a.dbg != 0};
+        const float v = row1_core<2, 2, 14, true>(a.wgu, b * 2, a.H / 32, a.H, 0, a.H / 32, op, a.ln2, a.eps, b == 0 ? a.x_out : nullptr, smem);
+        const float u = __shfl(v, (tid & 15) + 16);            // threads 0..15 hold gate, 16..31 up (wave 0)
+        CH_T(1);
+        if (tid < 16) gran_store(a.hgran + b * 16 + tid, epoch, (v / (1.f + __expf(-v))) * u);
+        CH_T(2);
+        return;
+    }
+    b -= nGU;
+    {
+        const int sp = b / nO, tile = b - sp * nO;
+        const int KS = a.inter / 32;
+        const int ks0 = (int)(((unsigned)KS * sp) / SK_MAXNP), ks1 = (int)(((unsigned)KS * (sp + 1)) / SK_MAXNP);
+        OpGran op{a.hgran, epoch, a.err, a.hgran + ks1 * 32 - 1, a.xgran + a.H - 1, false, a.dbg != 0};
+        const float v = row1_core<1, 4, 10, false>(a.wdown, tile, KS, a.inter, ks0, ks1, op, nullptr, 0.f, nullptr, smem);
+        CH_T(1);
+        if (tid < 16) a.parts[(size_t)sp * SK_ROWS_CAP * a.H + tile * 16 + tid] = v;
+        CH_T(2);
+    }
+}
+
 // ------------------------------------------------------------------ k_sample
 // Philox4x32-10, the same function as cv2amd/philox.py (counter = (seq, step, trial, 0), key = seed)
 __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -428,6 +499,7 @@ struct SampleArgs {
     int bi_speech;                              // bistream: speech tokens per text block (mix_ratio[1] = 15)
     float top_p; int top_k, win; float rep_thr; // ras_sampling constants (conf/cosyvoice2.yaml:33-37): nucleus mass / size, repetition window, win_size * tau_r
     int prefill_seq, row, prefill_pos;          // prefill: one block, reads logits row `row`, updates slot prefill_seq,
+    unsigned* epoch;                            // hand-off epoch of k_chain: advanced once per launch (chain.h)
 };                                              // whose next KV position becomes prefill_pos (= prompt length)
 #define SM_T 1024
 #define SM_W (SM_T / 64)
@@ -822,6 +894,7 @@ sample_done:
         // a finished slot idles on its last position; a slot waiting for text (fill) moves on: the text block goes to the next one
         if (!fin || a.prefill_seq >= 0 || (bimode == 1 && st[CV2_ST_WAIT])) st[CV2_ST_POS] = pos;
     }
+    if (blockIdx.x == 0 && tid == 0) *a.epoch += 1u;
     SK_STAMP(6);
     SK_STAMP_FLUSH;
 }
@@ -1022,6 +1095,10 @@ struct cv2_llm {
     float *pf_x, *pf_qkv, *pf_q, *pf_gu, *pf_last;
     uint16_t *pf_hi, *pf_lo;
     int* pf_int;               // row_seq[pf_rows], row_pos[pf_rows], seq tables 5 x 32
+    u64 *xgran, *hgran;        // k_chain hand-off granules [layers][hidden], [layers][inter]
+    unsigned* epoch;           // hand-off epoch (device), advanced by k_sample
+    size_t chain_off, chain_bytes;   // the region cv2_llm_create zeroes
+    bool use_chain;            // one-row decode steps run O projection -> gate/up -> down as one launch (CV2_LLM_CHAIN=0 disables)
     std::map<int, hipGraphExec_t> graphs;
     hipStream_t cap_stream;    // private stream used only to capture the decode-step graph (the caller's may be the null stream)
 };
@@ -1049,6 +1126,11 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     p = take((size_t)32 * d.hidden * 4); if (h) h->o = (float*)p;
     p = take((size_t)32 * d.inter * 4); if (h) h->hbuf = (float*)p;
     p = take((size_t)SK_MAXNP * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
+    if (h) h->chain_off = off;
+    p = take(256); if (h) h->epoch = (unsigned*)p;
+    p = take((size_t)d.layers * d.hidden * 8); if (h) h->xgran = (u64*)p;
+    p = take((size_t)d.layers * d.inter * 8); if (h) h->hgran = (u64*)p;
+    if (h) h->chain_bytes = off - h->chain_off;
     const size_t R = (size_t)(d.max_prefill_rows > 0 ? (d.max_prefill_rows + 127) / 128 * 128 : 0);
     if (h) h->pf_rows = (int)R;
     if (R) {
@@ -1094,6 +1176,19 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
         delete h;
         return cv2_fail("cv2_llm_create: hipStreamCreateWithFlags failed");
     }
+    {   // hand-off state of k_chain: every granule tag 0, epoch 1 (tags are compared with the epoch, never 0)
+        const char* e = getenv("CV2_LLM_CHAIN");
+        h->use_chain = !(e && e[0] == '0') && d->hidden % 32 == 0 && d->inter % (32 * SK_MAXNP) == 0 &&
+                       d->hidden / 32 <= 2 * 14 && d->n_q * 64 / 32 <= 4 * 8 && d->inter / 32 / SK_MAXNP <= 4 * 10 &&
+                       d->n_q * 64 / 8 <= 128;
+        const unsigned one = 1u;
+        if (hipMemset((char*)ws + h->chain_off, 0, h->chain_bytes) != hipSuccess ||
+            hipMemcpy(h->epoch, &one, sizeof(one), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipStreamDestroy(h->cap_stream);
+            delete h;
+            return cv2_fail("cv2_llm_create: initialising the hand-off state failed");
+        }
+    }
     *out = h;
     return 0;
 }
@@ -1136,6 +1231,23 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm, d.n_q / d.n_kv};
             launch_attn(a, rows, s);
             STAMP_SET(-1);
+        }
+        if (rows == 1 && !rm.prefill && h->use_chain) {
+            // one decode row: O projection -> gate/up -> down projection as ONE launch (chain.h)
+            float* x2c = (x1 == h->xa) ? h->xb : h->xa;
+            ChainArgs a{};
+            a.wo = L.wo; a.wgu = L.wgu; a.wdown = L.wdown;
+            a.Xatt = SkinnyX{nullptr, h->att, h->nsplit, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt};
+            a.resid = x1; a.ln2 = L.ln2; a.eps = d.rms_eps; a.x_out = x2c; a.parts = h->parts;
+            a.xgran = h->xgran + (size_t)l * H; a.hgran = h->hgran + (size_t)l * d.inter;
+            a.epoch = h->epoch; a.err = h->io.state + CV2_ST_ERR;
+            a.H = H; a.NQ = d.n_q * 64; a.inter = d.inter; a.dbg = l == 1;
+            const int nks_max = std::max(std::max(KSH, d.n_q * 64 / 32), cdiv(d.inter / 32, SK_MAXNP));
+            const size_t sm = r1_smem_bytes<1, 4>(nks_max);
+            hipLaunchKernelGGL(k_chain, dim3(H / 16 + d.inter / 16 + SK_MAXNP * (H / 16)), dim3(256), sm, s, a);
+            xcur = x2c;
+            np = SK_MAXNP;
+            continue;
         }
         if (rows <= 4) {     // few rows: combine the key splits while loading the O-projection operand (saves a launch)
             StoreArgs a{};
@@ -1280,7 +1392,8 @@ static int init_attrs_once() {
 static int launch_sample(cv2_llm* h, int nblocks, int prefill_seq, int row, int prefill_pos, hipStream_t s) {
     const cv2_llm_dims& d = h->d;
     SampleArgs a{h->io.logits, d.vocab_pad, h->io.state, h->io.out_tokens, d.max_out, h->w.speech_emb, h->xnext,
-                 d.hidden, d.vocab, d.eos, d.max_pos, 15, d.top_p, d.top_k, d.win_size, (float)d.win_size * d.tau_r, prefill_seq, row, prefill_pos};
+                 d.hidden, d.vocab, d.eos, d.max_pos, 15, d.top_p, d.top_k, d.win_size, (float)d.win_size * d.tau_r, prefill_seq, row, prefill_pos,
+                 h->epoch};
     hipLaunchKernelGGL(k_sample, dim3(nblocks), dim3(SM_T), 0, s, a);
     CV2_LAUNCH_CHECK();
     return 0;

@@ -140,6 +140,10 @@ class LLMEngine:
         L.check(self.lib.cv2_llm_decode(self.handle, n_seqs, n_steps, L.stream_ptr()))
 
     ERR_MSG = 'sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!'      # llm.py:249
+    ERR_HANDOFF = 'LLM decode: an in-launch hand-off (k_chain) timed out; the device was too contended for the step to finish'
+
+    def _err(self, code):
+        return RuntimeError(self.ERR_HANDOFF if int(code) == 3 else self.ERR_MSG)
 
     def read(self, n_seqs, raise_on_error=True):
         """(state [n, 16] int32 cpu, list of emitted-token lists). One device->host sync.  A slot whose sampler gave up (ST_ERR,
@@ -149,14 +153,14 @@ class LLMEngine:
         if raise_on_error:
             for b in range(n_seqs):
                 if int(st[b, L.ST_ERR]):
-                    raise RuntimeError(self.ERR_MSG)
+                    raise self._err(st[b, L.ST_ERR])
         return st, [toks[b, :min(int(st[b, L.ST_NOUT]), self.max_out)].tolist() for b in range(n_seqs)]
 
     def read_slot(self, slot):
         """(state row [16] int32 cpu, emitted tokens of one slot).  One device->host sync."""
         st = self.state[slot].cpu()
         if int(st[L.ST_ERR]):
-            raise RuntimeError(self.ERR_MSG)
+            raise self._err(st[L.ST_ERR])
         n = min(int(st[L.ST_NOUT]), self.max_out)
         return st, self.out_tokens[slot, :n].cpu().tolist()
 
@@ -192,7 +196,7 @@ class LLMEngine:
             st, toks = self.read(n, raise_on_error=not return_errors)
             if bool(st[:, L.ST_DONE].all()):
                 if return_errors:
-                    return toks, [RuntimeError(self.ERR_MSG) if int(st[b, L.ST_ERR]) else None for b in range(n)]
+                    return toks, [self._err(st[b, L.ST_ERR]) if int(st[b, L.ST_ERR]) else None for b in range(n)]
                 return toks
             # no live request can finish before its min_len (EOS is re-drawn until then, llm.py:242-250): poll again only after the
             # earliest possible finish, then every sync_every steps (a finished slot idles inside a burst)
@@ -251,8 +255,8 @@ class LLMEngine:
                     outs.append(t)
                     if t < EOS:
                         yield t
-                if err == 1:
-                    raise RuntimeError(self.ERR_MSG)
+                if err in (1, 3):
+                    raise self._err(err)
                 if err == 2:
                     raise ValueError('should not get token {}'.format(outs[-1]))
                 real = [t for t in new if t < EOS]
