@@ -1,19 +1,23 @@
-// One-row decode chain: O projection -> gate/up -> down projection of a layer in ONE launch (llm.hip: k_chain).
+// One-row decode step as ONE launch (llm.hip: k_step): for every layer the roles Q (RMSNorm + QKV + RoPE), A (attention over one
+// 64-key tile), O (O projection), GU (gate/up + SwiGLU), D (down projection, split-K), then the head (final norm + llm_decoder).
 //
-// Why: at one row the five weight-streaming kernels of a layer are latency-bound (1.6 us dispatch + ~1 us first dependent
-// load + ~1 us of weight stream each).  Weights do not depend on activations: when the three GEMVs share a launch, every block
-// requests its weight fragments at kernel entry, so the gate/up (17.4 MB) and down (8.7 MB) streams land while the O projection
-// is still working, and what remains behind each dependency is the hand-off plus ~30 MFMAs.
+// Why: at one row a layer's five weight-streaming kernels are latency-bound (1.6 us dispatch + ~1 us first dependent load + ~1 us
+// of weight stream each, 24.6 us per layer for 30 MB).  Weights do not depend on activations: when the GEMVs share a launch, every
+// block requests its weight fragments when it is dispatched, i.e. while the blocks in front of it are still computing, and what is
+// left behind each dependency is the hand-off plus ~30 MFMAs.  The hardware dispatcher is the scheduler: blocks are laid out in
+// dependency order (layer by layer, role by role), a finished block frees its slot for the next undispatched one, so the chip
+// holds about one layer of look-ahead whose weights are already in registers when their operand arrives.
 //
 // Hand-offs (cdna_hip_programming.md Guideline 16, form R2): the data is the flag.  A value travels as one naturally aligned
-// 8-byte granule {tag = epoch, fp32 bits}, written by ONE write-through (sc1) store and polled with sc1 loads; no fence, no
-// separate flag.  epoch = a device counter k_sample advances once per decode step, every layer has granule buffers of its own,
-// so a granule of an earlier step never matches and nothing is re-initialised between steps (the buffers are zeroed once at
-// create, epoch starts at 1).
+// 8-byte granule {fp32 bits, tag = epoch}, written by ONE write-through (sc1) store and read with sc1 loads; no fence, no separate
+// flag.  epoch = a device counter k_sample advances once per decode step; every layer has granule buffers of its own, so a granule
+// of an earlier step never matches and nothing is re-initialised between steps (zeroed once at create, epoch starts at 1).
+// A consumer first polls ONE granule of the producer expected last (cheap beside the weight streams), then sweeps its whole
+// operand and checks every tag; the sweep repeats until all match.
 //
-// Forward progress: producers never wait inside the launch and have the LOWEST block indices of their consumers (O < gate/up <
-// down); blocks are dispatched in index order (per XCD too), so a polling consumer can never keep its producer off the chip.
-// Every poll is bounded (0.5 s) and reports through the slot's CV2_ST_ERR.
+// Forward progress: a block only waits for blocks with LOWER indices, and blocks are dispatched in index order (per XCD too), so
+// the lowest unfinished block is always resident and never waits for an undispatched one.  Every wait is bounded (0.5 s) and
+// reports through the slot's CV2_ST_ERR (3) instead of hanging; once one block has given up every other wait ends at its next check.
 #pragma once
 #include "skinny.h"
 #ifndef R1_T_OPERAND
@@ -22,133 +26,242 @@
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-__device__ __forceinline__ void gran_store(u64* p, unsigned epoch, float v) {
-    __hip_atomic_store((gu64*)p, ((u64)epoch << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+#define GRAN_TIMEOUT_TICKS 20000000ull     // s_memrealtime runs at 100 MHz: 0.2 s
 
-#define GRAN_TIMEOUT_TICKS 50000000ull     // s_memrealtime runs at 100 MHz: 0.5 s
-
-// One wave gathers 8 consecutive granules per active lane; returns false when the tags did not all match within the time limit.
-__device__ __forceinline__ bool gran_gather8(const u64* g, unsigned epoch, bool active, f32x8& v) {
-    const gu64* p = (const gu64*)g;
-    const u64 t0 = __builtin_amdgcn_s_memrealtime();
-    for (unsigned spin = 0;; spin++) {
+struct Gran {                 // all granule buffers of the engine behind one buffer descriptor (32-bit byte offsets)
+    __amdgpu_buffer_rsrc_t rsrc; u64* base; unsigned epoch; int* err;
+    __device__ __forceinline__ void init(u64* b, unsigned bytes, unsigned ep, int* e) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)bytes, 0x00020000);
+        base = b; epoch = ep; err = e;
+    }
+    // idx = granule index from the start of the buffer
+    __device__ __forceinline__ void store(unsigned idx, float v) const {
+        __hip_atomic_store((gu64*)(base + idx), ((u64)epoch << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ u32x4 ld2(unsigned idx) const {      // two granules {v0, tag0, v1, tag1}; idx even
+        return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, idx * 8u, 0, 16));   // aux 16 = sc1
+    }
+    __device__ __forceinline__ bool ld8(unsigned idx, f32x8& v) const {   // 8 consecutive granules; true when every tag matches
+        u32x4 x[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = ld2(idx + 2 * i);
         bool ok = true;
-        if (active) {
-            u64 x[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) x[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int k = 0; k < 8; k++) { ok &= (unsigned)(x[k] >> 32) == epoch; v[k] = __builtin_bit_cast(float, (unsigned)x[k]); }
+        for (int i = 0; i < 4; i++) {
+            ok &= x[i][1] == epoch && x[i][3] == epoch;
+            v[2 * i] = __builtin_bit_cast(float, x[i][0]); v[2 * i + 1] = __builtin_bit_cast(float, x[i][2]);
         }
-        if (__all(ok)) return true;
-        if ((spin & 15) == 15 && __builtin_amdgcn_s_memrealtime() - t0 > GRAN_TIMEOUT_TICKS) return false;
-        __builtin_amdgcn_s_sleep(2);
+        return ok;
     }
-}
-
-// One wave waits for ONE granule (every lane loads the same word: one request); cheap enough to poll while other blocks stream.
-__device__ __forceinline__ bool gran_wait1(const u64* g, unsigned epoch) {
-    const gu64* p = (const gu64*)g;
-    const u64 t0 = __builtin_amdgcn_s_memrealtime();
-    for (unsigned spin = 0;; spin++) {
-        const u64 x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__builtin_amdgcn_readfirstlane((unsigned)(x >> 32)) == epoch) return true;
-        if ((spin & 15) == 15 && __builtin_amdgcn_s_memrealtime() - t0 > GRAN_TIMEOUT_TICKS) return false;
-        __builtin_amdgcn_s_sleep(8);
+    __device__ __forceinline__ bool ld4(unsigned idx, f32x4& v) const {   // 4 consecutive granules
+        const u32x4 x0 = ld2(idx), x1 = ld2(idx + 2);
+        v[0] = __builtin_bit_cast(float, x0[0]); v[1] = __builtin_bit_cast(float, x0[2]);
+        v[2] = __builtin_bit_cast(float, x1[0]); v[3] = __builtin_bit_cast(float, x1[2]);
+        return x0[1] == epoch && x0[3] == epoch && x1[1] == epoch && x1[3] == epoch;
     }
-}
-
-// ---- operand providers of row1_core: before_weights() / issue() run before the weight loads, finish() after (all threads call them)
-struct OpGran {              // the vector arrives as granules from another block of this launch
-    const u64* gran; unsigned epoch; int* err;
-    const u64* sentinel;     // the granule expected LAST (the highest-indexed producer's): wave 0 polls it alone, then everyone sweeps
-    const u64* gate;         // != null: hold the weight requests back until this granule (of an EARLIER hand-off) has arrived, so that
-                             // this block's stream does not compete with the phases in front of it
-    bool delay;              // hold the weight requests back by ~0.5 us (the phase in front of this one requests first)
-    bool dbg;
-    __device__ __forceinline__ void before_weights(int wave) {
-        if (gate) {
-            if (wave == 0 && !gran_wait1(gate, epoch) && (threadIdx.x & 63) == 0) *err = 3;
-            __syncthreads();
-        } else if (delay) {
-            __builtin_amdgcn_s_sleep(19);
+    __device__ __forceinline__ void fail() const { if ((threadIdx.x & 63) == 0) __hip_atomic_store((__attribute__((address_space(1))) int*)err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    // a wait gives up when its own time is over OR when any block of the launch has given up (the flag is re-read every 16 polls):
+    // one broken dependency then costs one timeout, not one per block behind it
+    __device__ __forceinline__ bool give_up(u64 t0) const {
+        if (__hip_atomic_load((const __attribute__((address_space(1))) int*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > GRAN_TIMEOUT_TICKS) { fail(); return true; }
+        return false;
+    }
+    // one wave waits until the n <= 64 granules base[idx0 + lane * stride] carry the epoch (lanes >= n idle)
+    __device__ __forceinline__ bool wait(unsigned idx0, unsigned stride, int n) const {
+        const int lane = threadIdx.x & 63;
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spin = 0;; spin++) {
+            bool ok = true;
+            if (lane < n) {
+                const u64 x = __hip_atomic_load((const gu64*)(base + idx0 + lane * stride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (unsigned)(x >> 32) == epoch;
+            }
+            if (__all(ok)) return true;
+            if ((spin & 15) == 15 && give_up(t0)) return false;
+            __builtin_amdgcn_s_sleep(6);
         }
     }
+    // wave-level retry loop around a per-lane sweep `f` (returns the lane's ok)
+    template <class F>
+    __device__ __forceinline__ void sweep(F f) const {
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spin = 0;; spin++) {
+            if (__all(f())) return;
+            if ((spin & 15) == 15 && give_up(t0)) return;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+};
+
+// ---- operand providers of row1_core: issue() runs before the weight loads, finish() after (all threads call both)
+
+// x = base + p0 + p1 + p2 + p3 (the residual stream entering a layer: x_mid of the previous layer + its four down-projection
+// partials, summed in this order), every vector [H] granules; or a plain fp32 vector (layer 0: the embedding k_sample left).
+struct OpFold {
+    const Gran* G; unsigned xg, dg; int H;      // granule indices of x_mid [H] and the partials [SK_MAXNP][H] of the previous layer
+    const float* plain; int dbg;
+    __device__ __forceinline__ void issue(int, int, bool) {}
+    // one value at column c (call wave-uniformly)
+    __device__ __forceinline__ float get1(int c, bool active) const {
+        float v = 0.f;
+        if (plain) { if (active) v = plain[c]; return v; }
+        G->sweep([&]() {
+            if (!active) return true;
+            u64 x[1 + SK_MAXNP];
+            x[0] = __hip_atomic_load((const gu64*)(G->base + xg + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < SK_MAXNP; i++) x[1 + i] = __hip_atomic_load((const gu64*)(G->base + dg + i * H + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i <= SK_MAXNP; i++) ok &= (unsigned)(x[i] >> 32) == G->epoch;
+            v = __builtin_bit_cast(float, (unsigned)x[0]);
+#pragma unroll
+            for (int i = 0; i < SK_MAXNP; i++) v += __builtin_bit_cast(float, (unsigned)x[1 + i]);
+            return ok;
+        });
+        return v;
+    }
+    static constexpr int IW = 4;                 // operand columns per thread: 5 vectors x 4 granules in flight per lane
+    __device__ __forceinline__ f32x8 finish(int k, int wave, int nitems, bool active, char*) {
+        f32x8 r = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (wave * 64 >= nitems) return r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (plain) {
+            if (active) v = *reinterpret_cast<const f32x4*>(plain + k);
+        } else {
+            G->wait(dg + H - 1, H, SK_MAXNP);                      // the last tile of each split
+            G->sweep([&]() {
+                bool ok = true;
+                if (active) {
+                    f32x4 p[SK_MAXNP];
+                    ok = G->ld4(xg + k, v);
+#pragma unroll
+                    for (int i = 0; i < SK_MAXNP; i++) ok &= G->ld4(dg + i * H + k, p[i]);
+#pragma unroll
+                    for (int i = 0; i < SK_MAXNP; i++) v += p[i];
+                }
+                return ok;
+            });
+        }
+        r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3];
+        return r;
+    }
+};
+// a single granule vector (x_mid for gate/up, h for the down projection)
+template <int IW_>
+struct OpGran {
+    static constexpr int IW = IW_;
+    const Gran* G; unsigned g0, sentinel; int dbg;
     __device__ __forceinline__ void issue(int, int, bool) {}
     __device__ __forceinline__ f32x8 finish(int k, int wave, int nitems, bool active, char*) {
         f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (wave == 0 && !gran_wait1(sentinel, epoch) && (threadIdx.x & 63) == 0) *err = 3;
-        __syncthreads();
-        if (wave * 64 < nitems) {                                  // wave-uniform: waves without an item do not poll
-            if (!gran_gather8(gran + k, epoch, active, v) && (threadIdx.x & 63) == 0) *err = 3;
+        if (wave * 64 >= nitems) return v;
+        G->wait(sentinel, 0, 1);
+        if (IW == 8) {
+            G->sweep([&]() { return active ? G->ld8(g0 + k, v) : true; });
+        } else {
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+            G->sweep([&]() { return active ? G->ld4(g0 + k, q) : true; });
+            v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
         }
         return v;
     }
 };
-struct OpAtt {               // the vector is the split-key attention output: combined while loading (skinny.h, half-fold form)
-    SkinnyX X; int K; bool dbg;
-    SkRawHalf raw; int hgrp, htid;
-    __device__ __forceinline__ void before_weights(int) {}
-    __device__ __forceinline__ void issue(int tid, int nitems, bool) {
-        hgrp = tid >> 7; htid = tid & 127;
-        if (htid < nitems) sk_issue_att_half(X, 0, K, htid * 8, hgrp * SK_HALFSPLIT, raw);
-    }
-    __device__ __forceinline__ f32x8 finish(int, int, int nitems, bool, char* xch_) {
-        float hM = -INFINITY, hden = 0.f;
-        f32x8 hacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v = hacc;
-        if (htid < nitems) sk_partial_att_half(raw, hgrp * SK_HALFSPLIT, hM, hden, hacc);
+// the attention output: the live 64-key tiles' unnormalised partials {o[rep * 64], (max, sum)[rep]} per kv head, combined here
+// (flash-decoding merge).  Two thread groups take alternate tiles and merge through LDS.
+#define AT_GSTRIDE 464                         // granules per (tile, kv head): rep * 64 outputs, then rep x {max, sum}; rep <= 7
+struct OpAtt {
+    static constexpr int IW = 8;
+    const Gran* G; unsigned ag; int n_kv, rep, cnt; int dbg;      // cnt = live tiles
+    const OpFold* fold; int col0;                                  // the block's 16 residual columns, fetched beside the attention sweep
+    __device__ __forceinline__ void issue(int, int, bool) {}
+    __device__ __forceinline__ f32x8 finish(int, int wave, int nitems, bool, char* xch_) {
+        const int tid = threadIdx.x, hgrp = tid >> 7, htid = tid & 127;
+        const bool act = htid < nitems;
+        const int k = htid * 8, hd = k >> 6, g = hd / rep, hh = hd - g * rep;
+        if (wave == 0) G->wait(ag + rep * 64, AT_GSTRIDE, cnt * n_kv);   // one granule of every live (tile, head) pair; cnt * n_kv <= 64
+        __syncthreads();
         float* xch = reinterpret_cast<float*>(xch_);
-        if (hgrp == 1 && htid < nitems) {
+        if (wave == 3) {                                           // its last 16 lanes own no item: they fetch the residual columns
+            const float rv = fold->get1(col0 + (tid & 15), tid >= 240);
+            if (tid >= 240) xch[1200 + (tid & 15)] = rv;
+        }
+        float M = -INFINITY, den = 0.f;
+        f32x8 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v = acc;
+        for (int s = hgrp; s < cnt; s += 2) {                      // (trip count uniform per 128-thread group, i.e. per wave)
+            const unsigned a0 = ag + (unsigned)(s * n_kv + g) * AT_GSTRIDE;
+            f32x8 o = acc; float m = 0.f, l = 0.f;
+            G->sweep([&]() {
+                if (!act) return true;
+                bool ok = G->ld8(a0 + hh * 64 + (k & 63), o);
+                const u32x4 ml = G->ld2(a0 + rep * 64 + hh * 2);
+                ok &= ml[1] == G->epoch && ml[3] == G->epoch;
+                m = __builtin_bit_cast(float, ml[0]); l = __builtin_bit_cast(float, ml[2]);
+                return ok;
+            });
+            const float Mn = fmaxf(M, m);
+            const float w0 = __expf(M - Mn), w1 = __expf(m - Mn);  // first tile: M = -inf -> w0 = 0
+            den = den * w0 + l * w1;
+            acc = acc * w0 + o * w1;
+            M = Mn;
+        }
+        if (hgrp == 1 && act) {
             float* d = xch + htid * 10;
-            d[0] = hM; d[1] = hden;
+            d[0] = M; d[1] = den;
 #pragma unroll
-            for (int e = 0; e < 8; e++) d[2 + e] = hacc[e];
+            for (int e = 0; e < 8; e++) d[2 + e] = acc[e];
         }
         __syncthreads();
-        if (hgrp == 0 && htid < nitems) {
+        if (hgrp == 0 && act) {
             const float* d = xch + htid * 10;
-            const float M1 = d[0], M = fmaxf(hM, M1);
-            const float w0 = __expf(hM - M), w1 = __expf(M1 - M);
-            const float den = hden * w0 + d[1] * w1;
+            const float M1 = d[0], Mn = fmaxf(M, M1);
+            const float w0 = __expf(M - Mn), w1 = __expf(M1 - Mn); // a group without tiles has max = -inf: weight 0
+            const float dn = den * w0 + d[1] * w1;
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (hacc[e] * w0 + d[2 + e] * w1) * (1.f / den);
+            for (int e = 0; e < 8; e++) v[e] = (acc[e] * w0 + d[2 + e] * w1) * (1.f / dn);
         }
         return v;
     }
 };
 
-// LDS of one block: operand stage (hi / lo planes, 64 B per 32-wide k-step and plane: only column 0 of the MFMA's B operand is
-// real at one row, every lane of a 16-lane quarter reads the same 16 bytes), exchange area of OpAtt, reduction slots.
+// LDS of one GEMV block: operand stage (hi / lo planes, 64 B per 32-wide k-step and plane: only column 0 of the MFMA's B operand
+// is real at one row, every lane of a 16-lane quarter reads the same 16 bytes), exchange area of OpAtt, reduction slots.
 #define R1_STAGE_BYTES(nks) ((nks) * 128)
 #define R1_XCH_BYTES (128 * 10 * 4)
-template <int NWR, int NWK>
-__device__ __host__ constexpr int r1_smem_bytes(int nks) { return R1_STAGE_BYTES(nks) + R1_XCH_BYTES + 16 + NWK * NWR * 4 * 16; }
+__device__ __host__ constexpr int r1_smem_bytes(int nks) { return R1_STAGE_BYTES(nks) + R1_XCH_BYTES + 16 + 4 * 4 * 16; }
 
-// out[f] (f < NWR * 16) = sum_k W[tile0 * 16 + f][k] * x[k] over the block's k-steps [ks0, ks1), x = op's vector [* RMSNorm].
-// Returns the feature's value in thread f (threads >= NWR * 16: unspecified).  256 threads = NWR x NWK waves.
-template <int NWR, int NWK, int MAXKS, bool NORM, class OP>
-__device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int tile0, int KS, int K, int ks0, int ks1, OP& op,
-                                           const float* norm_w, float eps, float* x_out, char* smem) {
+// out[f] (f < NWR * 16) = sum_k W[(tile0 + (f / 16) * tstride) * 16 + f % 16][k] * x[k] over the k-steps [ks0, ks1),
+// x = op's vector [* RMSNorm weight, scaled by the row's rstd].  Returns feature f's value in thread f (other threads: 0).
+// 256 threads = NWR x NWK waves; every wave's weight fragments (<= MAXKS) are requested first.
+struct R1NoHook { __device__ __forceinline__ void operator()() const {} };
+// `issued` runs right after the weight requests: the place for a role's own dependent loads (Q: position -> RoPE table).
+template <int NWR, int NWK, int MAXKS, bool NORM, class OP, class HOOK = R1NoHook>
+__device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int tile0, int tstride, int KS, int K, int ks0, int ks1, OP& op,
+                                           const float* norm_w, float eps, char* smem, HOOK issued = HOOK()) {
     static_assert(NWR * NWK == 4, "row1_core: 256 threads");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave % NWR, wk = wave / NWR;
     const int nks = ks1 - ks0;
     const int w0 = ks0 + (nks * wk) / NWK, w1 = ks0 + (nks * (wk + 1)) / NWK;
-    const int nitems = nks * 4;                                   // groups of 8 operand values; item i belongs to thread i
+    constexpr int IW = OP::IW;                                    // operand columns per thread (4 or 8)
+    const int nitems = nks * (32 / IW);                           // item i belongs to thread i (<= 256)
     const bool active = tid < nitems;
-    const int k = ks0 * 32 + tid * 8;
+    const int k = ks0 * 32 + tid * IW;
     char* stage = smem;
     char* xch = smem + R1_STAGE_BYTES(nks);
     float* sqs = reinterpret_cast<float*>(xch + R1_XCH_BYTES);     // [4] per-wave sums of squares
-    f32x4* red = reinterpret_cast<f32x4*>(xch + R1_XCH_BYTES + 16);   // [NWK][NWR][4 quarters]
-    op.before_weights(wave);
+    float* red = reinterpret_cast<float*>(xch + R1_XCH_BYTES + 16);   // [NWK][NWR][4 quarters][4]
     op.issue(tid, nitems, active);
     f32x8 g0 = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-    if (NORM && active) g0 = *reinterpret_cast<const f32x8*>(norm_w + k);
-    const char* wbase = reinterpret_cast<const char*>(W) + ((size_t)(tile0 + wr) * KS + w0) * 1024;
+    if (NORM && active) {
+        if (IW == 8) g0 = *reinterpret_cast<const f32x8*>(norm_w + k);
+        else { const f32x4 g4 = *reinterpret_cast<const f32x4*>(norm_w + k); g0[0] = g4[0]; g0[1] = g4[1]; g0[2] = g4[2]; g0[3] = g4[3]; }
+    }
+    const char* wbase = reinterpret_cast<const char*>(W) + ((size_t)(tile0 + wr * tstride) * KS + w0) * 1024;
     const unsigned wlane = lane * 16;
     s16x8 abuf[MAXKS];
     const int nw = w1 - w0;
@@ -156,22 +269,32 @@ __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int t
     for (int i = 0; i < MAXKS; i++)
         abuf[i] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wbase + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024 + wlane));
     __builtin_amdgcn_sched_barrier(0);
+    issued();
     f32x8 v = op.finish(k, wave, nitems, active, xch);
     R1_T_OPERAND;
     if (NORM) {
         float sq = 0.f;
-        if (active) sq = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+        if (active) {
+            sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            if (IW == 8) sq += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
+        }
         sq = wave_sum(sq);
         if (lane == 0) sqs[wave] = sq;
     }
     if (active) {
-        if (x_out) *reinterpret_cast<f32x8*>(x_out + k) = v;
         if (NORM) v = g0 * v;
         bf16x8 hi, lo;
         split8(v, hi, lo);
-        bf16x8* dst = reinterpret_cast<bf16x8*>(stage + (size_t)(tid >> 2) * 128) + (tid & 3);
-        dst[0] = hi;
-        dst[4] = lo;
+        if (IW == 8) {
+            bf16x8* dst = reinterpret_cast<bf16x8*>(stage + (size_t)(tid >> 2) * 128) + (tid & 3);
+            dst[0] = hi;
+            dst[4] = lo;
+        } else {                                                   // the lower four of the pair: half of a 16-byte k-group
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4* dst = reinterpret_cast<bf16x4*>(stage + (size_t)(tid >> 3) * 128) + (tid & 7);
+            dst[0] = __builtin_shufflevector(hi, hi, 0, 1, 2, 3);
+            dst[8] = __builtin_shufflevector(lo, lo, 0, 1, 2, 3);
+        }
     }
     __syncthreads();
     float rs = 1.f;
@@ -188,15 +311,14 @@ __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int t
         }
     }
     // every column of the tile holds the same vector: the lanes of column 0 carry it out
-    if ((lane & 15) == 0) red[(wk * NWR + wr) * 4 + (lane >> 4)] = acc;
+    if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(red + ((wk * NWR + wr) * 4 + (lane >> 4)) * 4) = acc;
     __syncthreads();
     float out = 0.f;
     if (tid < NWR * 16) {
         const int wr_ = tid >> 4, q = (tid >> 2) & 3, r = tid & 3;
-        const float* rf = reinterpret_cast<const float*>(red);
-        out = rf[((0 * NWR + wr_) * 4 + q) * 4 + r];
+        out = red[((0 * NWR + wr_) * 4 + q) * 4 + r];
 #pragma unroll
-        for (int j = 1; j < NWK; j++) out += rf[((j * NWR + wr_) * 4 + q) * 4 + r];
+        for (int j = 1; j < NWK; j++) out += red[((j * NWR + wr_) * 4 + q) * 4 + r];
         out *= rs;
     }
     return out;

@@ -14,7 +14,7 @@
 #include "skinny.h"
 #ifdef CV2_STAMPS
 extern __device__ unsigned long long g_chain_t[1024][4];
-#define R1_T_OPERAND do { if (op.dbg && threadIdx.x == 0) g_chain_t[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define R1_T_OPERAND do { if (op.dbg >= 0 && threadIdx.x == 0) g_chain_t[op.dbg][3] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #endif
 #include "chain.h"
 #include "skinny_launch.h"
@@ -409,23 +409,24 @@ __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
   }
 }
 
-// ------------------------------------------------------------------ k_chain (one row: O projection -> gate/up -> down, chain.h)
-struct ChainArgs {
-    const uint16_t* wo; const uint16_t* wgu; const uint16_t* wdown;
-    SkinnyX Xatt;                               // attention partials (split-key combine)
-    const float* resid;                         // x1 [hidden]: residual stream entering the attention block
-    const float* ln2; float eps;
-    float* x_out;                               // x_mid [hidden] for the next layer's residual (written by gate/up block 0)
-    float* parts;                               // down-projection split-K partials [SK_MAXNP][SK_ROWS_CAP][hidden]
-    u64* xgran; u64* hgran;                     // this layer's hand-off granules: x_mid [hidden], h [inter]
-    const unsigned* epoch; int* err;
-    int H, NQ, inter;
-    int dbg;
+// ------------------------------------------------------------------ k_step: a whole one-row decode step in one launch (chain.h)
+struct StepLayer { const uint16_t *wqkv, *wo, *wgu, *wdown; const float *bqkv, *ln1, *ln2; float *kc, *vc; };
+struct StepArgs {
+    const StepLayer* layers; int n_layers;
+    const uint16_t* wdec; const float* bdec; const float* final_norm; float* logits;
+    const float* xin;                            // layer 0 input [hidden] (the embedding k_sample gathered)
+    const int* state;                            // slot 0
+    const float* cosT; const float* sinT;
+    u64* gran; unsigned gran_bytes; const unsigned* epoch; int* err;
+    int H, NQ, inter, n_q, n_kv, rep, max_pos, ntiles;
+    float eps;
+    int per;                                     // blocks per layer: Q, A, O, GU, D in this order
+    unsigned gl, off_dg, off_qg, off_kv, off_ag, off_hg;     // granules per layer; offsets of the buffers inside a layer (x_mid at 0)
+    int dbg_layer;
 };
-// blocks [0, H/16): O projection tiles; then inter/16 gate/up tiles; then SK_MAXNP x H/16 down tiles (split-major)
 #ifdef CV2_STAMPS
-__device__ unsigned long long g_chain_t[1024][4] = {};      // per block of layer 1's k_chain: start, operand ready, published (100 MHz ticks)
-#define CH_T(i) do { if (a.dbg && threadIdx.x == 0) g_chain_t[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_chain_t[1024][4] = {};      // per block of one layer: start, result, published, operand ready (100 MHz ticks)
+#define CH_T(i) do { if (dbg && threadIdx.x == 0) g_chain_t[r_dbg][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int cv2_debug_chain(unsigned long long* out_host) {
     CV2_HIP(hipDeviceSynchronize());
     CV2_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_chain_t), sizeof(unsigned long long) * 1024 * 4));
@@ -434,41 +435,200 @@ extern "C" int cv2_debug_chain(unsigned long long* out_host) {
 #else
 #define CH_T(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
+
+// Attention of one 64-key tile for the rep query heads of kv head g (the arithmetic of k_attn<1>): q, and the new token's key /
+// value row when it falls into this tile, arrive as granules from the Q role; older rows are plain cache reads.
+__device__ __forceinline__ void attn_role(const Gran& G, const float* K, const float* V, int pos, int j0, int rep,
+                                          unsigned qg, unsigned kg, unsigned vg, unsigned og, char* smem) {
+    float* qs = reinterpret_cast<float*>(smem);       // [8 * 64]
+    float* ps = qs + 512;                             // [8 * 64]
+    float* po_s = ps + 512;                           // [8 key eighths][8 heads][64]
+    float* run_m = po_s + 4096; float* run_l = run_m + 8;
+    float* knew = run_l + 8; float* vnew = knew + 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int d4 = tid & 15, kq = (tid >> 4) & 7, hs = tid >> 7;
+    const int key_t = tid >> 2, qd = tid & 3;
+    f32x4 kk[4], vv[8];
+    {
+        const unsigned ko = (unsigned)(j0 + key_t) * 64u + qd * 16, vo = (unsigned)(j0 + kq * 8) * 64u + d4 * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) kk[i] = *reinterpret_cast<const f32x4*>(K + ko + 4 * i);
+#pragma unroll
+        for (int k = 0; k < 8; k++) vv[k] = *reinterpret_cast<const f32x4*>(V + vo + 64 * k);
+    }
+    const int n = min(AT_KB, pos + 1 - j0);           // live keys of the tile (>= 1)
+    const int jn = pos - j0;                          // the new row's index in this tile (>= 64: it is in a later tile)
+    if (w == 0) G.wait(qg + rep * 64 - 1, 0, 1);      // the group's last query feature
+    __syncthreads();
+    {
+        float q0 = 0.f, q1 = 0.f;
+        const bool two = tid + 256 < rep * 64;
+        G.sweep([&]() {
+            const u64 x0 = __hip_atomic_load((const gu64*)(G.base + qg + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 x1 = __hip_atomic_load((const gu64*)(G.base + qg + (two ? tid + 256 : tid)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q0 = __builtin_bit_cast(float, (unsigned)x0); q1 = __builtin_bit_cast(float, (unsigned)x1);
+            return (unsigned)(x0 >> 32) == G.epoch && (unsigned)(x1 >> 32) == G.epoch;
+        });
+        qs[tid] = q0;
+        if (two) qs[tid + 256] = q1;
+    }
+    if (jn < AT_KB && w < 2) {                         // the new token's key / value row
+        float x = 0.f;
+        const unsigned gi = tid < 64 ? kg + tid : vg + tid - 64;
+        G.sweep([&]() {
+            const u64 xx = __hip_atomic_load((const gu64*)(G.base + gi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x = __builtin_bit_cast(float, (unsigned)xx);
+            return (unsigned)(xx >> 32) == G.epoch;
+        });
+        (tid < 64 ? knew : vnew)[tid & 63] = x;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) vv[k] = kq * 8 + k < n ? vv[k] : (f32x4){0.f, 0.f, 0.f, 0.f};     // rows past the length may hold anything
+    __syncthreads();
+    if (jn < AT_KB) {
+        if (key_t == jn) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) kk[i] = *reinterpret_cast<const f32x4*>(&knew[qd * 16 + 4 * i]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (kq * 8 + k == jn) vv[k] = *reinterpret_cast<const f32x4*>(&vnew[d4 * 4]);
+    }
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+        if (h < rep) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[h * 64 + qd * 16 + 4 * i]);
+                acc += kk[i][0] * qv[0] + kk[i][1] * qv[1] + kk[i][2] * qv[2] + kk[i][3] * qv[3];
+            }
+            acc += dpp_mov_f32<0xB1, 0xf>(0.f, acc);
+            acc += dpp_mov_f32<0x4E, 0xf>(0.f, acc);
+            if (qd == 0) ps[h * AT_KB + key_t] = key_t < n ? acc * 0.125f : -INFINITY;
+        }
+    }
+    __syncthreads();
+    for (int h = w; h < rep; h += 4) {
+        const float s0 = ps[h * AT_KB + lane];
+        const float mt = wave_max(s0);
+        const float p0 = __expf(s0 - mt);
+        ps[h * AT_KB + lane] = p0;
+        const float lt = wave_sum(p0);
+        if (lane == 0) { run_m[h] = mt; run_l[h] = lt; }
+    }
+    __syncthreads();
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int h = min(hs * 4 + i, rep - 1);
+#pragma unroll
+        for (int k4 = 0; k4 < 2; k4++) {
+            const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[h * AT_KB + kq * 8 + 4 * k4]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[i] += pa[e] * vv[4 * k4 + e];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (hs * 4 + i < rep) *reinterpret_cast<f32x4*>(&po_s[(kq * 8 + hs * 4 + i) * 64 + d4 * 4]) = o[i];
+    __syncthreads();
+    for (int e = tid; e < rep * 64; e += 256) {
+        const float* pp = &po_s[e];
+        G.store(og + e, ((pp[0] + pp[512]) + (pp[1024] + pp[1536])) + ((pp[2048] + pp[2560]) + (pp[3072] + pp[3584])));
+    }
+    if (tid < rep) { G.store(og + rep * 64 + tid * 2, run_m[tid]); G.store(og + rep * 64 + tid * 2 + 1, run_l[tid]); }
+}
+
+__global__ __launch_bounds__(256) void k_step(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
+    const int gb = blockIdx.x;
+    const int layer = gb / a.per;
+    int r = gb - layer * a.per;
+    const int H = a.H;
+    const int nQ = 2 * (a.n_q + 2 * a.n_kv), nA = a.ntiles * a.n_kv, nO = H / 16, nGU = a.inter / 16;
+    const bool dbg = layer == a.dbg_layer;
+    const int r_dbg = r, od = dbg ? r : -1; (void)r_dbg; (void)dbg;
     CH_T(0);
-    const unsigned epoch = *a.epoch;
-    const int nO = a.H / 16, nGU = a.inter / 16;
-    int b = blockIdx.x;
-    if (b < nO) {
-        const float rv = a.resid[b * 16 + (tid & 15)];          // requested before anything else; needed last
-        OpAtt op{a.Xatt, a.NQ, a.dbg != 0};
-        const float o = row1_core<1, 4, 8, false>(a.wo, b, a.NQ / 32, a.NQ, 0, a.NQ / 32, op, nullptr, 0.f, nullptr, smem);
+    Gran G;
+    G.init(a.gran, a.gran_bytes, *a.epoch, a.err);
+    const unsigned gl = (unsigned)min(layer, a.n_layers - 1) * a.gl;        // this layer's granules (head: the last layer's)
+    const unsigned gp = layer > 0 ? (unsigned)(layer - 1) * a.gl : 0u;      // the previous layer's
+    if (layer >= a.n_layers) {      // head: final norm -> llm_decoder (+ bias) -> logits (read by k_sample, the next launch)
+        OpFold op{&G, gl, gl + a.off_dg, H, nullptr, -1};
+        const float out = row1_core<1, 4, 8, true>(a.wdec, r, 0, H / 32, H, 0, H / 32, op, a.final_norm, a.eps, smem);
+        if (tid < 16) a.logits[r * 16 + tid] = out + a.bdec[r * 16 + tid];
+        return;
+    }
+    const StepLayer L = a.layers[layer];
+    OpFold xin{&G, gp, gp + a.off_dg, H, layer == 0 ? a.xin : nullptr, od};
+    if (r < nQ) {                   // ---- Q: RMSNorm -> QKV -> + bias -> RoPE -> q granules / key, value granules + cache rows
+        const int head = r >> 1, half = r & 1;
+        const int pos = a.state[CV2_ST_POS];
+        const int f = half * 16 + ((tid >> 4) & 1) * 32 + (tid & 15);
+        const float bias = L.bqkv[head * 64 + f];
+        float c, sn;
+        auto hook = [&]() { c = a.cosT[pos * 32 + (f & 31)]; sn = a.sinT[pos * 32 + (f & 31)]; };
+        float v = row1_core<2, 2, 14, true>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin, L.ln1, a.eps, smem, hook) + bias;
+        const float vp = __shfl(v, (tid & 63) ^ 16);
+        if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);      // rotate-half RoPE on q and k heads
         CH_T(1);
-        if (tid < 16) gran_store(a.xgran + b * 16 + tid, epoch, rv + o);
+        if (tid < 32) {
+            if (head < a.n_q) G.store(gl + a.off_qg + head * 64 + f, v);
+            else if (head < a.n_q + a.n_kv) {
+                const int kvh = head - a.n_q;
+                G.store(gl + a.off_kv + kvh * 64 + f, v);
+                L.kc[((size_t)kvh * a.max_pos + pos) * 64 + f] = v;
+            } else {
+                const int kvh = head - a.n_q - a.n_kv;
+                G.store(gl + a.off_kv + (a.n_kv + kvh) * 64 + f, v);
+                L.vc[((size_t)kvh * a.max_pos + pos) * 64 + f] = v;
+            }
+        }
         CH_T(2);
         return;
     }
-    b -= nO;
-    if (b < nGU) {
-        OpGran op{a.xgran, epoch, a.err, a.xgran + a.H - 1, nullptr, true, a.dbg != 0};
-        const float v = row1_core<2, 2, 14, true>(a.wgu, b * 2, a.H / 32, a.H, 0, a.H / 32, op, a.ln2, a.eps, b == 0 ? a.x_out : nullptr, smem);
+    r -= nQ;
+    if (r < nA) {                   // ---- A: one 64-key tile of one kv head
+        const int tile = r / a.n_kv, g = r - tile * a.n_kv;
+        const int pos = a.state[CV2_ST_POS];
+        if (tile * AT_KB > pos) return;                 // tile beyond the sequence: the consumer derives the live count from pos too
+        attn_role(G, L.kc + (size_t)g * a.max_pos * 64, L.vc + (size_t)g * a.max_pos * 64, pos, tile * AT_KB, a.rep,
+                  gl + a.off_qg + g * a.rep * 64, gl + a.off_kv + g * 64, gl + a.off_kv + (a.n_kv + g) * 64,
+                  gl + a.off_ag + (unsigned)r * AT_GSTRIDE, smem);
+        CH_T(2);
+        return;
+    }
+    r -= nA;
+    if (r < nO) {                   // ---- O: attention combine -> O projection -> + residual -> x_mid granules
+        const int pos = a.state[CV2_ST_POS];
+        OpAtt op{&G, gl + a.off_ag, a.n_kv, a.rep, pos / AT_KB + 1, od, &xin, r * 16};
+        const float o = row1_core<1, 4, 8, false>(L.wo, r, 0, a.NQ / 32, a.NQ, 0, a.NQ / 32, op, nullptr, 0.f, smem);
+        CH_T(1);
+        if (tid < 16) G.store(gl + r * 16 + tid, reinterpret_cast<const float*>(smem + R1_STAGE_BYTES(a.NQ / 32))[1200 + tid] + o);
+        CH_T(2);
+        return;
+    }
+    r -= nO;
+    if (r < nGU) {                  // ---- GU: RMSNorm -> gate / up -> SiLU(g) * u -> h granules
+        OpGran<4> op{&G, gl, gl + H - 1, od};
+        const float v = row1_core<2, 2, 14, true>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, op, L.ln2, a.eps, smem);
         const float u = __shfl(v, (tid & 15) + 16);            // threads 0..15 hold gate, 16..31 up (wave 0)
         CH_T(1);
-        if (tid < 16) gran_store(a.hgran + b * 16 + tid, epoch, (v / (1.f + __expf(-v))) * u);
+        if (tid < 16) G.store(gl + a.off_hg + r * 16 + tid, (v / (1.f + __expf(-v))) * u);
         CH_T(2);
         return;
     }
-    b -= nGU;
-    {
-        const int sp = b / nO, tile = b - sp * nO;
+    r -= nGU;
+    {                               // ---- D: down projection, K split SK_MAXNP ways -> partial granules
+        const int sp = r / nO, tile = r - sp * nO;
         const int KS = a.inter / 32;
         const int ks0 = (int)(((unsigned)KS * sp) / SK_MAXNP), ks1 = (int)(((unsigned)KS * (sp + 1)) / SK_MAXNP);
-        OpGran op{a.hgran, epoch, a.err, a.hgran + ks1 * 32 - 1, a.xgran + a.H - 1, false, a.dbg != 0};
-        const float v = row1_core<1, 4, 10, false>(a.wdown, tile, KS, a.inter, ks0, ks1, op, nullptr, 0.f, nullptr, smem);
+        OpGran<8> op{&G, gl + a.off_hg, gl + a.off_hg + ks1 * 32 - 1, od};
+        const float v = row1_core<1, 4, 10, false>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op, nullptr, 0.f, smem);
         CH_T(1);
-        if (tid < 16) a.parts[(size_t)sp * SK_ROWS_CAP * a.H + tile * 16 + tid] = v;
+        if (tid < 16) G.store(gl + a.off_dg + sp * H + tile * 16 + tid, v);
         CH_T(2);
     }
 }
@@ -1095,10 +1255,14 @@ struct cv2_llm {
     float *pf_x, *pf_qkv, *pf_q, *pf_gu, *pf_last;
     uint16_t *pf_hi, *pf_lo;
     int* pf_int;               // row_seq[pf_rows], row_pos[pf_rows], seq tables 5 x 32
-    u64 *xgran, *hgran;        // k_chain hand-off granules [layers][hidden], [layers][inter]
+    u64* gran;                 // k_step hand-off granules [layers][gl]
+    unsigned gran_bytes;
+    StepArgs step;             // launch arguments of k_step (fixed at create)
+    StepLayer* step_layers;    // device copy of the per-layer pointer table
+    int step_blocks;
     unsigned* epoch;           // hand-off epoch (device), advanced by k_sample
     size_t chain_off, chain_bytes;   // the region cv2_llm_create zeroes
-    bool use_chain;            // one-row decode steps run O projection -> gate/up -> down as one launch (CV2_LLM_CHAIN=0 disables)
+    bool use_chain;            // a one-row decode step is ONE launch, k_step (CV2_LLM_CHAIN=0: the five launches per layer)
     std::map<int, hipGraphExec_t> graphs;
     hipStream_t cap_stream;    // private stream used only to capture the decode-step graph (the caller's may be the null stream)
 };
@@ -1128,8 +1292,13 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     p = take((size_t)SK_MAXNP * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
     if (h) h->chain_off = off;
     p = take(256); if (h) h->epoch = (unsigned*)p;
-    p = take((size_t)d.layers * d.hidden * 8); if (h) h->xgran = (u64*)p;
-    p = take((size_t)d.layers * d.inter * 8); if (h) h->hgran = (u64*)p;
+    {   // per layer: x_mid [H], down partials [SK_MAXNP][H], q [NQ], new key / value rows [2 n_kv 64], attention partials
+        // [tiles][n_kv][AT_GSTRIDE], h [inter]
+        const size_t ntiles = (d.max_pos + AT_KB - 1) / AT_KB;
+        const size_t gl = (size_t)d.hidden * (1 + SK_MAXNP) + (size_t)d.n_q * 64 + (size_t)2 * d.n_kv * 64 + ntiles * d.n_kv * AT_GSTRIDE + d.inter;
+        p = take((size_t)d.layers * gl * 8); if (h) { h->gran = (u64*)p; h->gran_bytes = (unsigned)((size_t)d.layers * gl * 8); }
+        p = take((size_t)d.layers * sizeof(StepLayer)); if (h) h->step_layers = (StepLayer*)p;
+    }
     if (h) h->chain_bytes = off - h->chain_off;
     const size_t R = (size_t)(d.max_prefill_rows > 0 ? (d.max_prefill_rows + 127) / 128 * 128 : 0);
     if (h) h->pf_rows = (int)R;
@@ -1176,18 +1345,40 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
         delete h;
         return cv2_fail("cv2_llm_create: hipStreamCreateWithFlags failed");
     }
-    {   // hand-off state of k_chain: every granule tag 0, epoch 1 (tags are compared with the epoch, never 0)
+    {   // hand-off state of k_step: every granule tag 0, epoch 1 (tags are compared with the epoch, never 0)
         const char* e = getenv("CV2_LLM_CHAIN");
-        h->use_chain = !(e && e[0] == '0') && d->hidden % 32 == 0 && d->inter % (32 * SK_MAXNP) == 0 &&
+        const int ntiles = (d->max_pos + AT_KB - 1) / AT_KB, rep = d->n_q / d->n_kv;
+        h->use_chain = !(e && e[0] == '0') && d->hidden % 32 == 0 && d->inter % (32 * SK_MAXNP) == 0 && d->vocab_pad % 16 == 0 &&
                        d->hidden / 32 <= 2 * 14 && d->n_q * 64 / 32 <= 4 * 8 && d->inter / 32 / SK_MAXNP <= 4 * 10 &&
-                       d->n_q * 64 / 8 <= 128;
+                       d->n_q * 64 / 8 <= 112 && rep * 64 + rep * 2 <= AT_GSTRIDE && rep * 64 <= 512 && ntiles * d->n_kv <= 64 &&
+                       d->hidden % 2 == 0;
         const unsigned one = 1u;
+        std::vector<StepLayer> tab(d->layers);
+        const size_t cache_l = (size_t)d->max_seqs * d->n_kv * d->max_pos * 64;
+        for (int l = 0; l < d->layers; l++) {
+            const cv2_llm_layer& L = h->layers[l];
+            tab[l] = StepLayer{L.wqkv, L.wo, L.wgu, L.wdown, L.bqkv, L.ln1, L.ln2, h->kc + l * cache_l, h->vc + l * cache_l};
+        }
         if (hipMemset((char*)ws + h->chain_off, 0, h->chain_bytes) != hipSuccess ||
-            hipMemcpy(h->epoch, &one, sizeof(one), hipMemcpyHostToDevice) != hipSuccess) {
+            hipMemcpy(h->epoch, &one, sizeof(one), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->step_layers, tab.data(), tab.size() * sizeof(StepLayer), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipStreamDestroy(h->cap_stream);
             delete h;
             return cv2_fail("cv2_llm_create: initialising the hand-off state failed");
         }
+        StepArgs& a = h->step;
+        a = StepArgs{};
+        a.layers = h->step_layers; a.n_layers = d->layers;
+        a.wdec = h->w.wdec; a.bdec = h->w.bdec; a.final_norm = h->w.final_norm; a.logits = h->io.logits;
+        a.xin = h->xnext; a.state = h->io.state; a.cosT = h->w.rope_cos; a.sinT = h->w.rope_sin;
+        a.gran = h->gran; a.gran_bytes = h->gran_bytes; a.epoch = h->epoch; a.err = h->io.state + CV2_ST_ERR;
+        a.H = d->hidden; a.NQ = d->n_q * 64; a.inter = d->inter; a.n_q = d->n_q; a.n_kv = d->n_kv; a.rep = rep; a.max_pos = d->max_pos;
+        a.ntiles = ntiles; a.eps = d->rms_eps;
+        a.per = 2 * (d->n_q + 2 * d->n_kv) + ntiles * d->n_kv + d->hidden / 16 + d->inter / 16 + SK_MAXNP * (d->hidden / 16);
+        a.off_dg = d->hidden; a.off_qg = a.off_dg + SK_MAXNP * d->hidden; a.off_kv = a.off_qg + d->n_q * 64;
+        a.off_ag = a.off_kv + 2 * d->n_kv * 64; a.off_hg = a.off_ag + ntiles * d->n_kv * AT_GSTRIDE; a.gl = a.off_hg + d->inter;
+        a.dbg_layer = -1;
+        h->step_blocks = d->layers * a.per + d->vocab_pad / 16;
     }
     *out = h;
     return 0;
@@ -1231,23 +1422,6 @@ static int run_layers(cv2_llm* h, int rows, const float* xin, RowMap rm, hipStre
             AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm, d.n_q / d.n_kv};
             launch_attn(a, rows, s);
             STAMP_SET(-1);
-        }
-        if (rows == 1 && !rm.prefill && h->use_chain) {
-            // one decode row: O projection -> gate/up -> down projection as ONE launch (chain.h)
-            float* x2c = (x1 == h->xa) ? h->xb : h->xa;
-            ChainArgs a{};
-            a.wo = L.wo; a.wgu = L.wgu; a.wdown = L.wdown;
-            a.Xatt = SkinnyX{nullptr, h->att, h->nsplit, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt};
-            a.resid = x1; a.ln2 = L.ln2; a.eps = d.rms_eps; a.x_out = x2c; a.parts = h->parts;
-            a.xgran = h->xgran + (size_t)l * H; a.hgran = h->hgran + (size_t)l * d.inter;
-            a.epoch = h->epoch; a.err = h->io.state + CV2_ST_ERR;
-            a.H = H; a.NQ = d.n_q * 64; a.inter = d.inter; a.dbg = l == 1;
-            const int nks_max = std::max(std::max(KSH, d.n_q * 64 / 32), cdiv(d.inter / 32, SK_MAXNP));
-            const size_t sm = r1_smem_bytes<1, 4>(nks_max);
-            hipLaunchKernelGGL(k_chain, dim3(H / 16 + d.inter / 16 + SK_MAXNP * (H / 16)), dim3(256), sm, s, a);
-            xcur = x2c;
-            np = SK_MAXNP;
-            continue;
         }
         if (rows <= 4) {     // few rows: combine the key splits while loading the O-projection operand (saves a launch)
             StoreArgs a{};
@@ -1530,6 +1704,17 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, hipGraphExec_t* out) {
         RowMap rm{h->io.state, 0, 0, 0};
         int rc = 0;
         for (int u = 0; u < unroll && !rc; u++) {
+            if (n_seqs == 1 && h->use_chain) {
+                const cv2_llm_dims& d = h->d;
+                const int nks_max = std::max(std::max(d.hidden / 32, d.n_q * 64 / 32), cdiv(d.inter / 32, SK_MAXNP));
+                const size_t sm = std::max((size_t)r1_smem_bytes(nks_max), (size_t)(512 + 512 + 4096 + 16 + 128) * sizeof(float));
+                StepArgs a = h->step;
+#ifdef CV2_STAMPS
+                a.dbg_layer = 12;
+#endif
+                hipLaunchKernelGGL(k_step, dim3(h->step_blocks), dim3(256), sm, cs, a);
+                if (hipGetLastError() != hipSuccess) rc = cv2_fail("k_step launch failed");
+            } else
             rc = n_seqs <= 16 ? run_layers<1>(h, n_seqs, h->xnext, rm, cs) : run_layers_pre(h, n_seqs, h->xnext, rm, cs);
             STAMP_SET_ON(cs, 5);
             if (!rc) rc = launch_sample(h, n_seqs, -1, 0, 0, cs);
