@@ -22,6 +22,7 @@
 #include "skinny.h"
 #ifndef R1_T_OPERAND
 #define R1_T_OPERAND do { } while (0)
+#define R1_T(i) do { } while (0)
 #endif
 
 typedef unsigned long long u64;
@@ -29,6 +30,9 @@ typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 #define GRAN_TIMEOUT_TICKS 20000000ull     // s_memrealtime runs at 100 MHz: 0.2 s
+
+// (by value on purpose: clang lowers __builtin_bit_cast of a vector ELEMENT lvalue as a load from the vector's address, i.e. element 0)
+__device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
 
 struct Gran {                 // all granule buffers of the engine behind one buffer descriptor (32-bit byte offsets)
     __amdgpu_buffer_rsrc_t rsrc; u64* base; unsigned epoch; int* err;
@@ -51,14 +55,14 @@ struct Gran {                 // all granule buffers of the engine behind one bu
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             ok &= x[i][1] == epoch && x[i][3] == epoch;
-            v[2 * i] = __builtin_bit_cast(float, x[i][0]); v[2 * i + 1] = __builtin_bit_cast(float, x[i][2]);
+            v[2 * i] = u2f(x[i][0]); v[2 * i + 1] = u2f(x[i][2]);
         }
         return ok;
     }
     __device__ __forceinline__ bool ld4(unsigned idx, f32x4& v) const {   // 4 consecutive granules
         const u32x4 x0 = ld2(idx), x1 = ld2(idx + 2);
-        v[0] = __builtin_bit_cast(float, x0[0]); v[1] = __builtin_bit_cast(float, x0[2]);
-        v[2] = __builtin_bit_cast(float, x1[0]); v[3] = __builtin_bit_cast(float, x1[2]);
+        v[0] = u2f(x0[0]); v[1] = u2f(x0[2]);
+        v[2] = u2f(x1[0]); v[3] = u2f(x1[2]);
         return x0[1] == epoch && x0[3] == epoch && x1[1] == epoch && x1[3] == epoch;
     }
     __device__ __forceinline__ void fail() const { if ((threadIdx.x & 63) == 0) __hip_atomic_store((__attribute__((address_space(1))) int*)err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -77,6 +81,23 @@ struct Gran {                 // all granule buffers of the engine behind one bu
             bool ok = true;
             if (lane < n) {
                 const u64 x = __hip_atomic_load((const gu64*)(base + idx0 + lane * stride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (unsigned)(x >> 32) == epoch;
+            }
+            if (__all(ok)) return true;
+            if ((spin & 15) == 15 && give_up(t0)) return false;
+            __builtin_amdgcn_s_sleep(6);
+        }
+    }
+    // the same with an index function: lane i < n polls granule idx(i)
+    template <class F>
+    __device__ __forceinline__ bool wait_f(int n, F idx) const {
+        const int lane = threadIdx.x & 63;
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned my = lane < n ? idx(lane) : 0u;
+        for (unsigned spin = 0;; spin++) {
+            bool ok = true;
+            if (lane < n) {
+                const u64 x = __hip_atomic_load((const gu64*)(base + my), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = (unsigned)(x >> 32) == epoch;
             }
             if (__all(ok)) return true;
@@ -132,7 +153,7 @@ struct OpFold {
         if (plain) {
             if (active) v = *reinterpret_cast<const f32x4*>(plain + k);
         } else {
-            G->wait(dg + H - 1, H, SK_MAXNP);                      // the last tile of each split
+            G->wait_f(2 * SK_MAXNP, [&](int i) { return dg + (unsigned)(i >> 1) * H + ((i & 1) ? H - 1 : H / 2 - 1); });   // middle and last tile of each split
             G->sweep([&]() {
                 bool ok = true;
                 if (active) {
@@ -154,12 +175,12 @@ struct OpFold {
 template <int IW_>
 struct OpGran {
     static constexpr int IW = IW_;
-    const Gran* G; unsigned g0, sentinel; int dbg;
+    const Gran* G; unsigned g0, sentinel, sstride; int dbg;     // four sentinels: sentinel + i * sstride (producers at the quarter points)
     __device__ __forceinline__ void issue(int, int, bool) {}
     __device__ __forceinline__ f32x8 finish(int k, int wave, int nitems, bool active, char*) {
         f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (wave * 64 >= nitems) return v;
-        G->wait(sentinel, 0, 1);
+        G->wait(sentinel, sstride, 4);
         if (IW == 8) {
             G->sweep([&]() { return active ? G->ld8(g0 + k, v) : true; });
         } else {
@@ -171,58 +192,66 @@ struct OpGran {
     }
 };
 // the attention output: the live 64-key tiles' unnormalised partials {o[rep * 64], (max, sum)[rep]} per kv head, combined here
-// (flash-decoding merge).  Two thread groups take alternate tiles and merge through LDS.
+// (flash-decoding merge).  A thread owns 4 columns and walks every live tile, AT_CHUNK tiles' loads in flight at a time.
 #define AT_GSTRIDE 464                         // granules per (tile, kv head): rep * 64 outputs, then rep x {max, sum}; rep <= 7
+#define AT_CHUNK 6
 struct OpAtt {
-    static constexpr int IW = 8;
+    static constexpr int IW = 4;
     const Gran* G; unsigned ag; int n_kv, rep, cnt; int dbg;      // cnt = live tiles
-    const OpFold* fold; int col0;                                  // the block's 16 residual columns, fetched beside the attention sweep
+    const OpFold* fold; int col0;                                  // the block's 16 residual columns, fetched by 16 idle lanes beside the first chunk
     __device__ __forceinline__ void issue(int, int, bool) {}
-    __device__ __forceinline__ f32x8 finish(int, int wave, int nitems, bool, char* xch_) {
-        const int tid = threadIdx.x, hgrp = tid >> 7, htid = tid & 127;
-        const bool act = htid < nitems;
-        const int k = htid * 8, hd = k >> 6, g = hd / rep, hh = hd - g * rep;
-        if (wave == 0) G->wait(ag + rep * 64, AT_GSTRIDE, cnt * n_kv);   // one granule of every live (tile, head) pair; cnt * n_kv <= 64
-        __syncthreads();
+    __device__ __forceinline__ f32x8 finish(int k, int, int, bool act, char* xch_) {
+        const int tid = threadIdx.x;
+        const int hd = k >> 6, g = hd / rep, hh = hd - g * rep;
+        const bool res = tid >= 240;                               // nitems = 224: the last 32 lanes own no item
         float* xch = reinterpret_cast<float*>(xch_);
-        if (wave == 3) {                                           // its last 16 lanes own no item: they fetch the residual columns
-            const float rv = fold->get1(col0 + (tid & 15), tid >= 240);
-            if (tid >= 240) xch[1200 + (tid & 15)] = rv;
-        }
+        G->wait(ag + rep * 64, AT_GSTRIDE, cnt * n_kv);            // one granule of every live (tile, head) pair; cnt * n_kv <= 64
         float M = -INFINITY, den = 0.f;
-        f32x8 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v = acc;
-        for (int s = hgrp; s < cnt; s += 2) {                      // (trip count uniform per 128-thread group, i.e. per wave)
-            const unsigned a0 = ag + (unsigned)(s * n_kv + g) * AT_GSTRIDE;
-            f32x8 o = acc; float m = 0.f, l = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < cnt; s0 += AT_CHUNK) {               // (block-uniform trip count)
+            f32x4 o[AT_CHUNK]; float m[AT_CHUNK], l[AT_CHUNK];
+            float rv = 0.f;
             G->sweep([&]() {
-                if (!act) return true;
-                bool ok = G->ld8(a0 + hh * 64 + (k & 63), o);
-                const u32x4 ml = G->ld2(a0 + rep * 64 + hh * 2);
-                ok &= ml[1] == G->epoch && ml[3] == G->epoch;
-                m = __builtin_bit_cast(float, ml[0]); l = __builtin_bit_cast(float, ml[2]);
+                bool ok = true;
+                if (act) {
+#pragma unroll
+                    for (int i = 0; i < AT_CHUNK; i++) {
+                        const int s = min(s0 + i, cnt - 1);        // slots past the count repeat the last tile (loaded, not merged)
+                        const unsigned a0 = ag + (unsigned)(s * n_kv + g) * AT_GSTRIDE;
+                        ok &= G->ld4(a0 + hh * 64 + (k & 63), o[i]);
+                        const u32x4 ml = G->ld2(a0 + rep * 64 + hh * 2);
+                        ok &= ml[1] == G->epoch && ml[3] == G->epoch;
+                        m[i] = u2f(ml[0]); l[i] = u2f(ml[2]);
+                    }
+                } else if (res && s0 == 0 && !fold->plain) {
+                    const int c = col0 + (tid & 15);
+                    u64 x[1 + SK_MAXNP];
+                    x[0] = __hip_atomic_load((const gu64*)(G->base + fold->xg + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i < SK_MAXNP; i++)
+                        x[1 + i] = __hip_atomic_load((const gu64*)(G->base + fold->dg + i * fold->H + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i <= SK_MAXNP; i++) ok &= (unsigned)(x[i] >> 32) == G->epoch;
+                    rv = __builtin_bit_cast(float, (unsigned)x[0]);
+#pragma unroll
+                    for (int i = 0; i < SK_MAXNP; i++) rv += __builtin_bit_cast(float, (unsigned)x[1 + i]);
+                }
                 return ok;
             });
-            const float Mn = fmaxf(M, m);
-            const float w0 = __expf(M - Mn), w1 = __expf(m - Mn);  // first tile: M = -inf -> w0 = 0
-            den = den * w0 + l * w1;
-            acc = acc * w0 + o * w1;
-            M = Mn;
-        }
-        if (hgrp == 1 && act) {
-            float* d = xch + htid * 10;
-            d[0] = M; d[1] = den;
+            if (res && s0 == 0) xch[1200 + (tid & 15)] = fold->plain ? fold->plain[col0 + (tid & 15)] : rv;
 #pragma unroll
-            for (int e = 0; e < 8; e++) d[2 + e] = acc[e];
+            for (int i = 0; i < AT_CHUNK; i++) {
+                if (s0 + i < cnt) {
+                    const float Mn = fmaxf(M, m[i]);
+                    const float w0 = __expf(M - Mn), w1 = __expf(m[i] - Mn);   // first tile: M = -inf -> w0 = 0
+                    den = den * w0 + l[i] * w1;
+                    acc = acc * w0 + o[i] * w1;
+                    M = Mn;
+                }
+            }
         }
-        __syncthreads();
-        if (hgrp == 0 && act) {
-            const float* d = xch + htid * 10;
-            const float M1 = d[0], Mn = fmaxf(M, M1);
-            const float w0 = __expf(M - Mn), w1 = __expf(M1 - Mn); // a group without tiles has max = -inf: weight 0
-            const float dn = den * w0 + d[1] * w1;
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (acc[e] * w0 + d[2 + e] * w1) * (1.f / dn);
-        }
+        const float inv = 1.f / den;
+        f32x8 v = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv, 0.f, 0.f, 0.f, 0.f};
         return v;
     }
 };
@@ -297,6 +326,7 @@ __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int t
         }
     }
     __syncthreads();
+    R1_T(4);
     float rs = 1.f;
     if (NORM) rs = rsqrtf(((sqs[0] + sqs[1]) + (sqs[2] + sqs[3])) / (float)K + eps);    // waves without items contributed 0
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -310,9 +340,11 @@ __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int t
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[4], acc, 0, 0, 0);
         }
     }
+    R1_T(5);
     // every column of the tile holds the same vector: the lanes of column 0 carry it out
     if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(red + ((wk * NWR + wr) * 4 + (lane >> 4)) * 4) = acc;
     __syncthreads();
+    R1_T(6);
     float out = 0.f;
     if (tid < NWR * 16) {
         const int wr_ = tid >> 4, q = (tid >> 2) & 3, r = tid & 3;

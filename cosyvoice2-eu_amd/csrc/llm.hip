@@ -13,8 +13,9 @@
 // (727.6 MB at the real dims) plus the KV read.
 #include "skinny.h"
 #ifdef CV2_STAMPS
-extern __device__ unsigned long long g_chain_t[1024][4];
-#define R1_T_OPERAND do { if (op.dbg >= 0 && threadIdx.x == 0) g_chain_t[op.dbg][3] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern __device__ unsigned long long g_chain_t[1024][8];
+#define R1_T(i) do { if (op.dbg >= 0 && threadIdx.x == 0) g_chain_t[op.dbg][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define R1_T_OPERAND R1_T(3)
 #endif
 #include "chain.h"
 #include "skinny_launch.h"
@@ -425,11 +426,11 @@ struct StepArgs {
     int dbg_layer;
 };
 #ifdef CV2_STAMPS
-__device__ unsigned long long g_chain_t[1024][4] = {};      // per block of one layer: start, result, published, operand ready (100 MHz ticks)
+__device__ unsigned long long g_chain_t[1024][8] = {};      // per block of one layer: start, result, published, operand ready (100 MHz ticks)
 #define CH_T(i) do { if (dbg && threadIdx.x == 0) g_chain_t[r_dbg][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int cv2_debug_chain(unsigned long long* out_host) {
     CV2_HIP(hipDeviceSynchronize());
-    CV2_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_chain_t), sizeof(unsigned long long) * 1024 * 4));
+    CV2_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_chain_t), sizeof(unsigned long long) * 1024 * 8));
     return 0;
 }
 #else
@@ -458,8 +459,7 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
     }
     const int n = min(AT_KB, pos + 1 - j0);           // live keys of the tile (>= 1)
     const int jn = pos - j0;                          // the new row's index in this tile (>= 64: it is in a later tile)
-    if (w == 0) G.wait(qg + rep * 64 - 1, 0, 1);      // the group's last query feature
-    __syncthreads();
+    G.wait(qg + rep * 64 / 2 - 1, rep * 64 / 2, 2);   // a middle and the last query feature of the group (every wave polls for itself)
     {
         float q0 = 0.f, q1 = 0.f;
         const bool two = tid + 256 < rep * 64;
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
     }
     r -= nO;
     if (r < nGU) {                  // ---- GU: RMSNorm -> gate / up -> SiLU(g) * u -> h granules
-        OpGran<4> op{&G, gl, gl + H - 1, od};
+        OpGran<4> op{&G, gl, gl + (unsigned)(nO / 4) * 16 - 1, (unsigned)(nO / 4) * 16, od};
         const float v = row1_core<2, 2, 14, true>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, op, L.ln2, a.eps, smem);
         const float u = __shfl(v, (tid & 15) + 16);            // threads 0..15 hold gate, 16..31 up (wave 0)
         CH_T(1);
@@ -625,7 +625,8 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
         const int sp = r / nO, tile = r - sp * nO;
         const int KS = a.inter / 32;
         const int ks0 = (int)(((unsigned)KS * sp) / SK_MAXNP), ks1 = (int)(((unsigned)KS * (sp + 1)) / SK_MAXNP);
-        OpGran<8> op{&G, gl + a.off_hg, gl + a.off_hg + ks1 * 32 - 1, od};
+        const unsigned qtr = (unsigned)((ks1 - ks0) * 32 / 4);
+        OpGran<8> op{&G, gl + a.off_hg, gl + a.off_hg + ks0 * 32 + qtr - 1, qtr, od};
         const float v = row1_core<1, 4, 10, false>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op, nullptr, 0.f, smem);
         CH_T(1);
         if (tid < 16) G.store(gl + a.off_dg + sp * H + tile * 16 + tid, v);
@@ -1350,7 +1351,7 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
         const int ntiles = (d->max_pos + AT_KB - 1) / AT_KB, rep = d->n_q / d->n_kv;
         h->use_chain = !(e && e[0] == '0') && d->hidden % 32 == 0 && d->inter % (32 * SK_MAXNP) == 0 && d->vocab_pad % 16 == 0 &&
                        d->hidden / 32 <= 2 * 14 && d->n_q * 64 / 32 <= 4 * 8 && d->inter / 32 / SK_MAXNP <= 4 * 10 &&
-                       d->n_q * 64 / 8 <= 112 && rep * 64 + rep * 2 <= AT_GSTRIDE && rep * 64 <= 512 && ntiles * d->n_kv <= 64 &&
+                       d->n_q * 64 / 4 <= 240 && (d->hidden / 16) % 4 == 0 && rep * 64 + rep * 2 <= AT_GSTRIDE && rep * 64 <= 512 && ntiles * d->n_kv <= 64 &&
                        d->hidden % 2 == 0;
         const unsigned one = 1u;
         std::vector<StepLayer> tab(d->layers);
@@ -1381,6 +1382,16 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
         h->step_blocks = d->layers * a.per + d->vocab_pad / 16;
     }
     *out = h;
+    return 0;
+}
+
+// test / diagnostic hook: device addresses of the decode workspaces (tools/dbg_chain_vals.py compares the one-launch step with the launches)
+extern "C" int cv2_llm_debug_ptrs(cv2_llm* h, uint64_t* out) {
+    CV2_CHECK(h && out, "cv2_llm_debug_ptrs: null argument");
+    const StepArgs& a = h->step;
+    const uint64_t v[16] = {(uint64_t)h->q, (uint64_t)h->att, (uint64_t)h->att_ml, (uint64_t)h->o, (uint64_t)h->hbuf, (uint64_t)h->parts, (uint64_t)h->xa,
+                            (uint64_t)h->xb, (uint64_t)h->gran, a.gl, a.off_dg, a.off_qg, a.off_kv, a.off_ag, a.off_hg, (uint64_t)h->kc};
+    for (int i = 0; i < 16; i++) out[i] = v[i];
     return 0;
 }
 

@@ -21,9 +21,9 @@ roles = (('Q', nQ), ('A', nA), ('O', nO), ('gate/up', nGU), ('down', nD))
 for rep in range(3):
     eng.step(1, 64)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * (1024 * 4))()
+    buf = (C.c_ulonglong * (1024 * 8))()
     L.check(L.lib().cv2_debug_chain(buf))
-    t = np.array(buf, dtype=np.int64).reshape(1024, 4).astype(np.float64)
+    t = np.array(buf, dtype=np.int64).reshape(1024, 8).astype(np.float64)
     live = t[:, 2] > 0
     # the layer's time origin: when its Q blocks received their operand is the end of the previous layer
     print('rep', rep)
@@ -41,3 +41,6 @@ for rep in range(3):
         us = (r - t0) / 100.0
         f = lambda a: f'min {a.min():7.2f} med {np.median(a):7.2f} max {a.max():7.2f}'
         print(f'  {name:8s} n={len(r):3d} start [{f(us[:, 0])}]  operand [{f(us[:, 3])}]  result [{f(us[:, 1])}]  published [{f(us[:, 2])}]')
+        if (r[:, 4] > 0).all():
+            g = lambda a: f'{np.median(a):5.2f}/{a.max():5.2f}'
+            print(f'           operand->staged {g(us[:, 4] - us[:, 3])}  staged->mfma {g(us[:, 5] - us[:, 4])}  mfma->reduced {g(us[:, 6] - us[:, 5])}  reduced->result {g(us[:, 1] - us[:, 6])} (med/max us)')
