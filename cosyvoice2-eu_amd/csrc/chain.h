@@ -29,6 +29,7 @@ typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+#define CH_NP 2                                 // K splits of the down projection inside k_step (partials folded by the next consumer)
 #define GRAN_TIMEOUT_TICKS 20000000ull     // s_memrealtime runs at 100 MHz: 0.2 s
 
 // (by value on purpose: clang lowers __builtin_bit_cast of a vector ELEMENT lvalue as a load from the vector's address, i.e. element 0)
@@ -112,18 +113,18 @@ struct Gran {                 // all granule buffers of the engine behind one bu
         for (unsigned spin = 0;; spin++) {
             if (__all(f())) return;
             if ((spin & 15) == 15 && give_up(t0)) return;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(4);
         }
     }
 };
 
 // ---- operand providers of row1_core: issue() runs before the weight loads, finish() after (all threads call both)
 
-// x = base + p0 + p1 + p2 + p3 (the residual stream entering a layer: x_mid of the previous layer + its four down-projection
+// x = base + p0 + p1 (the residual stream entering a layer: x_mid of the previous layer + its CH_NP down-projection
 // partials, summed in this order), every vector [H] granules; or a plain fp32 vector (layer 0: the embedding k_sample left).
 struct OpFold {
-    const Gran* G; unsigned xg, dg; int H;      // granule indices of x_mid [H] and the partials [SK_MAXNP][H] of the previous layer
-    const float* plain; int dbg;
+    const Gran* G; unsigned xg, dg; int H;      // granule indices of x_mid [H] and the partials [CH_NP][H] of the previous layer
+    const float* plain; int dbg; unsigned arm;
     __device__ __forceinline__ void issue(int, int, bool) {}
     // one value at column c (call wave-uniformly)
     __device__ __forceinline__ float get1(int c, bool active) const {
@@ -131,16 +132,16 @@ struct OpFold {
         if (plain) { if (active) v = plain[c]; return v; }
         G->sweep([&]() {
             if (!active) return true;
-            u64 x[1 + SK_MAXNP];
+            u64 x[1 + CH_NP];
             x[0] = __hip_atomic_load((const gu64*)(G->base + xg + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int i = 0; i < SK_MAXNP; i++) x[1 + i] = __hip_atomic_load((const gu64*)(G->base + dg + i * H + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < CH_NP; i++) x[1 + i] = __hip_atomic_load((const gu64*)(G->base + dg + i * H + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool ok = true;
 #pragma unroll
-            for (int i = 0; i <= SK_MAXNP; i++) ok &= (unsigned)(x[i] >> 32) == G->epoch;
+            for (int i = 0; i <= CH_NP; i++) ok &= (unsigned)(x[i] >> 32) == G->epoch;
             v = __builtin_bit_cast(float, (unsigned)x[0]);
 #pragma unroll
-            for (int i = 0; i < SK_MAXNP; i++) v += __builtin_bit_cast(float, (unsigned)x[1 + i]);
+            for (int i = 0; i < CH_NP; i++) v += __builtin_bit_cast(float, (unsigned)x[1 + i]);
             return ok;
         });
         return v;
@@ -153,16 +154,17 @@ struct OpFold {
         if (plain) {
             if (active) v = *reinterpret_cast<const f32x4*>(plain + k);
         } else {
-            G->wait_f(2 * SK_MAXNP, [&](int i) { return dg + (unsigned)(i >> 1) * H + ((i & 1) ? H - 1 : H / 2 - 1); });   // middle and last tile of each split
+            G->wait(arm, 0, 1);                                     // armed: the previous layer's h has been published (the partials follow ~2 us later);
+                                                                    // from here the sweep itself polls (few consumer blocks: Q 36, head 411 once per step)
             G->sweep([&]() {
                 bool ok = true;
                 if (active) {
-                    f32x4 p[SK_MAXNP];
+                    f32x4 p[CH_NP];
                     ok = G->ld4(xg + k, v);
 #pragma unroll
-                    for (int i = 0; i < SK_MAXNP; i++) ok &= G->ld4(dg + i * H + k, p[i]);
+                    for (int i = 0; i < CH_NP; i++) ok &= G->ld4(dg + i * H + k, p[i]);
 #pragma unroll
-                    for (int i = 0; i < SK_MAXNP; i++) v += p[i];
+                    for (int i = 0; i < CH_NP; i++) v += p[i];
                 }
                 return ok;
             });
@@ -195,6 +197,7 @@ struct OpGran {
 // (flash-decoding merge).  A thread owns 4 columns and walks every live tile, AT_CHUNK tiles' loads in flight at a time.
 #define AT_GSTRIDE 464                         // granules per (tile, kv head): rep * 64 outputs, then rep x {max, sum}; rep <= 7
 #define AT_CHUNK 6
+#define AT_TILE 128                            // keys per attention block: two 64-key groups of 256 threads
 struct OpAtt {
     static constexpr int IW = 4;
     const Gran* G; unsigned ag; int n_kv, rep, cnt; int dbg;      // cnt = live tiles
@@ -225,16 +228,16 @@ struct OpAtt {
                     }
                 } else if (res && s0 == 0 && !fold->plain) {
                     const int c = col0 + (tid & 15);
-                    u64 x[1 + SK_MAXNP];
+                    u64 x[1 + CH_NP];
                     x[0] = __hip_atomic_load((const gu64*)(G->base + fold->xg + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int i = 0; i < SK_MAXNP; i++)
+                    for (int i = 0; i < CH_NP; i++)
                         x[1 + i] = __hip_atomic_load((const gu64*)(G->base + fold->dg + i * fold->H + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int i = 0; i <= SK_MAXNP; i++) ok &= (unsigned)(x[i] >> 32) == G->epoch;
+                    for (int i = 0; i <= CH_NP; i++) ok &= (unsigned)(x[i] >> 32) == G->epoch;
                     rv = __builtin_bit_cast(float, (unsigned)x[0]);
 #pragma unroll
-                    for (int i = 0; i < SK_MAXNP; i++) rv += __builtin_bit_cast(float, (unsigned)x[1 + i]);
+                    for (int i = 0; i < CH_NP; i++) rv += __builtin_bit_cast(float, (unsigned)x[1 + i]);
                 }
                 return ok;
             });
@@ -260,30 +263,31 @@ struct OpAtt {
 // is real at one row, every lane of a 16-lane quarter reads the same 16 bytes), exchange area of OpAtt, reduction slots.
 #define R1_STAGE_BYTES(nks) ((nks) * 128)
 #define R1_XCH_BYTES (128 * 10 * 4)
-__device__ __host__ constexpr int r1_smem_bytes(int nks) { return R1_STAGE_BYTES(nks) + R1_XCH_BYTES + 16 + 4 * 4 * 16; }
+#define R1_THREADS 512
+__device__ __host__ constexpr int r1_smem_bytes(int nks) { return R1_STAGE_BYTES(nks) + R1_XCH_BYTES + 32 + 8 * 4 * 16; }
 
 // out[f] (f < NWR * 16) = sum_k W[(tile0 + (f / 16) * tstride) * 16 + f % 16][k] * x[k] over the k-steps [ks0, ks1),
 // x = op's vector [* RMSNorm weight, scaled by the row's rstd].  Returns feature f's value in thread f (other threads: 0).
-// 256 threads = NWR x NWK waves; every wave's weight fragments (<= MAXKS) are requested first.
+// 512 threads = NWR x NWK waves; every wave's weight fragments (<= MAXKS) are requested first.
 struct R1NoHook { __device__ __forceinline__ void operator()() const {} };
 // `issued` runs right after the weight requests: the place for a role's own dependent loads (Q: position -> RoPE table).
 template <int NWR, int NWK, int MAXKS, bool NORM, class OP, class HOOK = R1NoHook>
 __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int tile0, int tstride, int KS, int K, int ks0, int ks1, OP& op,
                                            const float* norm_w, float eps, char* smem, HOOK issued = HOOK()) {
-    static_assert(NWR * NWK == 4, "row1_core: 256 threads");
+    static_assert(NWR * NWK == 8, "row1_core: 512 threads");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave % NWR, wk = wave / NWR;
     const int nks = ks1 - ks0;
     const int w0 = ks0 + (nks * wk) / NWK, w1 = ks0 + (nks * (wk + 1)) / NWK;
     constexpr int IW = OP::IW;                                    // operand columns per thread (4 or 8)
-    const int nitems = nks * (32 / IW);                           // item i belongs to thread i (<= 256)
+    const int nitems = nks * (32 / IW);                           // item i belongs to thread i (<= 512)
     const bool active = tid < nitems;
     const int k = ks0 * 32 + tid * IW;
     char* stage = smem;
     char* xch = smem + R1_STAGE_BYTES(nks);
-    float* sqs = reinterpret_cast<float*>(xch + R1_XCH_BYTES);     // [4] per-wave sums of squares
-    float* red = reinterpret_cast<float*>(xch + R1_XCH_BYTES + 16);   // [NWK][NWR][4 quarters][4]
+    float* sqs = reinterpret_cast<float*>(xch + R1_XCH_BYTES);     // [8] per-wave sums of squares
+    float* red = reinterpret_cast<float*>(xch + R1_XCH_BYTES + 32);   // [NWK][NWR][4 quarters][4]
     op.issue(tid, nitems, active);
     f32x8 g0 = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     if (NORM && active) {
@@ -328,7 +332,7 @@ __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int t
     __syncthreads();
     R1_T(4);
     float rs = 1.f;
-    if (NORM) rs = rsqrtf(((sqs[0] + sqs[1]) + (sqs[2] + sqs[3])) / (float)K + eps);    // waves without items contributed 0
+    if (NORM) rs = rsqrtf((((sqs[0] + sqs[1]) + (sqs[2] + sqs[3])) + ((sqs[4] + sqs[5]) + (sqs[6] + sqs[7]))) / (float)K + eps);    // waves without items contributed 0
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MAXKS; i++) {

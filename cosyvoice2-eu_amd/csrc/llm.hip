@@ -437,55 +437,62 @@ extern "C" int cv2_debug_chain(unsigned long long* out_host) {
 #define CH_T(i) do { } while (0)
 #endif
 
-// Attention of one 64-key tile for the rep query heads of kv head g (the arithmetic of k_attn<1>): q, and the new token's key /
-// value row when it falls into this tile, arrive as granules from the Q role; older rows are plain cache reads.
+// Attention of one 128-key tile for the rep query heads of kv head g: two groups of 256 threads take 64 keys each with the
+// arithmetic of k_attn<2> and merge through LDS.  q, and the new token's key / value row when it falls into this tile, arrive as
+// granules from the Q role; older rows are plain cache reads, requested before anything else.
+#define AT_SMEM_FLOATS (512 + 2 * 512 + 2 * 4096 + 32 + 128)
 __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const float* V, int pos, int j0, int rep,
                                           unsigned qg, unsigned kg, unsigned vg, unsigned og, char* smem) {
     float* qs = reinterpret_cast<float*>(smem);       // [8 * 64]
-    float* ps = qs + 512;                             // [8 * 64]
-    float* po_s = ps + 512;                           // [8 key eighths][8 heads][64]
-    float* run_m = po_s + 4096; float* run_l = run_m + 8;
-    float* knew = run_l + 8; float* vnew = knew + 64;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int d4 = tid & 15, kq = (tid >> 4) & 7, hs = tid >> 7;
-    const int key_t = tid >> 2, qd = tid & 3;
+    float* ps_ = qs + 512;                            // [2][8 * 64]
+    float* po_ = ps_ + 1024;                          // [2][8 key eighths][8 heads][64]
+    float* run_m = po_ + 8192; float* run_l = run_m + 16;     // [2][8]
+    float* knew = run_l + 16; float* vnew = knew + 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 8), t = tid & 255, w = t >> 6;
+    float* ps = ps_ + sub * 512; float* po_s = po_ + sub * 4096;
+    const int d4 = t & 15, kq = (t >> 4) & 7, hs = t >> 7;
+    const int key_t = t >> 2, qd = t & 3;
+    const int js = j0 + sub * AT_KB;                  // this group's first key
     f32x4 kk[4], vv[8];
     {
-        const unsigned ko = (unsigned)(j0 + key_t) * 64u + qd * 16, vo = (unsigned)(j0 + kq * 8) * 64u + d4 * 4;
+        const unsigned ko = (unsigned)(js + key_t) * 64u + qd * 16, vo = (unsigned)(js + kq * 8) * 64u + d4 * 4;
 #pragma unroll
         for (int i = 0; i < 4; i++) kk[i] = *reinterpret_cast<const f32x4*>(K + ko + 4 * i);
 #pragma unroll
         for (int k = 0; k < 8; k++) vv[k] = *reinterpret_cast<const f32x4*>(V + vo + 64 * k);
     }
-    const int n = min(AT_KB, pos + 1 - j0);           // live keys of the tile (>= 1)
-    const int jn = pos - j0;                          // the new row's index in this tile (>= 64: it is in a later tile)
-    G.wait(qg + rep * 64 / 2 - 1, rep * 64 / 2, 2);   // a middle and the last query feature of the group (every wave polls for itself)
+    const int n = max(0, min(AT_KB, pos + 1 - js));    // live keys of this group's 64 (the second group of the last tile may have none)
+    const int jn = pos - js;                          // the new row's index among this group's keys (outside [0, 64): not here)
+    const bool has_new = jn >= 0 && jn < AT_KB;
+    if (t < 8) { run_m[sub * 8 + t] = -INFINITY; run_l[sub * 8 + t] = 0.f; }
+    // q (and the new row) are polled directly: a few blocks per layer, one or two 8-byte loads per thread -- cheaper than a sentinel
+    // round trip in front of the sweep.  The poll starts once the layer's input has arrived at the Q role (armed by the caller).
     {
-        float q0 = 0.f, q1 = 0.f;
-        const bool two = tid + 256 < rep * 64;
+        float q0 = 0.f, x = 0.f;
+        const bool mine = tid < rep * 64, kv = has_new && w < 2;
+        const unsigned gi = t < 64 ? kg + t : vg + t - 64;
         G.sweep([&]() {
-            const u64 x0 = __hip_atomic_load((const gu64*)(G.base + qg + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u64 x1 = __hip_atomic_load((const gu64*)(G.base + qg + (two ? tid + 256 : tid)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q0 = __builtin_bit_cast(float, (unsigned)x0); q1 = __builtin_bit_cast(float, (unsigned)x1);
-            return (unsigned)(x0 >> 32) == G.epoch && (unsigned)(x1 >> 32) == G.epoch;
+            bool ok = true;
+            if (mine) {
+                const u64 x0 = __hip_atomic_load((const gu64*)(G.base + qg + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q0 = __builtin_bit_cast(float, (unsigned)x0);
+                ok = (unsigned)(x0 >> 32) == G.epoch;
+            }
+            if (kv) {
+                const u64 xx = __hip_atomic_load((const gu64*)(G.base + gi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x = __builtin_bit_cast(float, (unsigned)xx);
+                ok &= (unsigned)(xx >> 32) == G.epoch;
+            }
+            return ok;
         });
-        qs[tid] = q0;
-        if (two) qs[tid + 256] = q1;
-    }
-    if (jn < AT_KB && w < 2) {                         // the new token's key / value row
-        float x = 0.f;
-        const unsigned gi = tid < 64 ? kg + tid : vg + tid - 64;
-        G.sweep([&]() {
-            const u64 xx = __hip_atomic_load((const gu64*)(G.base + gi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            x = __builtin_bit_cast(float, (unsigned)xx);
-            return (unsigned)(xx >> 32) == G.epoch;
-        });
-        (tid < 64 ? knew : vnew)[tid & 63] = x;
+        if (mine) qs[tid] = q0;
+        if (kv) (t < 64 ? knew : vnew)[t & 63] = x;
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) vv[k] = kq * 8 + k < n ? vv[k] : (f32x4){0.f, 0.f, 0.f, 0.f};     // rows past the length may hold anything
     __syncthreads();
-    if (jn < AT_KB) {
+    if (has_new) {
         if (key_t == jn) {
 #pragma unroll
             for (int i = 0; i < 4; i++) kk[i] = *reinterpret_cast<const f32x4*>(&knew[qd * 16 + 4 * i]);
@@ -493,54 +500,69 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
 #pragma unroll
         for (int k = 0; k < 8; k++) if (kq * 8 + k == jn) vv[k] = *reinterpret_cast<const f32x4*>(&vnew[d4 * 4]);
     }
+    if (n > 0) {
 #pragma unroll
-    for (int h = 0; h < 8; h++) {
-        if (h < rep) {
-            float acc = 0.f;
+        for (int h = 0; h < 8; h++) {
+            if (h < rep) {
+                float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[h * 64 + qd * 16 + 4 * i]);
-                acc += kk[i][0] * qv[0] + kk[i][1] * qv[1] + kk[i][2] * qv[2] + kk[i][3] * qv[3];
+                for (int i = 0; i < 4; i++) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[h * 64 + qd * 16 + 4 * i]);
+                    acc += kk[i][0] * qv[0] + kk[i][1] * qv[1] + kk[i][2] * qv[2] + kk[i][3] * qv[3];
+                }
+                acc += dpp_mov_f32<0xB1, 0xf>(0.f, acc);
+                acc += dpp_mov_f32<0x4E, 0xf>(0.f, acc);
+                if (qd == 0) ps[h * AT_KB + key_t] = key_t < n ? acc * 0.125f : -INFINITY;
             }
-            acc += dpp_mov_f32<0xB1, 0xf>(0.f, acc);
-            acc += dpp_mov_f32<0x4E, 0xf>(0.f, acc);
-            if (qd == 0) ps[h * AT_KB + key_t] = key_t < n ? acc * 0.125f : -INFINITY;
         }
     }
     __syncthreads();
-    for (int h = w; h < rep; h += 4) {
-        const float s0 = ps[h * AT_KB + lane];
-        const float mt = wave_max(s0);
-        const float p0 = __expf(s0 - mt);
-        ps[h * AT_KB + lane] = p0;
-        const float lt = wave_sum(p0);
-        if (lane == 0) { run_m[h] = mt; run_l[h] = lt; }
+    if (n > 0) {
+        for (int h = w; h < rep; h += 4) {
+            const float s0 = ps[h * AT_KB + lane];
+            const float mt = wave_max(s0);
+            const float p0 = __expf(s0 - mt);
+            ps[h * AT_KB + lane] = p0;
+            const float lt = wave_sum(p0);
+            if (lane == 0) { run_m[sub * 8 + h] = mt; run_l[sub * 8 + h] = lt; }
+        }
     }
     __syncthreads();
     f32x4 o[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int h = min(hs * 4 + i, rep - 1);
+        if (n > 0) {
+            const int h = min(hs * 4 + i, rep - 1);
 #pragma unroll
-        for (int k4 = 0; k4 < 2; k4++) {
-            const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[h * AT_KB + kq * 8 + 4 * k4]);
+            for (int k4 = 0; k4 < 2; k4++) {
+                const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[h * AT_KB + kq * 8 + 4 * k4]);
 #pragma unroll
-            for (int e = 0; e < 4; e++) o[i] += pa[e] * vv[4 * k4 + e];
+                for (int e = 0; e < 4; e++) o[i] += pa[e] * vv[4 * k4 + e];
+            }
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (hs * 4 + i < rep) *reinterpret_cast<f32x4*>(&po_s[(kq * 8 + hs * 4 + i) * 64 + d4 * 4]) = o[i];
     __syncthreads();
-    for (int e = tid; e < rep * 64; e += 256) {
-        const float* pp = &po_s[e];
-        G.store(og + e, ((pp[0] + pp[512]) + (pp[1024] + pp[1536])) + ((pp[2048] + pp[2560]) + (pp[3072] + pp[3584])));
+    if (tid < rep * 64) {
+        const int h = tid >> 6;
+        const float m0 = run_m[h], m1 = run_m[8 + h], M = fmaxf(m0, m1);
+        const float* pp = &po_[tid];
+        const float* pq = &po_[4096 + tid];
+        const float a0 = ((pp[0] + pp[512]) + (pp[1024] + pp[1536])) + ((pp[2048] + pp[2560]) + (pp[3072] + pp[3584]));
+        const float a1 = ((pq[0] + pq[512]) + (pq[1024] + pq[1536])) + ((pq[2048] + pq[2560]) + (pq[3072] + pq[3584]));
+        G.store(og + tid, __expf(m0 - M) * a0 + __expf(m1 - M) * a1);       // a group that saw no key has max = -inf: weight 0
     }
-    if (tid < rep) { G.store(og + rep * 64 + tid * 2, run_m[tid]); G.store(og + rep * 64 + tid * 2 + 1, run_l[tid]); }
+    if (tid < rep) {
+        const float m0 = run_m[tid], m1 = run_m[8 + tid], M = fmaxf(m0, m1);
+        G.store(og + rep * 64 + tid * 2, M);
+        G.store(og + rep * 64 + tid * 2 + 1, __expf(m0 - M) * run_l[tid] + __expf(m1 - M) * run_l[8 + tid]);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_step(StepArgs a) {
+__global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int gb = blockIdx.x;
@@ -556,13 +578,13 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
     const unsigned gl = (unsigned)min(layer, a.n_layers - 1) * a.gl;        // this layer's granules (head: the last layer's)
     const unsigned gp = layer > 0 ? (unsigned)(layer - 1) * a.gl : 0u;      // the previous layer's
     if (layer >= a.n_layers) {      // head: final norm -> llm_decoder (+ bias) -> logits (read by k_sample, the next launch)
-        OpFold op{&G, gl, gl + a.off_dg, H, nullptr, -1};
-        const float out = row1_core<1, 4, 8, true>(a.wdec, r, 0, H / 32, H, 0, H / 32, op, a.final_norm, a.eps, smem);
+        OpFold op{&G, gl, gl + a.off_dg, H, nullptr, -1, gl + a.off_dg + H - 1};
+        const float out = row1_core<1, 8, 4, true>(a.wdec, r, 0, H / 32, H, 0, H / 32, op, a.final_norm, a.eps, smem);
         if (tid < 16) a.logits[r * 16 + tid] = out + a.bdec[r * 16 + tid];
         return;
     }
     const StepLayer L = a.layers[layer];
-    OpFold xin{&G, gp, gp + a.off_dg, H, layer == 0 ? a.xin : nullptr, od};
+    OpFold xin{&G, gp, gp + a.off_dg, H, layer == 0 ? a.xin : nullptr, od, gp + a.off_hg + a.inter - 1};
     if (r < nQ) {                   // ---- Q: RMSNorm -> QKV -> + bias -> RoPE -> q granules / key, value granules + cache rows
         const int head = r >> 1, half = r & 1;
         const int pos = a.state[CV2_ST_POS];
@@ -570,7 +592,7 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
         const float bias = L.bqkv[head * 64 + f];
         float c, sn;
         auto hook = [&]() { c = a.cosT[pos * 32 + (f & 31)]; sn = a.sinT[pos * 32 + (f & 31)]; };
-        float v = row1_core<2, 2, 14, true>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin, L.ln1, a.eps, smem, hook) + bias;
+        float v = row1_core<2, 4, 7, true>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin, L.ln1, a.eps, smem, hook) + bias;
         const float vp = __shfl(v, (tid & 63) ^ 16);
         if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);      // rotate-half RoPE on q and k heads
         CH_T(1);
@@ -593,8 +615,9 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
     if (r < nA) {                   // ---- A: one 64-key tile of one kv head
         const int tile = r / a.n_kv, g = r - tile * a.n_kv;
         const int pos = a.state[CV2_ST_POS];
-        if (tile * AT_KB > pos) return;                 // tile beyond the sequence: the consumer derives the live count from pos too
-        attn_role(G, L.kc + (size_t)g * a.max_pos * 64, L.vc + (size_t)g * a.max_pos * 64, pos, tile * AT_KB, a.rep,
+        if (tile * AT_TILE > pos) return;               // tile beyond the sequence: the consumer derives the live count from pos too
+        if (layer > 0) G.wait(gp + a.off_dg + H - 1, H, CH_NP);   // armed: the previous layer's down projection has published
+        attn_role(G, L.kc + (size_t)g * a.max_pos * 64, L.vc + (size_t)g * a.max_pos * 64, pos, tile * AT_TILE, a.rep,
                   gl + a.off_qg + g * a.rep * 64, gl + a.off_kv + g * 64, gl + a.off_kv + (a.n_kv + g) * 64,
                   gl + a.off_ag + (unsigned)r * AT_GSTRIDE, smem);
         CH_T(2);
@@ -603,8 +626,8 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
     r -= nA;
     if (r < nO) {                   // ---- O: attention combine -> O projection -> + residual -> x_mid granules
         const int pos = a.state[CV2_ST_POS];
-        OpAtt op{&G, gl + a.off_ag, a.n_kv, a.rep, pos / AT_KB + 1, od, &xin, r * 16};
-        const float o = row1_core<1, 4, 8, false>(L.wo, r, 0, a.NQ / 32, a.NQ, 0, a.NQ / 32, op, nullptr, 0.f, smem);
+        OpAtt op{&G, gl + a.off_ag, a.n_kv, a.rep, pos / AT_TILE + 1, od, &xin, r * 16};
+        const float o = row1_core<1, 8, 4, false>(L.wo, r, 0, a.NQ / 32, a.NQ, 0, a.NQ / 32, op, nullptr, 0.f, smem);
         CH_T(1);
         if (tid < 16) G.store(gl + r * 16 + tid, reinterpret_cast<const float*>(smem + R1_STAGE_BYTES(a.NQ / 32))[1200 + tid] + o);
         CH_T(2);
@@ -613,7 +636,7 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
     r -= nO;
     if (r < nGU) {                  // ---- GU: RMSNorm -> gate / up -> SiLU(g) * u -> h granules
         OpGran<4> op{&G, gl, gl + (unsigned)(nO / 4) * 16 - 1, (unsigned)(nO / 4) * 16, od};
-        const float v = row1_core<2, 2, 14, true>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, op, L.ln2, a.eps, smem);
+        const float v = row1_core<2, 4, 7, true>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, op, L.ln2, a.eps, smem);
         const float u = __shfl(v, (tid & 15) + 16);            // threads 0..15 hold gate, 16..31 up (wave 0)
         CH_T(1);
         if (tid < 16) G.store(gl + a.off_hg + r * 16 + tid, (v / (1.f + __expf(-v))) * u);
@@ -621,13 +644,13 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
         return;
     }
     r -= nGU;
-    {                               // ---- D: down projection, K split SK_MAXNP ways -> partial granules
+    {                               // ---- D: down projection, K split CH_NP ways -> partial granules
         const int sp = r / nO, tile = r - sp * nO;
         const int KS = a.inter / 32;
-        const int ks0 = (int)(((unsigned)KS * sp) / SK_MAXNP), ks1 = (int)(((unsigned)KS * (sp + 1)) / SK_MAXNP);
+        const int ks0 = (int)(((unsigned)KS * sp) / CH_NP), ks1 = (int)(((unsigned)KS * (sp + 1)) / CH_NP);
         const unsigned qtr = (unsigned)((ks1 - ks0) * 32 / 4);
         OpGran<8> op{&G, gl + a.off_hg, gl + a.off_hg + ks0 * 32 + qtr - 1, qtr, od};
-        const float v = row1_core<1, 4, 10, false>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op, nullptr, 0.f, smem);
+        const float v = row1_core<1, 8, 10, false>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op, nullptr, 0.f, smem);
         CH_T(1);
         if (tid < 16) G.store(gl + a.off_dg + sp * H + tile * 16 + tid, v);
         CH_T(2);
@@ -1293,10 +1316,10 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     p = take((size_t)SK_MAXNP * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
     if (h) h->chain_off = off;
     p = take(256); if (h) h->epoch = (unsigned*)p;
-    {   // per layer: x_mid [H], down partials [SK_MAXNP][H], q [NQ], new key / value rows [2 n_kv 64], attention partials
+    {   // per layer: x_mid [H], down partials [CH_NP][H], q [NQ], new key / value rows [2 n_kv 64], attention partials
         // [tiles][n_kv][AT_GSTRIDE], h [inter]
-        const size_t ntiles = (d.max_pos + AT_KB - 1) / AT_KB;
-        const size_t gl = (size_t)d.hidden * (1 + SK_MAXNP) + (size_t)d.n_q * 64 + (size_t)2 * d.n_kv * 64 + ntiles * d.n_kv * AT_GSTRIDE + d.inter;
+        const size_t ntiles = (d.max_pos + AT_TILE - 1) / AT_TILE;
+        const size_t gl = (size_t)d.hidden * (1 + CH_NP) + (size_t)d.n_q * 64 + (size_t)2 * d.n_kv * 64 + ntiles * d.n_kv * AT_GSTRIDE + d.inter;
         p = take((size_t)d.layers * gl * 8); if (h) { h->gran = (u64*)p; h->gran_bytes = (unsigned)((size_t)d.layers * gl * 8); }
         p = take((size_t)d.layers * sizeof(StepLayer)); if (h) h->step_layers = (StepLayer*)p;
     }
@@ -1348,9 +1371,9 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
     }
     {   // hand-off state of k_step: every granule tag 0, epoch 1 (tags are compared with the epoch, never 0)
         const char* e = getenv("CV2_LLM_CHAIN");
-        const int ntiles = (d->max_pos + AT_KB - 1) / AT_KB, rep = d->n_q / d->n_kv;
-        h->use_chain = !(e && e[0] == '0') && d->hidden % 32 == 0 && d->inter % (32 * SK_MAXNP) == 0 && d->vocab_pad % 16 == 0 &&
-                       d->hidden / 32 <= 2 * 14 && d->n_q * 64 / 32 <= 4 * 8 && d->inter / 32 / SK_MAXNP <= 4 * 10 &&
+        const int ntiles = (d->max_pos + AT_TILE - 1) / AT_TILE, rep = d->n_q / d->n_kv;
+        h->use_chain = !(e && e[0] == '0') && d->hidden % 32 == 0 && d->inter % (32 * CH_NP) == 0 && d->vocab_pad % 16 == 0 &&
+                       d->hidden / 32 <= 4 * 7 && d->n_q * 64 / 32 <= 8 * 4 && d->inter / 32 / CH_NP <= 8 * 10 && d->inter / 8 / CH_NP <= R1_THREADS &&
                        d->n_q * 64 / 4 <= 240 && (d->hidden / 16) % 4 == 0 && rep * 64 + rep * 2 <= AT_GSTRIDE && rep * 64 <= 512 && ntiles * d->n_kv <= 64 &&
                        d->hidden % 2 == 0;
         const unsigned one = 1u;
@@ -1375,8 +1398,8 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
         a.gran = h->gran; a.gran_bytes = h->gran_bytes; a.epoch = h->epoch; a.err = h->io.state + CV2_ST_ERR;
         a.H = d->hidden; a.NQ = d->n_q * 64; a.inter = d->inter; a.n_q = d->n_q; a.n_kv = d->n_kv; a.rep = rep; a.max_pos = d->max_pos;
         a.ntiles = ntiles; a.eps = d->rms_eps;
-        a.per = 2 * (d->n_q + 2 * d->n_kv) + ntiles * d->n_kv + d->hidden / 16 + d->inter / 16 + SK_MAXNP * (d->hidden / 16);
-        a.off_dg = d->hidden; a.off_qg = a.off_dg + SK_MAXNP * d->hidden; a.off_kv = a.off_qg + d->n_q * 64;
+        a.per = 2 * (d->n_q + 2 * d->n_kv) + ntiles * d->n_kv + d->hidden / 16 + d->inter / 16 + CH_NP * (d->hidden / 16);
+        a.off_dg = d->hidden; a.off_qg = a.off_dg + CH_NP * d->hidden; a.off_kv = a.off_qg + d->n_q * 64;
         a.off_ag = a.off_kv + 2 * d->n_kv * 64; a.off_hg = a.off_ag + ntiles * d->n_kv * AT_GSTRIDE; a.gl = a.off_hg + d->inter;
         a.dbg_layer = -1;
         h->step_blocks = d->layers * a.per + d->vocab_pad / 16;
@@ -1717,13 +1740,13 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, hipGraphExec_t* out) {
         for (int u = 0; u < unroll && !rc; u++) {
             if (n_seqs == 1 && h->use_chain) {
                 const cv2_llm_dims& d = h->d;
-                const int nks_max = std::max(std::max(d.hidden / 32, d.n_q * 64 / 32), cdiv(d.inter / 32, SK_MAXNP));
-                const size_t sm = std::max((size_t)r1_smem_bytes(nks_max), (size_t)(512 + 512 + 4096 + 16 + 128) * sizeof(float));
+                const int nks_max = std::max(std::max(d.hidden / 32, d.n_q * 64 / 32), cdiv(d.inter / 32, CH_NP));
+                const size_t sm = std::max((size_t)r1_smem_bytes(nks_max), (size_t)AT_SMEM_FLOATS * sizeof(float));
                 StepArgs a = h->step;
 #ifdef CV2_STAMPS
                 a.dbg_layer = 12;
 #endif
-                hipLaunchKernelGGL(k_step, dim3(h->step_blocks), dim3(256), sm, cs, a);
+                hipLaunchKernelGGL(k_step, dim3(h->step_blocks), dim3(R1_THREADS), sm, cs, a);
                 if (hipGetLastError() != hipSuccess) rc = cv2_fail("k_step launch failed");
             } else
             rc = n_seqs <= 16 ? run_layers<1>(h, n_seqs, h->xnext, rm, cs) : run_layers_pre(h, n_seqs, h->xnext, rm, cs);

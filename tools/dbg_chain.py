@@ -16,7 +16,7 @@ eng = LLMEngine(sd, 'cuda:0', max_seqs=1, max_pos=2048, max_out=2048)
 inp = synth.synthetic_inputs(seed=0, text_len=50, prompt_len=255)
 x = eng.build_lm_input(inp['text'], inp['prompt_text'], inp['prompt_token'])
 eng.add_request(0, x, 2000, 2000, mode=1, seed=7, force_len=True)
-nQ, nA, nO, nGU, nD = 36, 64, 56, 304, 224
+nQ, nA, nO, nGU, nD = 36, 32, 56, 304, 112
 roles = (('Q', nQ), ('A', nA), ('O', nO), ('gate/up', nGU), ('down', nD))
 for rep in range(3):
     eng.step(1, 64)
