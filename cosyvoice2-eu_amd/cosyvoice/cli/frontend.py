@@ -36,7 +36,8 @@ class PrecomputedFrontEnd:
         if not text:
             return [''] if split else ''
         sents = U.split_sentences(text) if multilingual else [text]
-        normalized = [U.normalize_sentence(s, U.detect_lang(s)) for s in sents]
+        parser = getattr(self, 'inflect_parser', None)              # frontend.py:122: inflect.engine(); the restatement when absent
+        normalized = [U.normalize_sentence(s, U.detect_lang(s), parser) for s in sents]
         tok = self.tokenize
         if pack_mode == 'paragraph':
             n = int(target_token_len)

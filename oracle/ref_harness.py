@@ -128,6 +128,11 @@ def activate():
     _stub('onnxruntime')
     _stub('whisper')
     _stub('hyperpyyaml', load_hyperpyyaml=None)
+    # imported by cli/frontend.py at module level, used only inside CosyVoiceFrontEnd.__init__ (never called here)
+    _stub('inflect', engine=None)
+    _stub('tn'); _stub('tn.chinese'); _stub('tn.english')
+    _stub('tn.chinese.normalizer', Normalizer=None)
+    _stub('tn.english.normalizer', Normalizer=None)
     _stub('modelscope', snapshot_download=None)
     _stub('conformer', ConformerBlock=type('ConformerBlock', (nn.Module,), {}))
     _stub('matcha.utils.pylogger', get_pylogger=lambda n=None: logging.getLogger(n))
@@ -146,7 +151,7 @@ def activate():
 def deactivate():
     for k in list(sys.modules):
         if k.split('.')[0] in _OURS + ('diffusers', 'conformer', 'torchaudio', 'omegaconf', 'onnxruntime', 'whisper',
-                                       'hyperpyyaml', 'modelscope'):
+                                       'hyperpyyaml', 'modelscope', 'inflect', 'tn'):
             sys.modules.pop(k)
     for p in REF_PATHS:
         if p in sys.path:

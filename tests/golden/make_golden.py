@@ -271,6 +271,64 @@ def gen_text():
     print('wrote split_paragraph.json', len(cases))
 
 
+NORM_SAMPLES = [
+    "Das kostet ca. 1.234,50 € bzw. 12 % mehr, z.B. am 3. Mai bei 120 km/h & 30°C.",
+    "Genau genommen seit 2020. Die Nr. 7 steht auf S. 12, d.h. u.a. im Kapitel 3.",
+    "Wir haben 1 000 000 Gründe und 2.500 Ideen; insb. die 4. ist gut (siehe § 5) @ home.",
+    "M. Dupont a 25 % de 300 € etc. Mme Curie habite bd. Voltaire, c-à-d. près de la pl. Monge.",
+    "Bonjour, je suis le Dr. Martin et j'ai 2 chats & 1 chien : c'est 100 % vrai + ou - 5 °.",
+    "I have 3 cats (and 12 dogs) in 2020. Call 555-1202 or visit room 1001b at 10:30.",
+    "Version 2.0 was released on 2021-03-04 with 007 fixes and 1234567 downloads",
+    "No digits here, only words `quoted` and an em dash——like this.",
+    "Heute ist es schön.\nMorgen wird es 21 Grad.",
+    "这是一个测试句子 with 12 numbers。",
+    "Short. Two sentences here! And a third one? Yes… indeed.",
+]
+
+
+def gen_textnorm():
+    """The dependency-free branches of the reference's text normalisation (cli/frontend.py:64-140, 293-319, 340-417, 419-480;
+    utils/frontend_utils.py:57-73) on sample sentences -> text_normalize.json.  num2words / NeMo / WeTextProcessing / lingua are
+    absent here exactly as they are optional there; `inflect` (a hard import of the reference, absent here) is replaced by the
+    product's restatement NumberWords, so the digit-run scan of spell_out_number is pinned and number_to_words itself is not."""
+    import json
+    import importlib.util
+    from cosyvoice.cli import frontend as RF
+    from cosyvoice.utils import frontend_utils as RU
+    spec = importlib.util.spec_from_file_location('amd_frontend_utils', os.path.join(ROOT, 'cosyvoice2-eu_amd', 'cosyvoice', 'utils', 'frontend_utils.py'))
+    AU = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(AU)
+    fe = RF.CosyVoiceFrontEnd.__new__(RF.CosyVoiceFrontEnd)
+    fe.use_ttsfrd = False
+    fe.en_tn_model = None
+    fe.zh_tn_model = None
+    fe.lid = None
+    fe.nemo_norm = {}
+    fe.inflect_parser = AU.NumberWords()
+    fe.allowed_special = 'all'
+
+    class Tok:
+        def encode(self, t, allowed_special=None):
+            return t.split()
+    fe.tokenizer = Tok()
+    out = dict(contains_german={}, expand_abbr_de={}, spell_de={}, symbols_de={}, spell_en={}, detect={}, normalize={}, text_normalize={})
+    for t in NORM_SAMPLES:
+        out['contains_german'][t] = bool(RF._fallback_contains_german(t))
+        out['expand_abbr_de'][t] = RF._fallback_expand_abbreviations_german(t)
+        out['spell_de'][t] = RF._fallback_spell_out_number_german(t)
+        out['symbols_de'][t] = RF._fallback_replace_symbols_german(t)
+        out['spell_en'][t] = RU.spell_out_number(t, fe.inflect_parser)
+        out['text_normalize'][t] = fe.text_normalize(t, split=True, text_frontend=True)
+        for sent in fe._split_sentences(t):
+            lang = fe._detect_lang(sent)
+            out['detect'][sent] = lang
+            out['normalize'][sent] = fe._normalize_sentence(sent, lang)
+    out['num2words_present'] = bool(RF._HAS_NUM2WORDS)
+    with open(os.path.join(HERE, 'text_normalize.json'), 'w') as f:
+        json.dump(out, f, ensure_ascii=False, indent=0)
+    print('wrote text_normalize.json', len(NORM_SAMPLES), 'samples,', len(out['normalize']), 'sentences')
+
+
 def gen_sampler():
     from cosyvoice.utils.common import nucleus_sampling
     g = torch.Generator().manual_seed(77)
@@ -294,6 +352,6 @@ def gen_sampler():
 if __name__ == '__main__':
     assert R.available(), 'needs /root/reference'
     R.activate()
-    which = sys.argv[1:] or ['hift', 'flow', 'llm', 'llm_bf16w', 'bistream', 'fullsize', 'text', 'sampler']
+    which = sys.argv[1:] or ['hift', 'flow', 'llm', 'llm_bf16w', 'bistream', 'fullsize', 'text', 'textnorm', 'sampler']
     for w in which:
         globals()['gen_' + w]()
