@@ -421,6 +421,8 @@ def run_sharded(args):
         dist.init_process_group(backend)
     else:
         assert torch.cuda.is_available(), 'bench.py needs a GPU (the hot path has no CPU fallback)'
+        if 'CV2_BENCH_DEVICE' not in os.environ and torch.cuda.device_count() < world:
+            sys.exit(f'bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) are visible (one process per GPU)')
         dev_index = int(os.environ.get('CV2_BENCH_DEVICE', os.environ.get('LOCAL_RANK', 0)))
         torch.cuda.set_device(dev_index)
         dev = torch.device('cuda', dev_index)
@@ -451,7 +453,21 @@ def run_sharded(args):
         model.coalesce_ms = 50.0
     st = StepTimer(model.llm) if model is not None else None
 
+    work = {'s': 0.0, 'utts': 0, 'audio_s': 0.0}          # this rank's own synthesis time inside the timed steps (collectives excluded)
+
     def synth_fn(my_texts, p):
+        t_in = time.perf_counter()
+        try:
+            return synth_inner(my_texts, p)
+        finally:
+            sync()
+            if timing['on']:
+                work['s'] += time.perf_counter() - t_in
+                work['utts'] += len(my_texts)
+                work['audio_s'] += sum(960 * 5 * t.numel() for t in my_texts) / 24000.0
+    timing = {'on': False}
+
+    def synth_inner(my_texts, p):
         if fake:
             return [torch.full((960 * 5 * t.numel(),), float(t.numel())) for t in my_texts]
         base = dict(prompt_text=p['prompt_text'].to(dev), llm_prompt_speech_token=p['prompt_token'].to(dev),
@@ -466,14 +482,20 @@ def run_sharded(args):
     barrier()
     if st is not None:
         st.on = True
+    timing['on'] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         waves = shard.synthesize_sharded(texts, prompt, synth_fn)
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    timing['on'] = False
+    # bench bookkeeping only (the product path has no all-reduce): every rank's wall time and own work, gathered as objects
+    mine = {'rank': rank, 'wall_s': round(dt, 4), 'work_s': round(work['s'], 4), 'utts_per_step': work['utts'] // max(args.steps, 1),
+            'audio_s_per_step': round(work['audio_s'] / max(args.steps, 1), 2),
+            'device': 'cpu' if fake else f'cuda:{dev.index} ' + torch.cuda.get_device_name(dev)}
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
+    dt = max(r['wall_s'] for r in per_rank)
     if rank == 0:
         assert len(waves) == n_utts and all(w.numel() == 960 * 5 * x.numel() for w, x in zip(waves, texts)), 'gather returned the wrong waveforms'
         audio_per_step = sum(w.numel() for w in waves) / 24000.0
@@ -481,6 +503,10 @@ def run_sharded(args):
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'FAKE (plumbing test, no model)' if fake else 'synthetic',
                'rtf': round(dt / (audio_per_step * args.steps), 5),
+               'ranks_seen': dist.get_world_size(),
+               'backend': (f'nccl = RCCL {".".join(map(str, torch.cuda.nccl.version()))} over xGMI' if backend == 'nccl' and not fake else backend),
+               'per_rank': per_rank,
+               'imbalance': round(max(r['work_s'] for r in per_rank) / max(min(r['work_s'] for r in per_rank), 1e-9), 3),
                'config': {'workload': f'configs[3]: {n_utts} utterances sharded over {world} ranks ({per} per GPU, length-balanced), zero-shot FR, P=255, texts of '
                                       f'30..100 tokens, 5 x text length forced speech tokens (150..500), non-streaming; broadcast prompt / scatter text ids / '
                                       f'gather waveforms over {"RCCL" if backend == "nccl" else backend} inside the timed region; every rank runs its shard as '

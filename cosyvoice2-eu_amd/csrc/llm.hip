@@ -1408,6 +1408,8 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
     return 0;
 }
 
+extern "C" int cv2_llm_one_launch_step(const cv2_llm* h) { return h && h->use_chain ? 1 : 0; }
+
 // test / diagnostic hook: device addresses of the decode workspaces (tools/dbg_chain_vals.py compares the one-launch step with the launches)
 extern "C" int cv2_llm_debug_ptrs(cv2_llm* h, uint64_t* out) {
     CV2_CHECK(h && out, "cv2_llm_debug_ptrs: null argument");

@@ -121,8 +121,17 @@ int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int
  * bistream modes out_tokens receives EVERY drawn id (fill and EOS included), as the reference's out_tokens list does. */
 int cv2_llm_extend(cv2_llm* h, int32_t seq, const float* embeds, int32_t len, int32_t pos0, void* stream);
 /* n_steps iterations of the decode loop for slots 0..n_seqs-1 in lock step (one hipGraph replay per step);
- * finished slots idle.  No host synchronisation inside. */
+ * finished slots idle.  No host synchronisation inside.
+ * n_seqs == 1: a step is ONE launch (k_step, csrc/chain.h: every layer's Q / attention / O / gate-up / down roles and the head
+ * as blocks of one grid in dependency order, activations handed over as epoch-tagged granules) followed by the sampler; the
+ * environment variable CV2_LLM_CHAIN=0 (read at create) selects the five launches per layer used for 2..16 rows instead.
+ * CV2_ST_ERR = 3 reports a hand-off that timed out. */
 int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream);
+/* 1 when one-row decode steps of this engine run as one launch (k_step), 0 when they run as launches (dims outside k_step's
+ * limits, or CV2_LLM_CHAIN=0). */
+int cv2_llm_one_launch_step(const cv2_llm* h);
+/* test / diagnostic hook: device addresses of the decode workspaces and the granule layout (16 values; tools/dbg_chain_vals.py) */
+int cv2_llm_debug_ptrs(cv2_llm* h, uint64_t* out);
 
 /* Stand-alone skinny GEMM used by the LLM (exported for unit tests and for the flow time-MLP):
  * out[r][n] = sum_k W[n][k] x[r][k] (+bias[n]); rows <= 32; W packed; K % 32 == 0; N % 16 == 0. */

@@ -148,6 +148,22 @@ def test_sharded_synthesis_gloo_world2():
     assert q.get(timeout=5) is True
 
 
+def test_sharded_synthesis_gloo_world4_uneven_shards():
+    """Four ranks, seven utterances: the shards hold 2 / 2 / 2 / 1 texts of very different lengths; padded scatter rows and the
+    padded gather must still return every waveform in input order on rank 0."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_api_surface_matches_reference_signatures():
     """Names, order and defaults of the public entry points (standalone_infer/src/cosyvoice2_eu/__init__.py:43-128,
     cosy_repo/cosyvoice/cli/cosyvoice.py:92-115,144-151, cli/model.py:300,336)."""
@@ -266,6 +282,9 @@ def test_bench_gpus2_spawns_ranks_and_gathers(tmp_path):
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1 and out['scaling'] == 'weak' and out['value'] > 0
     assert out['config']['batch_per_gpu'] == 5 and 'configs[3]' in out['config']['workload'] and out['data'].startswith('FAKE')
+    # what a driver run needs to judge the line: the world the process group saw, its backend, every rank's own time and share
+    assert out['ranks_seen'] == 2 and out['backend'] == 'gloo' and [r['rank'] for r in out['per_rank']] == [0, 1]
+    assert all(r['utts_per_step'] == 5 and r['work_s'] >= 0 and r['wall_s'] > 0 for r in out['per_rank']) and out['imbalance'] >= 1.0
     # a launcher / flag mismatch fails loudly instead of reporting a 1-GPU number as N = 2's line
     env2 = dict(env, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env2, capture_output=True, text=True, timeout=120)

@@ -8,14 +8,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cosyvoice2-eu_amd'))
 import torch
 from cv2amd import synth, lib as L
-from cv2amd.pipeline import Synthesizer, synthetic_request
+from cv2amd.flow import FlowEngine
 
-syn = Synthesizer(synth.make_llm(layers=1), synth.make_flow(), synth.make_hift(), 'cuda:0', max_batch=1, max_text=128,
-                  max_prompt_tokens=320, max_new_tokens=512)
-req = synthetic_request(device='cuda:0')
-toks = [[int(t) for t in torch.randint(0, 6561, (250,))]]
+flow = FlowEngine(synth.make_flow(), 'cuda:0', max_utts=1, max_len=2 * (320 + 512))
+inp = synth.synthetic_inputs(seed=1986, text_len=50, prompt_len=255, prompt_text_len=20)
+utt = dict(token=torch.randint(0, 6561, (1, 250), dtype=torch.int32), prompt_token=inp['prompt_token'].to('cuda:0'),
+           prompt_feat=inp['prompt_feat'].to('cuda:0'), embedding=inp['embedding'].to('cuda:0'))
 for rep in range(2):
-    syn.token2wav([req], toks)
+    flow.inference_batch([utt], streaming=False, finalize=True)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * (64 * 8))()
 L.check(L.lib().cv2_debug_stamps_flow(buf))
