@@ -112,12 +112,12 @@ class StepTimer:
         self._orig = llm.step
         llm.step = self._step
 
-    def _step(self, n_seqs, n_steps=1):
+    def _step(self, n_seqs, n_steps=1, **kw):
         if not self.on:
-            return self._orig(n_seqs, n_steps)
+            return self._orig(n_seqs, n_steps, **kw)
         e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
         e0.record()
-        self._orig(n_seqs, n_steps)
+        self._orig(n_seqs, n_steps, **kw)
         e1.record()
         self.rec.append((e0, e1, n_seqs, n_steps))
 

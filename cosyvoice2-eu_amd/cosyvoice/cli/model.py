@@ -421,15 +421,16 @@ class CosyVoice2Model:
             raise p.exc
 
     # the helpers below run under self.run_lock
-    def _llm_advance(self, n_steps):
+    def _llm_advance(self, n_steps, shared=False):
         """n_steps decode steps for EVERY active slot (slots 0..highest active; parked slots in between idle), enqueued on the LLM
-        stream; `_enq[slot]` = the tokens a live slot holds at most once everything enqueued so far has run."""
+        stream; `_enq[slot]` = the tokens a live slot holds at most once everything enqueued so far has run.  shared: the burst runs
+        beside a chunk's flow + HiFT on the other streams."""
         if n_steps <= 0:
             return
         with self._mode:
             act = sorted(self._active_slots)
         with torch.cuda.stream(self.llm_stream):
-            self.llm.step(act[-1] + 1, n_steps)
+            self.llm.step(act[-1] + 1, n_steps, shared=shared)
             ev = torch.cuda.Event()
             ev.record(self.llm_stream)
         while self._bursts and self._bursts[0].query():                       # finished bursts nobody had to wait for
@@ -682,7 +683,7 @@ class CosyVoice2Model:
                         ended = self.llm_end_dict[this_uuid]
                         if len(toks) >= need:
                             if not ended:                                      # the next chunk's tokens beyond what is already enqueued (by this
-                                self._llm_advance(need + hop - max(len(toks), self._enq.get(slot, 0)))    # or another stream): the burst
+                                self._llm_advance(need + hop - max(len(toks), self._enq.get(slot, 0)), shared=True)    # or another stream): the burst
                             this_tok = torch.tensor(toks[:need], dtype=torch.int32).unsqueeze(0)          # overlaps this chunk's flow + HiFT
                         elif ended:
                             finished = True

@@ -441,8 +441,13 @@ extern "C" int cv2_debug_chain(unsigned long long* out_host) {
 // arithmetic of k_attn<2> and merge through LDS.  q, and the new token's key / value row when it falls into this tile, arrive as
 // granules from the Q role; older rows are plain cache reads, requested before anything else.
 #define AT_SMEM_FLOATS (512 + 2 * 512 + 2 * 4096 + 32 + 128)
+#ifdef CV2_STAMPS
+#define AT_T(i) do { if (dbg_slot >= 0 && threadIdx.x == 0) g_chain_t[dbg_slot][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AT_T(i) do { } while (0)
+#endif
 __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const float* V, int pos, int j0, int rep,
-                                          unsigned qg, unsigned kg, unsigned vg, unsigned og, char* smem) {
+                                          unsigned qg, unsigned kg, unsigned vg, unsigned og, char* smem, int dbg_slot) {
     float* qs = reinterpret_cast<float*>(smem);       // [8 * 64]
     float* ps_ = qs + 512;                            // [2][8 * 64]
     float* po_ = ps_ + 1024;                          // [2][8 key eighths][8 heads][64]
@@ -489,6 +494,7 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
         if (mine) qs[tid] = q0;
         if (kv) (t < 64 ? knew : vnew)[t & 63] = x;
     }
+    AT_T(3);
 #pragma unroll
     for (int k = 0; k < 8; k++) vv[k] = kq * 8 + k < n ? vv[k] : (f32x4){0.f, 0.f, 0.f, 0.f};     // rows past the length may hold anything
     __syncthreads();
@@ -517,6 +523,7 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
         }
     }
     __syncthreads();
+    AT_T(4);
     if (n > 0) {
         for (int h = w; h < rep; h += 4) {
             const float s0 = ps[h * AT_KB + lane];
@@ -528,6 +535,7 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
         }
     }
     __syncthreads();
+    AT_T(5);
     f32x4 o[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -546,6 +554,7 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
     for (int i = 0; i < 4; i++)
         if (hs * 4 + i < rep) *reinterpret_cast<f32x4*>(&po_s[(kq * 8 + hs * 4 + i) * 64 + d4 * 4]) = o[i];
     __syncthreads();
+    AT_T(6);
     if (tid < rep * 64) {
         const int h = tid >> 6;
         const float m0 = run_m[h], m1 = run_m[8 + h], M = fmaxf(m0, m1);
@@ -619,7 +628,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
         if (layer > 0) G.wait(gp + a.off_dg + H - 1, H, CH_NP);   // armed: the previous layer's down projection has published
         attn_role(G, L.kc + (size_t)g * a.max_pos * 64, L.vc + (size_t)g * a.max_pos * 64, pos, tile * AT_TILE, a.rep,
                   gl + a.off_qg + g * a.rep * 64, gl + a.off_kv + g * 64, gl + a.off_kv + (a.n_kv + g) * 64,
-                  gl + a.off_ag + (unsigned)r * AT_GSTRIDE, smem);
+                  gl + a.off_ag + (unsigned)r * AT_GSTRIDE, smem, od);
         CH_T(2);
         return;
     }
@@ -1730,8 +1739,8 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
 }
 
 // one captured graph holds `unroll` consecutive decode steps for n_seqs slots (key = n_seqs * 64 + unroll)
-static int get_graph(cv2_llm* h, int n_seqs, int unroll, hipGraphExec_t* out) {
-    const int key = n_seqs * 64 + unroll;
+static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGraphExec_t* out) {
+    const int key = (n_seqs * 64 + unroll) * 2 + (one_launch ? 1 : 0);
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
         hipGraph_t g;
@@ -1740,7 +1749,7 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, hipGraphExec_t* out) {
         RowMap rm{h->io.state, 0, 0, 0};
         int rc = 0;
         for (int u = 0; u < unroll && !rc; u++) {
-            if (n_seqs == 1 && h->use_chain) {
+            if (one_launch) {
                 const cv2_llm_dims& d = h->d;
                 const int nks_max = std::max(std::max(d.hidden / 32, d.n_q * 64 / 32), cdiv(d.inter / 32, CH_NP));
                 const size_t sm = std::max((size_t)r1_smem_bytes(nks_max), (size_t)AT_SMEM_FLOATS * sizeof(float));
@@ -1767,8 +1776,14 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, hipGraphExec_t* out) {
     return 0;
 }
 
-extern "C" int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream) {
+extern "C" int cv2_llm_decode_ex(cv2_llm* h, int32_t n_seqs, int32_t n_steps, int32_t flags, void* stream);
+extern "C" int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream) { return cv2_llm_decode_ex(h, n_seqs, n_steps, 0, stream); }
+
+extern "C" int cv2_llm_decode_ex(cv2_llm* h, int32_t n_seqs, int32_t n_steps, int32_t flags, void* stream) {
     CV2_CHECK(h, "cv2_llm_decode: null handle");
+    // one row and the device to itself: the whole step is one launch (k_step); CV2_DECODE_SHARED asks for the launches instead -- k_step
+    // keeps ~1000 polling waves resident, which slows kernels of other streams running beside it more than the launches do
+    const bool one_launch = n_seqs == 1 && h->use_chain && !(flags & CV2_DECODE_SHARED);
     CV2_CHECK(n_seqs >= 1 && n_seqs <= h->d.max_seqs, "cv2_llm_decode: n_seqs %d out of range", n_seqs);
     if (init_attrs_once()) return -1;
     hipStream_t s = (hipStream_t)stream;
@@ -1777,11 +1792,11 @@ extern "C" int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void*
     hipGraphExec_t g8 = nullptr, g1 = nullptr;
     int i = 0;
     if (n_steps >= UNROLL) {
-        if (get_graph(h, n_seqs, UNROLL, &g8)) return -1;
+        if (get_graph(h, n_seqs, UNROLL, one_launch, &g8)) return -1;
         for (; i + UNROLL <= n_steps; i += UNROLL) CV2_HIP(hipGraphLaunch(g8, s));
     }
     if (i < n_steps) {
-        if (get_graph(h, n_seqs, 1, &g1)) return -1;
+        if (get_graph(h, n_seqs, 1, one_launch, &g1)) return -1;
         for (; i < n_steps; i++) CV2_HIP(hipGraphLaunch(g1, s));
     }
     return 0;

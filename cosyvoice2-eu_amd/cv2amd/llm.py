@@ -139,8 +139,9 @@ class LLMEngine:
         return (f'LLM decode step = one hipGraph replay ({L24} x {{k_prep, k_qkv, k_attn, k_prep, k_store(o)+norm2, k_gateup, k_store(down)}} + head + '
                 f'k_sample), {n_seqs} rows')
 
-    def step(self, n_seqs, n_steps=1):
-        L.check(self.lib.cv2_llm_decode(self.handle, n_seqs, n_steps, L.stream_ptr()))
+    def step(self, n_seqs, n_steps=1, shared=False):
+        """shared: kernels of other streams run beside these steps (CV2_DECODE_SHARED: the launches instead of the one-launch step)."""
+        L.check(self.lib.cv2_llm_decode_ex(self.handle, n_seqs, n_steps, 1 if shared else 0, L.stream_ptr()))
 
     ERR_MSG = 'sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!'      # llm.py:249
     ERR_HANDOFF = 'LLM decode: an in-launch hand-off (k_chain) timed out; the device was too contended for the step to finish'

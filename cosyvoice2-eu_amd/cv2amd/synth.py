@@ -210,3 +210,73 @@ def synthetic_inputs(seed=1986, text_len=50, prompt_len=255, prompt_text_len=0):
         prompt_feat=(torch.randn(1, 2 * prompt_len, 80, generator=g) * 2 - 4).clamp(-11.5, 2.0),
         embedding=torch.randn(1, 192, generator=g),
     )
+
+
+# ---- heavy-tailed variants (parity off the Gaussian) --------------------------------------------------------------------------
+def heavy_tail_llm(sd, seed=7, massive=(7, 300, 555), massive_scale=400.0, bias_outlier=8.0, boost=2.5):
+    """A copy of an LLM checkpoint with the statistics real Qwen2 checkpoints show and N(0, s) weights do not, built so that the
+    network stays WELL-CONDITIONED (a first version that simply multiplied gains made the 24-layer net chaotic: its own fp32 and
+    fp64 evaluations differed by 17 %, which no implementation can be compared against):
+      * RMSNorm gains spread over [0.05, 30]: every gain vector is multiplied by a log-normal factor s (sigma 1.0) and the columns
+        of the matrices that consume the normalised vector (q / k / v, gate / up, llm_decoder) are divided by s -- the function of
+        the real-valued network is unchanged, its operands are not: products of huge and tiny factors, as in trained checkpoints;
+      * 'massive activation' residual channels: the first layer's down projection writes values ~400x larger into three channels;
+        from then on those channels dominate every RMS, their gains are small and the other channels' gains `boost` x larger, the
+        compensation trained models show;
+      * outlier q / k biases and embedding rows of very different norms.
+    Conditioning of the 24-layer result (its fp32 against its fp64 evaluation, prefill logits): 1.5e-6, as on the Gaussian weights."""
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed)
+    out = {k: v.clone() for k, v in sd.items()}
+    hidden = out['llm.model.model.norm.weight'].numel()
+    layers = 0
+    while f'llm.model.model.layers.{layers}.input_layernorm.weight' in out:
+        layers += 1
+    mc = torch.tensor([c for c in massive if c < hidden])
+
+    def regain(norm_key, consumers, after_massive):
+        w = out[norm_key].clone()
+        if after_massive:
+            w = w * boost
+            w[mc] = 0.05
+        s = torch.exp(torch.randn(hidden, generator=g) * 1.0)
+        s = torch.minimum(torch.maximum(s, 0.05 / w.abs().clamp_min(1e-6)), 30.0 / w.abs().clamp_min(1e-6))      # keep w * s inside [0.05, 30]
+        out[norm_key] = w * s
+        for k in consumers:
+            out[k] = out[k] / s.view(1, -1)
+    for i in range(layers):
+        p = f'llm.model.model.layers.{i}.'
+        regain(p + 'input_layernorm.weight', [p + f'self_attn.{n}_proj.weight' for n in 'qkv'], i >= 1)
+        regain(p + 'post_attention_layernorm.weight', [p + 'mlp.gate_proj.weight', p + 'mlp.up_proj.weight'], i >= 1)
+        for n in ('q_proj', 'k_proj'):
+            b = out[p + f'self_attn.{n}.bias']
+            idx = torch.randint(0, b.numel(), (6,), generator=g)
+            b[idx] = (torch.rand(6, generator=g) * 2 - 1) * bias_outlier
+    out['llm.model.model.layers.0.mlp.down_proj.weight'][mc] *= massive_scale
+    regain('llm.model.model.norm.weight', ['llm_decoder.weight'], True)
+    out['llm_decoder.weight'] = out['llm_decoder.weight'] * 3.0           # the massive channels shrink every normalised vector: usable top-1 margins
+    for name in ('speech_embedding.weight', 'llm.model.model.embed_tokens.weight'):
+        e = out[name]
+        rows = torch.randint(0, e.shape[0], (max(8, e.shape[0] // 50),), generator=g)
+        e[rows] *= 4.0
+    if 'llm.model.lm_head.weight' in out:
+        out['llm.model.lm_head.weight'] = out['llm.model.model.embed_tokens.weight']
+    return out
+
+
+def heavy_tail_flow(sd, seed=8):
+    """A copy of a flow checkpoint with LayerNorm gains over [0.1, 10] (log-normal) and every convolution / linear weight scaled
+    per output channel by a factor spread over 10x (log-uniform in [0.3, 3]): the products keep their shapes, their operands lose
+    the uniform scale that makes bf16 rounding benign."""
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed)
+    out = {k: v.clone() for k, v in sd.items()}
+    for k, v in out.items():
+        if not k.startswith('decoder.estimator') and not k.startswith('encoder.'):
+            continue
+        if k.endswith('.weight') and v.dim() == 1:                                        # LayerNorm gains
+            out[k] = torch.exp(torch.randn(v.numel(), generator=g) * 0.8).clamp(0.1, 10.0)
+        elif k.endswith('.weight') and v.dim() >= 2 and 'pos_bias' not in k:
+            s = torch.exp(torch.empty(v.shape[0]).uniform_(math.log(0.3), math.log(3.0), generator=g))
+            out[k] = v * s.view(-1, *([1] * (v.dim() - 1)))
+    return out

@@ -127,6 +127,11 @@ int cv2_llm_extend(cv2_llm* h, int32_t seq, const float* embeds, int32_t len, in
  * environment variable CV2_LLM_CHAIN=0 (read at create) selects the five launches per layer used for 2..16 rows instead.
  * CV2_ST_ERR = 3 reports a hand-off that timed out. */
 int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream);
+/* The same with flags.  CV2_DECODE_SHARED: other streams' kernels run beside these steps (the streaming scheduler overlaps a decode
+ * burst with the previous chunk's flow + HiFT): use the launches even at one row -- k_step's resident polling waves cost the
+ * neighbours more than they save here (one stream: 34 -> 40 ms between chunks with k_step beside the chunk work). */
+#define CV2_DECODE_SHARED 1
+int cv2_llm_decode_ex(cv2_llm* h, int32_t n_seqs, int32_t n_steps, int32_t flags, void* stream);
 /* 1 when one-row decode steps of this engine run as one launch (k_step), 0 when they run as launches (dims outside k_step's
  * limits, or CV2_LLM_CHAIN=0). */
 int cv2_llm_one_launch_step(const cv2_llm* h);

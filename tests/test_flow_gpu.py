@@ -81,8 +81,11 @@ def test_estimator_vs_reference_golden(golden, eng, dev, T, tag, streaming):
     ref = torch.from_numpy(gd[f'y_T{T}_{tag}'])
     got = y.cpu()
     assert torch.isfinite(got).all()
-    assert rel(got, ref) < 4e-2, f'rel max err {rel(got, ref):.3e}'
-    assert ((got - ref).abs().mean() / ref.abs().mean()).item() < 1.5e-2
+    # bars = what is measured (max 1.3e-2, mean 1.0e-2 of bf16 operand rounding through 56 blocks, gpurun_out/flow_rounded_operand_errors.jsonl)
+    # plus margin; the x1.25 rounded-operand budget test below is the tight guard
+    _record(f'estimator_golden_T{T}_{tag}', max=rel(got, ref), mean=_mrel(got, ref))
+    assert rel(got, ref) < 2e-2, f'rel max err {rel(got, ref):.3e}'
+    assert _mrel(got, ref) < 1.2e-2
 
 
 @pytest.mark.parametrize('T', [28, 53])
@@ -96,7 +99,8 @@ def test_encoder_vs_reference_golden(golden, eng, T):
         torch.cuda.synchronize()
         ref = torch.from_numpy(gd[f'h_T{T}_{tag}'])
         got = h[0, :, ::8].cpu()
-        assert rel(got, ref) < 3e-2, f'{tag}: rel max err {rel(got, ref):.3e}'
+        _record(f'encoder_golden_T{T}_{tag}', max=rel(got, ref), mean=_mrel(got, ref))
+        assert rel(got, ref) < 2e-2, f'{tag}: rel max err {rel(got, ref):.3e}'
 
 
 @pytest.mark.parametrize('tag,streaming,finalize', [('full', False, True), ('stream', True, True),
@@ -112,9 +116,10 @@ def test_flow_inference_vs_reference_golden(golden, eng, tag, streaming, finaliz
     got = mel.cpu()
     assert got.shape == ref.shape
     assert torch.isfinite(got).all()
-    # 10 Euler steps through the bf16 estimator: error relative to the mel range
-    assert rel(got, ref) < 5e-2, f'rel max err {rel(got, ref):.3e}'
-    assert ((got - ref).abs().mean() / ref.abs().mean()).item() < 2e-2
+    # 10 Euler steps through the bf16 estimator: error relative to the mel range (measured 5.8e-3 max, 7.6e-3 mean)
+    _record(f'flow_e2e_golden_{tag}', max=rel(got, ref), mean=_mrel(got, ref))
+    assert rel(got, ref) < 1.5e-2, f'rel max err {rel(got, ref):.3e}'
+    assert _mrel(got, ref) < 1.2e-2
 
 
 def test_ragged_batch_equals_single(eng):

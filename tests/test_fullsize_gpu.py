@@ -108,8 +108,8 @@ def test_flow_T1010_vs_reference_golden(golden, flow1):
     ref = torch.from_numpy(gd['mel']).unsqueeze(0)
     got = mel.cpu()
     assert got.shape == ref.shape == (1, 80, 500) and torch.isfinite(got).all()
-    assert rel(got, ref) < 5e-2, f'rel max err {rel(got, ref):.3e}'
-    assert ((got - ref).abs().mean() / ref.abs().mean()).item() < 2e-2
+    assert rel(got, ref) < 1.5e-2, f'rel max err {rel(got, ref):.3e}'
+    assert ((got - ref).abs().mean() / ref.abs().mean()).item() < 1.2e-2, f'{((got - ref).abs().mean() / ref.abs().mean()).item():.3e}'
 
 
 def test_hift_500_frames_vs_reference_golden(golden, dev):

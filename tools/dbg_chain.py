@@ -41,6 +41,9 @@ for rep in range(3):
         us = (r - t0) / 100.0
         f = lambda a: f'min {a.min():7.2f} med {np.median(a):7.2f} max {a.max():7.2f}'
         print(f'  {name:8s} n={len(r):3d} start [{f(us[:, 0])}]  operand [{f(us[:, 3])}]  result [{f(us[:, 1])}]  published [{f(us[:, 2])}]')
-        if (r[:, 4] > 0).all():
+        if name == 'A':
+            g = lambda a: f'{np.median(a):5.2f}/{a.max():5.2f}'
+            print(f'           q arrived [{f(us[:, 3])}]  q->scores {g(us[:, 4] - us[:, 3])}  scores->softmax {g(us[:, 5] - us[:, 4])}  softmax->pv {g(us[:, 6] - us[:, 5])}  pv->published {g(us[:, 2] - us[:, 6])}')
+        elif (r[:, 4] > 0).all():
             g = lambda a: f'{np.median(a):5.2f}/{a.max():5.2f}'
             print(f'           operand->staged {g(us[:, 4] - us[:, 3])}  staged->mfma {g(us[:, 5] - us[:, 4])}  mfma->reduced {g(us[:, 6] - us[:, 5])}  reduced->result {g(us[:, 1] - us[:, 6])} (med/max us)')
