@@ -177,12 +177,15 @@ struct OpFold {
 template <int IW_>
 struct OpGran {
     static constexpr int IW = IW_;
-    const Gran* G; unsigned g0, sentinel, sstride; int dbg;     // four sentinels: sentinel + i * sstride (producers at the quarter points)
+    const Gran* G; unsigned g0, sentinel, sstride; int dbg;     // sentinel: one granule of the FIRST producer of this vector
     __device__ __forceinline__ void issue(int, int, bool) {}
     __device__ __forceinline__ f32x8 finish(int k, int wave, int nitems, bool active, char*) {
         f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (wave * 64 >= nitems) return v;
-        G->wait(sentinel, sstride, 4);
+        // armed by the first producer (cheap one-word polls while the vector is still far away), then the sweep itself polls: the
+        // producers finish within ~0.6 us of each other, so this costs one or two extra sweeps and saves the round trip that a
+        // wait for the LAST producer's granule would put in front of the sweep
+        G->wait(sentinel, 0, 1);
         if (IW == 8) {
             G->sweep([&]() { return active ? G->ld8(g0 + k, v) : true; });
         } else {
@@ -196,12 +199,13 @@ struct OpGran {
 // the attention output: the live 64-key tiles' unnormalised partials {o[rep * 64], (max, sum)[rep]} per kv head, combined here
 // (flash-decoding merge).  A thread owns 4 columns and walks every live tile, AT_CHUNK tiles' loads in flight at a time.
 #define AT_GSTRIDE 464                         // granules per (tile, kv head): rep * 64 outputs, then rep x {max, sum}; rep <= 7
-#define AT_CHUNK 6
+#define AT_CHUNK 5
 #define AT_TILE 128                            // keys per attention block: two 64-key groups of 256 threads
 struct OpAtt {
     static constexpr int IW = 4;
     const Gran* G; unsigned ag; int n_kv, rep, cnt; int dbg;      // cnt = live tiles
     const OpFold* fold; int col0;                                  // the block's 16 residual columns, fetched by 16 idle lanes beside the first chunk
+    unsigned qg, kvg;                                              // q [n_q * 64] and the new token's key / value rows [2][n_kv][64] of this layer
     __device__ __forceinline__ void issue(int, int, bool) {}
     __device__ __forceinline__ f32x8 finish(int k, int, int, bool act, char* xch_) {
         const int tid = threadIdx.x;
@@ -209,14 +213,22 @@ struct OpAtt {
         const bool res = tid >= 240;                               // nitems = 224: the last 32 lanes own no item
         float* xch = reinterpret_cast<float*>(xch_);
         G->wait(ag + rep * 64, AT_GSTRIDE, cnt * n_kv);            // one granule of every live (tile, head) pair; cnt * n_kv <= 64
+        // the new token attends to itself: score = q . k_new / 8 per head, value v_new -- one more partial {o = v_new, max = score,
+        // sum = 1}, merged first.  Its three vectors were published by the Q role long before the attention tiles.
         float M = -INFINITY, den = 0.f;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 q4 = acc, k4 = acc, v4 = acc;                        // (loaded beside the first chunk of tiles: no round trip of their own)
         for (int s0 = 0; s0 < cnt; s0 += AT_CHUNK) {               // (block-uniform trip count)
             f32x4 o[AT_CHUNK]; float m[AT_CHUNK], l[AT_CHUNK];
             float rv = 0.f;
             G->sweep([&]() {
                 bool ok = true;
                 if (act) {
+                    if (s0 == 0) {
+                        ok = G->ld4(qg + k, q4);
+                        ok &= G->ld4(kvg + g * 64 + (k & 63), k4);
+                        ok &= G->ld4(kvg + (n_kv + g) * 64 + (k & 63), v4);
+                    }
 #pragma unroll
                     for (int i = 0; i < AT_CHUNK; i++) {
                         const int s = min(s0 + i, cnt - 1);        // slots past the count repeat the last tile (loaded, not merged)
@@ -242,6 +254,14 @@ struct OpAtt {
                 return ok;
             });
             if (res && s0 == 0) xch[1200 + (tid & 15)] = fold->plain ? fold->plain[col0 + (tid & 15)] : rv;
+            if (s0 == 0) {
+                float sc = (q4[0] * k4[0] + q4[1] * k4[1]) + (q4[2] * k4[2] + q4[3] * k4[3]);
+                sc += dpp_mov_f32<0x128, 0xf>(0.f, sc);            // row_ror 8 / 4 / 2 / 1: the 16 lanes of a head (64 columns) sum up
+                sc += dpp_mov_f32<0x124, 0xf>(0.f, sc);
+                sc += dpp_mov_f32<0x122, 0xf>(0.f, sc);
+                sc += dpp_mov_f32<0x121, 0xf>(0.f, sc);
+                M = sc * 0.125f; den = 1.f; acc = v4;
+            }
 #pragma unroll
             for (int i = 0; i < AT_CHUNK; i++) {
                 if (s0 + i < cnt) {
@@ -333,16 +353,36 @@ __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int t
     R1_T(4);
     float rs = 1.f;
     if (NORM) rs = rsqrtf((((sqs[0] + sqs[1]) + (sqs[2] + sqs[3])) + ((sqs[4] + sqs[5]) + (sqs[6] + sqs[7]))) / (float)K + eps);    // waves without items contributed 0
+    // The B operands of a group of k-steps are requested together, THEN the group's MFMAs run: left to itself the compiler reads
+    // each step's operand right in front of its MFMA pair (ds_read -> wait -> 2 MFMAs, ~85 ns per k-step in the ISA), a serial
+    // chain of LDS latencies.  A k-step beyond the wave's share multiplies a zero fragment (no branches inside a group).
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int GRP = MAXKS <= 7 ? MAXKS : (MAXKS + 1) / 2;
 #pragma unroll
-    for (int i = 0; i < MAXKS; i++) {
-        if (w0 + i < w1) {
-            const int s = w0 + i - ks0;
-            const bf16x8 a = __builtin_bit_cast(bf16x8, abuf[i]);
-            const bf16x8* xb = reinterpret_cast<const bf16x8*>(stage + (size_t)s * 128) + (lane >> 4);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[4], acc, 0, 0, 0);
+    for (int g0 = 0; g0 < MAXKS; g0 += GRP) {
+        bf16x8 bh[GRP], bl[GRP];
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            const int i = g0 + j;
+            if (i < MAXKS) {
+                const int s = (w0 + i < w1 ? w0 + i : w1 - 1) - ks0;
+                const bf16x8* xb = reinterpret_cast<const bf16x8*>(stage + (size_t)s * 128) + (lane >> 4);
+                bh[j] = xb[0];
+                bl[j] = xb[4];
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            const int i = g0 + j;
+            if (i < MAXKS) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, w0 + i < w1 ? abuf[i] : zero8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh[j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl[j], acc, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     R1_T(5);
     // every column of the tile holds the same vector: the lanes of column 0 carry it out

@@ -437,22 +437,23 @@ extern "C" int cv2_debug_chain(unsigned long long* out_host) {
 #define CH_T(i) do { } while (0)
 #endif
 
-// Attention of one 128-key tile for the rep query heads of kv head g: two groups of 256 threads take 64 keys each with the
-// arithmetic of k_attn<2> and merge through LDS.  q, and the new token's key / value row when it falls into this tile, arrive as
-// granules from the Q role; older rows are plain cache reads, requested before anything else.
-#define AT_SMEM_FLOATS (512 + 2 * 512 + 2 * 4096 + 32 + 128)
+// Attention of one 128-key tile for the rep query heads of kv head g over the keys ALREADY in the cache (positions < pos): two groups of
+// 256 threads take 64 keys each with the arithmetic of k_attn<2> and merge through LDS.  q arrives as granules from the Q role; the
+// cache rows are plain reads, requested before anything else.  The new token's own key / value row is NOT waited for here (the key
+// and value heads are the last blocks of the Q role: the tile that owned the row was the layer's straggler): the O role merges it as
+// one more partial (chain.h, OpAtt).
+#define AT_SMEM_FLOATS (512 + 2 * 512 + 2 * 4096 + 32)
 #ifdef CV2_STAMPS
 #define AT_T(i) do { if (dbg_slot >= 0 && threadIdx.x == 0) g_chain_t[dbg_slot][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define AT_T(i) do { } while (0)
 #endif
 __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const float* V, int pos, int j0, int rep,
-                                          unsigned qg, unsigned kg, unsigned vg, unsigned og, char* smem, int dbg_slot) {
+                                          unsigned qg, unsigned og, char* smem, int dbg_slot) {
     float* qs = reinterpret_cast<float*>(smem);       // [8 * 64]
     float* ps_ = qs + 512;                            // [2][8 * 64]
     float* po_ = ps_ + 1024;                          // [2][8 key eighths][8 heads][64]
     float* run_m = po_ + 8192; float* run_l = run_m + 16;     // [2][8]
-    float* knew = run_l + 16; float* vnew = knew + 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 8), t = tid & 255, w = t >> 6;
     float* ps = ps_ + sub * 512; float* po_s = po_ + sub * 4096;
@@ -467,45 +468,32 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
 #pragma unroll
         for (int k = 0; k < 8; k++) vv[k] = *reinterpret_cast<const f32x4*>(V + vo + 64 * k);
     }
-    const int n = max(0, min(AT_KB, pos + 1 - js));    // live keys of this group's 64 (the second group of the last tile may have none)
-    const int jn = pos - js;                          // the new row's index among this group's keys (outside [0, 64): not here)
-    const bool has_new = jn >= 0 && jn < AT_KB;
+    // the tile must be IN registers before the polling starts: left to itself the compiler sinks these loads to their first use,
+    // behind the q wait (stamps: +0.6 us in the PV phase, +1 us in front of the scores).  The block has nothing else to do here.
+#pragma unroll
+    for (int i = 0; i < 4; i++) asm volatile("" : "+v"(kk[i]));
+#pragma unroll
+    for (int k = 0; k < 8; k++) asm volatile("" : "+v"(vv[k]));
+    __builtin_amdgcn_sched_barrier(0);
+    const int n = max(0, min(AT_KB, pos - js));        // cached keys of this group's 64 (the second group of the last tile may have none)
     if (t < 8) { run_m[sub * 8 + t] = -INFINITY; run_l[sub * 8 + t] = 0.f; }
-    // q (and the new row) are polled directly: a few blocks per layer, one or two 8-byte loads per thread -- cheaper than a sentinel
-    // round trip in front of the sweep.  The poll starts once the layer's input has arrived at the Q role (armed by the caller).
+    // q is polled directly: a few blocks per layer, one 8-byte load per thread -- cheaper than a sentinel round trip in front of the
+    // sweep.  The poll starts once the previous layer's down projection has published (armed by the caller).
     {
-        float q0 = 0.f, x = 0.f;
-        const bool mine = tid < rep * 64, kv = has_new && w < 2;
-        const unsigned gi = t < 64 ? kg + t : vg + t - 64;
+        float q0 = 0.f;
+        const bool mine = tid < rep * 64;
         G.sweep([&]() {
-            bool ok = true;
-            if (mine) {
-                const u64 x0 = __hip_atomic_load((const gu64*)(G.base + qg + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                q0 = __builtin_bit_cast(float, (unsigned)x0);
-                ok = (unsigned)(x0 >> 32) == G.epoch;
-            }
-            if (kv) {
-                const u64 xx = __hip_atomic_load((const gu64*)(G.base + gi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                x = __builtin_bit_cast(float, (unsigned)xx);
-                ok &= (unsigned)(xx >> 32) == G.epoch;
-            }
-            return ok;
+            if (!mine) return true;
+            const u64 x0 = __hip_atomic_load((const gu64*)(G.base + qg + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q0 = __builtin_bit_cast(float, (unsigned)x0);
+            return (unsigned)(x0 >> 32) == G.epoch;
         });
         if (mine) qs[tid] = q0;
-        if (kv) (t < 64 ? knew : vnew)[t & 63] = x;
     }
     AT_T(3);
 #pragma unroll
     for (int k = 0; k < 8; k++) vv[k] = kq * 8 + k < n ? vv[k] : (f32x4){0.f, 0.f, 0.f, 0.f};     // rows past the length may hold anything
     __syncthreads();
-    if (has_new) {
-        if (key_t == jn) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) kk[i] = *reinterpret_cast<const f32x4*>(&knew[qd * 16 + 4 * i]);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) if (kq * 8 + k == jn) vv[k] = *reinterpret_cast<const f32x4*>(&vnew[d4 * 4]);
-    }
     if (n > 0) {
 #pragma unroll
         for (int h = 0; h < 8; h++) {
@@ -624,18 +612,17 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     if (r < nA) {                   // ---- A: one 64-key tile of one kv head
         const int tile = r / a.n_kv, g = r - tile * a.n_kv;
         const int pos = a.state[CV2_ST_POS];
-        if (tile * AT_TILE > pos) return;               // tile beyond the sequence: the consumer derives the live count from pos too
+        if (tile * AT_TILE >= pos) return;              // no cached key in this tile: the consumer derives the live count from pos too
         if (layer > 0) G.wait(gp + a.off_dg + H - 1, H, CH_NP);   // armed: the previous layer's down projection has published
         attn_role(G, L.kc + (size_t)g * a.max_pos * 64, L.vc + (size_t)g * a.max_pos * 64, pos, tile * AT_TILE, a.rep,
-                  gl + a.off_qg + g * a.rep * 64, gl + a.off_kv + g * 64, gl + a.off_kv + (a.n_kv + g) * 64,
-                  gl + a.off_ag + (unsigned)r * AT_GSTRIDE, smem, od);
+                  gl + a.off_qg + g * a.rep * 64, gl + a.off_ag + (unsigned)r * AT_GSTRIDE, smem, od);
         CH_T(2);
         return;
     }
     r -= nA;
     if (r < nO) {                   // ---- O: attention combine -> O projection -> + residual -> x_mid granules
         const int pos = a.state[CV2_ST_POS];
-        OpAtt op{&G, gl + a.off_ag, a.n_kv, a.rep, pos / AT_TILE + 1, od, &xin, r * 16};
+        OpAtt op{&G, gl + a.off_ag, a.n_kv, a.rep, (pos + AT_TILE - 1) / AT_TILE, od, &xin, r * 16, gl + a.off_qg, gl + a.off_kv};
         const float o = row1_core<1, 8, 4, false>(L.wo, r, 0, a.NQ / 32, a.NQ, 0, a.NQ / 32, op, nullptr, 0.f, smem);
         CH_T(1);
         if (tid < 16) G.store(gl + r * 16 + tid, reinterpret_cast<const float*>(smem + R1_STAGE_BYTES(a.NQ / 32))[1200 + tid] + o);
@@ -644,7 +631,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     }
     r -= nO;
     if (r < nGU) {                  // ---- GU: RMSNorm -> gate / up -> SiLU(g) * u -> h granules
-        OpGran<4> op{&G, gl, gl + (unsigned)(nO / 4) * 16 - 1, (unsigned)(nO / 4) * 16, od};
+        OpGran<4> op{&G, gl, gl + 15, 0, od};
         const float v = row1_core<2, 4, 7, true>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, op, L.ln2, a.eps, smem);
         const float u = __shfl(v, (tid & 15) + 16);            // threads 0..15 hold gate, 16..31 up (wave 0)
         CH_T(1);
@@ -657,8 +644,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
         const int sp = r / nO, tile = r - sp * nO;
         const int KS = a.inter / 32;
         const int ks0 = (int)(((unsigned)KS * sp) / CH_NP), ks1 = (int)(((unsigned)KS * (sp + 1)) / CH_NP);
-        const unsigned qtr = (unsigned)((ks1 - ks0) * 32 / 4);
-        OpGran<8> op{&G, gl + a.off_hg, gl + a.off_hg + ks0 * 32 + qtr - 1, qtr, od};
+        OpGran<8> op{&G, gl + a.off_hg, gl + a.off_hg + ks0 * 32 + 15, 0, od};
         const float v = row1_core<1, 8, 10, false>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op, nullptr, 0.f, smem);
         CH_T(1);
         if (tid < 16) G.store(gl + a.off_dg + sp * H + tile * 16 + tid, v);
