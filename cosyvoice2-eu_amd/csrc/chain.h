@@ -179,13 +179,22 @@ struct OpGran {
     static constexpr int IW = IW_;
     const Gran* G; unsigned g0, sentinel, sstride; int dbg;     // sentinel: one granule of the FIRST producer of this vector
     __device__ __forceinline__ void issue(int, int, bool) {}
-    __device__ __forceinline__ f32x8 finish(int k, int wave, int nitems, bool active, char*) {
+    __device__ __forceinline__ f32x8 finish(int k, int wave, int nitems, bool active, char* xch_) {
         f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (wave * 64 >= nitems) return v;
         // armed by the first producer (cheap one-word polls while the vector is still far away), then the sweep itself polls: the
         // producers finish within ~0.6 us of each other, so this costs one or two extra sweeps and saves the round trip that a
-        // wait for the LAST producer's granule would put in front of the sweep
-        G->wait(sentinel, 0, 1);
+        // wait for the LAST producer's granule would put in front of the sweep.  ONE wave per block polls the arming word (hundreds
+        // of blocks wait for the same 128-byte line: every poll of it goes to the same memory channel); the others watch an LDS word.
+        volatile int* armed = reinterpret_cast<volatile int*>(xch_);
+        if (threadIdx.x == 0) *armed = 0;
+        __syncthreads();
+        if (wave * 64 >= nitems) return v;
+        if (wave == 0) {
+            G->wait(sentinel, 0, 1);
+            if ((threadIdx.x & 63) == 0) *armed = 1;
+        } else {
+            while (*armed == 0) __builtin_amdgcn_s_sleep(2);
+        }
         if (IW == 8) {
             G->sweep([&]() { return active ? G->ld8(g0 + k, v) : true; });
         } else {
