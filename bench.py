@@ -398,7 +398,60 @@ def extras(model, st, flow_t, hift_t, dev):
         out[n].update({'forced250_audio_s_per_s': round(audio / dts, 1),
                        'chunk_gap_ms_p50_chunks_2_4': round(gaps_early[len(gaps_early) // 2] * 1e3, 1),
                        'chunk_gap_ms_p50_chunks_8_10': round(gaps_late[len(gaps_late) // 2] * 1e3, 1)})
-    ex['streaming'] = {'flow_cache': bool(getattr(model, 'flow_cache', False)),
+    # ---- configs[4] as BASELINE words it: "bistream LLM + chunk-CFM, batch=8" -- the text of every call is a Python GENERATOR (llm_job's
+    # bistream branch, cli/model.py:120-128): 120 text tokens arriving in pieces of 5, interleaved 5 text : 15 speech tokens on the device.
+    # Random weights never draw the fill / EOS ids on their own: for this leg the decoder bias of the three special ids is raised (the idea
+    # of tests/test_fullsize_gpu.py:_bistream_sd; EOS +24, fill +6: the fill id appears once on its own and is forced every
+    # 16 entries from then on, llm.py:783-804; in the final decode EOS always beats it) and the sampler is the greedy harness
+    # (with RAS an EOS that dominates while text is still expected exhausts the 100 re-draws of llm.py:242-250); both are put back afterwards.
+    bis = None
+    keep_mode = model.sampling_mode
+    try:
+        from cv2amd.llm import MODE_GREEDY
+        bd = model.llm.bdec
+        keep = bd[6561:6564].clone()
+        bd[6563] += 6.0; bd[6561] += 24.0; bd[6562] = -30.0
+        model.sampling_mode = MODE_GREEDY
+        breq = request(1986, P_TOK, 120, dev)          # the first 17 blocks of 5 text tokens carry the 255 prompt speech tokens (5 : 15)
+        pieces = [breq['text'][:, i:i + 5] for i in range(0, 120, 5)]
+
+        def bcall(n):
+            firsts, audio = [None] * n, [0.0] * n
+            errs = []
+            t0 = time.perf_counter()
+
+            def work(i):
+                try:
+                    kw = dict(breq)
+                    kw['text'] = (p for p in pieces)
+                    for o in model.tts(**kw, stream=True):
+                        if firsts[i] is None:
+                            firsts[i] = time.perf_counter() - t0
+                        audio[i] += o['tts_speech'].shape[1] / 24000.0
+                except Exception as e:      # noqa: BLE001
+                    errs.append(e)
+            ths = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            if errs:
+                raise errs[0]
+            return firsts, sum(audio), time.perf_counter() - t0
+        bcall(8)
+        fs, au, dts = [], 0.0, 0.0
+        for _ in range(3):
+            f, a, d = bcall(8)
+            fs += f; au += a; dts += d
+        fs.sort()
+        bis = {'workload': '8 concurrent tts(text=<generator>, stream=True) calls (llm_job bistream branch): 120 text tokens in pieces of 5, P=255, greedy harness, EOS live',
+               'first_chunk_ms_p50': round(fs[len(fs) // 2] * 1e3, 1), 'first_chunk_ms_max': round(fs[-1] * 1e3, 1),
+               'audio_s_per_s': round(au / dts, 1), 'audio_s_per_call': round(au / 24, 2)}
+    except Exception as e:      # noqa: BLE001
+        bis = {'error': repr(e)}
+    finally:
+        model.llm.bdec[6561:6564] = keep
+        model.sampling_mode = keep_mode
+        torch.cuda.synchronize()
+    ex['streaming'] = {'flow_cache': bool(getattr(model, 'flow_cache', False)), 'bistream_8': bis,
                        'prompt_cache': 'the streams share a prompt the model has served before: its whole chunks come from the prompt flow cache '
                                        '(first_chunk_ms_p50_new_prompt: without it)' if getattr(model, 'prompt_cache_max', 0) > 0 else 'off',
                        'workload': 'configs[4]: streaming (hop 25, look-ahead 3), P=255: the first chunk needs prefill + 48 tokens, chunk-masked flow at '

@@ -70,6 +70,8 @@ class CosyVoice2Model:
         if not torch.cuda.is_available():
             raise L.Cv2Error('CosyVoice2Model (MI355X build) needs a GPU: the hot path has no CPU fallback')
         self.device = torch.device(device or 'cuda')
+        if self.device.index is None:                  # set_device needs an index (threads started later switch to this device)
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.fp16 = fp16                       # accepted for signature compatibility; the HIP path fixes its own dtypes
         from cv2amd.config import Config
         self.config = config or Config()       # hyper-parameters of cosyvoice2.yaml (the reference receives built modules instead)
@@ -104,6 +106,7 @@ class CosyVoice2Model:
         self._noise_hook_takes_uuid = False    # tests with concurrent calls: callable(T, uuid)
         self._on_call = None                   # tests: callable(uuid), invoked in the caller's thread when a tts() call starts
         self._trace = None                     # tests: list receiving (flow mel, token_offset, finalize, noise) per token2wav call
+        self._token_log = None                 # tests: dict uuid -> the call's speech tokens, filled when a call ends
         # non-final chunks of streaming calls keep a per-call flow cache (cv2_flow_inference_chunk): a chunk costs its own 50 frames
         # instead of the whole prefix the reference re-runs (model.py:351-381).  CV2_FLOW_CACHE=0: recompute like the reference.
         self.flow_cache = os.environ.get('CV2_FLOW_CACHE', '1') != '0'
@@ -220,6 +223,7 @@ class CosyVoice2Model:
         """Background: the flow cache of a prompt alone (its whole chunks), kept for later calls with the same prompt — their first
         chunk then computes ~100 frames instead of the prompt's ~500 + its own.  At most `prompt_cache_max` prompts are kept (LRU)."""
         try:
+            torch.cuda.set_device(self.device)
             with self.run_lock:
                 if pkey not in self._prompt_caches:
                     pc = self.flow.prompt_cache(fpt, feat, femb, hop=self.token_hop_len)
@@ -610,6 +614,8 @@ class CosyVoice2Model:
                     self.llm_stream.synchronize()
                 self._exit_shared(slot)
             with self.lock:
+                if self._token_log is not None:
+                    self._token_log[this_uuid] = list(self.tts_speech_token_dict.get(this_uuid, []))
                 self.tts_speech_token_dict.pop(this_uuid, None)
                 self.llm_end_dict.pop(this_uuid, None)
                 self.hift_cache_dict.pop(this_uuid, None)
@@ -631,6 +637,9 @@ class CosyVoice2Model:
         if not vc and not bistream and not isinstance(text, torch.Tensor):
             raise TypeError('text must be a tensor of token ids or a generator of such tensors')
         this_uuid = str(uuid.uuid1())
+        # the current device is per thread and a new thread starts on device 0: callers run tts() from pool threads (the evaluation
+        # harness, evaluation/cosyvoice_synthesizer.py:260) while the model may live on another GPU of the node (one rank per GPU)
+        torch.cuda.set_device(self.device)
         if self._on_call is not None:
             self._on_call(this_uuid)
         with self.lock:

@@ -64,11 +64,12 @@ class LLMEngine:
         bdec[:vocab] = sd['llm_decoder.bias']
         cos, sin = W.rope_tables(max_pos)
         self.speech_emb = dv(sd['speech_embedding.weight'])
+        self.bdec = dv(bdec)                           # llm_decoder.bias on the device (padded to vocab_pad)
         self.llm_emb = dv(sd['llm_embedding.weight'])
         self.text_emb = dv(sd['llm.model.model.embed_tokens.weight'])
         self._w = L.LlmWeights(layers=C.cast(self._layers, C.POINTER(L.LlmLayer)),
                                final_norm=dv(sd['llm.model.model.norm.weight']).data_ptr(), wdec=wdec.data_ptr(),
-                               bdec=dv(bdec).data_ptr(), speech_emb=self.speech_emb.data_ptr(),
+                               bdec=self.bdec.data_ptr(), speech_emb=self.speech_emb.data_ptr(),
                                rope_cos=dv(cos).data_ptr(), rope_sin=dv(sin).data_ptr())
         self.state = torch.zeros(max_seqs, L.STATE_STRIDE, dtype=torch.int32, device=dev)
         self.out_tokens = torch.zeros(max_seqs, max_out, dtype=torch.int32, device=dev)

@@ -463,6 +463,67 @@ def test_generator_text_and_vc_through_the_scheduler(dev):
     assert sorted(mdl._slot_free) == [0, 1] and not mdl.tts_speech_token_dict
 
 
+def test_config4_eight_generator_text_streams_vs_oracle_bistream(dev):
+    """BASELINE configs[4] as it is worded ("bistream LLM + chunk-CFM, batch=8"): EIGHT concurrent streaming calls whose text is a
+    Python generator (llm_job's bistream branch, cli/model.py:120-128 x 8) on one model.  Every stream owns one LLM slot; the eight
+    device state machines (fill id stops a slot, forced fill, final decode) share the decode steps.  For every stream: the speech
+    token ids equal oracle.llm.inference_bistream on the same text pieces (greedy, 24 layers), the chunk boundaries follow
+    cli/model.py:351-381 (first chunk hop + pad tokens, then hop; look-ahead 3), and the audio length is 960 samples per token."""
+    from cv2amd import synth, weights as W
+    from cosyvoice.cli.model import CosyVoice2Model
+    from oracle import llm as OL
+    sd = _bistream_sd(24)
+    sdr = W.round_llm_sd(sd)
+    mdl = CosyVoice2Model(sd, synth.make_flow(), synth.make_hift(), max_batch=8, max_text=96, max_prompt_tokens=96, max_new_tokens=512, sampling='greedy')
+    cases = []
+    for i, (seed, P, cuts) in enumerate(((1, 31, (0, 3, 10, 15, 23)), (2, 58, (0, 5, 10, 17, 26, 31)))):
+        inp = synth.synthetic_inputs(seed=seed, text_len=cuts[-1], prompt_len=P, prompt_text_len=6)
+        pieces = [inp['text'][:, a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+        want, _ = OL.inference_bistream(sdr, pieces, inp['prompt_text'], inp['prompt_token'])
+        cases.append((inp, pieces, want, P))
+    calls = [cases[i % 2] for i in range(8)]
+    mdl._token_log, mdl._trace = {}, []
+    out, errs, uuid_of, tl = [None] * 8, [], {}, threading.local()
+    mdl._on_call = lambda u: uuid_of.__setitem__(tl.i, u)
+
+    def work(i):
+        tl.i = i
+        inp, pieces, _, _ = calls[i]
+        try:
+            out[i] = [o['tts_speech'] for o in mdl.tts(text=(p for p in pieces), stream=True, flow_embedding=inp['embedding'], llm_embedding=inp['embedding'],
+                                                       prompt_text=inp['prompt_text'], llm_prompt_speech_token=inp['prompt_token'],
+                                                       flow_prompt_speech_token=inp['prompt_token'], prompt_speech_feat=inp['prompt_feat'])]
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ths]
+    [t.join(900) for t in ths]
+    trace, log = mdl._trace, mdl._token_log
+    mdl._trace, mdl._token_log, mdl._on_call = None, None, None
+    assert not errs, errs
+    hop = 25
+    by_uuid = {}
+    for t in trace:
+        by_uuid.setdefault(t[4], []).append(t)
+    for i in range(8):
+        inp, pieces, want, P = calls[i]
+        u = uuid_of[i]
+        assert log[u] == want, f'stream {i}: ids differ from oracle.llm.inference_bistream (first at {next((k for k, (a, b) in enumerate(zip(log[u], want)) if a != b), -1)})'
+        assert sum(c.shape[1] for c in out[i]) == 960 * len(want) and all(torch.isfinite(c).all() for c in out[i])
+        tr = by_uuid[u]
+        pad = int(np.ceil(P / hop) * hop - P)
+        offs = [t[1] for t in tr]
+        assert len(tr) == len(out[i]) and [t[2] for t in tr] == [False] * (len(tr) - 1) + [True]
+        assert offs[0] == 0 and (len(offs) == 1 or offs[1] == hop + pad) and all(b - a == hop for a, b in zip(offs[1:-1], offs[2:]))
+        n_chunks = 0
+        off = 0
+        while len(want) - off >= (hop + pad if off == 0 else hop) + 3:
+            off += hop + pad if off == 0 else hop
+            n_chunks += 1
+        assert len(tr) == n_chunks + 1, f'stream {i}: {len(tr)} chunks, the reference loop gives {n_chunks + 1}'
+    assert sorted(mdl._slot_free) == list(range(8)) and not mdl._active_slots and not mdl.tts_speech_token_dict
+
+
 def test_flow_cache_policy_and_regrowth(cv_from_disk):
     """The scheduler's use of the per-call flow cache: (1) by default one stream alone recomputes (no cache is allocated) — the cache
     only pays from two chunks per round on; (2) forced on with a capacity hint that is far too small, the cache is replaced by a
