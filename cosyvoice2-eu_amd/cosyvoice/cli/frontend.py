@@ -1,7 +1,7 @@
 """Prompt / text frontend (cosyvoice/cli/frontend.py of the reference).  OUT OF THE HOT PATH ("next #1"):
 it runs once per prompt on third-party models (Qwen tokenizer, whisper log-mel -> speech_tokenizer_v2.onnx,
-kaldi fbank -> campplus.onnx).  This module keeps the interface the API layer calls and delegates to those packages
-when they are installed; `PrecomputedFrontEnd` serves pre-extracted prompts (the reference's own `spk2info` mechanism,
+kaldi fbank -> campplus.onnx).  This module keeps the interface the API layer calls; the two feature extractors and the prompt mel
+run on the device (cv2amd/prompt.py), the two ONNX graphs through onnxruntime when it is installed; `PrecomputedFrontEnd` serves pre-extracted prompts (the reference's own `spk2info` mechanism,
 cli/cosyvoice.py:70-76) and is what the tests and the benchmark use.
 """
 import os
@@ -101,11 +101,10 @@ class CosyVoiceFrontEnd(PrecomputedFrontEnd):
     def __init__(self, model_dir, allowed_special='all'):
         try:
             import onnxruntime
-            import whisper
             from transformers import AutoTokenizer
         except ImportError as e:
-            raise FrontEndUnavailable('CosyVoiceFrontEnd needs onnxruntime, openai-whisper and transformers: {}'.format(e))
-        self._whisper = whisper
+            raise FrontEndUnavailable('CosyVoiceFrontEnd needs onnxruntime and transformers: {}'.format(e))
+        self._speech = None                                                      # cv2amd.prompt.SpeechFeatures (device), built on first use
         tok_dir = os.path.join(model_dir, 'CosyVoice-BlankEN')
         self._tok = AutoTokenizer.from_pretrained(tok_dir)
         special = {'eos_token': '<|endoftext|>', 'pad_token': '<|endoftext|>',
@@ -125,9 +124,15 @@ class CosyVoiceFrontEnd(PrecomputedFrontEnd):
         if os.path.exists(spk):
             self.spk2info = torch.load(spk, map_location='cpu')
 
+    def _speech_features(self):
+        if self._speech is None:
+            from cv2amd.prompt import SpeechFeatures
+            self._speech = SpeechFeatures()
+        return self._speech
+
     def _extract_speech_token(self, speech):                                    # frontend.py:262-274
         assert speech.shape[1] / 16000 <= 30, 'do not support extract speech token for audio longer than 30s'
-        feat = self._whisper.log_mel_spectrogram(speech, n_mels=128)
+        feat = self._speech_features().whisper_log_mel(speech)                   # whisper.log_mel_spectrogram(speech, n_mels=128) on the device
         ort_in = self.speech_tokenizer_session.get_inputs()
         tok = self.speech_tokenizer_session.run(None, {ort_in[0].name: feat.detach().cpu().numpy(),
                                                        ort_in[1].name: __import__('numpy').array([feat.shape[2]], dtype='int32')})[0].flatten().tolist()
@@ -135,9 +140,7 @@ class CosyVoiceFrontEnd(PrecomputedFrontEnd):
         return t, torch.tensor([t.shape[1]], dtype=torch.int32)
 
     def _extract_spk_embedding(self, speech):                                   # frontend.py:276-283
-        import torchaudio.compliance.kaldi as kaldi
-        feat = kaldi.fbank(speech, num_mel_bins=80, dither=0, sample_frequency=16000)
-        feat = feat - feat.mean(dim=0, keepdim=True)
+        feat = self._speech_features().kaldi_fbank(speech)                       # kaldi.fbank(...) - mean over frames, on the device
         emb = self.campplus_session.run(None, {self.campplus_session.get_inputs()[0].name: feat.unsqueeze(0).cpu().numpy()})[0].flatten().tolist()
         return torch.tensor([emb])
 

@@ -107,3 +107,89 @@ class PromptFeatures:
     def prompt_feat(self, speech_16k):
         """cli/frontend.py:497-498: Resample(16000, 24000) then feat_extractor, [1, frames, 80]."""
         return self.mel(self.resample(speech_16k))
+
+
+# ---- the feature extractors in front of the ONNX prompt models (cli/frontend.py:262-283) ------------------------------------------
+class FrameFeatCfg(C.Structure):
+    _fields_ = [('n_fft', C.c_int32), ('win', C.c_int32), ('hop', C.c_int32), ('n_bins', C.c_int32), ('n_mels', C.c_int32),
+                ('window', C.c_void_p), ('twiddle', C.c_void_p), ('mel_fb', C.c_void_p), ('fb_lo', C.c_void_p), ('fb_hi', C.c_void_p),
+                ('center', C.c_int32), ('remove_dc', C.c_int32), ('preemph', C.c_float), ('log10', C.c_int32), ('floor', C.c_float)]
+
+
+def _kaldi_mel_banks(num_bins=80, padded=512, sr=16000.0, low=20.0, high=0.0):
+    """torchaudio.compliance.kaldi.get_mel_banks without VTLN: triangles in the mel domain 1127 ln(1 + f / 700) over the first
+    padded / 2 FFT bins, one zero column appended (fbank pads the Nyquist bin): [num_bins][padded / 2 + 1].  Evaluated in torch fp32
+    with the package's own expression order: its table carries fp32 round-off of ~1e-5 in the weights, which a float64 table would
+    not reproduce (visible in bins that only receive the skirt of a loud neighbour)."""
+    nyq = 0.5 * sr
+    if high <= 0.0:
+        high += nyq
+    lo, hi = 1127.0 * math.log(1.0 + low / 700.0), 1127.0 * math.log(1.0 + high / 700.0)
+    delta = (hi - lo) / (num_bins + 1)
+    b = torch.arange(num_bins).unsqueeze(1)
+    left, center, right = lo + b * delta, lo + (b + 1.0) * delta, lo + (b + 2.0) * delta
+    m = (1127.0 * (1.0 + ((sr / padded) * torch.arange(padded // 2)) / 700.0).log()).unsqueeze(0)
+    bins = torch.max(torch.zeros(1), torch.min((m - left) / (center - left), (right - m) / (right - center)))
+    return torch.nn.functional.pad(bins, (0, 1)).numpy().astype(np.float32)
+
+
+class SpeechFeatures:
+    """whisper.log_mel_spectrogram(speech, n_mels=128) and kaldi.fbank(speech, num_mel_bins=80, dither=0, sample_frequency=16000)
+    (- column mean) of the reference frontend (cli/frontend.py:264, 277-278) on one device: what feeds speech_tokenizer_v2.onnx and
+    campplus.onnx.  16 kHz input, [1, n] in [-1, 1]."""
+
+    def __init__(self, device='cuda:0'):
+        if not torch.cuda.is_available():
+            raise L.Cv2Error('SpeechFeatures needs a GPU: the prompt features have no CPU fallback in this build')
+        self.device = dev = torch.device(device)
+        self.lib = L.lib()
+        self.lib.cv2_framefeat.argtypes = [C.POINTER(FrameFeatCfg), C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
+        self.lib.cv2_whisper_post.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        self.lib.cv2_sub_col_mean.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        self._keep = []
+
+        def tables(n_fft, window, fb):
+            j = np.arange(n_fft, dtype=np.float64)
+            tw = np.stack([np.cos(2 * math.pi * j / n_fft), np.sin(2 * math.pi * j / n_fft)], 1)
+            nz = fb > 0
+            lo = np.where(nz.any(1), nz.argmax(1), 0).astype(np.int32)
+            hi = np.where(nz.any(1), fb.shape[1] - nz[:, ::-1].argmax(1), 0).astype(np.int32)
+            t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (window, tw, fb, lo, hi)]
+            self._keep.append(t)
+            return t
+        j = np.arange(400, dtype=np.float64)
+        # whisper audio.py: torch.hann_window(400) (periodic), N_FFT 400, HOP 160, mel_filters(n_mels) = librosa.filters.mel(sr=16000, n_fft=400)
+        w, tw, fb, lo, hi = tables(400, 0.5 - 0.5 * np.cos(2 * math.pi * j / 400), _slaney_fb(16000, 400, 128, 0.0, 8000.0))
+        self._whisper = FrameFeatCfg(400, 400, 160, 201, 128, w.data_ptr(), tw.data_ptr(), fb.data_ptr(), lo.data_ptr(), hi.data_ptr(), 1, 0, 0.0, 1, 1e-10)
+        # kaldi.py: povey window = hann(400, periodic=False) ** 0.85, round_to_power_of_two -> 512, preemphasis 0.97, remove_dc_offset,
+        # log(max(., torch.finfo(float).eps))
+        w, tw, fb, lo, hi = tables(512, (0.5 - 0.5 * np.cos(2 * math.pi * j / 399)) ** 0.85, _kaldi_mel_banks())
+        self._kaldi = FrameFeatCfg(512, 400, 160, 257, 80, w.data_ptr(), tw.data_ptr(), fb.data_ptr(), lo.data_ptr(), hi.data_ptr(), 0, 1, 0.97, 0,
+                                   float(np.finfo(np.float32).eps))
+
+    def _run(self, cfg, x, frames):
+        out = torch.empty(frames, cfg.n_mels, dtype=torch.float32, device=self.device)
+        L.check(self.lib.cv2_framefeat(C.byref(cfg), x.data_ptr(), x.numel(), out.data_ptr(), frames, L.stream_ptr()))
+        return out
+
+    def whisper_log_mel(self, speech_16k):
+        """[1, n] -> [1, 128, n // 160] (device), the tensor the reference hands to speech_tokenizer_v2.onnx."""
+        x = speech_16k.reshape(-1).to(self.device, torch.float32).contiguous()
+        if x.numel() <= 200:
+            raise ValueError(f'{x.numel()} samples are too short for whisper features')
+        frames = x.numel() // 160
+        raw = self._run(self._whisper, x, frames)
+        out = torch.empty(128, frames, dtype=torch.float32, device=self.device)
+        L.check(self.lib.cv2_whisper_post(raw.data_ptr(), out.data_ptr(), frames, 128, L.stream_ptr()))
+        return out.unsqueeze(0)
+
+    def kaldi_fbank(self, speech_16k, subtract_mean=True):
+        """[1, n] -> [1 + (n - 400) // 160, 80] (device); subtract_mean: the `feat - feat.mean(dim=0)` of frontend.py:278."""
+        x = speech_16k.reshape(-1).to(self.device, torch.float32).contiguous()
+        if x.numel() < 400:
+            raise ValueError(f'{x.numel()} samples are shorter than one 25 ms frame')
+        frames = 1 + (x.numel() - 400) // 160
+        out = self._run(self._kaldi, x, frames)
+        if subtract_mean:
+            L.check(self.lib.cv2_sub_col_mean(out.data_ptr(), frames, 80, L.stream_ptr()))
+        return out

@@ -349,6 +349,30 @@ int cv2_melspec(const cv2_melspec_cfg* cfg, const float* wav, int64_t n, float* 
 int cv2_resample(const float* in, int64_t n_in, const float* kernel, int32_t up, int32_t down, int32_t klen, int32_t pad_left,
                  float* out, int64_t n_out, void* stream);
 
+/* The two feature extractors in front of the ONNX prompt models (cosyvoice/cli/frontend.py:262-283; third-party algorithms):
+ *   whisper.log_mel_spectrogram(speech, n_mels=128) -> speech_tokenizer_v2.onnx   (frontend.py:264): center = 1, win = n_fft = 400, hop 160,
+ *       periodic Hann window, |X|^2 of every frame but the last, Slaney filters [128][201], log10(max(., 1e-10));
+ *       cv2_whisper_post: max(x, max(x) - 8), (x + 4) / 4, transposed to [n_mels][frames] (the layout the ONNX graph takes)
+ *   torchaudio.compliance.kaldi.fbank(speech, num_mel_bins=80, dither=0, sample_frequency=16000) -> campplus.onnx (frontend.py:277):
+ *       center = 0 (snip_edges), win 400, n_fft 512 (zero padded), hop 160, remove_dc = 1, preemph 0.97, povey window, |X|^2, kaldi mel
+ *       banks [80][257] (20 Hz .. Nyquist), ln(max(., FLT_EPSILON)); cv2_sub_col_mean: feat - feat.mean(dim=0) (frontend.py:278)
+ * cv2_framefeat: wav fp32 [n]; out fp32 [n_frames][n_mels]; n_frames = n / hop (center) or 1 + (n - win) / hop (snip_edges).
+ * Tables are DEVICE pointers computed by the host (cv2amd/prompt.py). */
+typedef struct {
+    int32_t n_fft, win, hop, n_bins, n_mels;     /* win <= n_fft: the windowed frame is zero-padded to the DFT length */
+    const double* window;                        /* [win] fp64 */
+    const double* twiddle;                       /* [n_fft][2] fp64: cos, sin of 2 pi j / n_fft */
+    const float* mel_fb;                         /* [n_mels][n_bins] */
+    const int32_t* fb_lo; const int32_t* fb_hi;  /* [n_mels]: filter m is zero outside bins [fb_lo[m], fb_hi[m]) */
+    int32_t center, remove_dc;
+    float preemph;
+    int32_t log10;                               /* 1: log10, 0: natural log */
+    float floor;                                 /* clamp before the log */
+} cv2_framefeat_cfg;
+int cv2_framefeat(const cv2_framefeat_cfg* cfg, const float* wav, int64_t n, float* out, int32_t n_frames, void* stream);
+int cv2_whisper_post(const float* in, float* out, int32_t n_frames, int32_t n_mels, void* stream);
+int cv2_sub_col_mean(float* x, int32_t n_rows, int32_t n_cols, void* stream);
+
 /* Test hooks: the element-wise functions exactly as the kernels evaluate them (fast-math exp / sin / reciprocal), so that their
  * error against libm can be swept over the input ranges of the real checkpoint (tests/test_math_gpu.py).
  *   act: 1 exact-erf GELU (diffusers GELU, matcha transformer.py FeedForward), 2 SiLU, 3 Mish, 4 leaky ReLU (slope)

@@ -101,3 +101,70 @@ def resample(x, orig_freq=16000, new_freq=24000):
 def prompt_feat(speech_16k):
     """cli/frontend.py:497-498: resample to 24 kHz, mel, time-major: [1, frames, 80]."""
     return mel_spectrogram(resample(speech_16k)).squeeze(0).transpose(0, 1).unsqueeze(0)
+
+
+# ---- the feature extractors in front of the ONNX prompt models (cli/frontend.py:262-283): third-party algorithms, PARITY-UNPINNED ----
+def whisper_log_mel(audio, n_mels=128, exact_dft=False):
+    """openai-whisper audio.py log_mel_spectrogram (the call of cli/frontend.py:264; package absent here, its published code
+    restated): hann(400) STFT at hop 160 (center, reflect), |X|^2 without the last frame, librosa Slaney filters (mel_filterbank
+    above), log10(clamp 1e-10), max(x, max - 8), (x + 4) / 4.  audio fp32 [1, n] -> [1, n_mels, n // 160].  The STFT is torch.stft as
+    in the package (exact_dft: the DFT by its definition in float64, what the device evaluates)."""
+    a = audio.reshape(-1)
+    if exact_dft:
+        ap = torch.nn.functional.pad(a[None, None].double(), (200, 200), mode='reflect')[0, 0]
+        fr = ap.unfold(0, 400, 160) * torch.hann_window(400, dtype=torch.float64)
+        k = torch.arange(201, dtype=torch.float64)[:, None] * torch.arange(400, dtype=torch.float64)[None, :]
+        ang = 2 * math.pi * torch.remainder(k, 400) / 400
+        re, im = (fr @ torch.cos(ang).t()).float(), (-(fr @ torch.sin(ang).t())).float()
+        mag = (re * re + im * im).t()[:, :-1]
+    else:
+        st = torch.stft(a, 400, 160, window=torch.hann_window(400), return_complex=True)
+        mag = st[..., :-1].abs() ** 2
+    fb = torch.from_numpy(mel_filterbank(16000, 400, n_mels, 0.0, 8000.0))
+    log_spec = torch.clamp(fb @ mag, min=1e-10).log10()
+    log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
+    return ((log_spec + 4.0) / 4.0).unsqueeze(0)
+
+
+def kaldi_mel_banks(num_bins=80, padded=512, sr=16000.0, low=20.0, high=0.0):
+    """torchaudio.compliance.kaldi.get_mel_banks (no VTLN), in torch fp32 as the package computes it."""
+    nyq = 0.5 * sr
+    if high <= 0.0:
+        high += nyq
+    mel = lambda f: 1127.0 * torch.log(1.0 + f / 700.0)       # noqa: E731
+    lo, hi = 1127.0 * math.log(1.0 + low / 700.0), 1127.0 * math.log(1.0 + high / 700.0)
+    delta = (hi - lo) / (num_bins + 1)
+    b = torch.arange(num_bins).unsqueeze(1)
+    left, center, right = lo + b * delta, lo + (b + 1.0) * delta, lo + (b + 2.0) * delta
+    m = mel((sr / padded) * torch.arange(padded // 2)).unsqueeze(0)
+    return torch.max(torch.zeros(1), torch.min((m - left) / (center - left), (right - m) / (right - center)))
+
+
+def kaldi_fbank(waveform, num_mel_bins=80, sr=16000.0, exact_dft=False):
+    """torchaudio.compliance.kaldi.fbank(waveform, num_mel_bins=80, dither=0, sample_frequency=16000) with its defaults (the call of
+    cli/frontend.py:277; package absent here, its published code restated with the same torch ops): snip_edges frames of 400 at stride
+    160, remove_dc_offset, pre-emphasis 0.97 with the first sample replicated, povey window, zero padding to 512, |rfft|^2, mel banks
+    above (+ a zero Nyquist column), log(max(., eps)).  [1, n] -> [frames, 80]."""
+    x = waveform[0]
+    m = 1 + (x.numel() - 400) // 160
+    fr = x.unfold(0, 400, 160)[:m].clone()
+    fr = fr - fr.mean(dim=1, keepdim=True)
+    off = torch.nn.functional.pad(fr.unsqueeze(0), (1, 0), mode='replicate').squeeze(0)
+    fr = fr - 0.97 * off[:, :-1]
+    fr = fr * torch.hann_window(400, periodic=False).pow(0.85).unsqueeze(0)
+    fr = torch.nn.functional.pad(fr, (0, 112))
+    if exact_dft:
+        k = torch.arange(257, dtype=torch.float64)[:, None] * torch.arange(512, dtype=torch.float64)[None, :]
+        ang = 2 * math.pi * torch.remainder(k, 512) / 512
+        f64 = fr.double()
+        # the device applies window etc. in float64: redo the frame arithmetic there
+        x64 = x.double().unfold(0, 400, 160)[:m]
+        x64 = x64 - x64.mean(dim=1, keepdim=True)
+        o64 = torch.cat([x64[:, :1], x64[:, :-1]], 1)
+        f64 = torch.nn.functional.pad((x64 - 0.97 * o64) * torch.hann_window(400, periodic=False, dtype=torch.float64).pow(0.85), (0, 112))
+        re, im = (f64 @ torch.cos(ang).t()).float(), (-(f64 @ torch.sin(ang).t())).float()
+        power = re * re + im * im
+    else:
+        power = torch.fft.rfft(fr).abs().pow(2.0)
+    banks = torch.nn.functional.pad(kaldi_mel_banks(num_mel_bins, 512, sr), (0, 1))
+    return torch.max(power @ banks.t(), torch.tensor(torch.finfo(torch.float).eps)).log()

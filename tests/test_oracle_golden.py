@@ -131,3 +131,24 @@ def test_llm_bistream_ids(golden):
     ids, outs = OL.inference_bistream(sd, chunks, inp['prompt_text'], inp['prompt_token'])
     assert ids == gd[f'ids_prompt_{seed}'].tolist() and outs == gd[f'out_tokens_prompt_{seed}'].tolist()
     assert outs.count(OL.FILL_TOKEN) == 3 and outs[-1] == OL.SPEECH_TOKEN_SIZE
+
+
+def test_speech_feature_oracles_are_self_consistent():
+    """oracle.frontend.whisper_log_mel / kaldi_fbank restate third-party algorithms (openai-whisper, torchaudio: both absent, PARITY-UNPINNED
+    against the packages).  What can be pinned here: their torch.stft / torch.fft forms (the packages' own calls) agree with the DFT taken by
+    its definition in float64 (framing, window, sign, padding conventions), shapes follow the packages' frame rules, the kaldi banks are
+    triangles that cover 20 Hz .. Nyquist, and the product's bank table is the same fp32 table."""
+    from oracle import frontend as OFE
+    from cv2amd import prompt as P
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 16000 * 2 + 33, generator=g) * 0.1
+    a, b = OFE.whisper_log_mel(x), OFE.whisper_log_mel(x, exact_dft=True)
+    assert a.shape == b.shape == (1, 128, x.shape[1] // 160) and (a - b).abs().max().item() < 2e-5
+    assert a.max().item() - a.min().item() <= 2.0 + 1e-6                    # the max - 8 clamp, scaled by 1 / 4
+    k, kd = OFE.kaldi_fbank(x), OFE.kaldi_fbank(x, exact_dft=True)
+    assert k.shape == kd.shape == (1 + (x.shape[1] - 400) // 160, 80) and (k - kd).abs().max().item() < 1e-3
+    banks = torch.nn.functional.pad(OFE.kaldi_mel_banks(), (0, 1)).numpy()
+    assert banks.shape == (80, 257) and (banks >= 0).all() and (banks.max(1) > 0.5).all() and banks[:, 0].max() == 0
+    peaks = banks.argmax(1)
+    assert (np.diff(peaks) >= 0).all() and peaks[0] >= 1 and peaks[-1] <= 255
+    assert np.array_equal(banks, P._kaldi_mel_banks())

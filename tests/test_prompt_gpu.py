@@ -70,3 +70,53 @@ def test_prompt_feat_end_to_end_and_errors(pf):
     assert (got - want).abs()[live].max().item() < 1e-4
     with pytest.raises(ValueError):
         pf.mel(torch.zeros(1, 300))                                           # shorter than the reflect padding
+
+
+# ---- whisper log-mel and kaldi fbank (cli/frontend.py:262-283) -------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def sf():
+    from cv2amd.prompt import SpeechFeatures
+    return SpeechFeatures('cuda:0')
+
+
+def _signals16():
+    g = torch.Generator().manual_seed(13)
+    n = 16000 * 3 + 77
+    t = torch.arange(n, dtype=torch.float64) / 16000
+    return dict(chirp=(0.5 * torch.sin(2 * np.pi * (60 * t + 900 * t * t))).float()[None],
+                noise=torch.randn(1, 16000 * 2, generator=g) * 0.1,
+                speechy=(0.3 * torch.sin(2 * np.pi * 140 * t) * (1 + 0.5 * torch.sin(2 * np.pi * 3 * t))).float()[None] + 0.01 * torch.randn(1, n, generator=g),
+                short=torch.randn(1, 800, generator=g) * 0.05)
+
+
+@pytest.mark.parametrize('name', ['chirp', 'noise', 'speechy', 'short'])
+def test_whisper_log_mel_matches_oracle(sf, name):
+    """Device features against the restated whisper.log_mel_spectrogram: the float64-DFT form within 1e-5 (after the /4 scaling, where the
+    energy is well above the 1e-10 clamp), and never further from the package's fp32 torch.stft form than that form's own FFT round-off."""
+    from oracle import frontend as OF
+    x = _signals16()[name]
+    want, fft32 = OF.whisper_log_mel(x, exact_dft=True), OF.whisper_log_mel(x)
+    got = sf.whisper_log_mel(x).cpu()
+    assert got.shape == want.shape == (1, 128, x.shape[1] // 160) and torch.isfinite(got).all()
+    live = want > want.max() - 1.5                      # (x + 4) / 4: within 6 decades of the loudest bin, away from the max - 8 clamp
+    assert live.any()
+    assert (got - want).abs()[live].max().item() < 1e-5
+    assert (got - want).abs().max().item() < 2e-2        # at the clamps a 1e-7 round-off of the energy moves the log more
+    assert (got - fft32).abs()[live].max().item() <= (want - fft32).abs()[live].max().item() + 1e-5
+
+
+@pytest.mark.parametrize('name', ['chirp', 'noise', 'speechy', 'short'])
+def test_kaldi_fbank_matches_oracle(sf, name):
+    from oracle import frontend as OF
+    x = _signals16()[name]
+    want, fft32 = OF.kaldi_fbank(x, exact_dft=True), OF.kaldi_fbank(x)
+    got = sf.kaldi_fbank(x, subtract_mean=False).cpu()
+    assert got.shape == want.shape == (1 + (x.shape[1] - 400) // 160, 80) and torch.isfinite(got).all()
+    live = want > want.max() - 11.5                     # natural log: within 5 decades of the loudest bin
+    assert (got - want).abs()[live].max().item() < 1e-4
+    assert (got - fft32).abs()[live].max().item() <= (want - fft32).abs()[live].max().item() + 1e-4
+    # frontend.py:278: feat - feat.mean(dim=0, keepdim=True)
+    got_m = sf.kaldi_fbank(x).cpu()
+    assert (got_m - (got - got.mean(dim=0, keepdim=True))).abs().max().item() < 2e-5
+    with pytest.raises(ValueError):
+        sf.kaldi_fbank(torch.zeros(1, 399))
