@@ -148,7 +148,7 @@ def test_speech_feature_oracles_are_self_consistent():
     k, kd = OFE.kaldi_fbank(x), OFE.kaldi_fbank(x, exact_dft=True)
     assert k.shape == kd.shape == (1 + (x.shape[1] - 400) // 160, 80) and (k - kd).abs().max().item() < 1e-3
     banks = torch.nn.functional.pad(OFE.kaldi_mel_banks(), (0, 1)).numpy()
-    assert banks.shape == (80, 257) and (banks >= 0).all() and (banks.max(1) > 0.5).all() and banks[:, 0].max() == 0
+    assert banks.shape == (80, 257) and (banks >= 0).all() and (banks.max(1) > 0.4).all() and banks[:, 0].max() == 0
     peaks = banks.argmax(1)
     assert (np.diff(peaks) >= 0).all() and peaks[0] >= 1 and peaks[-1] <= 255
     assert np.array_equal(banks, P._kaldi_mel_banks())
