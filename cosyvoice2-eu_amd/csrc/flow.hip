@@ -458,7 +458,9 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
     uint16_t (*Ks)[64 * AK_LD] = Ks_[kgrp];
     uint16_t (*Vs)[64 * AV_LD] = Vs_[kgrp];
     constexpr int RB = 16 * NW;                                  // rows per query sub-tile group
-    const int m0 = blockIdx.x * RB * QS, h = blockIdx.y;
+    // grid (8 heads, query tiles): consecutive block ids go round the 8 XCDs, so XCD x serves head x only and a sequence's K / V^T of
+    // that head is fetched into ONE L2 instead of all eight (r3_pmc_flow: 36 MB of fabric reads per launch before, for 6 MB of q/k/v)
+    const int m0 = blockIdx.y * RB * QS, h = blockIdx.x;
     const int q16 = lane & 15, g = lane >> 4;
     const int s = a.seq.tile_seq[m0 >> 6];           // sequences start on 128-row boundaries: one sequence per block
     uint16_t* orow[QS];
@@ -857,13 +859,13 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
             hipLaunchKernelGGL(k_kv_append, dim3(M / 64, 8), dim3(256), 0, c.s, k);
         }
         if (c.inc) {
-            if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4, 1, true>), dim3(M / 128, 8), dim3(256), 0, c.s, a);
-            else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4, 1, true>), dim3(M / 64, 8), dim3(256), 0, c.s, a);
-            else hipLaunchKernelGGL((k_attn_est<1, 2, 2, true>), dim3(M / 32, 8), dim3(256), 0, c.s, a);
+            if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4, 1, true>), dim3(8, M / 128), dim3(256), 0, c.s, a);
+            else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4, 1, true>), dim3(8, M / 64), dim3(256), 0, c.s, a);
+            else hipLaunchKernelGGL((k_attn_est<1, 2, 2, true>), dim3(8, M / 32), dim3(256), 0, c.s, a);
         }
-        else if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(M / 128, 8), dim3(256), 0, c.s, a);   // enough blocks to fill the chip twice
-        else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(M / 64, 8), dim3(256), 0, c.s, a);
-        else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(M / 32, 8), dim3(256), 0, c.s, a);       // one utterance: split keys over two wave groups
+        else if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(8, M / 128), dim3(256), 0, c.s, a);   // enough blocks to fill the chip twice
+        else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(8, M / 64), dim3(256), 0, c.s, a);
+        else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(8, M / 32), dim3(256), 0, c.s, a);       // one utterance: split keys over two wave groups
     }
     static const bool tail_rows_off = getenv("CV2_FLOW_TAIL_ROWS") && getenv("CV2_FLOW_TAIL_ROWS")[0] == '0';     // A/B switch (diagnostics)
     static const long tail_rows_min = getenv("CV2_FLOW_TAIL_ROWS_MIN") ? atol(getenv("CV2_FLOW_TAIL_ROWS_MIN")) : 96;    // 64-row tiles from which the 64-row blocks are used (8 streaming chunks: 192 -> 184 ms first chunk)

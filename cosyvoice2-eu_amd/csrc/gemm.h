@@ -118,6 +118,18 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): consecutive block ids are dealt round the 8 XCDs, so the N
+// tiles of one row tile would land in 8 different L2s and its A rows would cross the fabric up to 8 times.  Blocks with equal
+// id % 8 take one contiguous share of the tile list instead (n fastest): an A row tile is fetched by one L2.  A speed choice only.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by) {
+    const int gx = gridDim.x, T = gx * gridDim.y;
+    bx = blockIdx.x; by = blockIdx.y;
+    if (gridDim.z != 1 || gx == 1 || T < 16) return;
+    const int L = bx + by * gx, x = L & 7, q = T >> 3, r = T & 7;
+    const int Lp = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (L >> 3);
+    bx = Lp % gx; by = Lp / gx;
+}
+
 template <int BM, int BN, int WM, int WN, bool WPACKED, bool SPLITA = false, int NSTAGE = 2>
 __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     constexpr int NW = WM * WN, NT_ = NW * 64;
@@ -129,7 +141,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int bx_, by_;
+    xcd_tile(bx_, by_);
+    const int m0 = by_ * BM, n0 = bx_ * BN;
     const uint16_t* A = a.A + (size_t)blockIdx.z * a.a_bstride;
     const uint16_t* W = a.W + (size_t)blockIdx.z * a.w_bstride;
     const int KS = a.K / 32;                                                  // 32-wide k blocks in the packed W
