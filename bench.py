@@ -109,8 +109,8 @@ class StepTimer:
     def __init__(self, llm):
         import torch
         self.torch, self.llm, self.rec, self.on = torch, llm, [], False
-        self._orig = llm.step
-        llm.step = self._step
+        self._orig, self._orig_rows = llm.step, llm.step_rows
+        llm.step, llm.step_rows = self._step, self._step_rows
 
     def _step(self, n_seqs, n_steps=1, **kw):
         if not self.on:
@@ -120,6 +120,15 @@ class StepTimer:
         self._orig(n_seqs, n_steps, **kw)
         e1.record()
         self.rec.append((e0, e1, n_seqs, n_steps))
+
+    def _step_rows(self, slots, n_steps=1, **kw):                # decode over the live slots only (a batch past its first finished request)
+        if not self.on:
+            return self._orig_rows(slots, n_steps, **kw)
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._orig_rows(slots, n_steps, **kw)
+        e1.record()
+        self.rec.append((e0, e1, len(slots), n_steps))
 
     def result(self):
         """(total ms, total steps) of the recorded bursts; call after a device synchronize."""

@@ -43,12 +43,13 @@ extern "C" int cv2_version(void) { return 1; }
 #define ST CV2_LLM_STATE_STRIDE
 
 struct RowMap {          // row r of a launch -> (sequence slot, position)
-    const int* state;    // decode: seq = r, pos = state[r][POS]
+    const int* state;    // decode: seq = slots ? slots[r] : r, pos = state[seq][POS]
     int prefill;         // prefill: seq = seq0, pos = pos0 + r
     int seq0, pos0;
+    const int* slots;    // decode over the live slots only (cv2_llm_decode_rows): row -> slot, null = identity
     __device__ __forceinline__ void get(int r, int& seq, int& pos) const {
         if (prefill) { seq = seq0; pos = pos0 + r; }
-        else { seq = r; pos = state[r * ST + CV2_ST_POS]; }
+        else { seq = slots ? slots[r] : r; pos = state[seq * ST + CV2_ST_POS]; }
     }
 };
 
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256 * NSUB) void k_attn(AttnArgs a) {
     // the sequence's length BEFORE fetching their tiles - speculative tiles of empty splits were twice the live KV traffic at 32
     // rows.  Few rows (latency-bound): fetch first, mask later.
     if (gridDim.z > 4 && split_lo >= pos + 1) return;
-    const int seq_s = a.rm.prefill ? a.rm.seq0 : r;
+    const int seq_s = a.rm.prefill ? a.rm.seq0 : (a.rm.slots ? seq : r);     // (live-row decode: one scalar load ahead of K / V)
     const float* K = a.kc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
     const float* V = a.vc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
     f32x4 kk[4];
@@ -679,6 +680,7 @@ struct SampleArgs {
     float top_p; int top_k, win; float rep_thr; // ras_sampling constants (conf/cosyvoice2.yaml:33-37): nucleus mass / size, repetition window, win_size * tau_r
     int prefill_seq, row, prefill_pos;          // prefill: one block, reads logits row `row`, updates slot prefill_seq,
     unsigned* epoch;                            // hand-off epoch of k_chain: advanced once per launch (chain.h)
+    const int* slots; float* x_rows;            // decode over live slots: block b serves slot slots[b] and also leaves the next input in row b
 };                                              // whose next KV position becomes prefill_pos (= prompt length)
 #define SM_T 1024
 #define SM_W (SM_T / 64)
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
     __shared__ int ci[SM_CAP];
     __shared__ double s_u2;
     const int tid = threadIdx.x;
-    const int seq = a.prefill_seq >= 0 ? a.prefill_seq : blockIdx.x;
+    const int seq = a.prefill_seq >= 0 ? a.prefill_seq : (a.slots ? a.slots[blockIdx.x] : (int)blockIdx.x);
     const int row = a.prefill_seq >= 0 ? a.row : blockIdx.x;
     int* st = a.state + seq * ST;
     const int V = a.vocab;
@@ -1041,7 +1043,11 @@ sample_done:
     SK_STAMP(5);                                                              // token drawn
     const int top = done ? sv[CV2_ST_LAST] : s_top;
     // next input embedding (llm.py:711, 719); harmless for finished slots
-    for (int k = tid; k < a.hidden; k += SM_T) a.x_next[(size_t)seq * a.hidden + k] = a.speech_emb[(size_t)top * a.hidden + k];
+    for (int k = tid; k < a.hidden; k += SM_T) {
+        const float e = a.speech_emb[(size_t)top * a.hidden + k];
+        a.x_next[(size_t)seq * a.hidden + k] = e;
+        if (a.x_rows) a.x_rows[(size_t)row * a.hidden + k] = e;
+    }
     if (tid == 0 && !done) {
         int nout = sv[CV2_ST_NOUT];
         int fin = 0;
@@ -1258,7 +1264,9 @@ struct cv2_llm {
     // workspace carve
     float *kc, *vc;            // [layers][max_seqs][n_kv][max_pos][64]
     float *xa, *xb;            // residual stream ping-pong [32][hidden]
-    float *xnext;              // [32][hidden] next-step input embeddings (k_sample)
+    float *xnext;              // [32][hidden] next-step input embeddings (k_sample), by slot
+    float *xrows;              // [32][hidden] the same by ROW of a decode over live slots (cv2_llm_decode_rows)
+    int *row_slots;            // [32] row -> slot of that decode
     float *q, *att, *o;        // [32][n_q*64], attention partials [nsplit][32][n_q*64], [32][hidden]
     float *att_ml;             // [nsplit][32][n_q][2]
     int *att_cnt;              // [32] non-empty splits per row
@@ -1297,6 +1305,8 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     p = take((size_t)32 * d.hidden * 4); if (h) h->xa = (float*)p;
     p = take((size_t)32 * d.hidden * 4); if (h) h->xb = (float*)p;
     p = take((size_t)32 * d.hidden * 4); if (h) h->xnext = (float*)p;
+    p = take((size_t)32 * d.hidden * 4); if (h) h->xrows = (float*)p;
+    p = take(32 * 4); if (h) h->row_slots = (int*)p;
     p = take((size_t)32 * d.n_q * 64 * 4); if (h) h->q = (float*)p;
     p = take((size_t)SK_MAXSPLIT * 32 * d.n_q * 64 * 4); if (h) h->att = (float*)p;
     p = take((size_t)SK_MAXSPLIT * 32 * d.n_q * 2 * 4); if (h) h->att_ml = (float*)p;
@@ -1594,11 +1604,11 @@ static int init_attrs_once() {
     return 0;
 }
 
-static int launch_sample(cv2_llm* h, int nblocks, int prefill_seq, int row, int prefill_pos, hipStream_t s) {
+static int launch_sample(cv2_llm* h, int nblocks, int prefill_seq, int row, int prefill_pos, hipStream_t s, bool mapped = false) {
     const cv2_llm_dims& d = h->d;
     SampleArgs a{h->io.logits, d.vocab_pad, h->io.state, h->io.out_tokens, d.max_out, h->w.speech_emb, h->xnext,
                  d.hidden, d.vocab, d.eos, d.max_pos, 15, d.top_p, d.top_k, d.win_size, (float)d.win_size * d.tau_r, prefill_seq, row, prefill_pos,
-                 h->epoch};
+                 h->epoch, mapped ? h->row_slots : nullptr, mapped ? h->xrows : nullptr};
     hipLaunchKernelGGL(k_sample, dim3(nblocks), dim3(SM_T), 0, s, a);
     CV2_LAUNCH_CHECK();
     return 0;
@@ -1725,14 +1735,15 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
 }
 
 // one captured graph holds `unroll` consecutive decode steps for n_seqs slots (key = n_seqs * 64 + unroll)
-static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGraphExec_t* out) {
-    const int key = (n_seqs * 64 + unroll) * 2 + (one_launch ? 1 : 0);
+static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGraphExec_t* out, bool mapped = false) {
+    const int key = ((n_seqs * 64 + unroll) * 2 + (one_launch ? 1 : 0)) * 2 + (mapped ? 1 : 0);
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
         hipGraph_t g;
         hipStream_t cs = h->cap_stream;
         CV2_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        RowMap rm{h->io.state, 0, 0, 0};
+        RowMap rm{h->io.state, 0, 0, 0, mapped ? h->row_slots : nullptr};
+        const float* xin = mapped ? h->xrows : h->xnext;
         int rc = 0;
         for (int u = 0; u < unroll && !rc; u++) {
             if (one_launch) {
@@ -1746,9 +1757,9 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGra
                 hipLaunchKernelGGL(k_step, dim3(h->step_blocks), dim3(R1_THREADS), sm, cs, a);
                 if (hipGetLastError() != hipSuccess) rc = cv2_fail("k_step launch failed");
             } else
-            rc = n_seqs <= 16 ? run_layers<1>(h, n_seqs, h->xnext, rm, cs) : run_layers_pre(h, n_seqs, h->xnext, rm, cs);
+            rc = n_seqs <= 16 ? run_layers<1>(h, n_seqs, xin, rm, cs) : run_layers_pre(h, n_seqs, xin, rm, cs);
             STAMP_SET_ON(cs, 5);
-            if (!rc) rc = launch_sample(h, n_seqs, -1, 0, 0, cs);
+            if (!rc) rc = launch_sample(h, n_seqs, -1, 0, 0, cs, mapped);
         }
         hipError_t e = hipStreamEndCapture(cs, &g);
         if (rc) return rc;
@@ -1783,6 +1794,48 @@ extern "C" int cv2_llm_decode_ex(cv2_llm* h, int32_t n_seqs, int32_t n_steps, in
     }
     if (i < n_steps) {
         if (get_graph(h, n_seqs, 1, one_launch, &g1)) return -1;
+        for (; i < n_steps; i++) CV2_HIP(hipGraphLaunch(g1, s));
+    }
+    return 0;
+}
+
+// decode over the LIVE slots only: row r of every launch serves slot slots[r].  cv2_llm_decode(n_seqs) steps slots 0 .. n_seqs - 1
+// whether or not they have finished (a finished slot idles, its row is still computed); a batch whose requests end at different
+// lengths spends most of its steps on rows nobody needs.  The map lives in device memory (the captured graphs read it), it is
+// written here in stream order together with the rows' pending input embeddings (k_sample keeps those by slot).
+struct SetRowsArgs { int slots[32]; int n; int* dst; const float* xnext; float* xrows; int hidden; };
+__global__ __launch_bounds__(256) void k_set_rows(SetRowsArgs a) {
+    const int r = blockIdx.x, slot = a.slots[r];
+    if (threadIdx.x == 0) a.dst[r] = slot;
+    for (int k = threadIdx.x; k < a.hidden; k += 256) a.xrows[(size_t)r * a.hidden + k] = a.xnext[(size_t)slot * a.hidden + k];
+}
+extern "C" int cv2_llm_decode_rows(cv2_llm* h, const int32_t* slots, int32_t n_rows, int32_t n_steps, int32_t flags, void* stream) {
+    CV2_CHECK(h && slots, "cv2_llm_decode_rows: null argument");
+    CV2_CHECK(n_rows >= 1 && n_rows <= h->d.max_seqs && n_rows <= 32, "cv2_llm_decode_rows: n_rows %d out of range", n_rows);
+    SetRowsArgs sa{};
+    unsigned seen = 0;
+    for (int r = 0; r < n_rows; r++) {
+        CV2_CHECK(slots[r] >= 0 && slots[r] < h->d.max_seqs, "cv2_llm_decode_rows: bad slot %d", slots[r]);
+        CV2_CHECK(!(seen >> slots[r] & 1u), "cv2_llm_decode_rows: slot %d listed twice", slots[r]);
+        seen |= 1u << slots[r];
+        sa.slots[r] = slots[r];
+    }
+    if (n_rows == 1 && slots[0] == 0) return cv2_llm_decode_ex(h, 1, n_steps, flags, stream);      // slot 0 alone: the one-launch step
+    (void)flags;
+    if (init_attrs_once()) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    sa.n = n_rows; sa.dst = h->row_slots; sa.xnext = h->xnext; sa.xrows = h->xrows; sa.hidden = h->d.hidden;
+    hipLaunchKernelGGL(k_set_rows, dim3(n_rows), dim3(256), 0, s, sa);
+    CV2_LAUNCH_CHECK();
+    constexpr int UNROLL = 8;
+    hipGraphExec_t g8 = nullptr, g1 = nullptr;
+    int i = 0;
+    if (n_steps >= UNROLL) {
+        if (get_graph(h, n_rows, UNROLL, false, &g8, true)) return -1;
+        for (; i + UNROLL <= n_steps; i += UNROLL) CV2_HIP(hipGraphLaunch(g8, s));
+    }
+    if (i < n_steps) {
+        if (get_graph(h, n_rows, 1, false, &g1, true)) return -1;
         for (; i < n_steps; i++) CV2_HIP(hipGraphLaunch(g1, s));
     }
     return 0;

@@ -144,6 +144,12 @@ class LLMEngine:
         """shared: kernels of other streams run beside these steps (CV2_DECODE_SHARED: the launches instead of the one-launch step)."""
         L.check(self.lib.cv2_llm_decode_ex(self.handle, n_seqs, n_steps, 1 if shared else 0, L.stream_ptr()))
 
+    def step_rows(self, slots, n_steps=1, shared=False):
+        """n_steps over the live slots only (cv2_llm_decode_rows): row r of every step serves slot slots[r]."""
+        import ctypes as C
+        arr = (C.c_int32 * len(slots))(*slots)
+        L.check(self.lib.cv2_llm_decode_rows(self.handle, arr, len(slots), n_steps, 1 if shared else 0, L.stream_ptr()))
+
     ERR_MSG = 'sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!'      # llm.py:249
     ERR_HANDOFF = 'LLM decode: an in-launch hand-off (k_chain) timed out; the device was too contended for the step to finish'
 
@@ -177,7 +183,7 @@ class LLMEngine:
             self.state[slot, L.ST_DONE] = 1
 
     def generate(self, requests, mode=MODE_GREEDY, seed=0, force_len=None, sync_every=16, min_ratio=2, max_ratio=20, batch_prefill=True,
-                 return_errors=False):
+                 return_errors=False, compact=True):
         """requests: list of (text, prompt_text, prompt_speech_token) int tensors.  Returns list of token lists; with
         return_errors=True also a list holding None or the RuntimeError of each request (a failing request finishes its own slot and
         never stops the others), otherwise the first error is raised."""
@@ -208,7 +214,11 @@ class LLMEngine:
             live = [b for b in range(n) if not int(st[b, L.ST_DONE])]
             to_min = min(int(st[b, L.ST_MINLEN]) - int(st[b, L.ST_STEP]) for b in live)
             to_max = max(int(st[b, L.ST_MAXLEN]) - int(st[b, L.ST_STEP]) for b in live)
-            self.step(n, max(1, min(max(sync_every, to_min), to_max)))
+            k = max(1, min(max(sync_every, to_min), to_max))
+            if compact and len(live) < n:
+                self.step_rows(live, k)               # the finished requests' rows are not computed any more
+            else:
+                self.step(n, k)
 
     # ---- llm.py:721-834 ------------------------------------------------------------------------------------------
     def bistream(self, slot, text, prompt_text, prompt_speech_token, mode=MODE_GREEDY, seed=0, mix_ratio=(5, 15), burst=16,

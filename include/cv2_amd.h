@@ -132,6 +132,11 @@ int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream);
  * neighbours more than they save here (one stream: 34 -> 40 ms between chunks with k_step beside the chunk work). */
 #define CV2_DECODE_SHARED 1
 int cv2_llm_decode_ex(cv2_llm* h, int32_t n_seqs, int32_t n_steps, int32_t flags, void* stream);
+/* n_steps of the decode loop over the LIVE slots only: row r of every step serves slot slots[r] (host array, n_rows distinct slot
+ * ids, copied before the call returns).  A batch of llm.py:649-719 generations ends request by request; the scheduler drops the
+ * finished slots from the list at every poll, so a step costs what its live rows cost (the slots' state, caches and results are
+ * the ones cv2_llm_decode uses: the two calls may alternate on the same slots). */
+int cv2_llm_decode_rows(cv2_llm* h, const int32_t* slots, int32_t n_rows, int32_t n_steps, int32_t flags, void* stream);
 /* 1 when one-row decode steps of this engine run as one launch (k_step), 0 when they run as launches (dims outside k_step's
  * limits, or CV2_LLM_CHAIN=0). */
 int cv2_llm_one_launch_step(const cv2_llm* h);

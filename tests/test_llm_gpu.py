@@ -132,6 +132,26 @@ def test_many_row_decode_path(small):
         assert ids == OL.inference(sdr, text, ptxt, ptok, force_len=8)
 
 
+def test_live_row_decode_equals_lockstep_and_oracle(small):
+    """Requests of one batch end at different lengths: generate() drops the finished slots from the decode rows at every poll
+    (cv2_llm_decode_rows, rows != slots, passing through the 17..32-row, 2..16-row and one-row kernels).  The ids equal those of the
+    lock-step run over all slots and the oracle's; RAS draws are keyed by slot, not by row."""
+    from cv2amd.llm import MODE_RAS
+    from oracle import llm as OL
+    sd, sdr, eng = small
+    reqs = _requests(19, seed=5)
+    fl = [6 + (7 * b) % 23 for b in range(19)]
+    got = eng.generate(reqs, force_len=fl, sync_every=4)
+    assert [len(g) for g in got] == fl
+    assert got == eng.generate(reqs, force_len=fl, sync_every=4, compact=False)
+    for (text, ptxt, ptok), ids, n in zip(reqs, got, fl):
+        assert ids == OL.inference(sdr, text, ptxt, ptok, force_len=n)
+    ras = eng.generate(reqs, mode=MODE_RAS, seed=77, force_len=fl, sync_every=4)
+    assert ras == eng.generate(reqs, mode=MODE_RAS, seed=77, force_len=fl, sync_every=4, compact=False)
+    # slot 0 is not among the survivors here (the shortest request): the last rows run the launches, not k_step
+    assert fl[0] == min(fl)
+
+
 def test_ras_sampling_matches_oracle_with_same_noise(small):
     from cv2amd import philox
     from cv2amd.llm import MODE_RAS

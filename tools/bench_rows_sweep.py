@@ -1,0 +1,27 @@
+"""Decode step time against the number of live rows (cv2_llm_decode_rows over slots 1..n, so that one row also takes the launches):
+python tools/bench_rows_sweep.py [prompt_len]"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cosyvoice2-eu_amd'))
+import torch
+from cv2amd import synth
+from cv2amd.llm import LLMEngine
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 255
+eng = LLMEngine(synth.make_llm(layers=24), 'cuda:0', max_seqs=32, max_pos=2048, max_out=2048)
+for b in range(32):
+    inp = synth.synthetic_inputs(seed=b, text_len=50, prompt_len=P)
+    eng.add_request(b, eng.build_lm_input(inp['text'], inp['prompt_text'], inp['prompt_token']), 5000, 5000, force_len=True)
+eng.step(32, 8)
+out = []
+for n in (32, 28, 24, 20, 17, 16, 12, 8, 6, 4, 3, 2, 1):
+    slots = list(range(32 - n, 32))
+    eng.step_rows(slots, 16)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    eng.step_rows(slots, 64)
+    e1.record()
+    torch.cuda.synchronize()
+    out.append((n, e0.elapsed_time(e1) / 64 * 1e3))
+    print(f'rows {n:2d}: {out[-1][1]:7.1f} us / step', flush=True)
