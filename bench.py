@@ -208,6 +208,49 @@ def run_calls(model, reqs, forces, stream=False, chunk_times=None):
     return wavs, first
 
 
+def pmc_stage_file(stage):
+    """profiles/r3_pmc_<stage>.json (tools/pmc_stages.sh: rocprofv3 --pmc passes of one stage alone) or None."""
+    p = os.path.join(ROOT, 'profiles', f'r3_pmc_{stage}.json')
+    return json.load(open(p)) if os.path.exists(p) else None
+
+
+def pmc_decode_traffic(desc):
+    """HBM bytes per decode-step launch from the committed counter files: the one-launch step (k_step) of round 3, else the older
+    per-step totals."""
+    note = '(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)'
+    pj = pmc_stage_file('decode')
+    if pj is not None and 'k_step' in desc:
+        for r in pj['kernels']:
+            if r['kernel'] == 'k_step' and r.get('hbm_read_MB_per_rep') is not None:
+                per = (r['hbm_read_MB_per_rep'] + r['hbm_write_MB_per_rep']) * 1e6 / r['launches_per_rep']
+                return int(per), f'profiles/r3_pmc_decode.json, k_step {note}'
+    for name in ('r2_pmc_decode.json', 'r1_pmc_decode.json'):
+        pmc = os.path.join(ROOT, 'profiles', name)
+        if 'k_step' not in desc and os.path.exists(pmc):
+            return json.load(open(pmc))['hbm_bytes_per_step'], f'profiles/{name} {note}'
+    return None, None
+
+
+def counter_fields(pmc_flow, pmc_hift, hift_tf):
+    """Counter-based companions of the computed stage figures (north_star: rocprof-reported MFMA utilisation for the GEMM stage, HBM
+    GB/s for the conv stacks).  From the committed PMC files; null when they are absent."""
+    flow = hift = None
+    if pmc_flow:
+        flow = {'util_counter': pmc_flow.get('mfma_util_wall_time_weighted'), 'util_counter_gui_active': pmc_flow.get('mfma_util_time_weighted'),
+                'hbm_read_MB_per_utt': pmc_flow['hbm_read_MB_per_rep'], 'hbm_write_MB_per_utt': pmc_flow['hbm_write_MB_per_rep'],
+                'source': 'profiles/r3_pmc_flow.json: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x 256 CU x cycles), time-weighted over the stage\'s kernels; '
+                          'cycles = kernel-trace duration x 2.4 GHz (util_counter) or GRBM_GUI_ACTIVE / 8 (util_counter_gui_active)'}
+    if pmc_hift:
+        tot = (pmc_hift['hbm_read_MB_per_rep'] + pmc_hift['hbm_write_MB_per_rep']) / 1e3
+        k6 = next((r for r in pmc_hift['kernels'] if r['kernel'] == 'k_conv6'), {})
+        hift = {'hbm_gbs': pmc_hift.get('hbm_GBs_over_kernel_time'), 'hbm_GB_per_10s_audio': round(tot, 3), 'survey_8d_GB_per_10s_audio': 0.28,
+                'k_conv6': {'hbm_gbs': k6.get('hbm_GBs'), 'mfma_util_counter': k6.get('mfma_util_wall'), 'avg_us': k6.get('avg_us')},
+                'source': 'profiles/r3_pmc_hift.json (500 mel frames = 10 s of audio per rep; FETCH_SIZE x 2 + WRITE_SIZE over the stage\'s kernel time); '
+                          'SURVEY 8(d) counts one fp32 pass over every layer\'s activations, the fused line-buffer kernels re-read halos and the '
+                          'three bf16 planes of each weight tile'}
+    return flow, hift
+
+
 def kv_positions_mean(L0s, forces):
     """mean over the decode steps of (sum over live sequences of cached positions): step i of a sequence attends L0 + i keys."""
     n_steps = max(forces) - 1
@@ -288,13 +331,9 @@ def run_single(args):
     flow_tf = sum(flow_flops(T) for T in Ts) * args.steps / (flow_t.ms() * 1e-3) / 1e12
     hift_tf = 30.6e9 * audio_per_step * args.steps / (hift_t.ms() * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    for name in ('r2_pmc_decode.json', 'r1_pmc_decode.json'):
-        pmc = os.path.join(ROOT, 'profiles', name)
-        if B == 1 and os.path.exists(pmc):          # PMC counters cannot be read from inside the bench: committed rocprofv3 --pmc measurement
-            pj = json.load(open(pmc))
-            traffic = pj['hbm_bytes_per_step']
-            traffic_src = f'profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)'
-            break
+    if B == 1:          # PMC counters cannot be read from inside the bench: committed rocprofv3 --pmc measurements of the same kernels
+        traffic, traffic_src = pmc_decode_traffic(model.llm.decode_kernel_desc(B))
+    pmc_flow, pmc_hift = pmc_stage_file('flow'), pmc_stage_file('hift')
     out = {
         'metric': 'audio-sec/sec, CosyVoice2-0.5B-EU zero-shot FR', 'value': round(value, 3), 'unit': 'audio-s/s',
         'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
@@ -313,8 +352,16 @@ def run_single(args):
                                    'rest (prefill, scheduler, D2H)': round((dt * 1e3 - dec_ms - flow_t.ms() - hift_t.ms()) / args.steps, 3)},
                    'flow_mfma': {'achieved': round(flow_tf, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(flow_tf / MFMA_BF16_PEAK, 4)},
                    'hift_fp32_mfma': {'achieved': round(hift_tf, 2), 'peak': FP32_MFMA_PEAK, 'unit': 'TFLOP/s', 'frac': round(hift_tf / FP32_MFMA_PEAK, 4),
-                                      'note': 'algorithmic (fp32-equivalent) FLOP/s against the fp32 matrix roof; k_conv6 issues 6 bf16 MFMAs per term'}},
+                                      'note': 'algorithmic (fp32-equivalent) FLOP/s against the fp32 matrix roof; k_conv6 issues 6 bf16 MFMAs per term'},
+                   'hift_bf16_mfma': {'achieved': round(6 * hift_tf, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(6 * hift_tf / MFMA_BF16_PEAK, 4),
+                                      'note': 'issued bf16 MFMA FLOP/s of the conv stack (6 plane products per fp32-equivalent term) against the bf16 roof its '
+                                              'instructions run on'}},
     }
+    cf, ch = counter_fields(pmc_flow, pmc_hift, hift_tf)
+    if cf:
+        out['stages']['flow_mfma'].update(cf)
+    if ch:
+        out['stages']['hift'] = ch
     if not args.no_extra and B == 1:
         out['extra'] = extras(model, st, flow_t, hift_t, dev)
     if not args.no_cpu_baseline:

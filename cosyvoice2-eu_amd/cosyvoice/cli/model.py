@@ -426,7 +426,7 @@ class CosyVoice2Model:
 
     # the helpers below run under self.run_lock
     def _llm_advance(self, n_steps, shared=False):
-        """n_steps decode steps for EVERY active slot (slots 0..highest active; parked slots in between idle), enqueued on the LLM
+        """n_steps decode steps for EVERY active slot (the rows of a step are the active slots: cv2_llm_decode_rows), enqueued on the LLM
         stream; `_enq[slot]` = the tokens a live slot holds at most once everything enqueued so far has run.  shared: the burst runs
         beside a chunk's flow + HiFT on the other streams."""
         if n_steps <= 0:
@@ -434,7 +434,7 @@ class CosyVoice2Model:
         with self._mode:
             act = sorted(self._active_slots)
         with torch.cuda.stream(self.llm_stream):
-            self.llm.step(act[-1] + 1, n_steps, shared=shared)
+            self.llm.step_rows(act, n_steps, shared=shared)
             ev = torch.cuda.Event()
             ev.record(self.llm_stream)
         while self._bursts and self._bursts[0].query():                       # finished bursts nobody had to wait for

@@ -146,7 +146,6 @@ class LLMEngine:
 
     def step_rows(self, slots, n_steps=1, shared=False):
         """n_steps over the live slots only (cv2_llm_decode_rows): row r of every step serves slot slots[r]."""
-        import ctypes as C
         arr = (C.c_int32 * len(slots))(*slots)
         L.check(self.lib.cv2_llm_decode_rows(self.handle, arr, len(slots), n_steps, 1 if shared else 0, L.stream_ptr()))
 
@@ -204,16 +203,22 @@ class LLMEngine:
             for b in range(n):
                 self.add_request(b, xs[b], mm[b][0], mm[b][1], mode, seed, forced)
         while True:
-            st, toks = self.read(n, raise_on_error=not return_errors)
-            if bool(st[:, L.ST_DONE].all()):
+            st = self.state[:n].cpu()                 # a poll reads the state records only (2 KB); the tokens are fetched once, at the end
+            S = st.tolist()
+            if all(r[L.ST_DONE] for r in S):
+                st, toks = self.read(n, raise_on_error=not return_errors)
                 if return_errors:
                     return toks, [self._err(st[b, L.ST_ERR]) if int(st[b, L.ST_ERR]) else None for b in range(n)]
                 return toks
+            if not return_errors:
+                for r in S:
+                    if r[L.ST_ERR]:
+                        raise self._err(r[L.ST_ERR])
             # no live request can finish before its min_len (EOS is re-drawn until then, llm.py:242-250): poll again only after the
             # earliest possible finish, then every sync_every steps (a finished slot idles inside a burst)
-            live = [b for b in range(n) if not int(st[b, L.ST_DONE])]
-            to_min = min(int(st[b, L.ST_MINLEN]) - int(st[b, L.ST_STEP]) for b in live)
-            to_max = max(int(st[b, L.ST_MAXLEN]) - int(st[b, L.ST_STEP]) for b in live)
+            live = [b for b in range(n) if not S[b][L.ST_DONE]]
+            to_min = min(S[b][L.ST_MINLEN] - S[b][L.ST_STEP] for b in live)
+            to_max = max(S[b][L.ST_MAXLEN] - S[b][L.ST_STEP] for b in live)
             k = max(1, min(max(sync_every, to_min), to_max))
             if compact and len(live) < n:
                 self.step_rows(live, k)               # the finished requests' rows are not computed any more
