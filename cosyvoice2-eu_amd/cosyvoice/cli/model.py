@@ -32,7 +32,6 @@ import uuid
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from cv2amd.flow import FlowEngine
 from cv2amd.hift import HiftEngine, HiftPool
@@ -193,7 +192,7 @@ class CosyVoice2Model:
         else:
             if speed != 1.0:
                 assert cache is None, 'speed change only support non-stream inference mode'
-                tts_mel = F.interpolate(tts_mel, size=int(tts_mel.shape[2] / speed), mode='linear')
+                tts_mel = hift.change_speed(tts_mel, speed)                     # F.interpolate(mode='linear') of model.py:329, on the device
             tts_speech, tts_source = hift.inference(speech_feat=tts_mel.contiguous(), cache_source=hift_cache_source, noise=noise)
             if cache is not None:
                 hift.fade_in_out(tts_speech, cache['speech'], self._window_dev)
@@ -505,7 +504,7 @@ class CosyVoice2Model:
             gm = []
             for p, m in good:
                 if p.speed != 1.0:                                            # model.py:328-330
-                    m = F.interpolate(m, size=int(m.shape[2] / p.speed), mode='linear')
+                    m = self.hift.change_speed(m, p.speed)
                 gm.append(m.contiguous())
             outs = self.hift_pool.inference_many(gm) if gm else []
             torch.cuda.synchronize(self.device)

@@ -45,6 +45,68 @@ __device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) 
     lo = f2bf(x - bf2f(hi));
 }
 
+// x = h0 + h1 + h2 EXACTLY, each the top 16 bits (sign, exponent, 7 mantissa bits) of what the previous ones left: truncation instead
+// of rounding makes the three-plane form lossless for a 24-bit mantissa and costs two ANDs and two subtractions per element
+// (round-to-nearest planes cost ~20 VALU operations per element, and this staging is VALU-bound: it runs once per block and chunk)
+__device__ __forceinline__ void split3t(float v, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
+    h0 = __builtin_bit_cast(uint32_t, v) & 0xFFFF0000u;
+    const float r1 = v - __builtin_bit_cast(float, h0);
+    h1 = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, h1);
+    h2 = __builtin_bit_cast(uint32_t, r2);               // <= 8 significant bits left: its low half is zero
+}
+// two planes' high halves -> one dword (element a low, element b high)
+__device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// the same for 8 / 4 consecutive values, packed as MFMA operand fragments (element e in half e & 1 of dword e >> 1)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+__device__ __forceinline__ void planes8(const f32x4 a, const f32x4 b, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    uint32_t h0[8], h1[8], h2[8];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { split3t(a[e], h0[e], h1[e], h2[e]); split3t(b[e], h0[4 + e], h1[4 + e], h2[4 + e]); }
+    p0 = __builtin_bit_cast(bf16x8, (u32x4_t){pack_hi(h0[0], h0[1]), pack_hi(h0[2], h0[3]), pack_hi(h0[4], h0[5]), pack_hi(h0[6], h0[7])});
+    p1 = __builtin_bit_cast(bf16x8, (u32x4_t){pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3]), pack_hi(h1[4], h1[5]), pack_hi(h1[6], h1[7])});
+    p2 = __builtin_bit_cast(bf16x8, (u32x4_t){pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3]), pack_hi(h2[4], h2[5]), pack_hi(h2[6], h2[7])});
+}
+__device__ __forceinline__ void planes4(const f32x4 v, s16x4& p0, s16x4& p1, s16x4& p2) {
+    uint32_t h0[4], h1[4], h2[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) split3t(v[e], h0[e], h1[e], h2[e]);
+    p0 = __builtin_bit_cast(s16x4, (u32x2_t){pack_hi(h0[0], h0[1]), pack_hi(h0[2], h0[3])});
+    p1 = __builtin_bit_cast(s16x4, (u32x2_t){pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3])});
+    p2 = __builtin_bit_cast(s16x4, (u32x2_t){pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3])});
+}
+// max / sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (same column of the four 16-lane rows), result in all of them: two
+// v_permlane*_swap (VALU) instead of two LDS-routed shuffles
+// (the swap exchanges halves of TWO registers: the second operand is an opaque copy, or the compiler hands the instruction one register
+// twice and nothing moves)
+// (clang lowers __builtin_bit_cast(float, vec[i]) on a vector ELEMENT lvalue as element 0: convert through a by-value helper)
+__device__ __forceinline__ float bits2f(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ void swap32(float v, float& a, float& b) {
+    unsigned u = __builtin_bit_cast(unsigned, v), w = u;
+    asm volatile("" : "+v"(w));
+    const auto r = __builtin_amdgcn_permlane32_swap(u, w, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = bits2f(r0); b = bits2f(r1);
+}
+__device__ __forceinline__ void swap16(float v, float& a, float& b) {
+    unsigned u = __builtin_bit_cast(unsigned, v), w = u;
+    asm volatile("" : "+v"(w));
+    const auto r = __builtin_amdgcn_permlane16_swap(u, w, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = bits2f(r0); b = bits2f(r1);
+}
+__device__ __forceinline__ float rows4_max(float v) {
+    float a, b;
+    swap32(v, a, b); v = fmaxf(a, b);
+    swap16(v, a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+    float a, b;
+    swap32(v, a, b); v = a + b;
+    swap16(v, a, b); return a + b;
+}
+
 // Wave-wide reductions through DPP row operations: one VALU instruction per step instead of an LDS-routed ds_bpermute per
 // __shfl_xor (~6 x 100+ cycles on the critical path of every norm / softmax / top-k).  row_shr 1/2/4/8 leave each 16-lane row's
 // reduction in its lane 15 (Hillis-Steele scan; lanes without a source contribute the identity), row_bcast 15 / 31 carry it

@@ -164,18 +164,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 // staging, epilogue and argument struct as k_conv; the line buffer holds the three planes of the pre-activated input.
 #define C6_G 4                                        // 16-channel steps per weight register set (4 = one tap of the 64-channel chunk)
 #define C6_LD 72                                      // bf16 elements per line-buffer row (64 + 8: 144-B stride, conflict-free ds_read_b128)
-// x = h0 + h1 + h2 EXACTLY, each the top 16 bits (sign, exponent, 7 mantissa bits) of what the previous ones left: truncation instead
-// of rounding makes the three-plane form lossless for a 24-bit mantissa and costs two ANDs and two subtractions per element
-// (round-to-nearest planes cost ~20 VALU operations per element, and this staging is VALU-bound: it runs once per block and chunk)
-__device__ __forceinline__ void split3t(float v, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
-    h0 = __builtin_bit_cast(uint32_t, v) & 0xFFFF0000u;
-    const float r1 = v - __builtin_bit_cast(float, h0);
-    h1 = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
-    const float r2 = r1 - __builtin_bit_cast(float, h1);
-    h2 = __builtin_bit_cast(uint32_t, r2);               // <= 8 significant bits left: its low half is zero
-}
-// two planes' high halves -> one dword (element a low, element b high)
-__device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// (split3t / pack_hi: common.h)
 __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -679,6 +668,26 @@ __global__ void k_fade(float* x, const float* old_tail, const float* win, int w)
 extern "C" int cv2_fade_in_out(float* fade_in, const float* old_tail, const float* window, int32_t w, void* stream) {
     CV2_CHECK(fade_in && old_tail && window && w > 0, "cv2_fade_in_out: bad argument");
     hipLaunchKernelGGL(k_fade, dim3((w + 255) / 256), dim3(256), 0, (hipStream_t)stream, fade_in, old_tail, window, (int)w);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
+// cli/model.py:328-330: tts_mel = F.interpolate(tts_mel, size=int(T / speed), mode='linear') ahead of the vocoder (non-streaming calls
+// with speed != 1).  align_corners = False: source position scale (j + 0.5) - 0.5 clamped at 0, scale = n_in / n_out in fp32, right
+// neighbour clamped at the last frame.  rows = channels (80 per utterance).
+__global__ __launch_bounds__(256) void k_interp_linear(const float* __restrict__ in, float* __restrict__ out, int n_in, int n_out, float scale) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_out) return;
+    const float* x = in + (size_t)blockIdx.y * n_in;
+    const float src = fmaxf(scale * ((float)j + 0.5f) - 0.5f, 0.f);
+    const int i0 = min((int)src, n_in - 1), i1 = min(i0 + 1, n_in - 1);
+    const float w1 = src - (float)i0, w0 = 1.f - w1;
+    out[(size_t)blockIdx.y * n_out + j] = w0 * x[i0] + w1 * x[i1];
+}
+extern "C" int cv2_interp_linear(const float* in, float* out, int32_t rows, int32_t n_in, int32_t n_out, void* stream) {
+    CV2_CHECK(in && out && rows >= 1 && rows <= 65535 && n_in >= 1 && n_out >= 1, "cv2_interp_linear: bad argument");
+    hipLaunchKernelGGL(k_interp_linear, dim3((n_out + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, in, out, (int)n_in, (int)n_out,
+                       (float)n_in / (float)n_out);
     CV2_LAUNCH_CHECK();
     return 0;
 }

@@ -443,41 +443,77 @@ extern "C" int cv2_debug_chain(unsigned long long* out_host) {
 // cache rows are plain reads, requested before anything else.  The new token's own key / value row is NOT waited for here (the key
 // and value heads are the last blocks of the Q role: the tile that owned the row was the layer's straggler): the O role merges it as
 // one more partial (chain.h, OpAtt).
-#define AT_SMEM_FLOATS (512 + 2 * 512 + 2 * 4096 + 32)
+#define AT_QLD 68                                // floats per q row in LDS (64 + 4: conflict-free ds_read_b128 of 16 rows)
+#define AT_SMEM_FLOATS (16 * AT_QLD + 8 * 8 * 64 + 2 * 8 * 16)
 #ifdef CV2_STAMPS
 #define AT_T(i) do { if (dbg_slot >= 0 && threadIdx.x == 0) g_chain_t[dbg_slot][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define AT_T(i) do { } while (0)
 #endif
+// S^T = K Q^T and O = P V at fp32 accuracy on the bf16 matrix cores: both operands as three exact bf16 planes, the six products of
+// weight >= 2^-16 (what is dropped is below an fp32 rounding of the term; same scheme as k_conv6, hift.hip)
+__device__ __forceinline__ f32x4 mm6_32(f32x4 acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+// One 128-key tile of one kv head against the step's rep (<= 8) query heads; wave w owns keys [16 w, 16 w + 16).
+//   before q arrives (the block has nothing else to do): the wave's K rows and V rows are fetched in MFMA operand order and split
+//     into planes -- K[key l & 15][dims 8 (l >> 4) .., + 32] = A operand of S^T = K Q^T, V[key 4 (l >> 4) + j][dim 16 t + (l & 15)]
+//     = B operand of O = P V (16x16x16);
+//   after: q -> LDS -> B fragments (head = column), 12 MFMAs -> S^T with its column on the lane and four keys in the registers, which IS
+//     the A-operand layout of the 16x16x16 product (k = 4 (l >> 4) + j): softmax over the wave's 16 keys per head (registers + two
+//     permlane swaps), P planes, 24 MFMAs -> the wave's partial O[head][dim]; the eight partials are merged through LDS with their
+//     (max, sum) and published as the tile's granules (o unnormalised, max, sum -- what OpAtt merges across tiles).
+// The scalar form this replaces took 3.3-4.0 us from q to the published tile (scores 1.2-1.9, softmax 0.6, PV 1.15, merge 0.35).
 __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const float* V, int pos, int j0, int rep,
                                           unsigned qg, unsigned og, char* smem, int dbg_slot) {
-    float* qs = reinterpret_cast<float*>(smem);       // [8 * 64]
-    float* ps_ = qs + 512;                            // [2][8 * 64]
-    float* po_ = ps_ + 1024;                          // [2][8 key eighths][8 heads][64]
-    float* run_m = po_ + 8192; float* run_l = run_m + 16;     // [2][8]
+    float* qs = reinterpret_cast<float*>(smem);       // [16][AT_QLD]; rows >= rep stay zero
+    float* po = qs + 16 * AT_QLD;                     // [8 waves][8 heads][64]
+    float* wm = po + 8 * 8 * 64; float* wl = wm + 128;    // [8 waves][16 heads] max, sum
     const int tid = threadIdx.x, lane = tid & 63;
-    const int sub = __builtin_amdgcn_readfirstlane(tid >> 8), t = tid & 255, w = t >> 6;
-    float* ps = ps_ + sub * 512; float* po_s = po_ + sub * 4096;
-    const int d4 = t & 15, kq = (t >> 4) & 7, hs = t >> 7;
-    const int key_t = t >> 2, qd = t & 3;
-    const int js = j0 + sub * AT_KB;                  // this group's first key
-    f32x4 kk[4], vv[8];
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g4 = lane >> 4;
+    const int kb = j0 + 16 * w;                        // the wave's first key
+    const int n = max(0, min(16, pos - kb));           // its cached keys (rows past the length may hold anything)
+    f32x4 kr[4];
+    float vr[16];
     {
-        const unsigned ko = (unsigned)(js + key_t) * 64u + qd * 16, vo = (unsigned)(js + kq * 8) * 64u + d4 * 4;
+        const float* kp = K + (size_t)(kb + c) * 64 + 8 * g4;
+        kr[0] = *reinterpret_cast<const f32x4*>(kp);      kr[1] = *reinterpret_cast<const f32x4*>(kp + 4);
+        kr[2] = *reinterpret_cast<const f32x4*>(kp + 32); kr[3] = *reinterpret_cast<const f32x4*>(kp + 36);
+        const float* vp = V + (size_t)(kb + 4 * g4) * 64 + c;
 #pragma unroll
-        for (int i = 0; i < 4; i++) kk[i] = *reinterpret_cast<const f32x4*>(K + ko + 4 * i);
+        for (int t = 0; t < 4; t++)
 #pragma unroll
-        for (int k = 0; k < 8; k++) vv[k] = *reinterpret_cast<const f32x4*>(V + vo + 64 * k);
+            for (int j = 0; j < 4; j++) vr[4 * t + j] = vp[j * 64 + 16 * t];
     }
-    // the tile must be IN registers before the polling starts: left to itself the compiler sinks these loads to their first use,
-    // behind the q wait (stamps: +0.6 us in the PV phase, +1 us in front of the scores).  The block has nothing else to do here.
+    for (int e = rep * AT_QLD + tid; e < 16 * AT_QLD; e += R1_THREADS) qs[e] = 0.f;
+    bf16x8 ka[2][3];
+    s16x4 vb[4][3];
+    planes8(kr[0], kr[1], ka[0][0], ka[0][1], ka[0][2]);
+    planes8(kr[2], kr[3], ka[1][0], ka[1][1], ka[1][2]);
 #pragma unroll
-    for (int i = 0; i < 4; i++) asm volatile("" : "+v"(kk[i]));
+    for (int t = 0; t < 4; t++) {
+        f32x4 v4;
 #pragma unroll
-    for (int k = 0; k < 8; k++) asm volatile("" : "+v"(vv[k]));
+        for (int j = 0; j < 4; j++) v4[j] = 4 * g4 + j < n ? vr[4 * t + j] : 0.f;
+        planes4(v4, vb[t][0], vb[t][1], vb[t][2]);
+    }
+    // the planes must be IN registers before the polling starts: left to itself the compiler sinks the loads (and what hangs on them)
+    // to their first use, behind the q wait
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) asm volatile("" : "+v"(ka[s][i]));
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) asm volatile("" : "+v"(vb[t][i]));
     __builtin_amdgcn_sched_barrier(0);
-    const int n = max(0, min(AT_KB, pos - js));        // cached keys of this group's 64 (the second group of the last tile may have none)
-    if (t < 8) { run_m[sub * 8 + t] = -INFINITY; run_l[sub * 8 + t] = 0.f; }
     // q is polled directly: a few blocks per layer, one 8-byte load per thread -- cheaper than a sentinel round trip in front of the
     // sweep.  The poll starts once the previous layer's down projection has published (armed by the caller).
     {
@@ -489,74 +525,79 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
             q0 = __builtin_bit_cast(float, (unsigned)x0);
             return (unsigned)(x0 >> 32) == G.epoch;
         });
-        if (mine) qs[tid] = q0;
+        if (mine) qs[(tid >> 6) * AT_QLD + (tid & 63)] = q0;
     }
     AT_T(3);
-#pragma unroll
-    for (int k = 0; k < 8; k++) vv[k] = kq * 8 + k < n ? vv[k] : (f32x4){0.f, 0.f, 0.f, 0.f};     // rows past the length may hold anything
     __syncthreads();
-    if (n > 0) {
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int h = 0; h < 8; h++) {
-            if (h < rep) {
-                float acc = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[h * 64 + qd * 16 + 4 * i]);
-                    acc += kk[i][0] * qv[0] + kk[i][1] * qv[1] + kk[i][2] * qv[2] + kk[i][3] * qv[3];
-                }
-                acc += dpp_mov_f32<0xB1, 0xf>(0.f, acc);
-                acc += dpp_mov_f32<0x4E, 0xf>(0.f, acc);
-                if (qd == 0) ps[h * AT_KB + key_t] = key_t < n ? acc * 0.125f : -INFINITY;
-            }
-        }
+    for (int s = 0; s < 2; s++) {
+        const float* qp = qs + c * AT_QLD + 32 * s + 8 * g4;
+        bf16x8 qb[3];
+        planes8(*reinterpret_cast<const f32x4*>(qp), *reinterpret_cast<const f32x4*>(qp + 4), qb[0], qb[1], qb[2]);
+        sc = mm6_32(sc, ka[s], qb);
     }
-    __syncthreads();
     AT_T(4);
-    if (n > 0) {
-        for (int h = w; h < rep; h += 4) {
-            const float s0 = ps[h * AT_KB + lane];
-            const float mt = wave_max(s0);
-            const float p0 = __expf(s0 - mt);
-            ps[h * AT_KB + lane] = p0;
-            const float lt = wave_sum(p0);
-            if (lane == 0) { run_m[sub * 8 + h] = mt; run_l[sub * 8 + h] = lt; }
-        }
-    }
-    __syncthreads();
+    // sc[j] = score of key kb + 4 g4 + j against head c
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { sc[j] = 4 * g4 + j < n ? sc[j] * 0.125f : -INFINITY; mx = fmaxf(mx, sc[j]); }
+    mx = rows4_max(mx);
+    const float mref = mx == -INFINITY ? 0.f : mx;       // a wave without a cached key: P = 0, weight 0 in the merge
+    f32x4 p;
+    float ls = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { p[j] = __expf(sc[j] - mref); ls += p[j]; }
+    ls = rows4_sum(ls);
     AT_T(5);
+    s16x4 pa[3];
+    planes4(p, pa[0], pa[1], pa[2]);
     f32x4 o[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (n > 0) {
-            const int h = min(hs * 4 + i, rep - 1);
+    for (int t = 0; t < 4; t++) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k4 = 0; k4 < 2; k4++) {
-                const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[h * AT_KB + kq * 8 + 4 * k4]);
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[2], vb[t][0], o[t], 0, 0, 0);
 #pragma unroll
-                for (int e = 0; e < 4; e++) o[i] += pa[e] * vv[4 * k4 + e];
-            }
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[1], vb[t][1], o[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[0], vb[t][2], o[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[1], vb[t][0], o[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[0], vb[t][1], o[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[0], vb[t][0], o[t], 0, 0, 0);
+    // o[t][j] = head 4 g4 + j, dim 16 t + c
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int h = 4 * g4 + j;
+        if (h < rep) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) po[(w * 8 + h) * 64 + 16 * t + c] = o[t][j];
         }
     }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-        if (hs * 4 + i < rep) *reinterpret_cast<f32x4*>(&po_s[(kq * 8 + hs * 4 + i) * 64 + d4 * 4]) = o[i];
+    if (g4 == 0) { wm[w * 16 + c] = mx; wl[w * 16 + c] = ls; }
     __syncthreads();
     AT_T(6);
     if (tid < rep * 64) {
-        const int h = tid >> 6;
-        const float m0 = run_m[h], m1 = run_m[8 + h], M = fmaxf(m0, m1);
-        const float* pp = &po_[tid];
-        const float* pq = &po_[4096 + tid];
-        const float a0 = ((pp[0] + pp[512]) + (pp[1024] + pp[1536])) + ((pp[2048] + pp[2560]) + (pp[3072] + pp[3584]));
-        const float a1 = ((pq[0] + pq[512]) + (pq[1024] + pq[1536])) + ((pq[2048] + pq[2560]) + (pq[3072] + pq[3584]));
-        G.store(og + tid, __expf(m0 - M) * a0 + __expf(m1 - M) * a1);       // a group that saw no key has max = -inf: weight 0
+        const int h = tid >> 6, d = tid & 63;
+        float M = wm[h];
+#pragma unroll
+        for (int i = 1; i < 8; i++) M = fmaxf(M, wm[i * 16 + h]);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc += __expf(wm[i * 16 + h] - M) * po[(i * 8 + h) * 64 + d];       // (wave 0 always holds a cached key: M is finite)
+        G.store(og + tid, acc);
     }
     if (tid < rep) {
-        const float m0 = run_m[tid], m1 = run_m[8 + tid], M = fmaxf(m0, m1);
+        float M = wm[tid];
+#pragma unroll
+        for (int i = 1; i < 8; i++) M = fmaxf(M, wm[i * 16 + tid]);
+        float l = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) l += __expf(wm[i * 16 + tid] - M) * wl[i * 16 + tid];
         G.store(og + rep * 64 + tid * 2, M);
-        G.store(og + rep * 64 + tid * 2 + 1, __expf(m0 - M) * run_l[tid] + __expf(m1 - M) * run_l[8 + tid]);
+        G.store(og + rep * 64 + tid * 2 + 1, l);
     }
 }
 

@@ -42,6 +42,7 @@ def _bind(lib):
     lib.cv2_hift_inference.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cv2_fade_in_out.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.cv2_interp_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib._hift_bound = True
 
 
@@ -201,6 +202,16 @@ class HiftEngine:
         L.check(self.lib.cv2_hift_inference(self.handle, L.ptr(mel), T, L.ptr(cs), cs.numel() if cs is not None else 0,
                                             L.ptr(nz), C.c_uint64(seed), L.ptr(wav), L.ptr(src), L.stream_ptr()))
         return wav, src
+
+    def change_speed(self, mel, speed):
+        """cli/model.py:328-330: F.interpolate(tts_mel, size=int(T / speed), mode='linear') on the device (cv2_interp_linear);
+        mel [1, 80, T] fp32."""
+        mel = mel.contiguous()
+        n_in = mel.shape[2]
+        n_out = int(n_in / speed)
+        out = torch.empty(mel.shape[0], mel.shape[1], n_out, dtype=torch.float32, device=mel.device)
+        L.check(self.lib.cv2_interp_linear(L.ptr(mel), L.ptr(out), mel.shape[0] * mel.shape[1], n_in, n_out, L.stream_ptr()))
+        return out
 
     def fade_in_out(self, fade_in, fade_out_tail, window):
         """utils/common.py:142-150, on the device and in place: fade_in [1,n], fade_out_tail [1,w], window [2w]."""

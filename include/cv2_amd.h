@@ -331,6 +331,9 @@ int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, const float* ca
 /* fade_in_out (cosyvoice/utils/common.py:142-150): new[:w] = new[:w] * win[:w] + old[-w:] * win[w:], in place on `fade_in`;
  * win fp32 [2w] (np.hamming(2w)), old_tail points at the last w samples of the previous chunk. */
 int cv2_fade_in_out(float* fade_in, const float* old_tail, const float* window, int32_t w, void* stream);
+/* cli/model.py:328-330 (speed != 1, non-streaming): out[r][j] = linear interpolation of in[r][.] at (j + 0.5) n_in / n_out - 0.5
+ * (torch.nn.functional.interpolate(mode='linear'), align_corners False); in [rows][n_in], out [rows][n_out], fp32 device. */
+int cv2_interp_linear(const float* in, float* out, int32_t rows, int32_t n_in, int32_t n_out, void* stream);
 
 /* =====================================================================================================================
  * Prompt features (the extractor that feeds this path): replaces the reference's

@@ -104,6 +104,18 @@ def test_fade_in_out(eng, dev):
     assert torch.allclose(got.cpu(), ref, atol=1e-6)
 
 
+@pytest.mark.parametrize('T,speed', [(500, 1.3), (137, 0.8), (64, 2.0), (3, 0.5), (1, 0.25)])
+def test_speed_change_matches_torch_linear_interpolation(eng, dev, T, speed):
+    """cli/model.py:328-330: tts_mel = F.interpolate(tts_mel, size=int(T / speed), mode='linear') — on the device (cv2_interp_linear);
+    fp32, 1e-6 of the value range (the two differ at most by the contraction of w0 a + w1 b)."""
+    g = torch.Generator().manual_seed(T)
+    mel = torch.randn(1, 80, T, generator=g) * 3.0
+    want = torch.nn.functional.interpolate(mel, size=int(T / speed), mode='linear')
+    got = eng.change_speed(mel.to(dev), speed).cpu()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
 def test_decoder_at_real_checkpoint_ranges(dev):
     """the device Snake uses __sinf, ELU / exp use __expf; on unit-variance synthetic weights their arguments stay
     small.  Here the checkpoint is pushed to the ranges a trained HiFT reaches: Snake alpha log-uniform in [0.05, 20] (a trained
