@@ -95,6 +95,10 @@ class CosyVoice2Model:
         self.seed = seed
         self._limits = (max_text, max_prompt_tokens, max_new_tokens)
         self.max_batch = max(1, int(max_batch))  # concurrent non-streaming calls coalesced into one batch (1 = serialise only)
+        # True: decode bursts of the streams step the active slots only (cv2_llm_decode_rows) instead of slots 0 .. highest active.  Off:
+        # 8 equal streams measured 85-88 audio-s/s in lock step against 81-82 with it (every new row count captures its graphs in the
+        # middle of a round, and equal streams never drop a row); worth turning on for long-lived servers with ragged streams
+        self.stream_live_rows = False
         self.coalesce_ms = coalesce_ms
         self._pending = []                     # queued non-streaming requests, guarded by self.lock
         self._chunk_q = []                     # queued chunks of streaming calls, guarded by self.lock
@@ -425,15 +429,18 @@ class CosyVoice2Model:
 
     # the helpers below run under self.run_lock
     def _llm_advance(self, n_steps, shared=False):
-        """n_steps decode steps for EVERY active slot (the rows of a step are the active slots: cv2_llm_decode_rows), enqueued on the LLM
-        stream; `_enq[slot]` = the tokens a live slot holds at most once everything enqueued so far has run.  shared: the burst runs
+        """n_steps decode steps for EVERY active slot (slots 0..highest active, parked slots in between idle; or the active slots only,
+        see stream_live_rows), enqueued on the LLM stream; `_enq[slot]` = the tokens a live slot holds at most once everything enqueued so far has run.  shared: the burst runs
         beside a chunk's flow + HiFT on the other streams."""
         if n_steps <= 0:
             return
         with self._mode:
             act = sorted(self._active_slots)
         with torch.cuda.stream(self.llm_stream):
-            self.llm.step_rows(act, n_steps, shared=shared)
+            if self.stream_live_rows:
+                self.llm.step_rows(act, n_steps, shared=shared)
+            else:
+                self.llm.step(act[-1] + 1, n_steps, shared=shared)   # slots 0 .. highest active, parked ones idle
             ev = torch.cuda.Event()
             ev.record(self.llm_stream)
         while self._bursts and self._bursts[0].query():                       # finished bursts nobody had to wait for

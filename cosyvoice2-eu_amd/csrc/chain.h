@@ -211,7 +211,9 @@ struct OpGran {
 // the attention output: the live 64-key tiles' unnormalised partials {o[rep * 64], (max, sum)[rep]} per kv head, combined here
 // (flash-decoding merge).  A thread owns 4 columns and walks every live tile, AT_CHUNK tiles' loads in flight at a time.
 #define AT_GSTRIDE 464                         // granules per (tile, kv head): rep * 64 outputs, then rep x {max, sum}; rep <= 7
-#define AT_CHUNK 5
+#ifndef AT_CHUNK
+#define AT_CHUNK 3                              // (measured at 3-5 / 9-11 live tiles: 2: 364 / 393 us per step, 3: 365 / 393, 4: 392 / 410, 5: 372 / 407, 8: 411 / 429)
+#endif
 #ifndef O_WAIT_ALL
 #define O_WAIT_ALL 0
 #endif

@@ -460,7 +460,12 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
     constexpr int RB = 16 * NW;                                  // rows per query sub-tile group
     // grid (8 heads, query tiles): consecutive block ids go round the 8 XCDs, so XCD x serves head x only and a sequence's K / V^T of
     // that head is fetched into ONE L2 instead of all eight (r3_pmc_flow: 36 MB of fabric reads per launch before, for 6 MB of q/k/v)
+#ifdef CV2_NO_XCD        // (A/B builds: tile-major block order, every XCD sees every head)
+    const int lin_ = blockIdx.x + 8 * blockIdx.y, mt_ = gridDim.y;
+    const int m0 = (lin_ % mt_) * RB * QS, h = lin_ / mt_;
+#else
     const int m0 = blockIdx.y * RB * QS, h = blockIdx.x;
+#endif
     const int q16 = lane & 15, g = lane >> 4;
     const int s = a.seq.tile_seq[m0 >> 6];           // sequences start on 128-row boundaries: one sequence per block
     uint16_t* orow[QS];

@@ -125,6 +125,9 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by) {
     const int gx = gridDim.x, T = gx * gridDim.y;
     bx = blockIdx.x; by = blockIdx.y;
     if (gridDim.z != 1 || gx == 1 || T < 16) return;
+#ifdef CV2_NO_XCD        // (A/B builds)
+    return;
+#endif
     const int L = bx + by * gx, x = L & 7, q = T >> 3, r = T & 7;
     const int Lp = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (L >> 3);
     bx = Lp % gx; by = Lp / gx;
