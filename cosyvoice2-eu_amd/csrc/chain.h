@@ -1,5 +1,5 @@
 // One-row decode step as ONE launch (llm.hip: k_step): for every layer the roles Q (RMSNorm + QKV + RoPE), A (attention over one
-// 64-key tile), O (O projection), GU (gate/up + SwiGLU), D (down projection, split-K), then the head (final norm + llm_decoder).
+// 128-key tile of one kv head, on the matrix cores), O (tile merge + O projection), GU (gate/up + SwiGLU), D (down projection, split-K), then the head (final norm + llm_decoder).
 //
 // Why: at one row a layer's five weight-streaming kernels are latency-bound (1.6 us dispatch + ~1 us first dependent load + ~1 us
 // of weight stream each, 24.6 us per layer for 30 MB).  Weights do not depend on activations: when the GEMVs share a launch, every
@@ -16,7 +16,7 @@
 // operand and checks every tag; the sweep repeats until all match.
 //
 // Forward progress: a block only waits for blocks with LOWER indices, and blocks are dispatched in index order (per XCD too), so
-// the lowest unfinished block is always resident and never waits for an undispatched one.  Every wait is bounded (0.5 s) and
+// the lowest unfinished block is always resident and never waits for an undispatched one.  Every wait is bounded (0.2 s) and
 // reports through the slot's CV2_ST_ERR (3) instead of hanging; once one block has given up every other wait ends at its next check.
 #pragma once
 #include "skinny.h"

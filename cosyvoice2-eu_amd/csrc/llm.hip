@@ -438,9 +438,9 @@ extern "C" int cv2_debug_chain(unsigned long long* out_host) {
 #define CH_T(i) do { } while (0)
 #endif
 
-// Attention of one 128-key tile for the rep query heads of kv head g over the keys ALREADY in the cache (positions < pos): two groups of
-// 256 threads take 64 keys each with the arithmetic of k_attn<2> and merge through LDS.  q arrives as granules from the Q role; the
-// cache rows are plain reads, requested before anything else.  The new token's own key / value row is NOT waited for here (the key
+// Attention of one 128-key tile for the rep query heads of kv head g over the keys ALREADY in the cache (positions < pos): eight waves
+// take 16 keys each (attn_role below).  q arrives as granules from the Q role; the cache rows are plain reads, requested before
+// anything else.  The new token's own key / value row is NOT waited for here (the key
 // and value heads are the last blocks of the Q role: the tile that owned the row was the layer's straggler): the O role merges it as
 // one more partial (chain.h, OpAtt).
 #define AT_QLD 68                                // floats per q row in LDS (64 + 4: conflict-free ds_read_b128 of 16 rows)
