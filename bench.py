@@ -246,8 +246,8 @@ def counter_fields(pmc_flow, pmc_hift, hift_tf):
         hift = {'hbm_gbs': pmc_hift.get('hbm_GBs_over_kernel_time'), 'hbm_GB_per_10s_audio': round(tot, 3), 'survey_8d_GB_per_10s_audio': 0.28,
                 'k_conv6': {'hbm_gbs': k6.get('hbm_GBs'), 'mfma_util_counter': k6.get('mfma_util_wall'), 'avg_us': k6.get('avg_us')},
                 'source': 'profiles/r3_pmc_hift.json (500 mel frames = 10 s of audio per rep; FETCH_SIZE x 2 + WRITE_SIZE over the stage\'s kernel time); '
-                          'SURVEY 8(d) counts one fp32 pass over every layer\'s activations, the fused line-buffer kernels re-read halos and the '
-                          'three bf16 planes of each weight tile'}
+                          'SURVEY 8(d)\'s 0.28 GB assumes whole ResBlocks fused (1.4 GB unfused); here every convolution is one launch: input + halo, the '
+                          'residual / MRF accumulator read by the epilogue, and the layer\'s three weight planes once per XCD L2'}
     return flow, hift
 
 

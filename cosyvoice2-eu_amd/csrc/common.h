@@ -134,6 +134,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// XCD-aware order of a 2-D grid (cdna_hip_programming.md T1, bijective form): consecutive block ids are dealt round the 8 XCDs; blocks
+// with equal id % 8 take one contiguous share of the (x, y) list with y fastest, so the gridDim.y blocks that read the same x tile share
+// one L2.  A speed choice only.
+__device__ __forceinline__ void xcd_tile_yfast(int& bx, int& by) {
+    const int gy = gridDim.y, T = gridDim.x * gy;
+    bx = blockIdx.x; by = blockIdx.y;
+    if (gridDim.z != 1 || gy == 1 || T < 16) return;
+    const int L = bx + by * gridDim.x, x = L & 7, q = T >> 3, r = T & 7;
+    const int Lp = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (L >> 3);
+    bx = Lp / gy; by = Lp - bx * gy;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Diagnostic build only (-DCV2_STAMPS, tools/dbg_stamps.py): wave 0 of block 0 records s_memtime at the phase boundaries of

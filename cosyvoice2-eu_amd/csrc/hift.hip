@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);                     // [rows][CV_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t0 = blockIdx.x * CV_BT, co0 = blockIdx.y * 64;
+    int bx_, by_;
+    xcd_tile_yfast(bx_, by_);                                       // the output-channel tiles of one frame tile read the same input rows: one L2
+    const int t0 = bx_ * CV_BT, co0 = by_ * 64;
     const int span = (a.taps - 1) * a.dil;
     const int rows = CV_BT + span;
     const int ntile = a.CoutP / 32;
@@ -168,7 +170,9 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t0 = blockIdx.x * CV_BT, co0 = blockIdx.y * 64;
+    int bx_, by_;
+    xcd_tile_yfast(bx_, by_);                                       // the output-channel tiles of one frame tile read the same input rows: one L2
+    const int t0 = bx_ * CV_BT, co0 = by_ * 64;
     const int span = (a.taps - 1) * a.dil;
     const int rows = CV_BT + span;
     uint16_t* xp[3];
