@@ -33,6 +33,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #ifndef SWEEP_SLEEP
 #define SWEEP_SLEEP 1                           // s_sleep units between two sweeps of a direct poll (measured: 4 -> 1: -2.5 us per step)
 #endif
+#ifndef POLL_GAP
+#define POLL_GAP 2                              // s_sleep units between two polls of a sentinel granule
+#endif
 #define GRAN_TIMEOUT_TICKS 20000000ull     // s_memrealtime runs at 100 MHz: 0.2 s
 
 // (by value on purpose: clang lowers __builtin_bit_cast of a vector ELEMENT lvalue as a load from the vector's address, i.e. element 0)
@@ -77,7 +80,9 @@ struct Gran {                 // all granule buffers of the engine behind one bu
         if (__builtin_amdgcn_s_memrealtime() - t0 > GRAN_TIMEOUT_TICKS) { fail(); return true; }
         return false;
     }
-    // one wave waits until the n <= 64 granules base[idx0 + lane * stride] carry the epoch (lanes >= n idle)
+    // one wave waits until the n <= 64 granules base[idx0 + lane * stride] carry the epoch (lanes >= n idle).  One poll in flight per
+    // wave: two or three in flight from ONE wave measured slower (363 -> 374 -> 381 us per step; hipcc also serialises them, the
+    // result registers are reused), and the gap between polls wants to be short (s_sleep 2: 361.6, 6: 362.9, 10: 368.5, 24: 389.9).
     __device__ __forceinline__ bool wait(unsigned idx0, unsigned stride, int n) const {
         const int lane = threadIdx.x & 63;
         const u64 t0 = __builtin_amdgcn_s_memrealtime();
@@ -89,7 +94,7 @@ struct Gran {                 // all granule buffers of the engine behind one bu
             }
             if (__all(ok)) return true;
             if ((spin & 15) == 15 && give_up(t0)) return false;
-            __builtin_amdgcn_s_sleep(6);
+            __builtin_amdgcn_s_sleep(POLL_GAP);
         }
     }
     // the same with an index function: lane i < n polls granule idx(i)
@@ -192,8 +197,8 @@ struct OpGran {
         if (threadIdx.x == 0) *armed = 0;
         __syncthreads();
         if (wave * 64 >= nitems) return v;
-        if (wave == 0) {
-            G->wait(sentinel, 0, 1);
+        if (wave == 0) {                 // (two to four staggered polling waves per block measured the same: 363.5 / 364.0 / 362.8 / 363.6 us per step --
+            G->wait(sentinel, 0, 1);     //  the arming is off the critical path, the sweep's own retries are what follows the last producer)
             if ((threadIdx.x & 63) == 0) *armed = 1;
         } else {
             while (*armed == 0) __builtin_amdgcn_s_sleep(2);
