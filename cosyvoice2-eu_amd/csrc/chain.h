@@ -217,7 +217,7 @@ struct OpGran {
 // (flash-decoding merge).  A thread owns 4 columns and walks every live tile, AT_CHUNK tiles' loads in flight at a time.
 #define AT_GSTRIDE 464                         // granules per (tile, kv head): rep * 64 outputs, then rep x {max, sum}; rep <= 7
 #ifndef AT_CHUNK
-#define AT_CHUNK 3                              // (measured at 3-5 / 9-11 live tiles: 2: 364 / 393 us per step, 3: 365 / 393, 4: 392 / 410, 5: 372 / 407, 8: 411 / 429)
+#define AT_CHUNK 4                              // tiles per sweep of the O role (new-token partial folded first: 3: 339.5 / 370.1 us per step at 3-5 / 9-11 live tiles, 4: 335.3 / 360.5, 5: 336.2 / 367.4, 6: 361.8 / 399.2)
 #endif
 #ifndef O_WAIT_ALL
 #define O_WAIT_ALL 0
@@ -234,33 +234,23 @@ struct OpAtt {
         const int hd = k >> 6, g = hd / rep, hh = hd - g * rep;
         const bool res = tid >= 240;                               // nitems = 224: the last 32 lanes own no item
         float* xch = reinterpret_cast<float*>(xch_);
-        G->wait(ag + rep * 64, AT_GSTRIDE, O_WAIT_ALL ? cnt * n_kv : 1);   // every live (tile, head) pair's (max, sum) granule, or only the first tile's (then the sweep polls)
         // the new token attends to itself: score = q . k_new / 8 per head, value v_new -- one more partial {o = v_new, max = score,
-        // sum = 1}, merged first.  Its three vectors were published by the Q role long before the attention tiles.
-        float M = -INFINITY, den = 0.f;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        f32x4 q4 = acc, k4 = acc, v4 = acc;                        // (loaded beside the first chunk of tiles: no round trip of their own)
-        for (int s0 = 0; s0 < cnt; s0 += AT_CHUNK) {               // (block-uniform trip count)
-            f32x4 o[AT_CHUNK]; float m[AT_CHUNK], l[AT_CHUNK];
+        // sum = 1}.  Its three vectors (and the block's 16 residual columns) were published by the Q role ~2 us before the first
+        // attention tile: they are fetched and folded FIRST, behind a sentinel of their own (the last value granule), so that the
+        // tiles' sweep carries only tiles and the dot product is off the path behind the attention.
+        float M, den;
+        f32x4 acc;
+        {
+            f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4, v4 = q4;
             float rv = 0.f;
+            G->wait(kvg + 2 * n_kv * 64 - 1, 0, 1);
             G->sweep([&]() {
                 bool ok = true;
                 if (act) {
-                    if (s0 == 0) {
-                        ok = G->ld4(qg + k, q4);
-                        ok &= G->ld4(kvg + g * 64 + (k & 63), k4);
-                        ok &= G->ld4(kvg + (n_kv + g) * 64 + (k & 63), v4);
-                    }
-#pragma unroll
-                    for (int i = 0; i < AT_CHUNK; i++) {
-                        const int s = min(s0 + i, cnt - 1);        // slots past the count repeat the last tile (loaded, not merged)
-                        const unsigned a0 = ag + (unsigned)(s * n_kv + g) * AT_GSTRIDE;
-                        ok &= G->ld4(a0 + hh * 64 + (k & 63), o[i]);
-                        const u32x4 ml = G->ld2(a0 + rep * 64 + hh * 2);
-                        ok &= ml[1] == G->epoch && ml[3] == G->epoch;
-                        m[i] = u2f(ml[0]); l[i] = u2f(ml[2]);
-                    }
-                } else if (res && s0 == 0 && !fold->plain) {
+                    ok = G->ld4(qg + k, q4);
+                    ok &= G->ld4(kvg + g * 64 + (k & 63), k4);
+                    ok &= G->ld4(kvg + (n_kv + g) * 64 + (k & 63), v4);
+                } else if (res && !fold->plain) {
                     const int c = col0 + (tid & 15);
                     u64 x[1 + CH_NP];
                     x[0] = __hip_atomic_load((const gu64*)(G->base + fold->xg + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -275,20 +265,38 @@ struct OpAtt {
                 }
                 return ok;
             });
-            if (res && s0 == 0) xch[1200 + (tid & 15)] = fold->plain ? fold->plain[col0 + (tid & 15)] : rv;
-            if (s0 == 0) {
-                float sc = (q4[0] * k4[0] + q4[1] * k4[1]) + (q4[2] * k4[2] + q4[3] * k4[3]);
-                sc += dpp_mov_f32<0x128, 0xf>(0.f, sc);            // row_ror 8 / 4 / 2 / 1: the 16 lanes of a head (64 columns) sum up
-                sc += dpp_mov_f32<0x124, 0xf>(0.f, sc);
-                sc += dpp_mov_f32<0x122, 0xf>(0.f, sc);
-                sc += dpp_mov_f32<0x121, 0xf>(0.f, sc);
-                M = sc * 0.125f; den = 1.f; acc = v4;
-            }
+            if (res) xch[1200 + (tid & 15)] = fold->plain ? fold->plain[col0 + (tid & 15)] : rv;
+            float sc = (q4[0] * k4[0] + q4[1] * k4[1]) + (q4[2] * k4[2] + q4[3] * k4[3]);
+            sc += dpp_mov_f32<0x128, 0xf>(0.f, sc);            // row_ror 8 / 4 / 2 / 1: the 16 lanes of a head (64 columns) sum up
+            sc += dpp_mov_f32<0x124, 0xf>(0.f, sc);
+            sc += dpp_mov_f32<0x122, 0xf>(0.f, sc);
+            sc += dpp_mov_f32<0x121, 0xf>(0.f, sc);
+            M = sc * 0.125f; den = 1.f; acc = v4;
+        }
+        asm volatile("" : "+v"(M), "+v"(acc));                     // (done before the wait below, not sunk behind it)
+        G->wait(ag + rep * 64, AT_GSTRIDE, O_WAIT_ALL ? cnt * n_kv : 1);   // every live (tile, head) pair's (max, sum) granule, or only the first tile's (then the sweep polls)
+        for (int s0 = 0; s0 < cnt; s0 += AT_CHUNK) {               // (block-uniform trip count)
+            f32x4 o[AT_CHUNK]; float m[AT_CHUNK], l[AT_CHUNK];
+            G->sweep([&]() {
+                bool ok = true;
+                if (act) {
+#pragma unroll
+                    for (int i = 0; i < AT_CHUNK; i++) {
+                        const int s = min(s0 + i, cnt - 1);        // slots past the count repeat the last tile (loaded, not merged)
+                        const unsigned a0 = ag + (unsigned)(s * n_kv + g) * AT_GSTRIDE;
+                        ok &= G->ld4(a0 + hh * 64 + (k & 63), o[i]);
+                        const u32x4 ml = G->ld2(a0 + rep * 64 + hh * 2);
+                        ok &= ml[1] == G->epoch && ml[3] == G->epoch;
+                        m[i] = u2f(ml[0]); l[i] = u2f(ml[2]);
+                    }
+                }
+                return ok;
+            });
 #pragma unroll
             for (int i = 0; i < AT_CHUNK; i++) {
                 if (s0 + i < cnt) {
                     const float Mn = fmaxf(M, m[i]);
-                    const float w0 = __expf(M - Mn), w1 = __expf(m[i] - Mn);   // first tile: M = -inf -> w0 = 0
+                    const float w0 = __expf(M - Mn), w1 = __expf(m[i] - Mn);
                     den = den * w0 + l[i] * w1;
                     acc = acc * w0 + o[i] * w1;
                     M = Mn;

@@ -8,11 +8,16 @@ cpu_baseline); the product path (cv2amd/prompt.py -> csrc/frontend.hip) never im
   resample_kernel      torchaudio.functional.functional._get_sinc_resample_kernel / _apply_sinc_resample_kernel behind
                        torchaudio.transforms.Resample(16000, 24000) (cli/frontend.py:497), defaults sinc_interp_hann,
                        lowpass_filter_width 6, rolloff 0.99
+  whisper_log_mel      openai-whisper audio.py log_mel_spectrogram(audio, n_mels=128), the call of cli/frontend.py:264
+  kaldi_fbank          torchaudio.compliance.kaldi.fbank(num_mel_bins=80, dither=0, sample_frequency=16000) (+ get_mel_banks), the call of
+                       cli/frontend.py:277
 
 Pins: the STFT half is checked against torch.stft (the reference's own call, importable here).  librosa and torchaudio are third-party
 dependencies absent from /root/reference and from this image (requirements.txt pins librosa==0.10.2, torchaudio==2.3.1): the
 filterbank and the resampling kernel restate their published algorithms and are PARITY-UNPINNED beyond the structural properties in
-tests/test_oracle_golden.py (filter areas, partition of unity of the polyphase kernel, DC gain).
+tests/test_oracle_golden.py (filter areas, partition of unity of the polyphase kernel, DC gain).  openai-whisper is absent too: whisper_log_mel
+and kaldi_fbank restate the packages' published code with the same torch ops and are PARITY-UNPINNED as well (self-consistency of the
+torch.stft / torch.fft form against the float64 DFT by definition is what the tests hold).
 """
 import math
 
