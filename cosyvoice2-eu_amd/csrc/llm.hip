@@ -1277,6 +1277,180 @@ __global__ __launch_bounds__(256) void k_attn_prefill(PfAttnArgs a) {
     }
 }
 
+// The same attention on the matrix cores (fp32 accuracy: three exact bf16 planes per operand, six products; attn_role above is the one-row
+// form).  Block = PFM_ROWS prompt rows x one GQA group x one sequence, 4 waves; the 8 x rep <= 64 (row, head) pairs are the COLUMNS of
+// S^T = K Q^T and of O^T = V^T P^T, so a pair's running (max, sum) and its rescale factor live on the lane that holds its column in both
+// products and nothing has to be exchanged between them.  Wave w owns keys [16 w, 16 w + 16) of every 64-key tile: K rows and V rows go
+// global -> registers -> planes (each value split once, next tile's loads in flight), q planes are read from LDS; no barrier inside the
+// key loop; the four waves' (max, sum, O^T) are merged through LDS at the end.  68 us -> 9 us per layer at one 307-row prompt.
+#define PFM_ROWS 8
+#define PFM_QLD 72                                 // bf16 per q-plane row (64 + 8: 144-B stride, conflict-free ds_read_b128)
+constexpr size_t pfm_smem_bytes() { return (size_t)3 * 64 * PFM_QLD * 2 + (size_t)3 * (64 * 65 + 2 * 64) * 4; }
+__global__ __launch_bounds__(256) void k_attn_prefill_mfma(PfAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t* qp = reinterpret_cast<uint16_t*>(smem);                        // [3 planes][64 pairs][PFM_QLD]
+    float* mg = reinterpret_cast<float*>(smem + (size_t)3 * 64 * PFM_QLD * 2);   // waves 1..3: [64 pairs][65] O^T values, then max[64], sum[64]
+    const int rep = a.n_q / a.n_kv;
+    const int qt = blockIdx.x, g = blockIdx.y, sq = blockIdx.z;
+    const int len = a.seq_len[sq];
+    if (qt * PFM_ROWS >= len) return;
+    const int row0 = a.seq_row0[sq] + qt * PFM_ROWS, slot = a.seq_slot[sq], pos0 = a.seq_pos0[sq] + qt * PFM_ROWS;
+    const int nrow = min(PFM_ROWS, len - qt * PFM_ROWS);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g4 = lane >> 4;
+    const float* K = a.kc + ((size_t)slot * a.n_kv + g) * a.max_pos * 64;
+    const float* V = a.vc + ((size_t)slot * a.n_kv + g) * a.max_pos * 64;
+    const int kend = pos0 + nrow;                                // keys 0 .. kend - 1 are visible to some row
+    const int ntile = (kend + 63) >> 6;
+    // this wave's 16 keys of a tile, in operand order (attn_role): K[key c][dims 8 g4 .., 32 + 8 g4 ..], V[key 4 g4 + j][dim 16 t + c]
+    f32x4 kr[4]; float vr[16];
+    auto fetch = [&](int tile) {
+        const int kb = tile * 64 + 16 * w;
+        const float* kp = K + (size_t)(kb + c) * 64 + 8 * g4;
+        kr[0] = *reinterpret_cast<const f32x4*>(kp);      kr[1] = *reinterpret_cast<const f32x4*>(kp + 4);
+        kr[2] = *reinterpret_cast<const f32x4*>(kp + 32); kr[3] = *reinterpret_cast<const f32x4*>(kp + 36);
+        const float* vp = V + (size_t)(kb + 4 * g4) * 64 + c;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) vr[4 * t + j] = vp[j * 64 + 16 * t];
+    };
+    fetch(0);
+    {   // q planes: pair p = head * 8 + row; thread = (pair, 16-dim quarter)
+        const int p = tid >> 2, d0 = (tid & 3) * 16, i = p & 7, hh = p >> 3;
+        const bool live = i < nrow && hh < rep;
+        const float* src = a.q + (size_t)(row0 + i) * a.n_q * 64 + (g * rep + hh) * 64 + d0;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+            if (live) { x0 = *reinterpret_cast<const f32x4*>(src + 8 * e); x1 = *reinterpret_cast<const f32x4*>(src + 8 * e + 4); }
+            bf16x8 p0, p1, p2;
+            planes8(x0, x1, p0, p1, p2);
+            *reinterpret_cast<bf16x8*>(qp + (size_t)(0 * 64 + p) * PFM_QLD + d0 + 8 * e) = p0;
+            *reinterpret_cast<bf16x8*>(qp + (size_t)(1 * 64 + p) * PFM_QLD + d0 + 8 * e) = p1;
+            *reinterpret_cast<bf16x8*>(qp + (size_t)(2 * 64 + p) * PFM_QLD + d0 + 8 * e) = p2;
+        }
+    }
+    __syncthreads();
+    f32x4 o[4][4];                                               // [pair tile u][dim tile t]: rows = dims 16 t + 4 g4 + reg, column = pair 16 u + c
+    float mrun[4], lrun[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        mrun[u] = -INFINITY; lrun[u] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t++) o[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int my_i = c & 7;                                      // the row of this lane's pairs (pair 16 u + c -> row (16 u + c) & 7 = c & 7)
+    for (int tile = 0; tile < ntile; tile++) {
+        const int kb = tile * 64 + 16 * w;
+        bf16x8 ka[2][3];
+        s16x4 va[4][3];
+        planes8(kr[0], kr[1], ka[0][0], ka[0][1], ka[0][2]);
+        planes8(kr[2], kr[3], ka[1][0], ka[1][1], ka[1][2]);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            f32x4 v4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v4[j] = kb + 4 * g4 + j < kend ? vr[4 * t + j] : 0.f;       // rows past the prompt may hold anything
+            planes4(v4, va[t][0], va[t][1], va[t][2]);
+        }
+        if (tile + 1 < ntile) fetch(tile + 1);                   // in flight during this tile's products
+        if (kb >= kend) continue;                                // (wave-uniform) none of this wave's keys is visible
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                bf16x8 qb[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    qb[pl] = *reinterpret_cast<const bf16x8*>(qp + (size_t)(pl * 64 + 16 * u + c) * PFM_QLD + 32 * s2 + 8 * g4);
+                sc = mm6_32(sc, ka[s2], qb);
+            }
+            // sc[j]: key kb + 4 g4 + j against pair 16 u + c (row my_i): visible when key <= pos0 + row
+            float mt = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                sc[j] = (my_i < nrow && kb + 4 * g4 + j <= pos0 + my_i) ? sc[j] * 0.125f : -INFINITY;
+                mt = fmaxf(mt, sc[j]);
+            }
+            mt = rows4_max(mt);
+            const float mn = fmaxf(mrun[u], mt);
+            const float mref = mn == -INFINITY ? 0.f : mn;
+            const float scale = __expf(mrun[u] - mref);           // 0 on the first visible tile (mrun = -inf)
+            f32x4 p;
+            float lt = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { p[j] = __expf(sc[j] - mref); lt += p[j]; }
+            lt = rows4_sum(lt);
+            lrun[u] = lrun[u] * scale + lt;
+            mrun[u] = mn;
+            s16x4 pb[3];
+            planes4(p, pb[0], pb[1], pb[2]);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                f32x4 acc = o[u][t] * scale;
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va[t][2], pb[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va[t][1], pb[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va[t][0], pb[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va[t][1], pb[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va[t][0], pb[1], acc, 0, 0, 0);
+                o[u][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va[t][0], pb[0], acc, 0, 0, 0);
+            }
+        }
+    }
+    // merge: waves 1..3 park (O^T, max, sum), wave 0 folds them in and stores the normalised rows as hi / lo bf16 planes
+    if (w > 0) {
+        float* d = mg + (size_t)(w - 1) * (64 * 65 + 128);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) d[(16 * u + c) * 65 + 16 * t + 4 * g4 + j] = o[u][t][j];
+            if (g4 == 0) { d[64 * 65 + 16 * u + c] = mrun[u]; d[64 * 65 + 64 + 16 * u + c] = lrun[u]; }
+        }
+    }
+    __syncthreads();
+    if (w > 0) return;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int p = 16 * u + c, i = p & 7, hh = p >> 3;
+        float M = mrun[u];
+#pragma unroll
+        for (int x = 0; x < 3; x++) M = fmaxf(M, mg[(size_t)x * (64 * 65 + 128) + 64 * 65 + p]);
+        const float mref = M == -INFINITY ? 0.f : M;
+        const float w0 = __expf(mrun[u] - mref);
+        float l = lrun[u] * w0;
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = o[u][t] * w0;
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            const float* d = mg + (size_t)x * (64 * 65 + 128);
+            const float wx = __expf(d[64 * 65 + p] - mref);
+            l += d[64 * 65 + 64 + p] * wx;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[t][j] += wx * d[p * 65 + 16 * t + 4 * g4 + j];
+        }
+        if (i < nrow && hh < rep) {
+            const float inv = l > 0.f ? 1.f / l : 0.f;
+            const size_t off = (size_t)(row0 + i) * a.n_q * 64 + (g * rep + hh) * 64;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                uint16_t hb[4], lb[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const float v = acc[t][j] * inv; hb[j] = f2bf(v); lb[j] = f2bf(v - bf2f(hb[j])); }
+                *reinterpret_cast<uint2*>(a.hi + off + 16 * t + 4 * g4) = make_uint2(hb[0] | ((uint32_t)hb[1] << 16), hb[2] | ((uint32_t)hb[3] << 16));
+                *reinterpret_cast<uint2*>(a.lo + off + 16 * t + 4 * g4) = make_uint2(lb[0] | ((uint32_t)lb[1] << 16), lb[2] | ((uint32_t)lb[3] << 16));
+            }
+        }
+    }
+}
+
 // gate / up (16-row tiles interleaved as packed for the decode kernels) -> SiLU(g) * u -> hi/lo planes [M][inter]
 __global__ __launch_bounds__(256) void k_swiglu_split(const float* gu, uint16_t* hi, uint16_t* lo, int M_valid, int Mp, int inter) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1695,7 +1869,11 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
     CV2_CHECK(h->pf_rows > 0, "cv2_llm_prefill_batch: created with max_prefill_rows == 0");
     if (init_attrs_once()) return -1;
     static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
-    if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_prefill), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    if (!once) {
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_prefill), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_prefill_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once = true;
+    }
     const cv2_llm_dims& d = h->d;
     hipStream_t s = (hipStream_t)stream;
     int M = 0, maxlen = 0;
@@ -1739,7 +1917,9 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
         }
         {
             PfAttnArgs a{h->pf_q, h->kc + l * cache_l, h->vc + l * cache_l, h->pf_hi, h->pf_lo, d_row0, d_len, d_slot, d_pos0, d.n_q, d.n_kv, d.max_pos};
-            hipLaunchKernelGGL(k_attn_prefill, dim3((maxlen + PF_ROWS - 1) / PF_ROWS, d.n_kv, n), dim3(256), pf_smem, s, a);
+            static const bool pf_scalar = getenv("CV2_PREFILL_ATTN") && getenv("CV2_PREFILL_ATTN")[0] == '0';     // A/B switch (diagnostics)
+            if (pf_scalar) hipLaunchKernelGGL(k_attn_prefill, dim3((maxlen + PF_ROWS - 1) / PF_ROWS, d.n_kv, n), dim3(256), pf_smem, s, a);
+            else hipLaunchKernelGGL(k_attn_prefill_mfma, dim3((maxlen + PFM_ROWS - 1) / PFM_ROWS, d.n_kv, n), dim3(256), pfm_smem_bytes(), s, a);
         }
         {
             GemmArgs g = gemm_args(h->pf_hi, NQ, 0, L.wo, Mp, H, NQ);
