@@ -33,6 +33,9 @@ wrap(model, '_run_batch', 'run_batch')
 wrap(model.llm, 'generate', ' llm.generate')
 wrap(model.llm, 'add_requests', '  prefill (add_requests)')
 wrap(model.llm, 'step', '  decode (step)')
+wrap(model.llm, 'step_rows', '  decode (step_rows)')
+wrap(model.llm, 'build_lm_input', '  build_lm_input')
+wrap(model.llm, 'read', '  read')
 wrap(model.flow, 'inference_batch', ' flow')
 wrap(model.hift_pool, 'inference_many', ' hift')
 bench.run_calls(model, reqs, forces)
