@@ -122,6 +122,22 @@ def test_long_context_attention_splits(dev, small, max_pos):
         assert ids == OL.inference(sdr, text, ptxt, ptok, force_len=12)
 
 
+def test_one_launch_step_at_a_long_context(dev, small):
+    """The one-launch step (k_step) far into the cache: a 1500-token prompt = 12 attention tiles of 128 keys per kv head, merged by the O
+    role in three sweeps of four; the new token's own (q.k, v) partial is folded first.  Greedy ids == the oracle's, and the engine
+    really takes the one-launch step."""
+    from cv2amd import synth
+    from cv2amd.llm import LLMEngine
+    from oracle import llm as OL
+    sd, sdr, _ = small
+    eng = LLMEngine(sd, dev, max_seqs=1, max_pos=2048, max_out=64)
+    assert eng.lib.cv2_llm_one_launch_step(eng.handle) == 1
+    inp = synth.synthetic_inputs(seed=77, text_len=9, prompt_len=1500, prompt_text_len=3)
+    req = (inp['text'], inp['prompt_text'], inp['prompt_token'])
+    got = eng.generate([req], force_len=14)
+    assert got[0] == OL.inference(sdr, *req, force_len=14)
+
+
 def test_many_row_decode_path(small):
     """More than 16 sequences per step take the prepared-operand kernels (k_prep + PRE variants): ids still equal the oracle's."""
     from oracle import llm as OL
