@@ -76,6 +76,24 @@ __device__ __forceinline__ void planes4(const f32x4 v, s16x4& p0, s16x4& p1, s16
     p1 = __builtin_bit_cast(s16x4, (u32x2_t){pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3])});
     p2 = __builtin_bit_cast(s16x4, (u32x2_t){pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3])});
 }
+// S^T = K Q^T and O = P V at fp32 accuracy on the bf16 matrix cores: both operands as three exact bf16 planes, the six products of
+// weight >= 2^-16 (what is dropped is below an fp32 rounding of the term; same scheme as k_conv6, hift.hip)
+__device__ __forceinline__ f32x4 mm6_32(f32x4 acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mm6_16(f32x4 acc, const s16x4 (&a)[3], const s16x4 (&b)[3]) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[1], acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
+}
 // max / sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (same column of the four 16-lane rows), result in all of them: two
 // v_permlane*_swap (VALU) instead of two LDS-routed shuffles
 // (the swap exchanges halves of TWO registers: the second operand is an opaque copy, or the compiler hands the instruction one register

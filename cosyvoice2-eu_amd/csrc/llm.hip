@@ -291,12 +291,151 @@ __global__ __launch_bounds__(256 * NSUB) void k_attn(AttnArgs a) {
     SK_STAMP(6);
     SK_STAMP_FLUSH;
 }
+// The same kernel on the matrix cores (fp32 accuracy: three exact bf16 planes per operand, six products; see attn_role, the form inside
+// k_step).  Grid, split layout and outputs are k_attn's.  A 64-key tile group = 4 waves x 16 keys: K rows / V rows go global -> registers
+// in operand order (requested at entry, before the position has arrived), S^T = K Q^T and O^T = V^T P^T keep the head on the lane's
+// column in both products, so the running (max, sum) and the rescale factor of a head never leave its lane; the waves of a block are
+// merged once, through LDS, at the end.  After the loads: ~3.3 us of scalar FMAs and four block barriers -> ~1.5 us.
+#define ATM_QLD 68
+template <int NSUB>
+__global__ __launch_bounds__(256 * NSUB) void k_attn_m(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float qs[16 * ATM_QLD];                 // heads >= rep stay zero
+    __shared__ __attribute__((aligned(16))) float po[4 * NSUB][8 * 64];             // per wave: O^T as [head][dim]
+    __shared__ float wm[4 * NSUB][16], wl[4 * NSUB][16];
+    const int rep = a.rep;
+    const int sp = blockIdx.x, g = blockIdx.y, r = blockIdx.z;    // grid = (key split, kv head, row)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave of the block; its tile group is wv >> 2, its 16 keys (wv & 3)
+    const int sub = wv >> 2, wk = wv & 3;
+    const int c = lane & 15, g4 = lane >> 4;
+    const int split_lo = sp * a.keys_per_split;
+    float qreg[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int e = tid + i * 256 * NSUB;
+        qreg[i] = a.q[(size_t)r * a.n_q * 64 + g * rep * 64 + min(e, rep * 64 - 1)];
+    }
+    int seq, pos;
+    a.rm.get(r, seq, pos);
+    if (gridDim.z > 4 && split_lo >= pos + 1) return;           // (many rows: skip the splits past the length before fetching, as k_attn)
+    const int seq_s = a.rm.prefill ? a.rm.seq0 : (a.rm.slots ? seq : r);
+    const float* K = a.kc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
+    const float* V = a.vc + ((size_t)seq_s * a.n_kv + g) * a.max_pos * 64;
+    f32x4 kr[4]; float vr[16];
+    auto fetch = [&](int kb) {                                    // this wave's 16 keys from kb on, in operand order
+        const float* kp = K + (size_t)(kb + c) * 64 + 8 * g4;
+        kr[0] = *reinterpret_cast<const f32x4*>(kp);      kr[1] = *reinterpret_cast<const f32x4*>(kp + 4);
+        kr[2] = *reinterpret_cast<const f32x4*>(kp + 32); kr[3] = *reinterpret_cast<const f32x4*>(kp + 36);
+        const float* vp = V + (size_t)(kb + 4 * g4) * 64 + c;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) vr[4 * t + j] = vp[j * 64 + 16 * t];
+    };
+    fetch(split_lo + sub * AT_KB + 16 * wk);
+    for (int e = rep * ATM_QLD + tid; e < 16 * ATM_QLD; e += 256 * NSUB) qs[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int e = tid + i * 256 * NSUB;
+        if (e < rep * 64) qs[(e >> 6) * ATM_QLD + (e & 63)] = qreg[i];
+    }
+    const int L = pos + 1;
+    const int j_hi = min(L, split_lo + a.keys_per_split);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.part_cnt[r] = (L + a.keys_per_split - 1) / a.keys_per_split;
+    float* ml = a.part_ml + (((size_t)sp * SK_ROWS_CAP + r) * a.n_q + g * rep) * 2;
+    if (split_lo >= j_hi) return;                                 // empty split: the consumer stops at part_cnt
+    __syncthreads();                                              // q in LDS
+    bf16x8 qb[2][3];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+        const float* qp = qs + c * ATM_QLD + 32 * s2 + 8 * g4;
+        planes8(*reinterpret_cast<const f32x4*>(qp), *reinterpret_cast<const f32x4*>(qp + 4), qb[s2][0], qb[s2][1], qb[s2][2]);
+    }
+    f32x4 o[4];                                                   // O^T: rows = dims 16 t + 4 g4 + reg, column = head c
+#pragma unroll
+    for (int t = 0; t < 4; t++) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lrun = 0.f;
+    const int rounds = (j_hi - split_lo + AT_KB * NSUB - 1) / (AT_KB * NSUB);
+    for (int it = 0; it < rounds; it++) {
+        const int kb = split_lo + (it * NSUB + sub) * AT_KB + 16 * wk;
+        bf16x8 ka[2][3];
+        s16x4 va[4][3];
+        planes8(kr[0], kr[1], ka[0][0], ka[0][1], ka[0][2]);
+        planes8(kr[2], kr[3], ka[1][0], ka[1][1], ka[1][2]);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            f32x4 v4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v4[j] = kb + 4 * g4 + j < j_hi ? vr[4 * t + j] : 0.f;      // rows past the length may hold anything
+            planes4(v4, va[t][0], va[t][1], va[t][2]);
+        }
+        if (it + 1 < rounds) fetch(kb + AT_KB * NSUB);             // a long split's next round (max_pos > 16 x 64 NSUB)
+        if (kb >= j_hi) continue;                                  // (wave-uniform) no key of this wave is live
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        sc = mm6_32(sc, ka[0], qb[0]);
+        sc = mm6_32(sc, ka[1], qb[1]);
+        float mt = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { sc[j] = kb + 4 * g4 + j < j_hi ? sc[j] * 0.125f : -INFINITY; mt = fmaxf(mt, sc[j]); }
+        mt = rows4_max(mt);
+        const float mn = fmaxf(mrun, mt);                          // finite: the wave holds a live key
+        const float scale = __expf(mrun - mn);                    // 0 on the wave's first live tile
+        f32x4 p;
+        float lt = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { p[j] = __expf(sc[j] - mn); lt += p[j]; }
+        lt = rows4_sum(lt);
+        lrun = lrun * scale + lt;
+        mrun = mn;
+        s16x4 pb[3];
+        planes4(p, pb[0], pb[1], pb[2]);
+#pragma unroll
+        for (int t = 0; t < 4; t++) o[t] = mm6_16(o[t] * scale, va[t], pb);
+    }
+    // merge the waves of the block through LDS; store the unnormalised partial output and (max, sum) of the split
+    if (c < 8) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) po[wv][c * 64 + 16 * t + 4 * g4 + j] = o[t][j];
+    }
+    if (g4 == 0) { wm[wv][c] = mrun; wl[wv][c] = lrun; }
+    __syncthreads();
+    float* pout = a.part_o + ((size_t)sp * SK_ROWS_CAP + r) * a.n_q * 64 + (size_t)g * rep * 64;
+    for (int e = tid; e < rep * 64; e += 256 * NSUB) {
+        const int h = e >> 6;
+        float M = wm[0][h];
+#pragma unroll
+        for (int u = 1; u < 4 * NSUB; u++) M = fmaxf(M, wm[u][h]);
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4 * NSUB; u++) acc += __expf(wm[u][h] - M) * po[u][e];      // a wave without a live key: max = -inf, weight 0, O^T = 0
+        pout[e] = acc;
+    }
+    if (tid < rep) {
+        float M = wm[0][tid], l = 0.f;
+#pragma unroll
+        for (int u = 1; u < 4 * NSUB; u++) M = fmaxf(M, wm[u][tid]);
+#pragma unroll
+        for (int u = 0; u < 4 * NSUB; u++) l += __expf(wm[u][tid] - M) * wl[u][tid];
+        ml[tid * 2] = M; ml[tid * 2 + 1] = l;
+    }
+}
 static void launch_attn(const AttnArgs& a, int rows, hipStream_t s) {
     const dim3 grid(a.nsplit, a.n_kv, rows);
     const int nsub = a.keys_per_split / AT_KB;
-    if (nsub >= 4) hipLaunchKernelGGL(k_attn<4>, grid, dim3(1024), 0, s, a);
-    else if (nsub == 2) hipLaunchKernelGGL(k_attn<2>, grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(k_attn<1>, grid, dim3(256), 0, s, a);
+    // few rows are latency-bound and take the matrix-core kernel (1 / 2 / 8 rows: 614 -> 596, 659 -> 638, 908 -> 887 us per step); many rows are
+    // throughput-bound, where its plane splits cost as many VALU operations as the scalar kernel's FMAs (16 rows: 1212 -> 1229, 32: 1276 -> 1356)
+    static const bool scalar = getenv("CV2_DECODE_ATTN") && getenv("CV2_DECODE_ATTN")[0] == '0';      // A/B switch (diagnostics): the scalar-FMA kernels everywhere
+    if (scalar || rows > 8) {
+        if (nsub >= 4) hipLaunchKernelGGL(k_attn<4>, grid, dim3(1024), 0, s, a);
+        else if (nsub == 2) hipLaunchKernelGGL(k_attn<2>, grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL(k_attn<1>, grid, dim3(256), 0, s, a);
+        return;
+    }
+    if (nsub >= 4) hipLaunchKernelGGL(k_attn_m<4>, grid, dim3(1024), 0, s, a);
+    else if (nsub == 2) hipLaunchKernelGGL(k_attn_m<2>, grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(k_attn_m<1>, grid, dim3(256), 0, s, a);
 }
 
 // split combine as its own pass (used when many rows share a launch: inside the O-projection every block would redo it)
@@ -450,16 +589,6 @@ extern "C" int cv2_debug_chain(unsigned long long* out_host) {
 #else
 #define AT_T(i) do { } while (0)
 #endif
-// S^T = K Q^T and O = P V at fp32 accuracy on the bf16 matrix cores: both operands as three exact bf16 planes, the six products of
-// weight >= 2^-16 (what is dropped is below an fp32 rounding of the term; same scheme as k_conv6, hift.hip)
-__device__ __forceinline__ f32x4 mm6_32(f32x4 acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
-}
 // One 128-key tile of one kv head against the step's rep (<= 8) query heads; wave w owns keys [16 w, 16 w + 16).
 //   before q arrives (the block has nothing else to do): the wave's K rows and V rows are fetched in MFMA operand order and split
 //     into planes -- K[key l & 15][dims 8 (l >> 4) .., + 32] = A operand of S^T = K Q^T, V[key 4 (l >> 4) + j][dim 16 t + (l & 15)]
