@@ -852,6 +852,10 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         GemmArgs a = gemm_args(GB(h->lnb, 256), 256, 0, tb.qkv.w, M, 1536, 256);
         a.out_bf16 = GB(h->qk, 1024); a.ldo16 = 1024; a.n_store = 1024;
         a.vt = h->vt + GUARD; a.vt_ld = h->R + GUARD + 8; a.vt_n0 = 1024;
+        if (c.inc) {                 // cached streaming: the epilogue also files this call's keys / values in the cache slot of (Euler step, block)
+            CV2_CHECK(c.tb_i < INC_TBLOCKS, "flow: transformer block counter overflow");
+            a.kvc = c.inc->kv; a.kvc_frames = c.inc->kv_frames; a.kvc_pos0 = c.inc->pos0; a.kvc_slot = (long)c.step * INC_TBLOCKS + c.tb_i; a.kvc_k0 = 512;
+        }
         if (est_gemm(c, a, 0)) return -1;
     }
     {
@@ -860,8 +864,11 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
             const int bi = c.tb_i++;
             CV2_CHECK(bi < INC_TBLOCKS, "flow: transformer block counter overflow");
             a.kv = c.inc->kv; a.kv_frames = c.inc->kv_frames; a.pos0 = c.inc->pos0; a.slot = (long)c.step * INC_TBLOCKS + bi;
-            KvAppendArgs k{GB(h->qk, 1024), h->vt + GUARD, a.R, c.L->tab(), *c.inc, a.slot};
-            hipLaunchKernelGGL(k_kv_append, dim3(M / 64, 8), dim3(256), 0, c.s, k);
+            static const bool sep = getenv("CV2_FLOW_KV_APPEND") && getenv("CV2_FLOW_KV_APPEND")[0] == '1';      // A/B switch (diagnostics): the separate copy launch as well
+            if (sep) {
+                KvAppendArgs k{GB(h->qk, 1024), h->vt + GUARD, a.R, c.L->tab(), *c.inc, a.slot};
+                hipLaunchKernelGGL(k_kv_append, dim3(M / 64, 8), dim3(256), 0, c.s, k);
+            }
         }
         if (c.inc) {
             if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4, 1, true>), dim3(8, M / 128), dim3(256), 0, c.s, a);

@@ -46,6 +46,10 @@ struct GemmArgs {
     const float* ln2_g; const float* ln2_b; float ln2_eps; float ln2_scale; uint16_t* out_ln2; long ldo_ln2;
     uint16_t* vt; long vt_ld; int vt_n0;                            // features n >= vt_n0: vt[(n - vt_n0) * vt_ld + m]
     int n_store;                                                    // only features n < n_store are written (N padded up)
+    // cached streaming (flow: cv2_flow_inference_chunk): the QKV projection also files the call's keys / values in each sequence's cache
+    // slot -- K rows [frames][512] for features [kvc_k0, vt_n0), V^T [512][frames] for features >= vt_n0 -- at frames pos0[s] + t
+    // (what a separate k_kv_append launch per transformer block did: 7.5 us x 560 per chunk round)
+    uint16_t* const* kvc; const int* kvc_frames; const int* kvc_pos0; long kvc_slot; int kvc_k0;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -313,6 +317,16 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
                 pk[r] = pack_bf16x2(v0, v1);
             }
             *reinterpret_cast<uint4*>(a.vt + (size_t)(n0 + n - a.vt_n0) * a.vt_ld + mrow) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if (a.kvc && s >= 0) {                         // the same 8 frames of this feature -> the sequence's V^T cache (pos0 and t are even: 4-byte pairs)
+                const long fr = a.kvc_frames[s];
+                const int t = mrow - start;
+                uint16_t* d = a.kvc[s] + a.kvc_slot * fr * 1024 + fr * 512 + (size_t)(n0 + n - a.vt_n0) * fr + a.kvc_pos0[s] + t;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (t + 2 * r + 1 < len) *reinterpret_cast<uint32_t*>(d + 2 * r) = pk[r];
+                    else if (t + 2 * r < len) d[2 * r] = (uint16_t)(pk[r] & 0xffffu);
+                }
+            }
         }
         return;
     }
@@ -348,6 +362,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
         if (out_f32 && wr) *reinterpret_cast<f32x4*>(out_f32 + (size_t)m * a.ldo + n) = v;
         if (out_bf16 && wr)
             *reinterpret_cast<uint2*>(out_bf16 + (size_t)m * a.ldo16 + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        if (a.kvc && n >= a.kvc_k0 && wr && valid && a.seq.tile_seq) {       // this row's key channels -> the sequence's K cache
+            const int s = a.seq.tile_seq[m >> 6];
+            const long fr = a.kvc_frames[s];
+            uint16_t* d = a.kvc[s] + a.kvc_slot * fr * 1024 + (size_t)(a.kvc_pos0[s] + m - a.seq.seq_start[s]) * 512 + (n - a.kvc_k0);
+            *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
         if (a.ln2_g) {
             const float mean = group_sum<LPR>(v[0] + v[1] + v[2] + v[3]) * (1.f / BN);
             const f32x4 d = v - mean;
