@@ -660,6 +660,7 @@ struct cv2_flow {
     // row buffers
     uint16_t *a0, *hb, *xa, *xbuf, *cat, *lnb, *qk, *vt, *att, *ff;      // bf16
     float *xf, *rf, *vf, *xs, *mu, *spk, *tmpf;                           // fp32
+    float *tail_part; int *tail_ticket;                                  // k_tail_panel<S > 1>: [128 panels][4 parts][16][256] partial tiles, [128] arrival counters (zero between launches)
     float *ac, *bd; uint16_t* probs; uint16_t *pos, *posp;
     // encoder buffers (C = 512)
     uint16_t *e_a, *e_b, *e_ln, *e_qkv, *e_vt, *e_att, *e_ff; float *e_x, *e_tmp;
@@ -690,6 +691,7 @@ static size_t flow_carve(const cv2_flow_dims& d, cv2_flow* h, char* base) {
     f.xbuf = c.take<uint16_t>(RG * 256); f.cat = c.take<uint16_t>(RG * 512); f.lnb = c.take<uint16_t>(RG * 256);
     f.qk = c.take<uint16_t>(RG * 1024); f.vt = c.take<uint16_t>((size_t)(512 + 64) * RG); f.att = c.take<uint16_t>(RG * 512);
     f.ff = c.take<uint16_t>(RG * 1024);
+    f.tail_part = c.take<float>((size_t)128 * 4 * 16 * 256); f.tail_ticket = c.take<int>(128);
     f.xf = c.take<float>(R * 256); f.rf = c.take<float>(R * 256); f.vf = c.take<float>(R * 80); f.xs = c.take<float>(R * 80);
     f.mu = c.take<float>(R * 80); f.spk = c.take<float>((size_t)d.max_seqs * 80); f.tmpf = c.take<float>(R * 512);
     f.ac = c.take<float>((size_t)8 * TP * TP); f.bd = c.take<float>((size_t)8 * TP * P); f.probs = c.take<uint16_t>((size_t)8 * TP * TP);
@@ -891,6 +893,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         t.gn = next_ln ? next_ln->g : nullptr; t.bn = next_ln ? next_ln->b : nullptr; t.epsn = 1e-5f;
         t.xf = h->xf; t.out_ln = GB(h->lnb, 256); t.ldo_ln = 256; t.out_x = xout; t.ldo_x = ldx;
         t.seq = c.L->tab(); t.M_valid = M;
+        t.part = h->tail_part; t.ticket = h->tail_ticket;
         return (long)(M / 64) < tail_rows_min ? tail_panel_go(t, M, c.s) : tail_rows_go(t, M, c.s);
     }
     {

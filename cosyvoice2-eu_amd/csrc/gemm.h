@@ -524,8 +524,14 @@ struct TailArgs {
     uint16_t* out_ln; long ldo_ln;                           // gn != null: LN'd bf16 [M][256]
     uint16_t* out_x; long ldo_x;                             // gn == null: x as bf16
     SeqTable seq; int M_valid;
+    float* part; int* ticket;                                // k_tail_panel<S > 1>: partial FF2 tiles [panels][S][16][256] and the panels' arrival counters (zero between launches)
 };
-template <int V>          // (template only so that the header can be included by several translation units)
+// S > 1: S workgroups share a panel, each takes 1024 / S hidden columns of the feed-forward (its slice of W1 and of W2's K range: one
+// workgroup ingests ~100 GB/s, and at few rows the 1.25 MB of weights per panel were the launch: 64 panels = 64 CUs busy for 20 us).
+// Everything up to norm3 is repeated by every part (W_o: 256 KB); the S partial FF2 tiles meet in the panel's last-arriving workgroup
+// (write-through partials, arrival counter, sc1 loads; cdna_hip_programming.md Guideline 16), which sums them in part order -- the
+// result does not depend on who arrives last -- and runs the row epilogue.  grid = (S, panels).
+template <int S>
 __global__ __launch_bounds__(1024) void k_tail_panel(TailArgs a) {
     constexpr int NW = 16, LDC = 260, KS0 = 16, KS1 = 8, KS2 = 32, CH = 8;
     constexpr size_t ATT_BYTES = (size_t)KS0 * 1024, X_OFF = 17 * 1024, H_OFF = X_OFF + KS1 * 1024, PAR_OFF = H_OFF + KS2 * 1024;
@@ -535,6 +541,8 @@ __global__ __launch_bounds__(1024) void k_tail_panel(TailArgs a) {
     float* par = reinterpret_cast<float*>(smem + PAR_OFF);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = S > 1 ? (int)blockIdx.x : 0;
+    constexpr int TPW = 4 / S, KS2P = KS2 / S;              // hidden column tiles per wave / k-steps of FF2 of one part
     const int m0 = blockIdx.y * 16, m = m0 + wave, n = lane * 4;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     {   // attention panel: piece kb = 16 rows x 32 k, one per wave
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(1024) void k_tail_panel(TailArgs a) {
         if (kb + CH < KS0) wr[kb % CH] = wop[(size_t)(kb + CH) * 64];
     }
     // first fragments of W1 requested now: they fly during the epilogue below
-    const s16x8* w1p = reinterpret_cast<const s16x8*>(a.W1) + ((size_t)(wave * 4) * KS1) * 64 + lane;
+    const s16x8* w1p = reinterpret_cast<const s16x8*>(a.W1) + ((size_t)(part * (64 / S) + wave * TPW) * KS1) * 64 + lane;
     s16x8 wa[KS1], wb[KS1];
 #pragma unroll
     for (int i = 0; i < KS1; i++) wa[i] = w1p[(size_t)i * 64];
@@ -599,10 +607,10 @@ __global__ __launch_bounds__(1024) void k_tail_panel(TailArgs a) {
     __syncthreads();
     // ---- GEMM 1: 4 column tiles of 16 hidden columns per wave, bias + GELU, hidden panel in operand layout
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < TPW; t++) {
         s16x8 (&cur)[KS1] = (t & 1) ? wb : wa;
         s16x8 (&nxt)[KS1] = (t & 1) ? wa : wb;
-        if (t + 1 < 4) {
+        if (t + 1 < TPW) {
 #pragma unroll
             for (int i = 0; i < KS1; i++) nxt[i] = w1p[(size_t)((t + 1) * KS1 + i) * 64];
         }
@@ -612,29 +620,61 @@ __global__ __launch_bounds__(1024) void k_tail_panel(TailArgs a) {
             const bf16x8 xf_ = *reinterpret_cast<const bf16x8*>(xs + (size_t)kb * 1024 + a_off);
             a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[kb]), xf_, a1, 0, 0, 0);
         }
-        const int c = wave * 64 + t * 16 + 4 * (lane >> 4);
-        f32x4 v = a1 + *reinterpret_cast<const f32x4*>(a.b1 + c);
+        const int c = wave * (16 * TPW) + t * 16 + 4 * (lane >> 4);        // hidden column within the part
+        f32x4 v = a1 + *reinterpret_cast<const f32x4*>(a.b1 + part * (1024 / S) + c);
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] = act_apply(v[e], ACT_GELU, 0.f);
         char* d = hs + (size_t)(c >> 5) * 1024 + subtile_off(lane & 15, (c & 31) >> 3) + (c & 7) * 2;
         *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     }
     // ---- GEMM 2
-    const s16x8* w2p = reinterpret_cast<const s16x8*>(a.W2) + ((size_t)wave * KS2) * 64 + lane;
+    const s16x8* w2p = reinterpret_cast<const s16x8*>(a.W2) + ((size_t)wave * KS2 + part * KS2P) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < CH; i++) wr[i] = w2p[(size_t)i * 64];
     __syncthreads();                                         // hidden panel complete (and the C tile of GEMM 0 consumed)
-    f32x4 acc2 = z4;
+    // FF2 is summed as four chains of 8 k-steps combined pairwise, (q0 + q1) + (q2 + q3), in EVERY variant (one workgroup holds 4, 2 or 1
+    // of the chains): a panel's result does not depend on how many workgroups shared it, so a cached streaming chunk (few rows, S = 4)
+    // and the whole-prefix recompute (S = 2 or 1) stay bit-identical.
+    f32x4 q2[KS2P / 8];
 #pragma unroll
-    for (int kb = 0; kb < KS2; kb++) {
+    for (int c8 = 0; c8 < KS2P / 8; c8++) q2[c8] = z4;
+#pragma unroll
+    for (int kb = 0; kb < KS2P; kb++) {
         const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (size_t)kb * 1024 + a_off);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[kb % CH]), hf, acc2, 0, 0, 0);
-        if (kb + CH < KS2) wr[kb % CH] = w2p[(size_t)(kb + CH) * 64];
+        q2[kb / 8] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[kb % CH]), hf, q2[kb / 8], 0, 0, 0);
+        if (kb + CH < KS2P) wr[kb % CH] = w2p[(size_t)(kb + CH) * 64];
     }
+    f32x4 acc2;
+    if (S == 1) acc2 = (q2[0] + q2[1 % (KS2P / 8)]) + (q2[2 % (KS2P / 8)] + q2[3 % (KS2P / 8)]);
+    else if (S == 2) acc2 = q2[0] + q2[1 % (KS2P / 8)];
+    else acc2 = q2[0];
     *reinterpret_cast<f32x4*>(&C[(lane & 15) * LDC + wave * 16 + 4 * (lane >> 4)]) = acc2;
     __syncthreads();
+    f32x4 ff = *reinterpret_cast<const f32x4*>(&C[wave * LDC + n]);
+    if (S > 1) {
+        float* slab = a.part + (((size_t)blockIdx.y * S + part) * 16 + wave) * 256 + n;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slab), "v"(ff) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* last = reinterpret_cast<int*>(C);                  // (the C tile has been read: its LDS carries the verdict)
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(a.ticket + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *last = old == S - 1;
+            if (*last) __hip_atomic_store(a.ticket + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!*last) return;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.part + (size_t)blockIdx.y * S * 16 * 256), 0, S * 16 * 256 * 4, 0x00020000);
+        f32x4 pp[S];
+#pragma unroll
+        for (int p = 0; p < S; p++) {                           // every part's tile (this workgroup's own from its registers)
+            const f32x4 o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((p * 16 + wave) * 256 + n) * 4, 0, 16));     // aux 16 = sc1
+            pp[p] = p == part ? ff : o;
+        }
+        ff = S == 2 ? pp[0] + pp[1 % S] : (pp[0] + pp[1 % S]) + (pp[2 % S] + pp[3 % S]);      // the same tree, whoever folds
+    }
     {   // x += ff + b2 ; stores
-        f32x4 v = *reinterpret_cast<const f32x4*>(&C[wave * LDC + n]) + pv[192] + xrow;
+        f32x4 v = ff + pv[192] + xrow;
         if (!valid) v = z4;
         if (a.gn) {
             *reinterpret_cast<f32x4*>(a.xf + (size_t)m * 256 + n) = v;

@@ -56,8 +56,20 @@ static int tail_rows_go(const TailArgs& a, int M, hipStream_t s) {
 static int tail_panel_go(const TailArgs& a, int M, hipStream_t s) {
     constexpr size_t sm = tail_panel_smem();
     static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
-    if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_panel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
-    hipLaunchKernelGGL(k_tail_panel<0>, dim3(1, M / 16, 1), dim3(1024), sm, s, a);
+    if (!once) {
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_panel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_panel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_panel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        once = true;
+    }
+    // fewer panels than CUs: split the feed-forward's hidden columns over 2 or 4 workgroups per panel (needs the scratch of TailArgs)
+    static const int split_env = getenv("CV2_FLOW_TAIL_SPLIT") ? atoi(getenv("CV2_FLOW_TAIL_SPLIT")) : -1;      // A/B switch (diagnostics): 1 / 2 / 4
+    const int panels = M / 16;
+    int S = a.part ? (panels <= 64 ? 4 : (panels <= 128 ? 2 : 1)) : 1;
+    if (split_env > 0 && a.part) S = split_env;
+    if (S == 4) hipLaunchKernelGGL(k_tail_panel<4>, dim3(4, panels, 1), dim3(1024), sm, s, a);
+    else if (S == 2) hipLaunchKernelGGL(k_tail_panel<2>, dim3(2, panels, 1), dim3(1024), sm, s, a);
+    else hipLaunchKernelGGL(k_tail_panel<1>, dim3(1, panels, 1), dim3(1024), sm, s, a);
     CV2_LAUNCH_CHECK();
     return 0;
 }
