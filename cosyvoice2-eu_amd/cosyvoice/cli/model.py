@@ -141,7 +141,7 @@ class CosyVoice2Model:
         self.flow = FlowEngine(flow_sd, self.device, max_utts=B, max_len=2 * (max_prompt + max_new), n_timesteps=cfg.n_timesteps,
                                cfg_rate=cfg.inference_cfg_rate)
         self.flow.pre_lookahead_len, self.flow.token_mel_ratio, self.flow.input_frame_rate = cfg.pre_lookahead_len, cfg.token_mel_ratio, cfg.input_frame_rate
-        self.hift_pool = HiftPool(hift_sd, self.device, max_frames=2 * max_new + self.mel_cache_len, n=min(4, B))
+        self.hift_pool = HiftPool(hift_sd, self.device, max_frames=2 * max_new + self.mel_cache_len, n=min(4, B), batch_lanes=min(8, B))
         self.hift = self.hift_pool.engines[0]
         self.llm.park()                            # no slot is live: decode steps that cover a free slot leave it alone
         torch.cuda.synchronize(self.device)
@@ -164,6 +164,54 @@ class CosyVoice2Model:
                                          finalize=finalize)
         return self._mel2wav(tts_mel, token_offset, uuid, finalize, speed)
 
+    def _chunk_post(self, uuid, cache, tts_mel, tts_speech, tts_source, hift):
+        """model.py:316-324 after the vocoder of a non-final chunk: cross-fade with the cached speech tail, new caches, trim."""
+        if cache is not None:
+            hift.fade_in_out(tts_speech, cache['speech'], self._window_dev)
+        self.hift_cache_dict[uuid] = {'mel': tts_mel[:, :, -self.mel_cache_len:].clone(),
+                                      'source': tts_source[:, :, -self.source_cache_len:].clone(),
+                                      'speech': tts_speech[:, -self.source_cache_len:].clone()}
+        return tts_speech[:, :-self.source_cache_len]
+
+    def _chunks_batched_hift(self, grp, mels):
+        """The non-final chunks of one round through ONE vocoder call per shape (HiftPool.batch_engine: gridDim.z = chunks) on the
+        current stream; returns the list of speech tensors (None where the chunk failed), or None when batching does not apply."""
+        eng = self.hift_pool.batch_engine
+        live = [i for i, m in enumerate(mels) if m is not None]
+        if eng is None or self._noise_hook is not None or self._trace is not None or len(live) < 2:
+            return None
+        cur, pre, out = torch.cuda.current_stream(), {}, [None] * len(grp)
+        for i in live:
+            c, (mel, first) = grp[i], mels[i]
+            assert c.offset * self.flow.token_mel_ratio >= first
+            mel = mel[:, :, c.offset * self.flow.token_mel_ratio - first:]
+            cache = self.hift_cache_dict[c.uuid]
+            cs = None
+            if cache is not None:
+                for t in cache.values():
+                    t.record_stream(cur)
+                mel, cs = torch.concat([cache['mel'], mel], dim=2), cache['source']
+            pre[i] = (cache, mel.contiguous(), cs)
+        shapes = {}
+        for i in live:
+            _, mel, cs = pre[i]
+            shapes.setdefault((mel.shape[2], 0 if cs is None else cs.numel()), []).append(i)
+        for (T, _nc), idx in shapes.items():
+            for j0 in range(0, len(idx), eng.lanes):
+                part = idx[j0:j0 + eng.lanes]
+                try:
+                    if len(part) >= 2 and T <= eng.max_frames:
+                        res = eng.inference_batch([pre[i][1] for i in part], [pre[i][2] for i in part])
+                    else:
+                        res = [self.hift.inference(speech_feat=pre[i][1], cache_source=pre[i][2]) for i in part]
+                    for i, (wav, src) in zip(part, res):
+                        out[i] = self._chunk_post(grp[i].uuid, pre[i][0], pre[i][1], wav, src, self.hift)
+                except Exception as e:
+                    for i in part:
+                        if out[i] is None:
+                            grp[i].exc = e
+        return out
+
     def _mel2wav(self, tts_mel, token_offset, uuid, finalize, speed, hift=None, mel_first=0):
         """model.py:311-334: everything of token2wav after the flow (slice, mel / source / speech caches, HiFT, cross-fade).
         mel_first: index of tts_mel's first frame in the mel flow.inference would have returned (cached chunks hold only the tail)."""
@@ -175,6 +223,8 @@ class CosyVoice2Model:
         tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio - mel_first:]
         cache = self.hift_cache_dict[uuid]
         if cache is not None:
+            for t in cache.values():                                           # (the previous round may have built them on another stream of the pool)
+                t.record_stream(torch.cuda.current_stream())
             tts_mel = torch.concat([cache['mel'], tts_mel], dim=2)
             hift_cache_source = cache['source']
         else:
@@ -187,12 +237,7 @@ class CosyVoice2Model:
             self._trace.append((flow_mel.cpu(), token_offset, finalize, noise, uuid))
         if finalize is False:
             tts_speech, tts_source = hift.inference(speech_feat=tts_mel.contiguous(), cache_source=hift_cache_source, noise=noise)
-            if cache is not None:
-                hift.fade_in_out(tts_speech, cache['speech'], self._window_dev)
-            self.hift_cache_dict[uuid] = {'mel': tts_mel[:, :, -self.mel_cache_len:].clone(),
-                                          'source': tts_source[:, :, -self.source_cache_len:].clone(),
-                                          'speech': tts_speech[:, -self.source_cache_len:].clone()}
-            tts_speech = tts_speech[:, :-self.source_cache_len]
+            tts_speech = self._chunk_post(uuid, cache, tts_mel, tts_speech, tts_source, hift)
         else:
             if speed != 1.0:
                 assert cache is None, 'speed change only support non-stream inference mode'
@@ -297,6 +342,12 @@ class CosyVoice2Model:
                 # to at its first chunk: the per-uuid caches are then allocated, read and freed on ONE stream (a cache block freed on
                 # stream A while stream B still reads it could be handed out again by the caching allocator), joined before anything is read
                 pool, main, sp = self.hift_pool, torch.cuda.current_stream(), []
+                batched = self._chunks_batched_hift(grp, mels) if (key[0] and not key[1]) else None
+                if batched is not None:                                        # one vocoder call per chunk shape instead of one per chunk
+                    for c, w in zip(grp, batched):
+                        if w is not None:
+                            c.speech = w.cpu()
+                    continue
                 used = sorted({self._hift_pin.setdefault(c.uuid, self._next_pin()) for c in grp})
                 for k in used:
                     pool.streams[k].wait_stream(main)

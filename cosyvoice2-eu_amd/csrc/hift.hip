@@ -42,6 +42,7 @@ struct ConvArgs {
     float* out; int ldo; long out_off;      // out[(t) * ldo + out_off + co]
     const float* res; int ldres;
     int post, acc;
+    long zs;                                // batched chunks (cv2_hift_inference_batch): lane blockIdx.z works zs floats further into the workspace
 };
 
 #define CV_BT 128
@@ -57,6 +58,7 @@ __device__ __forceinline__ float pre_apply(float v, int pre, float al, float slo
 
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    { const size_t zo = (size_t)blockIdx.z * a.zs; a.x += zo; a.out += zo; if (a.res) a.res += zo; }
     float* xs = reinterpret_cast<float*>(smem);                     // [rows][CV_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx_, by_;
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 // (split3t / pack_hi: common.h)
 __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    { const size_t zo = (size_t)blockIdx.z * a.zs; a.x += zo; a.out += zo; if (a.res) a.res += zo; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx_, by_;
     xcd_tile_yfast(bx_, by_);                                       // the output-channel tiles of one frame tile read the same input rows: one L2
@@ -292,8 +295,9 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
 }
 
 // source_downs: Conv1d(18 -> C, k, stride, pad) over s_stft [F][18] (generator.py:468-479); tiny, direct
-struct SdArgs { const float* x; int F; const float* w; const float* b; int C, k, stride, pad; float* out; int L_out; };
+struct SdArgs { const float* x; int F; const float* w; const float* b; int C, k, stride, pad; float* out; int L_out; long zs; };
 __global__ __launch_bounds__(256) void k_source_down(SdArgs a) {
+    a.x += (size_t)blockIdx.z * a.zs; a.out += (size_t)blockIdx.z * a.zs;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)a.L_out * a.C) return;
     const int t = idx / a.C, co = idx % a.C;
@@ -310,7 +314,8 @@ __global__ __launch_bounds__(256) void k_source_down(SdArgs a) {
 }
 
 // mel [80][T] channel-major -> [T][80]
-__global__ void k_mel_tm(const float* mel, float* out, int T) {
+__global__ void k_mel_tm(const float* mel, float* out, int T, long zs) {
+    mel += (size_t)blockIdx.z * zs; out += (size_t)blockIdx.z * zs;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= T * 80) return;
     const int t = idx / 80, c = idx % 80;
@@ -318,7 +323,8 @@ __global__ void k_mel_tm(const float* mel, float* out, int T) {
 }
 
 // f0 = |Linear(512 -> 1)| (f0_predictor.py:57-58): one wave per frame
-__global__ __launch_bounds__(256) void k_f0_head(const float* x, const float* w, const float* b, float* f0, int T) {
+__global__ __launch_bounds__(256) void k_f0_head(const float* x, const float* w, const float* b, float* f0, int T, long zs) {
+    x += (size_t)blockIdx.z * zs; f0 += (size_t)blockIdx.z * zs;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= T) return;
     float acc = 0.f;
@@ -331,7 +337,8 @@ __global__ __launch_bounds__(256) void k_f0_head(const float* x, const float* w,
 //   rad_h[i] = (f0[i] * h / 24000) % 1     (the 1/480 linear down-interpolation of the nearest-upsampled signal returns
 //   exactly the frame value: both taps, samples 480 i + 239 and + 240, lie inside frame i, so rand_ini at sample 0 never matters)
 //   phase = cumsum(rad) (float64 accumulate like torch's CPU cumsum) -> fp32 -> * 2 pi -> * 480
-__global__ void k_phase(const float* f0, float* phase, int T) {
+__global__ void k_phase(const float* f0, float* phase, int T, long zs) {
+    f0 += (size_t)blockIdx.z * zs; phase += (size_t)blockIdx.z * zs;
     const int h = threadIdx.x;            // 9 threads
     if (h >= 9) return;
     double acc = 0.0;
@@ -370,8 +377,15 @@ struct SrcArgs {
     const float* lw; const float* lb;    // m_source.l_linear
     const float* cache; int n_cache;     // cache_source overwrite (generator.py:579-580)
     float* s;                            // [480 T]
+    long zs;
 };
 __global__ __launch_bounds__(256) void k_source(SrcArgs a) {
+    {
+        const size_t zo = (size_t)blockIdx.z * a.zs;
+        a.f0 += zo; a.phase += zo; a.s += zo;
+        if (a.cache) a.cache += zo;
+        if (a.seed_dev) a.seed_dev = reinterpret_cast<const uint32_t*>(reinterpret_cast<const float*>(a.seed_dev) + zo);
+    }
     const long n = (long)blockIdx.x * 256 + threadIdx.x;
     const long Ls = (long)a.T * 480;
     if (n >= Ls) return;
@@ -411,7 +425,8 @@ __global__ __launch_bounds__(256) void k_source(SrcArgs a) {
 }
 
 // STFT n_fft 16 / hop 4 / periodic hann / center reflect (generator.py:504-510): s [L] -> [L/4 + 1][18] (9 real, 9 imag)
-__global__ __launch_bounds__(256) void k_stft(const float* s, int L, float* out, int F) {
+__global__ __launch_bounds__(256) void k_stft(const float* s, int L, float* out, int F, long zs) {
+    s += (size_t)blockIdx.z * zs; out += (size_t)blockIdx.z * zs;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)F * 9) return;
     const int f = idx / 9, k = idx % 9;
@@ -431,7 +446,8 @@ __global__ __launch_bounds__(256) void k_stft(const float* s, int L, float* out,
 }
 
 // conv_post output [F][18] -> magnitude / phase (generator.py:546-548) -> inverse rFFT(16) * window: frames [F][16]
-__global__ __launch_bounds__(256) void k_istft_frames(const float* x, int F, float* fr) {
+__global__ __launch_bounds__(256) void k_istft_frames(const float* x, int F, float* fr, long zs) {
+    x += (size_t)blockIdx.z * zs; fr += (size_t)blockIdx.z * zs;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)F * 16) return;
     const int f = idx / 16, n = idx % 16;
@@ -450,7 +466,8 @@ __global__ __launch_bounds__(256) void k_istft_frames(const float* x, int F, flo
     fr[idx] = acc * (1.0f / 16.0f) * w;
 }
 // overlap-add / window envelope, trim n_fft/2, clamp (generator.py:517-518, :551)
-__global__ __launch_bounds__(256) void k_istft_ola(const float* fr, int F, float* wav, int L, float limit) {
+__global__ __launch_bounds__(256) void k_istft_ola(const float* fr, int F, float* wav, int L, float limit, long zs) {
+    fr += (size_t)blockIdx.z * zs; wav += (size_t)blockIdx.z * zs;
     const long n = (long)blockIdx.x * 256 + threadIdx.x;
     if (n >= L) return;
     const long p = n + 8;                                          // position in the un-trimmed signal
@@ -466,12 +483,16 @@ __global__ __launch_bounds__(256) void k_istft_ola(const float* fr, int F, float
     wav[n] = fminf(fmaxf(v, -limit), limit);
 }
 // ReflectionPad1d((1, 0)) after the last upsample (generator.py:529-530): row 0 := row 2 of the shifted signal
-__global__ void k_reflect_row0(float* x, int C) {
+__global__ void k_reflect_row0(float* x, int C, long zs) {
+    x += (size_t)blockIdx.z * zs;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) x[c] = x[2 * C + c];
 }
 
 // =========================================================================== host
+// lanes of the launch being issued (cv2_hift_inference_batch: gridDim.z chunks, each zs floats further into the workspace); set by hift_run
+static thread_local int g_hz_n = 1;
+static thread_local long g_hz_zs = 0;
 struct cv2_hift {
     cv2_hift_dims d;
     cv2_hift_weights w;
@@ -482,6 +503,7 @@ struct cv2_hift {
     float *g_mel, *g_cs, *g_wav, *g_src; uint32_t* g_seed;
     std::map<long, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
+    long lane_floats = 0;      // workspace floats of one lane (d.lanes lanes behind one another: lane z's buffers = lane 0's + z * lane_floats)
 };
 #define HG_MAX_T 160          // longest call that goes through a graph (frames)
 #define HG_MAX_GRAPHS 24
@@ -505,7 +527,7 @@ static size_t hift_carve(const cv2_hift_dims& d, cv2_hift* h, char* base) {
     f.g_seed = reinterpret_cast<uint32_t*>(c.take(64));
     return c.off;
 }
-extern "C" size_t cv2_hift_workspace_bytes(const cv2_hift_dims* d) { return hift_carve(*d, nullptr, nullptr); }
+extern "C" size_t cv2_hift_workspace_bytes(const cv2_hift_dims* d) { return hift_carve(*d, nullptr, nullptr) * (size_t)(d->lanes > 1 ? d->lanes : 1); }
 
 extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w, void* ws, size_t ws_bytes, cv2_hift** out) {
     CV2_CHECK(d && w && ws && out, "cv2_hift_create: null argument");
@@ -513,7 +535,7 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
     CV2_CHECK(ws_bytes >= cv2_hift_workspace_bytes(d), "cv2_hift_create: workspace too small");
     cv2_hift* h = new cv2_hift();
     h->d = *d; h->w = *w;
-    hift_carve(*d, h, (char*)ws);
+    h->lane_floats = (long)(hift_carve(*d, h, (char*)ws) / 4);
     static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
     if (!once) {
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -542,17 +564,18 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
     a.x = x; a.L_in = L_in; a.Cin = cw.cin; a.wp = cw.w; a.bias = cw.b; a.CinP = cw.cin_pad; a.CoutP = cw.cout_pad;
     a.Cout_store = cw.cout; a.taps = cw.taps; a.dil = cw.dil; a.pad_left = cw.pad_left; a.pre = pre; a.alpha = alpha; a.slope = slope;
     a.L_out = L_out; a.out = out; a.ldo = ldo; a.out_off = out_off; a.res = res; a.ldres = ldres; a.post = post; a.acc = acc;
+    a.zs = g_hz_zs;
     CV2_CHECK(cw.cin_pad % 64 == 0 && cw.cout_pad % 64 == 0 && cw.w, "hift conv: bad packed weight (cin_pad %d cout_pad %d)", cw.cin_pad, cw.cout_pad);
     static const bool fp32_only = getenv("CV2_HIFT_FP32") && getenv("CV2_HIFT_FP32")[0] == '1';      // A/B switch: the fp32 matrix-core kernel everywhere
     if (cw.w3 && !fp32_only) {
         a.w3 = cw.w3;
         const size_t sm = (size_t)(CV_BT + (cw.taps - 1) * cw.dil) * C6_LD * 2 * 3;
-        hipLaunchKernelGGL(k_conv6, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64), dim3(256), sm, s, a);
+        hipLaunchKernelGGL(k_conv6, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
         CV2_LAUNCH_CHECK();
         return 0;
     }
     const size_t sm = (size_t)(CV_BT + (cw.taps - 1) * cw.dil) * CV_LD * 4;
-    hipLaunchKernelGGL(k_conv, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64), dim3(256), sm, s, a);
+    hipLaunchKernelGGL(k_conv, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
     CV2_LAUNCH_CHECK();
     return 0;
 }
@@ -579,6 +602,7 @@ extern "C" int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, cons
     CV2_CHECK(T >= 2 && T <= h->d.max_frames, "cv2_hift_inference: T=%d out of range (max %d)", T, h->d.max_frames);
     CV2_CHECK(n_cache >= 0 && n_cache <= 480 * T && (n_cache == 0 || cache_source), "cv2_hift_inference: bad cache_source");
     hipStream_t s = (hipStream_t)stream;
+    g_hz_n = 1; g_hz_zs = 0;
     static const bool graphs_off = getenv("CV2_HIFT_GRAPH") && getenv("CV2_HIFT_GRAPH")[0] == '0';
     if (noise || T > HG_MAX_T || graphs_off || !h->cap_stream) return hift_run(h, mel, T, cache_source, n_cache, noise, seed, nullptr, wav, source, s);
     // ---- graph path
@@ -610,11 +634,59 @@ extern "C" int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, cons
     return 0;
 }
 
+// n chunks of the SAME shape (T frames, n_cache cached source samples) as ONE set of launches: every kernel runs with gridDim.z = n, lane z
+// on its own copy of the workspace.  The streaming scheduler's rounds hold one chunk per stream, all of one shape; as separate calls they
+// are 8 x 330 small launches on four HIP streams (17 ms per round of 8), 31 % of a round's kernel time.
+extern "C" int cv2_hift_inference_batch(cv2_hift* h, int32_t n, const float* const* mel, int32_t T, const float* const* cache_source, int32_t n_cache,
+                                        const uint64_t* seeds, float* const* wav, float* const* source, void* stream) {
+    CV2_CHECK(h && mel && seeds && wav && source, "cv2_hift_inference_batch: null argument");
+    CV2_CHECK(n >= 1 && n <= (h->d.lanes > 1 ? h->d.lanes : 1), "cv2_hift_inference_batch: %d chunks, engine has %d lanes", n, h->d.lanes > 1 ? h->d.lanes : 1);
+    CV2_CHECK(T >= 2 && T <= h->d.max_frames && T <= HG_MAX_T, "cv2_hift_inference_batch: T=%d out of range (max %d)", T, h->d.max_frames < HG_MAX_T ? h->d.max_frames : HG_MAX_T);
+    CV2_CHECK(n_cache >= 0 && n_cache <= 480 * T && (n_cache == 0 || cache_source), "cv2_hift_inference_batch: bad cache_source");
+    CV2_CHECK(h->cap_stream, "cv2_hift_inference_batch: the engine has no capture stream");
+    hipStream_t s = (hipStream_t)stream;
+    const long zs = h->lane_floats;
+    const long key = ((long)T << 32) | ((long)n_cache << 8) | (long)n | (1l << 62);
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        if ((int)h->graphs.size() >= HG_MAX_GRAPHS) {
+            (void)hipGraphExecDestroy(h->graphs.begin()->second);
+            h->graphs.erase(h->graphs.begin());
+        }
+        hipGraph_t g;
+        CV2_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        g_hz_n = n; g_hz_zs = zs;
+        const int rc = hift_run(h, h->g_mel, T, n_cache ? h->g_cs : nullptr, n_cache, nullptr, 0, h->g_seed, h->g_wav, h->g_src, h->cap_stream);
+        g_hz_n = 1; g_hz_zs = 0;
+        const hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+        if (rc) return rc;
+        CV2_HIP(e);
+        hipGraphExec_t ge;
+        CV2_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CV2_HIP(hipGraphDestroy(g));
+        it = h->graphs.emplace(key, ge).first;
+    }
+    for (int z = 0; z < n; z++) {
+        CV2_CHECK(mel[z] && wav[z] && source[z] && (n_cache == 0 || cache_source[z]), "cv2_hift_inference_batch: null pointer for chunk %d", z);
+        CV2_HIP(hipMemcpyAsync(h->g_mel + z * zs, mel[z], (size_t)T * 80 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (n_cache) CV2_HIP(hipMemcpyAsync(h->g_cs + z * zs, cache_source[z], (size_t)n_cache * sizeof(float), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_set_seed, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t*>(reinterpret_cast<float*>(h->g_seed) + z * zs), (uint32_t)seeds[z], (uint32_t)(seeds[z] >> 32));
+    }
+    CV2_HIP(hipGraphLaunch(it->second, s));
+    for (int z = 0; z < n; z++) {
+        CV2_HIP(hipMemcpyAsync(wav[z], h->g_wav + z * zs, (size_t)480 * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+        CV2_HIP(hipMemcpyAsync(source[z], h->g_src + z * zs, (size_t)480 * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
 static int hift_run(cv2_hift* h, const float* mel, int32_t T, const float* cache_source, int32_t n_cache, const float* noise, uint64_t seed,
                     const uint32_t* seed_dev, float* wav, float* source, hipStream_t s) {
     const cv2_hift_weights& w = h->w;
     const int Ls = 480 * T, F = Ls / 4 + 1;
-    hipLaunchKernelGGL(k_mel_tm, dim3((T * 80 + 255) / 256), dim3(256), 0, s, mel, h->melT, (int)T);
+    const int Z = g_hz_n; const long zs = g_hz_zs;
+    hipLaunchKernelGGL(k_mel_tm, dim3((T * 80 + 255) / 256, 1, Z), dim3(256), 0, s, mel, h->melT, (int)T, zs);
     // f0 predictor: 5 x (conv k3 + ELU), Linear, abs
     {
         const float* in = h->melT; float* bufs[2] = {h->f0a, h->f0b};
@@ -622,15 +694,15 @@ static int hift_run(cv2_hift* h, const float* mel, int32_t T, const float* cache
             if (conv_launch(w.f0_conv[i], in, T, bufs[i & 1], 512, 0, T, PRE_NONE, nullptr, 0.f, nullptr, 0, POST_ELU, ACC_STORE, s)) return -1;
             in = bufs[i & 1];
         }
-        hipLaunchKernelGGL(k_f0_head, dim3((T + 3) / 4), dim3(256), 0, s, in, w.f0_w, w.f0_b, h->f0, (int)T);
+        hipLaunchKernelGGL(k_f0_head, dim3((T + 3) / 4, 1, Z), dim3(256), 0, s, in, w.f0_w, w.f0_b, h->f0, (int)T, zs);
     }
     // source
-    hipLaunchKernelGGL(k_phase, dim3(1), dim3(64), 0, s, (const float*)h->f0, h->phase, (int)T);
+    hipLaunchKernelGGL(k_phase, dim3(1, 1, Z), dim3(64), 0, s, (const float*)h->f0, h->phase, (int)T, zs);
     {
-        SrcArgs a{h->f0, h->phase, T, noise, (uint32_t)seed, (uint32_t)(seed >> 32), seed_dev, w.src_w, w.src_b, cache_source, n_cache, source};
-        hipLaunchKernelGGL(k_source, dim3((Ls + 255) / 256), dim3(256), 0, s, a);
+        SrcArgs a{h->f0, h->phase, T, noise, (uint32_t)seed, (uint32_t)(seed >> 32), seed_dev, w.src_w, w.src_b, cache_source, n_cache, source, zs};
+        hipLaunchKernelGGL(k_source, dim3((Ls + 255) / 256, 1, Z), dim3(256), 0, s, a);
     }
-    hipLaunchKernelGGL(k_stft, dim3(((long)F * 9 + 255) / 256), dim3(256), 0, s, (const float*)source, Ls, h->sstft, F);
+    hipLaunchKernelGGL(k_stft, dim3(((long)F * 9 + 255) / 256, 1, Z), dim3(256), 0, s, (const float*)source, Ls, h->sstft, F, zs);
     // decode
     if (conv_launch(w.conv_pre, h->melT, T, h->xpre, 512, 0, T, PRE_NONE, nullptr, 0.f, nullptr, 0, POST_NONE, ACC_STORE, s)) return -1;
     const int ups_u[3] = {8, 5, 3}, chans[4] = {512, 256, 128, 64};
@@ -643,12 +715,12 @@ static int hift_run(cv2_hift* h, const float* mel, int32_t T, const float* cache
         // leaky_relu(0.1) -> ConvTranspose1d as a polyphase conv: output [Lin][u*C] == [L][C]
         const long shift = i == 2 ? C : 0;                                            // reflect pad: frame t lands on row t+1
         if (conv_launch(w.ups[i], xin, Lin, h->x, u * C, shift, Lin, PRE_LRELU, nullptr, 0.1f, nullptr, 0, POST_NONE, ACC_STORE, s)) return -1;
-        if (i == 2) { hipLaunchKernelGGL(k_reflect_row0, dim3(1), dim3(256), 0, s, h->x, C); L += 1; }
+        if (i == 2) { hipLaunchKernelGGL(k_reflect_row0, dim3(1, 1, Z), dim3(256), 0, s, h->x, C, zs); L += 1; }
         // source branch: source_down -> source_resblock, added into x
         {
             CV2_CHECK((F + 2 * sd_p[i] - sd_k[i]) / sd_s[i] + 1 == L, "hift: source_down length %d != %d", (F + 2 * sd_p[i] - sd_k[i]) / sd_s[i] + 1, L);
-            SdArgs a{h->sstft, F, w.sd_w[i], w.sd_b[i], C, sd_k[i], sd_s[i], sd_p[i], h->sd, L};
-            hipLaunchKernelGGL(k_source_down, dim3(((long)L * C + 255) / 256), dim3(256), 0, s, a);
+            SdArgs a{h->sstft, F, w.sd_w[i], w.sd_b[i], C, sd_k[i], sd_s[i], sd_p[i], h->sd, L, zs};
+            hipLaunchKernelGGL(k_source_down, dim3(((long)L * C + 255) / 256, 1, Z), dim3(256), 0, s, a);
             if (resblock(h, w.src_rb[i], h->sd, L, C, h->x, ACC_ADD, s)) return -1;
         }
         // MRF: mean of 3 ResBlocks
@@ -659,8 +731,8 @@ static int hift_run(cv2_hift* h, const float* mel, int32_t T, const float* cache
     }
     // leaky_relu(0.01) -> conv_post -> exp / sin -> iSTFT -> clamp
     if (conv_launch(w.conv_post, xin, Lin, h->post, 18, 0, Lin, PRE_LRELU, nullptr, 0.01f, nullptr, 0, POST_NONE, ACC_STORE, s)) return -1;
-    hipLaunchKernelGGL(k_istft_frames, dim3(((long)F * 16 + 255) / 256), dim3(256), 0, s, (const float*)h->post, F, h->frames);
-    hipLaunchKernelGGL(k_istft_ola, dim3((Ls + 255) / 256), dim3(256), 0, s, (const float*)h->frames, F, wav, Ls, 0.99f);
+    hipLaunchKernelGGL(k_istft_frames, dim3(((long)F * 16 + 255) / 256, 1, Z), dim3(256), 0, s, (const float*)h->post, F, h->frames, zs);
+    hipLaunchKernelGGL(k_istft_ola, dim3((Ls + 255) / 256, 1, Z), dim3(256), 0, s, (const float*)h->frames, F, wav, Ls, 0.99f, zs);
     CV2_LAUNCH_CHECK();
     return 0;
 }

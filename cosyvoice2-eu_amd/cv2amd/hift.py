@@ -29,7 +29,7 @@ class HiftWeights(C.Structure):
 
 
 class HiftDims(C.Structure):
-    _fields_ = [('max_frames', C.c_int32)]
+    _fields_ = [('max_frames', C.c_int32), ('lanes', C.c_int32)]
 
 
 def _bind(lib):
@@ -42,6 +42,8 @@ def _bind(lib):
     lib.cv2_hift_inference.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cv2_fade_in_out.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.cv2_hift_inference_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]
     lib.cv2_interp_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib._hift_bound = True
 
@@ -99,7 +101,7 @@ def polyphase(wt, u, pad):
 
 
 class HiftEngine:
-    def __init__(self, sd, device='cuda:0', max_frames=2048, share_weights_with=None, split_products=True):
+    def __init__(self, sd, device='cuda:0', max_frames=2048, share_weights_with=None, split_products=True, lanes=1):
         """share_weights_with: another HiftEngine whose packed weights are reused (several engines = several workspaces, so
         independent utterances can run on different HIP streams at once).  split_products=False: every convolution on the fp32
         matrix cores (k_conv) instead of the three-plane bf16 products (k_conv6); the reference path of the A/B test."""
@@ -142,7 +144,8 @@ class HiftEngine:
         else:
             w = self._pack(sd, conv, resblock, f32)
         self._w = w
-        self.dims = HiftDims(max_frames=max_frames)
+        self.dims = HiftDims(max_frames=max_frames, lanes=lanes)
+        self.lanes = lanes
         self.max_frames = max_frames
         nbytes = self.lib.cv2_hift_workspace_bytes(C.byref(self.dims))
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -213,6 +216,32 @@ class HiftEngine:
         L.check(self.lib.cv2_interp_linear(L.ptr(mel), L.ptr(out), mel.shape[0] * mel.shape[1], n_in, n_out, L.stream_ptr()))
         return out
 
+    def inference_batch(self, mels, cache_sources, seeds=None):
+        """n <= lanes chunks of one shape as ONE set of launches (cv2_hift_inference_batch): mels = list of [1,80,T] fp32 device tensors,
+        cache_sources = list of [1,1,k] tensors (all the same k, or all None / empty).  Returns a list of (wav [1,480T], source [1,1,480T]);
+        equal to n inference() calls with the same seeds."""
+        n, dev = len(mels), self.device
+        assert 1 <= n <= self.lanes
+        ms = [m.to(dev, torch.float32).contiguous() for m in mels]
+        T = ms[0].shape[2]
+        assert all(m.shape == (1, 80, T) for m in ms)
+        cs = [None if (c is None or c.numel() == 0) else c.to(dev, torch.float32).contiguous() for c in cache_sources]
+        nc = 0 if cs[0] is None else cs[0].numel()
+        assert all((0 if c is None else c.numel()) == nc for c in cs)
+        if seeds is None:
+            seeds = [self._seed_fn() if self._seed_fn is not None else self._next_own_seed() for _ in range(n)]
+        wav = [torch.empty(1, 480 * T, dtype=torch.float32, device=dev) for _ in range(n)]
+        src = [torch.empty(1, 1, 480 * T, dtype=torch.float32, device=dev) for _ in range(n)]
+        P = C.c_void_p * n
+        L.check(self.lib.cv2_hift_inference_batch(self.handle, n, P(*[m.data_ptr() for m in ms]), T, P(*[0 if c is None else c.data_ptr() for c in cs]), nc,
+                                                  (C.c_uint64 * n)(*seeds), P(*[w.data_ptr() for w in wav]), P(*[s_.data_ptr() for s_ in src]),
+                                                  L.stream_ptr()))
+        return list(zip(wav, src))
+
+    def _next_own_seed(self):
+        self.seed += 1
+        return self.seed
+
     def fade_in_out(self, fade_in, fade_out_tail, window):
         """utils/common.py:142-150, on the device and in place: fade_in [1,n], fade_out_tail [1,w], window [2w]."""
         w = window.numel() // 2
@@ -224,17 +253,19 @@ class HiftPool:
     """Several HiftEngines (shared weights, own workspaces) on their own HIP streams: independent utterances of a batch run
     concurrently, which fills the chip where a single utterance's early conv stages launch fewer blocks than there are CUs."""
 
-    def __init__(self, sd, device='cuda:0', max_frames=2048, n=4):
+    def __init__(self, sd, device='cuda:0', max_frames=2048, n=4, batch_lanes=0):
         self.engines = [HiftEngine(sd, device, max_frames)]
         for _ in range(1, n):
             self.engines.append(HiftEngine(sd, device, max_frames, share_weights_with=self.engines[0]))
         self.streams = [torch.cuda.Stream(device) for _ in self.engines]
+        # the chunks of a streaming round (one per stream, one shape) run as ONE set of launches on an engine with a workspace lane per chunk
+        self.batch_engine = HiftEngine(sd, device, min(max_frames, 160), share_weights_with=self.engines[0], lanes=batch_lanes) if batch_lanes > 1 else None
         self._seed = 0
         self._seed_lock = threading.Lock()
         # one Philox seed counter for the whole pool, salted with the rank: concurrent streams served by different engines, other
         # model instances' pools on other ranks, never replay each other's noise (the reference draws from the device RNG)
         self._salt = (int(os.environ.get('RANK', '0')) + 1) << 40
-        for e in self.engines:
+        for e in self.engines + ([self.batch_engine] if self.batch_engine is not None else []):
             e._seed_fn = self.next_seed
 
     def next_seed(self):

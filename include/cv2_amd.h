@@ -317,7 +317,7 @@ typedef struct {
     cv2_resblock rb[9];
     cv2_conv conv_post;
 } cv2_hift_weights;
-typedef struct { int32_t max_frames; } cv2_hift_dims;   /* longest mel in frames */
+typedef struct { int32_t max_frames; int32_t lanes; } cv2_hift_dims;   /* longest mel in frames; lanes > 1: workspace copies for cv2_hift_inference_batch */
 
 size_t cv2_hift_workspace_bytes(const cv2_hift_dims* d);
 int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w, void* workspace, size_t workspace_bytes, cv2_hift** out);
@@ -327,6 +327,11 @@ int cv2_hift_destroy(cv2_hift* h);
  * to draw them on the device from Philox(seed); wav fp32 [480 T]; source fp32 [480 T]. */
 int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, const float* cache_source, int32_t n_cache,
                        const float* noise, uint64_t seed, float* wav, float* source, void* stream);
+/* n <= lanes chunks of ONE shape (T <= 160 frames, n_cache cached source samples each) as one set of launches (gridDim.z = n): the
+ * chunks of a streaming round (cli/model.py:351-381 x the concurrent streams).  Arrays of n device pointers / seeds on the host; the
+ * results equal n cv2_hift_inference calls with the same seeds. */
+int cv2_hift_inference_batch(cv2_hift* h, int32_t n, const float* const* mel, int32_t T, const float* const* cache_source, int32_t n_cache,
+                             const uint64_t* seeds, float* const* wav, float* const* source, void* stream);
 
 /* fade_in_out (cosyvoice/utils/common.py:142-150): new[:w] = new[:w] * win[:w] + old[-w:] * win[w:], in place on `fade_in`;
  * win fp32 [2w] (np.hamming(2w)), old_tail points at the last w samples of the previous chunk. */

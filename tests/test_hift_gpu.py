@@ -116,6 +116,26 @@ def test_speed_change_matches_torch_linear_interpolation(eng, dev, T, speed):
     assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
 
 
+@pytest.mark.parametrize('T,n_cache', [(58, 3840), (100, 0), (33, 480)])
+def test_batched_chunks_equal_single_calls(dev, hift_sd, T, n_cache):
+    """cv2_hift_inference_batch: the chunks of a streaming round (one per stream, one shape; cli/model.py:351-381 x the concurrent streams)
+    as ONE set of launches with gridDim.z = chunks, each on its own lane of the workspace.  With the same seeds the waveforms and
+    sources equal the single calls bit for bit."""
+    from cv2amd.hift import HiftEngine
+    one = HiftEngine(hift_sd, dev, max_frames=160)
+    many = HiftEngine(hift_sd, dev, max_frames=160, share_weights_with=one, lanes=5)
+    g = torch.Generator().manual_seed(T)
+    mels = [(torch.randn(1, 80, T, generator=g) * 0.6).to(dev) for _ in range(5)]
+    caches = [(torch.rand(1, 1, n_cache, generator=g) * 0.02 - 0.01).to(dev) if n_cache else None for _ in range(5)]
+    seeds = [1000 + 7 * i for i in range(5)]
+    want = [one.inference(m, c, seed=s) for m, c, s in zip(mels, caches, seeds)]
+    for n in (5, 2):
+        got = many.inference_batch(mels[:n], caches[:n], seeds[:n])
+        for (w0, s0), (w1, s1) in zip(want[:n], got):
+            assert torch.equal(w0, w1) and torch.equal(s0, s1)
+    assert float(want[0][0].abs().max()) > 1e-3 and not torch.equal(want[0][0], want[1][0])
+
+
 def test_decoder_at_real_checkpoint_ranges(dev):
     """the device Snake uses __sinf, ELU / exp use __expf; on unit-variance synthetic weights their arguments stay
     small.  Here the checkpoint is pushed to the ranges a trained HiFT reaches: Snake alpha log-uniform in [0.05, 20] (a trained
