@@ -502,8 +502,15 @@ struct cv2_hift {
     // (frames, cache length) over engine-owned staging buffers; the caller's tensors are copied in / out around the replay.
     float *g_mel, *g_cs, *g_wav, *g_src; uint32_t* g_seed;
     std::map<long, hipGraphExec_t> graphs;
-    hipStream_t cap_stream = nullptr;
     long lane_floats = 0;      // workspace floats of one lane (d.lanes lanes behind one another: lane z's buffers = lane 0's + z * lane_floats)
+};
+// The stream a graph is captured on lives only for the capture: every persistent HIP stream of the process takes a share of the few
+// hardware queues, and one more idle stream per engine changed which of the scheduler's streams share a queue (one extra engine in the
+// pool: 8 streaming calls 89 -> 74 audio-s/s, tools/bench_streams.py).
+struct CapStream {
+    hipStream_t s = nullptr;
+    CapStream() { if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr; }
+    ~CapStream() { if (s) (void)hipStreamDestroy(s); }
 };
 #define HG_MAX_T 160          // longest call that goes through a graph (frames)
 #define HG_MAX_GRAPHS 24
@@ -542,14 +549,12 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
-    if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) h->cap_stream = nullptr;      // no graphs then
     *out = h;
     return 0;
 }
 extern "C" int cv2_hift_destroy(cv2_hift* h) {
     if (!h) return 0;
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.second);
-    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     delete h;
     return 0;
 }
@@ -604,7 +609,7 @@ extern "C" int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, cons
     hipStream_t s = (hipStream_t)stream;
     g_hz_n = 1; g_hz_zs = 0;
     static const bool graphs_off = getenv("CV2_HIFT_GRAPH") && getenv("CV2_HIFT_GRAPH")[0] == '0';
-    if (noise || T > HG_MAX_T || graphs_off || !h->cap_stream) return hift_run(h, mel, T, cache_source, n_cache, noise, seed, nullptr, wav, source, s);
+    if (noise || T > HG_MAX_T || graphs_off) return hift_run(h, mel, T, cache_source, n_cache, noise, seed, nullptr, wav, source, s);
     // ---- graph path
     const long key = ((long)T << 32) | (long)n_cache;
     auto it = h->graphs.find(key);
@@ -614,9 +619,11 @@ extern "C" int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, cons
             h->graphs.erase(h->graphs.begin());
         }
         hipGraph_t g;
-        CV2_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        const int rc = hift_run(h, h->g_mel, T, n_cache ? h->g_cs : nullptr, n_cache, nullptr, 0, h->g_seed, h->g_wav, h->g_src, h->cap_stream);
-        const hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+        CapStream cap;
+        if (!cap.s) return hift_run(h, mel, T, cache_source, n_cache, noise, seed, nullptr, wav, source, s);
+        CV2_HIP(hipStreamBeginCapture(cap.s, hipStreamCaptureModeThreadLocal));
+        const int rc = hift_run(h, h->g_mel, T, n_cache ? h->g_cs : nullptr, n_cache, nullptr, 0, h->g_seed, h->g_wav, h->g_src, cap.s);
+        const hipError_t e = hipStreamEndCapture(cap.s, &g);
         if (rc) return rc;
         CV2_HIP(e);
         hipGraphExec_t ge;
@@ -643,7 +650,6 @@ extern "C" int cv2_hift_inference_batch(cv2_hift* h, int32_t n, const float* con
     CV2_CHECK(n >= 1 && n <= (h->d.lanes > 1 ? h->d.lanes : 1), "cv2_hift_inference_batch: %d chunks, engine has %d lanes", n, h->d.lanes > 1 ? h->d.lanes : 1);
     CV2_CHECK(T >= 2 && T <= h->d.max_frames && T <= HG_MAX_T, "cv2_hift_inference_batch: T=%d out of range (max %d)", T, h->d.max_frames < HG_MAX_T ? h->d.max_frames : HG_MAX_T);
     CV2_CHECK(n_cache >= 0 && n_cache <= 480 * T && (n_cache == 0 || cache_source), "cv2_hift_inference_batch: bad cache_source");
-    CV2_CHECK(h->cap_stream, "cv2_hift_inference_batch: the engine has no capture stream");
     hipStream_t s = (hipStream_t)stream;
     const long zs = h->lane_floats;
     const long key = ((long)T << 32) | ((long)n_cache << 8) | (long)n | (1l << 62);
@@ -654,11 +660,13 @@ extern "C" int cv2_hift_inference_batch(cv2_hift* h, int32_t n, const float* con
             h->graphs.erase(h->graphs.begin());
         }
         hipGraph_t g;
-        CV2_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        CapStream cap;
+        CV2_CHECK(cap.s, "cv2_hift_inference_batch: no stream to capture on");
+        CV2_HIP(hipStreamBeginCapture(cap.s, hipStreamCaptureModeThreadLocal));
         g_hz_n = n; g_hz_zs = zs;
-        const int rc = hift_run(h, h->g_mel, T, n_cache ? h->g_cs : nullptr, n_cache, nullptr, 0, h->g_seed, h->g_wav, h->g_src, h->cap_stream);
+        const int rc = hift_run(h, h->g_mel, T, n_cache ? h->g_cs : nullptr, n_cache, nullptr, 0, h->g_seed, h->g_wav, h->g_src, cap.s);
         g_hz_n = 1; g_hz_zs = 0;
-        const hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+        const hipError_t e = hipStreamEndCapture(cap.s, &g);
         if (rc) return rc;
         CV2_HIP(e);
         hipGraphExec_t ge;
