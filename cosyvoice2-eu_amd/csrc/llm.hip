@@ -1713,8 +1713,11 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
     h->keys_per_split = AT_KB;
     while ((d->max_pos + h->keys_per_split - 1) / h->keys_per_split > SK_MAXSPLIT) h->keys_per_split *= 2;
     h->nsplit = (d->max_pos + h->keys_per_split - 1) / h->keys_per_split;
+    // the stream the decode graphs are captured on lives only for a capture unless CV2_LLM_CAP_PERSIST=1 (A/B switch): an idle persistent
+    // stream takes a share of the process's few hardware queues and changes which of the scheduler's streams share one (hift.hip: CapStream)
     h->cap_stream = nullptr;
-    if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (getenv("CV2_LLM_CAP_PERSIST") && getenv("CV2_LLM_CAP_PERSIST")[0] == '1' &&
+        hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return cv2_fail("cv2_llm_create: hipStreamCreateWithFlags failed");
     }
@@ -1735,7 +1738,7 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
         if (hipMemset((char*)ws + h->chain_off, 0, h->chain_bytes) != hipSuccess ||
             hipMemcpy(h->epoch, &one, sizeof(one), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(h->step_layers, tab.data(), tab.size() * sizeof(StepLayer), hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipStreamDestroy(h->cap_stream);
+            if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
             delete h;
             return cv2_fail("cv2_llm_create: initialising the hand-off state failed");
         }
@@ -2091,6 +2094,8 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGra
     if (it == h->graphs.end()) {
         hipGraph_t g;
         hipStream_t cs = h->cap_stream;
+        const bool transient = cs == nullptr;
+        if (transient) CV2_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         CV2_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         RowMap rm{h->io.state, 0, 0, 0, mapped ? h->row_slots : nullptr};
         const float* xin = mapped ? h->xrows : h->xnext;
@@ -2112,6 +2117,7 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGra
             if (!rc) rc = launch_sample(h, n_seqs, -1, 0, 0, cs, mapped);
         }
         hipError_t e = hipStreamEndCapture(cs, &g);
+        if (transient) (void)hipStreamDestroy(cs);
         if (rc) return rc;
         CV2_HIP(e);
         hipGraphExec_t ge;
