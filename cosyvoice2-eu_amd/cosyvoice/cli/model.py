@@ -141,7 +141,7 @@ class CosyVoice2Model:
         self.flow = FlowEngine(flow_sd, self.device, max_utts=B, max_len=2 * (max_prompt + max_new), n_timesteps=cfg.n_timesteps,
                                cfg_rate=cfg.inference_cfg_rate)
         self.flow.pre_lookahead_len, self.flow.token_mel_ratio, self.flow.input_frame_rate = cfg.pre_lookahead_len, cfg.token_mel_ratio, cfg.input_frame_rate
-        self.hift_pool = HiftPool(hift_sd, self.device, max_frames=2 * max_new + self.mel_cache_len, n=min(int(os.environ.get('CV2_HIFT_STREAMS', '4')), B), batch_lanes=0 if os.environ.get('CV2_HIFT_BATCH') == '0' else min(8, B))
+        self.hift_pool = HiftPool(hift_sd, self.device, max_frames=2 * max_new + self.mel_cache_len, n=min(4, B), batch_lanes=0 if os.environ.get('CV2_HIFT_BATCH') == '0' else min(8, B))      # (CV2_HIFT_BATCH=0: A/B switch, one vocoder call per chunk)
         self.hift = self.hift_pool.engines[0]
         self.llm.park()                            # no slot is live: decode steps that cover a free slot leave it alone
         torch.cuda.synchronize(self.device)
@@ -178,7 +178,7 @@ class CosyVoice2Model:
         current stream; returns the list of speech tensors (None where the chunk failed), or None when batching does not apply."""
         eng = self.hift_pool.batch_engine
         live = [i for i, m in enumerate(mels) if m is not None]
-        if eng is None or self._noise_hook is not None or self._trace is not None or len(live) < 2 or os.environ.get('CV2_HIFT_BATCH') == '2':
+        if eng is None or self._noise_hook is not None or self._trace is not None or len(live) < 2:
             return None
         cur, pre, out = torch.cuda.current_stream(), {}, [None] * len(grp)
         for i in live:

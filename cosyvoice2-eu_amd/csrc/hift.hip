@@ -502,15 +502,14 @@ struct cv2_hift {
     // (frames, cache length) over engine-owned staging buffers; the caller's tensors are copied in / out around the replay.
     float *g_mel, *g_cs, *g_wav, *g_src; uint32_t* g_seed;
     std::map<long, hipGraphExec_t> graphs;
+    hipStream_t cap_stream = nullptr;   // graph capture stream of a one-lane engine (see cv2_hift_create)
     long lane_floats = 0;      // workspace floats of one lane (d.lanes lanes behind one another: lane z's buffers = lane 0's + z * lane_floats)
 };
-// The stream a graph is captured on lives only for the capture: every persistent HIP stream of the process takes a share of the few
-// hardware queues, and one more idle stream per engine changed which of the scheduler's streams share a queue (one extra engine in the
-// pool: 8 streaming calls 89 -> 74 audio-s/s, tools/bench_streams.py).
+// The stream a graph is captured on: the engine's own, or one that lives only for the capture (cv2_hift_create says which and why).
 struct CapStream {
-    hipStream_t s = nullptr;
-    CapStream() { if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr; }
-    ~CapStream() { if (s) (void)hipStreamDestroy(s); }
+    hipStream_t s = nullptr; bool own = false;
+    explicit CapStream(hipStream_t have) : s(have) { if (!s) { own = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess; if (!own) s = nullptr; } }
+    ~CapStream() { if (own && s) (void)hipStreamDestroy(s); }
 };
 #define HG_MAX_T 160          // longest call that goes through a graph (frames)
 #define HG_MAX_GRAPHS 24
@@ -543,6 +542,16 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
     cv2_hift* h = new cv2_hift();
     h->d = *d; h->w = *w;
     h->lane_floats = (long)(hift_carve(*d, h, (char*)ws) / 4);
+    // Capture streams and the process's hardware queues.  How HIP streams share the few hardware queues depends on how many streams the
+    // process holds, and it decides whether work on different streams really runs side by side.  Measured (bench.py, one model; the LLM
+    // engine holds one capture stream): with that stream alone, or one more, the HiFT pool's four streams serialise (HiFT of 32
+    // utterances 144-149 ms instead of 124); with four or five more (a persistent capture stream per vocoder engine) the scheduler's
+    // decode / flow / vocoder streams share queues (8 streaming calls: chunk gap 51-53 ms, 74-104 audio-s/s); with two or three more both
+    // are at their best (124 ms; gap 49.5-50 ms, 115-117 audio-s/s).  So the first two one-lane engines of the process keep their capture
+    // stream for life and every other engine borrows one per capture (CV2_HIFT_CAP_PERSIST = number kept, diagnostics).
+    static std::atomic<int> n_kept{0};
+    static const int keep = getenv("CV2_HIFT_CAP_PERSIST") ? atoi(getenv("CV2_HIFT_CAP_PERSIST")) : 2;
+    if (d->lanes <= 1 && n_kept.fetch_add(1) < keep && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) h->cap_stream = nullptr;
     static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
     if (!once) {
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -553,6 +562,7 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
     return 0;
 }
 extern "C" int cv2_hift_destroy(cv2_hift* h) {
+    if (h && h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (!h) return 0;
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.second);
     delete h;
@@ -619,7 +629,7 @@ extern "C" int cv2_hift_inference(cv2_hift* h, const float* mel, int32_t T, cons
             h->graphs.erase(h->graphs.begin());
         }
         hipGraph_t g;
-        CapStream cap;
+        CapStream cap(h->cap_stream);
         if (!cap.s) return hift_run(h, mel, T, cache_source, n_cache, noise, seed, nullptr, wav, source, s);
         CV2_HIP(hipStreamBeginCapture(cap.s, hipStreamCaptureModeThreadLocal));
         const int rc = hift_run(h, h->g_mel, T, n_cache ? h->g_cs : nullptr, n_cache, nullptr, 0, h->g_seed, h->g_wav, h->g_src, cap.s);
@@ -660,7 +670,7 @@ extern "C" int cv2_hift_inference_batch(cv2_hift* h, int32_t n, const float* con
             h->graphs.erase(h->graphs.begin());
         }
         hipGraph_t g;
-        CapStream cap;
+        CapStream cap(h->cap_stream);
         CV2_CHECK(cap.s, "cv2_hift_inference_batch: no stream to capture on");
         CV2_HIP(hipStreamBeginCapture(cap.s, hipStreamCaptureModeThreadLocal));
         g_hz_n = n; g_hz_zs = zs;

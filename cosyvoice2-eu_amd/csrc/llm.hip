@@ -1713,10 +1713,10 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
     h->keys_per_split = AT_KB;
     while ((d->max_pos + h->keys_per_split - 1) / h->keys_per_split > SK_MAXSPLIT) h->keys_per_split *= 2;
     h->nsplit = (d->max_pos + h->keys_per_split - 1) / h->keys_per_split;
-    // the stream the decode graphs are captured on lives only for a capture unless CV2_LLM_CAP_PERSIST=1 (A/B switch): an idle persistent
-    // stream takes a share of the process's few hardware queues and changes which of the scheduler's streams share one (hift.hip: CapStream)
+    // the stream the decode graphs are captured on is the engine's own (CV2_LLM_CAP_PERSIST=0: one per capture; measured the same -- the
+    // population of HIP streams decides how they share the process's hardware queues, see cv2_hift_create)
     h->cap_stream = nullptr;
-    if (getenv("CV2_LLM_CAP_PERSIST") && getenv("CV2_LLM_CAP_PERSIST")[0] == '1' &&
+    if (!(getenv("CV2_LLM_CAP_PERSIST") && getenv("CV2_LLM_CAP_PERSIST")[0] == '0') &&
         hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return cv2_fail("cv2_llm_create: hipStreamCreateWithFlags failed");
