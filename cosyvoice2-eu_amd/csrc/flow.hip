@@ -270,35 +270,7 @@ struct IncTabs {
     uint16_t* const* tails;     // [2U] conv tails of (stream, branch): [2 generations][n_steps][31][2 rows][512]
     const int* gen;             // [2U] generation to READ (the call writes the other one: a failed call can be repeated)
 };
-// keys / values of the call's new rows -> cache slot
-struct KvAppendArgs { const uint16_t* qk; const uint16_t* vt; long R; SeqTable seq; IncTabs inc; long slot; };
-__global__ __launch_bounds__(256) void k_kv_append(KvAppendArgs a) {      // grid (64-row tiles, 8 heads)
-    const int tile = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
-    const int s = a.seq.tile_seq[tile];
-    if (s < 0) return;
-    const int start = a.seq.seq_start[s], len = a.seq.seq_len[s], p0 = a.inc.pos0[s];
-    const int t0 = tile * 64 - start, n = min(64, len - t0);
-    if (n <= 0) return;
-    const long fr = a.inc.kv_frames[s];
-    uint16_t* kb = a.inc.kv[s] + a.slot * fr * 1024;
-    uint16_t* vb = kb + fr * 512;
-    // K: this head's 64 channels of every frame (8 x 16 B per frame)
-    for (int i = tid; i < n * 8; i += 256) {
-        const int r = i >> 3, ch = hd * 64 + (i & 7) * 8;
-        *reinterpret_cast<uint4*>(kb + (size_t)(p0 + t0 + r) * 512 + ch) =
-            *reinterpret_cast<const uint4*>(a.qk + (size_t)(tile * 64 + r) * 1024 + 512 + ch);
-    }
-    // V^T: 64 channels x n frames, two frames (4 B) per access: p0 and t0 are even
-    const int np = (n + 1) >> 1;
-    for (int i = tid; i < 64 * 32; i += 256) {
-        const int ch = hd * 64 + (i >> 5), pr = i & 31;
-        if (pr >= np) continue;
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(a.vt + (size_t)ch * a.R + tile * 64 + 2 * pr);
-        uint16_t* d = vb + (size_t)ch * fr + p0 + t0 + 2 * pr;
-        if (2 * pr + 1 < n) *reinterpret_cast<uint32_t*>(d) = v;
-        else *d = (uint16_t)(v & 0xffffu);
-    }
-}
+// (the call's new keys / values reach the cache slot through the QKV projection's epilogue: GemmArgs.kvc, gemm.h)
 // before a causal k=3 convolution reads `buf`: rows [start-2, start) <- the cached last two input rows of the previous call,
 // and the last two input rows of this call -> cache (other generation)
 struct ConvTailArgs { uint16_t* buf; int C; SeqTable seq; IncTabs inc; int rd_slot, wr_slot; };     // slot = (gen * n_steps + step) * 31 + conv
@@ -866,11 +838,6 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
             const int bi = c.tb_i++;
             CV2_CHECK(bi < INC_TBLOCKS, "flow: transformer block counter overflow");
             a.kv = c.inc->kv; a.kv_frames = c.inc->kv_frames; a.pos0 = c.inc->pos0; a.slot = (long)c.step * INC_TBLOCKS + bi;
-            static const bool sep = getenv("CV2_FLOW_KV_APPEND") && getenv("CV2_FLOW_KV_APPEND")[0] == '1';      // A/B switch (diagnostics): the separate copy launch as well
-            if (sep) {
-                KvAppendArgs k{GB(h->qk, 1024), h->vt + GUARD, a.R, c.L->tab(), *c.inc, a.slot};
-                hipLaunchKernelGGL(k_kv_append, dim3(M / 64, 8), dim3(256), 0, c.s, k);
-            }
         }
         if (c.inc) {
             if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4, 1, true>), dim3(8, M / 128), dim3(256), 0, c.s, a);

@@ -1303,111 +1303,14 @@ __global__ __launch_bounds__(256) void k_rope_cache(RopeArgs a) {
     dst[i] = o0; dst[32 + i] = o1;
 }
 
-// causal attention of PF_ROWS prompt rows x one GQA group over the cache, fp32; output as hi/lo bf16 planes [M][n_q*64]
-#define PF_ROWS 4
+// causal attention of the batched prefill: PFM_ROWS prompt rows x one GQA group over the cache; output as hi/lo bf16 planes [M][n_q*64]
 struct PfAttnArgs {
     const float* q; const float* kc; const float* vc; uint16_t* hi; uint16_t* lo;
     const int* seq_row0; const int* seq_len; const int* seq_slot; const int* seq_pos0;
     int n_q, n_kv, max_pos;
 };
-#define PF_KLD 68
-__global__ __launch_bounds__(256) void k_attn_prefill(PfAttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int rep = a.n_q / a.n_kv;                              // <= 8 ; pairs = PF_ROWS rows x rep heads <= 32
-    float* Ks = reinterpret_cast<float*>(smem);                  // [64][PF_KLD]
-    float* Vs = Ks + 64 * PF_KLD;                                // [64][64]
-    float* qs = Vs + 64 * 64;                                    // [128][64]
-    float* ss = qs + 128 * 64;                                   // [128][64]
-    float* m_run = ss + 128 * 64; float* l_run = m_run + 128; float* scl = l_run + 128;
-    const int qt = blockIdx.x, g = blockIdx.y, sq = blockIdx.z;
-    const int len = a.seq_len[sq];
-    if (qt * PF_ROWS >= len) return;
-    const int row0 = a.seq_row0[sq] + qt * PF_ROWS, slot = a.seq_slot[sq], pos0 = a.seq_pos0[sq] + qt * PF_ROWS;
-    const int nrow = min(PF_ROWS, len - qt * PF_ROWS);
-    const int npair = PF_ROWS * rep, ppg = npair / 4;                 // pairs per thread group (4 groups of 64 threads)
-    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
-    const float* K = a.kc + ((size_t)slot * a.n_kv + g) * a.max_pos * 64;
-    const float* V = a.vc + ((size_t)slot * a.n_kv + g) * a.max_pos * 64;
-    for (int e = tid; e < npair * 64; e += 256) {
-        const int pr = e >> 6, d = e & 63, i = pr / rep, hh = pr % rep;
-        qs[e] = i < nrow ? a.q[(size_t)(row0 + i) * a.n_q * 64 + (g * rep + hh) * 64 + d] : 0.f;
-    }
-    if (tid < 128) { m_run[tid] = -INFINITY; l_run[tid] = 0.f; }
-    float o[32];
-#pragma unroll
-    for (int p = 0; p < 32; p++) o[p] = 0.f;
-    const int kend = pos0 + nrow;                                // keys 0 .. pos0 + nrow - 1 are visible to some row
-    for (int j0 = 0; j0 < kend; j0 += 64) {
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = tid + 256 * u, key = idx >> 4, c4 = idx & 15;
-            const bool ok = j0 + key < kend;
-            *reinterpret_cast<f32x4*>(&Ks[key * PF_KLD + c4 * 4]) = ok ? *reinterpret_cast<const f32x4*>(K + (size_t)(j0 + key) * 64 + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(&Vs[key * 64 + c4 * 4]) = ok ? *reinterpret_cast<const f32x4*>(V + (size_t)(j0 + key) * 64 + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();
-        {   // scores: thread = (key, pair group)
-            f32x4 kr[16];
-#pragma unroll
-            for (int c4 = 0; c4 < 16; c4++) kr[c4] = *reinterpret_cast<const f32x4*>(&Ks[lane * PF_KLD + c4 * 4]);
-            for (int pp = 0; pp < ppg; pp++) {
-                const int pr = grp * ppg + pp, i = pr / rep;
-                float acc = 0.f;
-#pragma unroll
-                for (int c4 = 0; c4 < 16; c4++) {
-                    const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[pr * 64 + c4 * 4]);
-                    acc += kr[c4][0] * qv[0] + kr[c4][1] * qv[1] + kr[c4][2] * qv[2] + kr[c4][3] * qv[3];
-                }
-                const bool vis = i < nrow && (j0 + lane) <= (pos0 + i);
-                ss[pr * 64 + lane] = vis ? acc * 0.125f : -INFINITY;
-            }
-        }
-        __syncthreads();
-        for (int pp = 0; pp < ppg; pp++) {                       // wave grp owns its pair group: online softmax per pair
-            const int pr = grp * ppg + pp;
-            const float sv = ss[pr * 64 + lane];
-            const float mt = wave_max(sv);
-            const float mo = m_run[pr], mn = fmaxf(mo, mt);
-            const float pv = mn == -INFINITY ? 0.f : __expf(sv - mn);
-            ss[pr * 64 + lane] = pv;
-            const float lt = wave_sum(pv);
-            if (lane == 0) {
-                const float sc = mn == -INFINITY ? 1.f : __expf(mo - mn);
-                scl[pr] = sc; l_run[pr] = l_run[pr] * sc + lt; m_run[pr] = mn;
-            }
-        }
-        __syncthreads();
-        {   // PV: thread = (dim, pair group), V column in registers
-            float vv[64];
-#pragma unroll
-            for (int k = 0; k < 64; k++) vv[k] = Vs[k * 64 + lane];
-            for (int pp = 0; pp < ppg; pp++) {
-                const int pr = grp * ppg + pp;
-                float acc = o[pp] * scl[pr];
-#pragma unroll
-                for (int k4 = 0; k4 < 16; k4++) {
-                    const f32x4 pv = *reinterpret_cast<const f32x4*>(&ss[pr * 64 + 4 * k4]);
-                    acc += pv[0] * vv[4 * k4] + pv[1] * vv[4 * k4 + 1] + pv[2] * vv[4 * k4 + 2] + pv[3] * vv[4 * k4 + 3];
-                }
-                o[pp] = acc;
-            }
-        }
-    }
-    __syncthreads();
-    for (int pp = 0; pp < ppg; pp++) {
-        const int pr = grp * ppg + pp, i = pr / rep, hh = pr % rep;
-        if (i >= nrow) continue;
-        const float l = l_run[pr];
-        const float v = l > 0.f ? o[pp] / l : 0.f;
-        const size_t off = (size_t)(row0 + i) * a.n_q * 64 + (g * rep + hh) * 64 + lane;
-        const uint16_t hb = f2bf(v);
-        a.hi[off] = hb; a.lo[off] = f2bf(v - bf2f(hb));
-    }
-}
-
-// The same attention on the matrix cores (fp32 accuracy: three exact bf16 planes per operand, six products; attn_role above is the one-row
-// form).  Block = PFM_ROWS prompt rows x one GQA group x one sequence, 4 waves; the 8 x rep <= 64 (row, head) pairs are the COLUMNS of
+// On the matrix cores at fp32 accuracy (three exact bf16 planes per operand, six products; attn_role above is the one-row form; the
+// scalar fp32 kernel this replaced ran at 7 TFLOP/s: 68 us per layer at one 307-row prompt, 848 us at 32 prompts).  Block = PFM_ROWS prompt rows x one GQA group x one sequence, 4 waves; the 8 x rep <= 64 (row, head) pairs are the COLUMNS of
 // S^T = K Q^T and of O^T = V^T P^T, so a pair's running (max, sum) and its rescale factor live on the lane that holds its column in both
 // products and nothing has to be exchanged between them.  Wave w owns keys [16 w, 16 w + 16) of every 64-key tile: K rows and V rows go
 // global -> registers -> planes (each value split once, next tile's loads in flight), q planes are read from LDS; no barrier inside the
@@ -2002,7 +1905,6 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
     if (init_attrs_once()) return -1;
     static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
     if (!once) {
-        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_prefill), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_prefill_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
@@ -2033,7 +1935,6 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
     CV2_CHECK(H % 128 == 0 || H % 64 == 0, "prefill: hidden %% 64");
     CV2_CHECK(NQKV % 128 == 0 && H % 128 == 0 && (2 * I) % 128 == 0 && NQ % 64 == 0 && I % 64 == 0, "cv2_llm_prefill_batch: dims must be multiples of 128 / 64 for the GEMM tiles");
     const size_t cache_l = (size_t)d.max_seqs * d.n_kv * d.max_pos * 64;
-    const size_t pf_smem = (size_t)(64 * PF_KLD + 64 * 64 + 2 * 128 * 64 + 3 * 128) * 4;
     for (int l = 0; l < d.layers; l++) {
         const cv2_llm_layer& L = h->layers[l];
         hipLaunchKernelGGL(k_rms_split, dim3(Mp / 4), dim3(256), 0, s, (const float*)h->pf_x, L.ln1, d.rms_eps, h->pf_hi, h->pf_lo, M, Mp, H);
@@ -2049,9 +1950,7 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
         }
         {
             PfAttnArgs a{h->pf_q, h->kc + l * cache_l, h->vc + l * cache_l, h->pf_hi, h->pf_lo, d_row0, d_len, d_slot, d_pos0, d.n_q, d.n_kv, d.max_pos};
-            static const bool pf_scalar = getenv("CV2_PREFILL_ATTN") && getenv("CV2_PREFILL_ATTN")[0] == '0';     // A/B switch (diagnostics)
-            if (pf_scalar) hipLaunchKernelGGL(k_attn_prefill, dim3((maxlen + PF_ROWS - 1) / PF_ROWS, d.n_kv, n), dim3(256), pf_smem, s, a);
-            else hipLaunchKernelGGL(k_attn_prefill_mfma, dim3((maxlen + PFM_ROWS - 1) / PFM_ROWS, d.n_kv, n), dim3(256), pfm_smem_bytes(), s, a);
+            hipLaunchKernelGGL(k_attn_prefill_mfma, dim3((maxlen + PFM_ROWS - 1) / PFM_ROWS, d.n_kv, n), dim3(256), pfm_smem_bytes(), s, a);
         }
         {
             GemmArgs g = gemm_args(h->pf_hi, NQ, 0, L.wo, Mp, H, NQ);
