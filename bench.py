@@ -209,9 +209,16 @@ def run_calls(model, reqs, forces, stream=False, chunk_times=None):
 
 
 def pmc_stage_file(stage):
-    """profiles/r3_pmc_<stage>.json (tools/pmc_stages.sh: rocprofv3 --pmc passes of one stage alone) or None."""
-    p = os.path.join(ROOT, 'profiles', f'r3_pmc_{stage}.json')
-    return json.load(open(p)) if os.path.exists(p) else None
+    """The newest committed profiles/r<N>_pmc_<stage>.json (tools/pmc_stages.sh: rocprofv3 --pmc passes of one stage alone) or None.
+    The dict carries its own file name ('_file'): counters cannot be read from inside the bench, so every field derived from them is
+    stamped with where it came from and 'measured_in_this_run': False."""
+    for rnd in (4, 3):
+        p = os.path.join(ROOT, 'profiles', f'r{rnd}_pmc_{stage}.json')
+        if os.path.exists(p):
+            d = json.load(open(p))
+            d['_file'] = f'profiles/r{rnd}_pmc_{stage}.json'
+            return d
+    return None
 
 
 def pmc_decode_traffic(desc):
@@ -223,7 +230,7 @@ def pmc_decode_traffic(desc):
         for r in pj['kernels']:
             if r['kernel'] == 'k_step' and r.get('hbm_read_MB_per_rep') is not None:
                 per = (r['hbm_read_MB_per_rep'] + r['hbm_write_MB_per_rep']) * 1e6 / r['launches_per_rep']
-                return int(per), f'profiles/r3_pmc_decode.json, k_step {note}'
+                return int(per), f'{pj["_file"]}, k_step {note}; NOT measured in this run'
     for name in ('r2_pmc_decode.json', 'r1_pmc_decode.json'):
         pmc = os.path.join(ROOT, 'profiles', name)
         if 'k_step' not in desc and os.path.exists(pmc):
@@ -238,14 +245,14 @@ def counter_fields(pmc_flow, pmc_hift, hift_tf):
     if pmc_flow:
         flow = {'util_counter': pmc_flow.get('mfma_util_wall_time_weighted'), 'util_counter_gui_active': pmc_flow.get('mfma_util_time_weighted'),
                 'hbm_read_MB_per_utt': pmc_flow['hbm_read_MB_per_rep'], 'hbm_write_MB_per_utt': pmc_flow['hbm_write_MB_per_rep'],
-                'source': 'profiles/r3_pmc_flow.json: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x 256 CU x cycles), time-weighted over the stage\'s kernels; '
+                'measured_in_this_run': False, 'source': pmc_flow['_file'] + ': SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x 256 CU x cycles), time-weighted over the stage\'s kernels; '
                           'cycles = kernel-trace duration x 2.4 GHz (util_counter) or GRBM_GUI_ACTIVE / 8 (util_counter_gui_active)'}
     if pmc_hift:
         tot = (pmc_hift['hbm_read_MB_per_rep'] + pmc_hift['hbm_write_MB_per_rep']) / 1e3
         k6 = next((r for r in pmc_hift['kernels'] if r['kernel'] == 'k_conv6'), {})
         hift = {'hbm_gbs': pmc_hift.get('hbm_GBs_over_kernel_time'), 'hbm_GB_per_10s_audio': round(tot, 3), 'survey_8d_GB_per_10s_audio': 0.28,
                 'k_conv6': {'hbm_gbs': k6.get('hbm_GBs'), 'mfma_util_counter': k6.get('mfma_util_wall'), 'avg_us': k6.get('avg_us')},
-                'source': 'profiles/r3_pmc_hift.json (500 mel frames = 10 s of audio per rep; FETCH_SIZE x 2 + WRITE_SIZE over the stage\'s kernel time); '
+                'measured_in_this_run': False, 'source': pmc_hift['_file'] + ' (500 mel frames = 10 s of audio per rep; FETCH_SIZE x 2 + WRITE_SIZE over the stage\'s kernel time); '
                           'SURVEY 8(d)\'s 0.28 GB assumes whole ResBlocks fused (1.4 GB unfused); here every convolution is one launch: input + halo, the '
                           'residual / MRF accumulator read by the epilogue, and the layer\'s three weight planes once per XCD L2'}
     return flow, hift
@@ -616,6 +623,9 @@ def run_sharded(args):
                'backend': (f'nccl = RCCL {".".join(map(str, torch.cuda.nccl.version()))} over xGMI' if backend == 'nccl' and not fake else backend),
                'per_rank': per_rank,
                'imbalance': round(max(r['work_s'] for r in per_rank) / max(min(r['work_s'] for r in per_rank), 1e-9), 3),
+               # the one-GPU reference measured INSIDE this run: what each rank's own shard (its utterances, no collectives) ran at; the
+               # committed N = 1 line's extra.batch32.value (the same 32-utterance workload through the same path) is quoted beside it
+               'n1_reference': n1_reference(per_rank, args.steps),
                'config': {'workload': f'configs[3]: {n_utts} utterances sharded over {world} ranks ({per} per GPU, length-balanced), zero-shot FR, P=255, texts of '
                                       f'30..100 tokens, 5 x text length forced speech tokens (150..500), non-streaming; broadcast prompt / scatter text ids / '
                                       f'gather waveforms over {"RCCL" if backend == "nccl" else backend} inside the timed region; every rank runs its shard as '
@@ -631,6 +641,24 @@ def run_sharded(args):
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def n1_reference(per_rank, steps):
+    """Per-GPU throughput of the shards themselves (audio of a rank's shard / the time that rank spent synthesising it), and the
+    committed one-GPU measurement of the same workload, so that the N > 1 line carries its own scaling reference."""
+    rates = sorted(r['audio_s_per_step'] * steps / max(r['work_s'], 1e-9) for r in per_rank)
+    ref = {'unit': 'audio-s/s per GPU', 'per_rank_shard_rate_median': round(rates[len(rates) // 2], 2), 'per_rank_shard_rate_min': round(rates[0], 2),
+           'source': "each rank's own shard inside this run, collectives excluded"}
+    for name in ('r4_bench_b1.json', 'r3_bench_b1.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        try:
+            with open(path) as f:
+                line = json.loads(f.read().strip().splitlines()[-1])
+            ref['committed_n1_batch32'] = {'value': line['extra']['batch32']['value'], 'file': 'profiles/' + name}
+            break
+        except Exception:      # noqa: BLE001
+            continue
+    return ref
 
 
 def main():

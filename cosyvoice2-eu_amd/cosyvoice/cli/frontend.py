@@ -127,8 +127,14 @@ class CosyVoiceFrontEnd(PrecomputedFrontEnd):
     def _speech_features(self):
         if self._speech is None:
             from cv2amd.prompt import SpeechFeatures
-            self._speech = SpeechFeatures()
+            self._speech = SpeechFeatures(self._feature_device())
         return self._speech
+
+    @staticmethod
+    def _feature_device():
+        """the process's current device (one rank per GPU calls torch.cuda.set_device(LOCAL_RANK) first): the extractors' tables, buffers and
+        launches live there, not on cuda:0"""
+        return torch.device('cuda', torch.cuda.current_device())
 
     def _extract_speech_token(self, speech):                                    # frontend.py:262-274
         assert speech.shape[1] / 16000 <= 30, 'do not support extract speech token for audio longer than 30s'
@@ -161,7 +167,7 @@ class CosyVoiceFrontEnd(PrecomputedFrontEnd):
         # frontend.py:497-498: Resample(16000, resample_rate) + feat_extractor, both on the device (cv2_resample, cv2_melspec)
         if self._prompt is None or self._prompt_rate != resample_rate:
             from cv2amd.prompt import PromptFeatures
-            self._prompt, self._prompt_rate = PromptFeatures(sr=resample_rate), resample_rate
+            self._prompt, self._prompt_rate = PromptFeatures(self._feature_device(), sr=resample_rate), resample_rate
         feat = self._prompt.prompt_feat(prompt_speech_16k).cpu()
         tok, tok_len = self._extract_speech_token(prompt_speech_16k)
         n = min(int(feat.shape[1] / 2), tok.shape[1])                            # frontend.py:498-502: force feat = 2 x token

@@ -82,6 +82,13 @@ class CosyVoice2Model:
         self.lock = threading.Lock()           # guards the per-uuid dicts, as in the reference
         self.run_lock = _FairLock()            # one device operation at a time (a chunk's work, or a whole coalesced batch), FIFO
         self._leader_lock = threading.Lock()   # election of the batch leader among queued non-streaming callers
+        # the LLM engine has its own lock (taken INSIDE run_lock by the unistream paths, alone by the bistream hub): the hub's rounds
+        # (poll / batched text-block feed / shared decode burst on the LLM stream) go on while a chunk round holds run_lock
+        self.llm_lock = threading.Lock()
+        self._bi_cv = threading.Condition()    # guards _bi_calls and every BiStream's text side; signalled on new text / tokens / calls
+        self._bi_calls, self._bi_thread, self._bi_gen = [], None, 0
+        self.bistream_coalesce_ms = 3.0        # calls that start together are fed together (one pass over the weights for all first feeds)
+        self.bistream_burst = 16
         self._mode = threading.Condition()     # shared (streams, one LLM slot each) / exclusive (a batch) use of the engines
         self._n_shared, self._excl, self._excl_waiting = 0, False, 0
         self._slot_free, self._active_slots = [], set()
@@ -450,7 +457,7 @@ class CosyVoice2Model:
                     batch = self._prefill_q[:]
                     self._prefill_q.clear()
                 try:
-                    with torch.cuda.stream(self.llm_stream):
+                    with self.llm_lock, torch.cuda.stream(self.llm_stream):
                         xs = [self.llm.build_lm_input(b.text, b.prompt_text, b.ptok) for b in batch]
                         mms = [(int(b.text.shape[1] * self.min_token_text_ratio), int(b.text.shape[1] * self.max_token_text_ratio))
                                if b.force_len is None else (b.force_len, b.force_len) for b in batch]     # llm.py:643-644 (target text only)
@@ -487,7 +494,7 @@ class CosyVoice2Model:
             return
         with self._mode:
             act = sorted(self._active_slots)
-        with torch.cuda.stream(self.llm_stream):
+        with self.llm_lock, torch.cuda.stream(self.llm_stream):
             if self.stream_live_rows:
                 self.llm.step_rows(act, n_steps, shared=shared)
             else:
@@ -607,41 +614,161 @@ class CosyVoice2Model:
             raise p.exc
         return p.speech
 
+    # ---- llm_job's bistream branch (model.py:120-128) for ALL generator-text calls: one round loop -------------------------------
+    class _BiCall:
+        __slots__ = ('bs', 'uuid', 'toks', 'want_total', 'closed', 'exc', 'ended')
+
+    def _bi_register(self, bs, this_uuid, text):
+        """A generator-text call joins the hub: its text generator is drained by a small pump thread (host only: the reference's
+        llm_job thread iterates it the same way, model.py:118-128), the device side is driven by the hub thread for all calls."""
+        c = self._BiCall()
+        c.bs, c.uuid, c.toks, c.want_total, c.closed, c.exc, c.ended = bs, this_uuid, self.tts_speech_token_dict[this_uuid], 0, False, None, False
+
+        def pump():
+            try:
+                for piece in text:
+                    with self._bi_cv:
+                        if c.closed:
+                            return
+                        bs.push(piece)
+                        self._bi_gen += 1
+                        self._bi_cv.notify_all()
+            except BaseException as e:      # noqa: BLE001 -- the caller's generator failed: the call fails with it
+                c.exc = e
+            finally:
+                with self._bi_cv:
+                    bs.close()
+                    self._bi_gen += 1
+                    self._bi_cv.notify_all()
+        with self._bi_cv:
+            self._bi_calls.append(c)
+            self._bi_gen += 1
+            if self._bi_thread is None or not self._bi_thread.is_alive():
+                self._bi_thread = threading.Thread(target=self._bi_loop, daemon=True, name='cv2-bistream-hub')
+                self._bi_thread.start()
+            self._bi_cv.notify_all()
+        threading.Thread(target=pump, daemon=True, name='cv2-bistream-text').start()
+        return c
+
+    def _bi_unregister(self, c):
+        with self._bi_cv:
+            c.closed = True
+            if c in self._bi_calls:
+                self._bi_calls.remove(c)
+            self._bi_cv.notify_all()
+        with self.llm_lock:                                                   # (a round in flight has finished with the slot once this is held)
+            with torch.cuda.stream(self.llm_stream):
+                self.llm.park(c.bs.slot)
+            self.llm_stream.synchronize()
+
+    def _bi_loop(self):
+        """Scheduler-owned rounds over every generator-text call (Qwen2LM.inference_bistream x the concurrent calls, llm.py:721-834):
+          1. poll -- one read of the running slots' state records and new ids; tokens are published to the calls' lists;
+          2. feed -- every idle slot whose next input is there (text pieces are consumed on the host, no device work) goes into ONE
+             cv2_llm_extend_batch: the first [sos, 5 text : 15 prompt-speech blocks] of calls that start together, the 5-token text
+             blocks after a fill id, the final [pending, remaining text, task id];
+          3. burst -- one shared decode burst over the running slots only (cv2_llm_decode_rows: a slot stopped on the fill id is not
+             a row), as long as the earliest known stop / the earliest chunk somebody waits for.
+        The LLM work runs on the LLM stream under llm_lock only, so it goes on beside the chunk rounds (flow + HiFT under run_lock)."""
+        torch.cuda.set_device(self.device)
+        idle_since = None
+        while True:
+            with self._bi_cv:
+                if not self._bi_calls:
+                    if idle_since is None:
+                        idle_since = time.perf_counter()
+                    if time.perf_counter() - idle_since > 5.0:                # nothing to do for a while: the next call starts a new thread
+                        self._bi_thread = None
+                        return
+                    self._bi_cv.wait(0.5)
+                    continue
+                idle_since = None
+                calls = [c for c in self._bi_calls if not c.closed]
+                # calls that start together are fed together: wait (briefly) until the newcomers' first input is complete
+                if any(not c.bs.started for c in calls) and not any(c.bs.running for c in calls):
+                    t_end = time.perf_counter() + self.bistream_coalesce_ms * 1e-3
+                    while time.perf_counter() < t_end:
+                        gen = self._bi_gen
+                        self._bi_cv.wait(0.0005)
+                        if self._bi_gen == gen and all(c.bs.started or c.bs.next_feed() is not None for c in self._bi_calls if not c.closed):
+                            break
+                    calls = [c for c in self._bi_calls if not c.closed]
+                for c in calls:
+                    c.bs.want = max(0, c.want_total - len(c.toks)) if c.want_total else None
+            if not calls:
+                continue
+            try:
+                ev = None
+                with self.llm_lock, torch.cuda.stream(self.llm_stream):
+                    eng = self.llm
+                    streams = [c.bs for c in calls if not c.closed]
+                    eng.bi_poll(streams)
+                    self._bi_publish(calls)
+                    with self._bi_cv:                                         # text pieces are pushed under this lock: consume them under it,
+                        for b in streams:                                     # feed outside it (the consumers' pull() takes it too)
+                            if not b.running and not b.finished:
+                                b.next_feed()
+                    fed = eng.bi_feed(streams, prepared=True)
+                    n = eng.bi_burst_len(streams, self.bistream_burst)
+                    if n:
+                        eng.bi_burst(streams, n, shared=True)
+                    if fed or n:
+                        ev = torch.cuda.Event()
+                        ev.record(self.llm_stream)
+                if ev is not None:
+                    ev.synchronize()                                          # the round's device work, outside the lock
+                else:
+                    with self._bi_cv:                                         # every slot waits for text (or has ended): sleep until something arrives
+                        if all(not c.bs.running and (c.bs.finished or c.bs.next_feed() is None) for c in self._bi_calls):
+                            self._bi_cv.wait(0.05)
+            except BaseException as e:      # noqa: BLE001 -- not attributable to one call: all of this round's calls see it
+                with self._bi_cv:
+                    for c in calls:
+                        if c.exc is None:
+                            c.exc = e
+                        c.ended = True
+                        c.bs.finished, c.bs.running = True, False
+                    self._bi_cv.notify_all()
+
+    def _bi_publish(self, calls):
+        with self._bi_cv:
+            for c in calls:
+                new = c.bs.take()
+                if new:
+                    c.toks.extend(new)
+                if c.bs.err is not None and c.exc is None:
+                    c.exc = c.bs.err
+                if c.bs.finished and not c.ended:
+                    c.ended = True
+                    self.llm_end_dict[c.uuid] = True
+            self._bi_cv.notify_all()
+
     def _tts_pulled(self, text, prompt_text, llm_ptok, source_speech_token, fpt, feat, femb, this_uuid, stream, speed, vc):
         """tts() for the two token sources that are not the batched unistream LLM: voice conversion (vc_job, model.py:141-143: the
-        speech tokens of the source utterance ARE the tokens) and generator text (inference_bistream on one LLM slot, llm.py:721-834).
-        Tokens are pulled from the source exactly as far as the next chunk needs; the chunk arithmetic is model.py:351-394."""
+        speech tokens of the source utterance ARE the tokens) and generator text (inference_bistream, llm.py:721-834: the call owns
+        one LLM slot, the hub above drives it together with every other generator-text call).  The chunk arithmetic is model.py:351-394."""
         hop, la = self.token_hop_len, self.flow.pre_lookahead_len
         slot = None if vc else self._enter_shared()
         toks = self.tts_speech_token_dict[this_uuid]
+        call = None
         try:
             if vc:
                 toks.extend(source_speech_token.flatten().tolist())
-                src = iter(())
+                self.llm_end_dict[this_uuid] = True
             else:
-                def on_device(fn):
-                    with self.run_lock:
-                        with torch.cuda.stream(self.llm_stream):
-                            r = fn()
-                        self.llm_stream.synchronize()
-                        return r
-
-                def n_seqs():
-                    with self._mode:
-                        return max(self._active_slots) + 1
                 self.seed += 1
-                src = self.llm.bistream(slot, text, prompt_text.to(self.device), llm_ptok.to(self.device), mode=self.sampling_mode,
-                                        seed=self.seed, n_seqs=n_seqs, on_device=on_device)
-            ended = vc
+                call = self._bi_register(self.llm.new_bistream(slot, prompt_text, llm_ptok, mode=self.sampling_mode, seed=self.seed), this_uuid, text)
 
             def pull(n_total):
-                nonlocal ended
-                while len(toks) < n_total and not ended:
-                    try:
-                        toks.append(next(src))
-                    except StopIteration:
-                        ended = True
-                        self.llm_end_dict[this_uuid] = True
+                """wait until the call holds n_total tokens or its LLM has ended (the reference polls the shared list, model.py:353-366)"""
+                if call is None:
+                    return
+                with self._bi_cv:
+                    call.want_total = n_total
+                    while len(toks) < n_total and not call.ended and call.exc is None:
+                        self._bi_cv.wait(0.5)
+                    if call.exc is not None:
+                        raise call.exc
             if stream is True:
                 token_offset = 0
                 prompt_token_pad = int(np.ceil(fpt.shape[1] / hop) * hop - fpt.shape[1])
@@ -655,20 +782,18 @@ class CosyVoice2Model:
                     token_offset += this_hop
                     yield {'tts_speech': speech}
                 pull(1 << 30)
-                this_tok = torch.tensor(toks, dtype=torch.int32).unsqueeze(0)
+                this_tok = torch.tensor(list(toks), dtype=torch.int32).unsqueeze(0)
                 yield {'tts_speech': self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, False, True)}
             else:
                 pull(1 << 30)
                 with self.run_lock:
-                    this_tok = torch.tensor(toks, dtype=torch.int32).unsqueeze(0)
+                    this_tok = torch.tensor(list(toks), dtype=torch.int32).unsqueeze(0)
                     speech = self.token2wav(this_tok, fpt, feat, femb, 0, this_uuid, finalize=True, speed=speed).cpu()
                 yield {'tts_speech': speech}
         finally:
+            if call is not None:
+                self._bi_unregister(call)
             if slot is not None:
-                with self.run_lock:
-                    with torch.cuda.stream(self.llm_stream):
-                        self.llm.park(slot)
-                    self.llm_stream.synchronize()
                 self._exit_shared(slot)
             with self.lock:
                 if self._token_log is not None:
@@ -783,7 +908,7 @@ class CosyVoice2Model:
                     speech = self.token2wav(this_tok, fpt, feat, femb, 0, this_uuid, finalize=True, speed=speed).cpu()
                 yield {'tts_speech': speech}
         finally:
-            with self.run_lock:                                               # an abandoned generator leaves a live slot behind: park it
+            with self.run_lock, self.llm_lock:                                # an abandoned generator leaves a live slot behind: park it
                 with torch.cuda.stream(self.llm_stream):
                     self.llm.park(slot)
                 self.llm_stream.synchronize()

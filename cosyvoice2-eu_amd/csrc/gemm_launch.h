@@ -66,7 +66,8 @@ static int tail_panel_go(const TailArgs& a, int M, hipStream_t s) {
     static const int split_env = getenv("CV2_FLOW_TAIL_SPLIT") ? atoi(getenv("CV2_FLOW_TAIL_SPLIT")) : -1;      // A/B switch (diagnostics): 1 / 2 / 4
     const int panels = M / 16;
     int S = a.part ? (panels <= 64 ? 4 : (panels <= 128 ? 2 : 1)) : 1;
-    if (split_env > 0 && a.part) S = split_env;
+    // the scratch holds 128 panels x 4 parts and 128 tickets: a forced split only where it fits, else the default for this panel count
+    if (split_env > 0 && a.part && (split_env == 1 || ((split_env == 2 || split_env == 4) && panels <= 128))) S = split_env;
     if (S == 4) hipLaunchKernelGGL(k_tail_panel<4>, dim3(4, panels, 1), dim3(1024), sm, s, a);
     else if (S == 2) hipLaunchKernelGGL(k_tail_panel<2>, dim3(2, panels, 1), dim3(1024), sm, s, a);
     else hipLaunchKernelGGL(k_tail_panel<1>, dim3(1, panels, 1), dim3(1024), sm, s, a);

@@ -564,6 +564,7 @@ struct StepArgs {
     int per;                                     // blocks per layer: Q, A, O, GU, D in this order
     unsigned gl, off_dg, off_qg, off_kv, off_ag, off_hg;     // granules per layer; offsets of the buffers inside a layer (x_mid at 0)
     int dbg_layer;
+    const int* dbg_skip;                         // test hook (cv2_llm_debug_skip_publish): block index + 1 of a Q-role block that does not publish; 0 = none
 };
 #ifdef CV2_STAMPS
 __device__ unsigned long long g_chain_t[1024][8] = {};      // per block of one layer: start, result, published, operand ready (100 MHz ticks)
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int gb = blockIdx.x;
-    const int layer = gb / a.per;
+    const int layer = min(gb / a.per, a.n_layers);           // the head's blocks (vocab_pad / 16 of them, possibly more than `per`) follow the layers
     int r = gb - layer * a.per;
     const int H = a.H;
     const int nQ = 2 * (a.n_q + 2 * a.n_kv), nA = a.ntiles * a.n_kv, nO = H / 16, nGU = a.inter / 16;
@@ -756,6 +757,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     if (r < nQ) {                   // ---- Q: RMSNorm -> QKV -> + bias -> RoPE -> q granules / key, value granules + cache rows
         const int head = r >> 1, half = r & 1;
         const int pos = a.state[CV2_ST_POS];
+        const int skip = *a.dbg_skip;
         const int f = half * 16 + ((tid >> 4) & 1) * 32 + (tid & 15);
         const float bias = L.bqkv[head * 64 + f];
         float c, sn;
@@ -764,6 +766,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
         const float vp = __shfl(v, (tid & 63) ^ 16);
         if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);      // rotate-half RoPE on q and k heads
         CH_T(1);
+        if (skip == gb + 1) return;                    // (test hook: a hand-off that never arrives -> the consumers' bounded waits, CV2_ST_ERR = 3)
         if (tid < 32) {
             if (head < a.n_q) G.store(gl + a.off_qg + head * 64 + f, v);
             else if (head < a.n_q + a.n_kv) {
@@ -956,7 +959,10 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
 #pragma unroll
         for (int i = 0; i < ST; i++) sv[i] = stc[i];
     }
-    const int done = sv[CV2_ST_DONE];
+    // CV2_ST_ERR == 3: a hand-off of this step's k_step timed out (chain.h) -- the logits are not this step's: nothing is drawn and
+    // nothing committed (state, tokens and the pending input stay as they were; the epoch still advances), so the host can clear the
+    // flag and run the step again on the launches
+    const int done = sv[CV2_ST_DONE] | (sv[CV2_ST_ERR] == 3 ? 1 : 0);
     const int step = sv[CV2_ST_STEP];
     // repetition window (last 10 emitted tokens): lanes 0..9 of wave 0 hold one entry each; a serial loop of dependent global
     // loads in the sampling thread cost ~10 memory round trips per step
@@ -1657,6 +1663,7 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
         a.off_dg = d->hidden; a.off_qg = a.off_dg + CH_NP * d->hidden; a.off_kv = a.off_qg + d->n_q * 64;
         a.off_ag = a.off_kv + 2 * d->n_kv * 64; a.off_hg = a.off_ag + ntiles * d->n_kv * AT_GSTRIDE; a.gl = a.off_hg + d->inter;
         a.dbg_layer = -1;
+        a.dbg_skip = (const int*)(h->epoch + 16);
         h->step_blocks = d->layers * a.per + d->vocab_pad / 16;
     }
     *out = h;
@@ -1672,6 +1679,16 @@ extern "C" int cv2_llm_debug_ptrs(cv2_llm* h, uint64_t* out) {
     const uint64_t v[16] = {(uint64_t)h->q, (uint64_t)h->att, (uint64_t)h->att_ml, (uint64_t)h->o, (uint64_t)h->hbuf, (uint64_t)h->parts, (uint64_t)h->xa,
                             (uint64_t)h->xb, (uint64_t)h->gran, a.gl, a.off_dg, a.off_qg, a.off_kv, a.off_ag, a.off_hg, (uint64_t)h->kc};
     for (int i = 0; i < 16; i++) out[i] = v[i];
+    return 0;
+}
+
+// test hook: Q-role block `q_block` of layer `layer` of every following one-launch step keeps its results to itself (layer < 0: off).
+// The blocks behind it run into their bounded waits: CV2_ST_ERR = 3, the step commits nothing (k_sample), the host re-runs it on the launches.
+extern "C" int cv2_llm_debug_skip_publish(cv2_llm* h, int32_t layer, int32_t q_block) {
+    CV2_CHECK(h, "cv2_llm_debug_skip_publish: null handle");
+    const int v = layer < 0 ? 0 : layer * h->step.per + q_block + 1;
+    CV2_HIP(hipDeviceSynchronize());
+    CV2_HIP(hipMemcpy((void*)(h->epoch + 16), &v, sizeof(v), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -1898,8 +1915,10 @@ extern "C" int cv2_llm_extend(cv2_llm* h, int32_t seq, const float* embeds, int3
     return launch_sample(h, 1, seq, (len - 1) % 32, pos0 + len, s);
 }
 
-// Step 0 of inference_wrapper for several slots at once: embeds = the prompts' rows concatenated [sum(lens)][hidden] fp32
-extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int32_t* lens, const float* embeds, void* stream) {
+// Input rows of several slots at once through the GEMM path: embeds = the slots' rows concatenated [sum(lens)][hidden] fp32; slot i's rows
+// sit at KV positions pos0[i] .. pos0[i] + lens[i] - 1 (pos0 == nullptr: 0, step 0 of inference_wrapper) and attend to everything the
+// slot's cache holds below them; one draw per slot from its last row.
+static int rows_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int32_t* lens, const int32_t* pos0, const float* embeds, void* stream) {
     CV2_CHECK(h && slots && lens && embeds && n >= 1 && n <= 32, "cv2_llm_prefill_batch: bad argument");
     CV2_CHECK(h->pf_rows > 0, "cv2_llm_prefill_batch: created with max_prefill_rows == 0");
     if (init_attrs_once()) return -1;
@@ -1913,7 +1932,9 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
     int M = 0, maxlen = 0;
     for (int i = 0; i < n; i++) {
         CV2_CHECK(slots[i] >= 0 && slots[i] < d.max_seqs, "cv2_llm_prefill_batch: bad slot %d", slots[i]);
-        CV2_CHECK(lens[i] >= 1 && lens[i] + 1 < d.max_pos, "cv2_llm_prefill_batch: prompt length %d does not fit max_pos %d", lens[i], d.max_pos);
+        const int p0 = pos0 ? pos0[i] : 0;
+        CV2_CHECK(lens[i] >= 1 && p0 >= 0 && p0 + lens[i] + 1 < d.max_pos, "cv2_llm_prefill_batch: rows [%d, %d) do not fit max_pos %d", p0, p0 + lens[i], d.max_pos);
+        for (int j = 0; j < i; j++) CV2_CHECK(slots[j] != slots[i], "cv2_llm_prefill_batch: slot %d listed twice", slots[i]);
         M += lens[i]; maxlen = lens[i] > maxlen ? lens[i] : maxlen;
     }
     const int Mp = (M + 127) / 128 * 128;
@@ -1923,8 +1944,9 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
     int* row_seq = host.data(); int* row_pos = row_seq + R;
     int* row0 = row_pos + R; int* slen = row0 + 32; int* sslot = slen + 32; int* spos0 = sslot + 32; int* lastrow = spos0 + 32;
     for (int i = 0, r = 0; i < n; i++) {
-        row0[i] = r; slen[i] = lens[i]; sslot[i] = slots[i]; spos0[i] = 0; lastrow[i] = r + lens[i] - 1;
-        for (int t = 0; t < lens[i]; t++, r++) { row_seq[r] = slots[i]; row_pos[r] = t; }
+        const int p0 = pos0 ? pos0[i] : 0;
+        row0[i] = r; slen[i] = lens[i]; sslot[i] = slots[i]; spos0[i] = p0; lastrow[i] = r + lens[i] - 1;
+        for (int t = 0; t < lens[i]; t++, r++) { row_seq[r] = slots[i]; row_pos[r] = p0 + t; }
     }
     CV2_HIP(hipMemcpyAsync(h->pf_int, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     CV2_HIP(hipMemcpyAsync(h->pf_x, embeds, (size_t)M * d.hidden * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1981,9 +2003,20 @@ extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots
         else { const size_t sm = skinny_smem_bytes<2, 1, 4>(a.KS); hipLaunchKernelGGL((k_store<2, 8>), dim3(d.vocab_pad / 16, 1), dim3(256), sm, s, a); }
     }
     for (int i = 0; i < n; i++)
-        if (launch_sample(h, 1, slots[i], i, lens[i], s)) return -1;
+        if (launch_sample(h, 1, slots[i], i, (pos0 ? pos0[i] : 0) + lens[i], s)) return -1;
     CV2_LAUNCH_CHECK();
     return 0;
+}
+
+// Step 0 of inference_wrapper for several slots at once: embeds = the prompts' rows concatenated [sum(lens)][hidden] fp32
+extern "C" int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int32_t* lens, const float* embeds, void* stream) {
+    return rows_batch(h, n, slots, lens, nullptr, embeds, stream);
+}
+// cv2_llm_extend for several slots in one pass over the weights (the text blocks of concurrent inference_bistream calls, llm.py:787-811)
+extern "C" int cv2_llm_extend_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int32_t* lens, const int32_t* pos0, const float* embeds,
+                                    void* stream) {
+    CV2_CHECK(pos0, "cv2_llm_extend_batch: null argument");
+    return rows_batch(h, n, slots, lens, pos0, embeds, stream);
 }
 
 // one captured graph holds `unroll` consecutive decode steps for n_seqs slots (key = n_seqs * 64 + unroll)

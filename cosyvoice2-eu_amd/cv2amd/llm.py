@@ -63,10 +63,14 @@ class LLMEngine:
         bdec = torch.zeros(vocab_pad)
         bdec[:vocab] = sd['llm_decoder.bias']
         cos, sin = W.rope_tables(max_pos)
-        self.speech_emb = dv(sd['speech_embedding.weight'])
+        # one table [text ++ speech ++ (sos, task)] with the three embeddings as views: the input rows of a feed (any mixture of the
+        # three kinds, llm.py:766-786) are ONE gather over host-built indices
+        n_text = sd['llm.model.model.embed_tokens.weight'].shape[0]
+        self.emb_all = dv(torch.cat([sd['llm.model.model.embed_tokens.weight'].float(), sd['speech_embedding.weight'].float(),
+                                     sd['llm_embedding.weight'].float()], dim=0))
+        self.text_emb, self.speech_emb, self.llm_emb = self.emb_all[:n_text], self.emb_all[n_text:n_text + vocab], self.emb_all[n_text + vocab:]
+        self.IDX_SPEECH, self.IDX_SOS, self.IDX_TASK = n_text, n_text + vocab, n_text + vocab + 1
         self.bdec = dv(bdec)                           # llm_decoder.bias on the device (padded to vocab_pad)
-        self.llm_emb = dv(sd['llm_embedding.weight'])
-        self.text_emb = dv(sd['llm.model.model.embed_tokens.weight'])
         self._w = L.LlmWeights(layers=C.cast(self._layers, C.POINTER(L.LlmLayer)),
                                final_norm=dv(sd['llm.model.model.norm.weight']).data_ptr(), wdec=wdec.data_ptr(),
                                bdec=self.bdec.data_ptr(), speech_emb=self.speech_emb.data_ptr(),
@@ -82,6 +86,9 @@ class LLMEngine:
         L.check(self.lib.cv2_llm_create(C.byref(self.dims), C.byref(self._w), C.byref(self._io), self.workspace.data_ptr(),
                                         nbytes, C.byref(h)))
         self.handle = h
+        # a one-launch step whose in-launch hand-off timed out (CV2_ST_ERR = 3) commits nothing; the host clears the flag, repeats the
+        # steps and keeps this engine on the launches from then on (_recover_handoff)
+        self.chain_broken, self.handoff_recoveries = False, 0
         self.weight_bytes = sum(t.numel() * t.element_size() for t in keep if t.dtype == torch.int16)
 
     def __del__(self):
@@ -142,15 +149,29 @@ class LLMEngine:
 
     def step(self, n_seqs, n_steps=1, shared=False):
         """shared: kernels of other streams run beside these steps (CV2_DECODE_SHARED: the launches instead of the one-launch step)."""
-        L.check(self.lib.cv2_llm_decode_ex(self.handle, n_seqs, n_steps, 1 if shared else 0, L.stream_ptr()))
+        L.check(self.lib.cv2_llm_decode_ex(self.handle, n_seqs, n_steps, 1 if (shared or self.chain_broken) else 0, L.stream_ptr()))
 
     def step_rows(self, slots, n_steps=1, shared=False):
         """n_steps over the live slots only (cv2_llm_decode_rows): row r of every step serves slot slots[r]."""
         arr = (C.c_int32 * len(slots))(*slots)
-        L.check(self.lib.cv2_llm_decode_rows(self.handle, arr, len(slots), n_steps, 1 if shared else 0, L.stream_ptr()))
+        L.check(self.lib.cv2_llm_decode_rows(self.handle, arr, len(slots), n_steps, 1 if (shared or self.chain_broken) else 0, L.stream_ptr()))
+
+    def _recover_handoff(self, slots):
+        """CV2_ST_ERR = 3: a hand-off inside the one-launch step (k_step, csrc/chain.h) did not arrive within its bound -- the device
+        was contended in a way that broke the step's forward progress.  k_sample commits nothing for such a step (nor for the steps
+        enqueued behind it): tokens, positions and the pending input are those before it and the KV rows it wrote are rewritten by the
+        repeat.  The flag is cleared, the caller's loop issues the missing steps again, and from here on this engine runs every step
+        on the launches (the structure that needs no co-residency)."""
+        import logging
+        for s in slots:
+            self.state[s, L.ST_ERR] = 0
+        self.chain_broken = True
+        self.handoff_recoveries += 1
+        logging.warning('LLM decode: an in-launch hand-off of the one-launch step timed out (slot %s); the step is repeated on the launches and '
+                        'this engine stays on them', list(slots))
 
     ERR_MSG = 'sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!'      # llm.py:249
-    ERR_HANDOFF = 'LLM decode: an in-launch hand-off (k_chain) timed out; the device was too contended for the step to finish'
+    ERR_HANDOFF = 'LLM decode: an in-launch hand-off (k_step) timed out; the device was too contended for the step to finish'
 
     def _err(self, code):
         return RuntimeError(self.ERR_HANDOFF if int(code) == 3 else self.ERR_MSG)
@@ -159,6 +180,10 @@ class LLMEngine:
         """(state [n, 16] int32 cpu, list of emitted-token lists). One device->host sync.  A slot whose sampler gave up (ST_ERR,
         llm.py:242-250) is finished; with raise_on_error=False the caller inspects st[:, ST_ERR] and fails only that request."""
         st = self.state[:n_seqs].cpu()
+        bad = [b for b in range(n_seqs) if int(st[b, L.ST_ERR]) == 3]
+        if bad:
+            self._recover_handoff(bad)
+            st[bad, L.ST_ERR] = 0
         toks = self.out_tokens[:n_seqs].cpu()
         if raise_on_error:
             for b in range(n_seqs):
@@ -169,6 +194,9 @@ class LLMEngine:
     def read_slot(self, slot):
         """(state row [16] int32 cpu, emitted tokens of one slot).  One device->host sync."""
         st = self.state[slot].cpu()
+        if int(st[L.ST_ERR]) == 3:
+            self._recover_handoff([slot])
+            st[L.ST_ERR] = 0
         if int(st[L.ST_ERR]):
             raise self._err(st[L.ST_ERR])
         n = min(int(st[L.ST_NOUT]), self.max_out)
@@ -205,6 +233,11 @@ class LLMEngine:
         while True:
             st = self.state[:n].cpu()                 # a poll reads the state records only (2 KB); the tokens are fetched once, at the end
             S = st.tolist()
+            bad = [b for b in range(n) if S[b][L.ST_ERR] == 3]
+            if bad:                                   # nothing of the failed steps was committed: the loop below issues them again
+                self._recover_handoff(bad)
+                for b in bad:
+                    S[b][L.ST_ERR] = 0
             if all(r[L.ST_DONE] for r in S):
                 st, toks = self.read(n, raise_on_error=not return_errors)
                 if return_errors:
@@ -226,94 +259,123 @@ class LLMEngine:
                 self.step(n, k)
 
     # ---- llm.py:721-834 ------------------------------------------------------------------------------------------
+    def new_bistream(self, slot, prompt_text, prompt_speech_token, mode=MODE_GREEDY, seed=0, mix_ratio=(5, 15)):
+        """Host bookkeeping of one Qwen2LM.inference_bistream call on slot `slot` (no device work)."""
+        return BiStream(self, slot, prompt_text, prompt_speech_token, mode, seed, mix_ratio)
+
+    def bi_poll(self, streams):
+        """Read the slots of the RUNNING streams (one copy of the state records, one of the new out_tokens entries): new ids, fill /
+        EOS stops (llm.py:805-811, 826-832), errors.  Blocks until the current stream's work has run."""
+        run = [b for b in streams if b.running]
+        if not run:
+            return
+        st = self.state.cpu().tolist()
+        bad = [b.slot for b in run if st[b.slot][L.ST_ERR] == 3]
+        if bad:
+            self._recover_handoff(bad)
+            for s_ in bad:
+                st[s_][L.ST_ERR] = 0
+        lo = min(b.n_read for b in run)
+        hi = max(min(st[b.slot][L.ST_NOUT], self.max_out) for b in run)
+        toks = self.out_tokens[:, lo:hi].cpu().tolist() if hi > lo else None
+        for b in run:
+            b._polled(st[b.slot], toks[b.slot][b.n_read - lo:min(st[b.slot][L.ST_NOUT], self.max_out) - lo] if toks is not None else [])
+
+    def bi_feed(self, streams, prepared=False):
+        """Every idle stream that has its next input (the text block after a fill, the first [sos, text / prompt-speech blocks], or the
+        final [pending input, remaining text, task id]; llm.py:766-786, 817) is fed in ONE pass over the weights
+        (cv2_llm_extend_batch) followed by one draw per slot.  Returns the streams fed.  prepared: the caller has already called
+        next_feed() on the idle streams (under the lock its text producers push under); only those results are used."""
+        feeds = []
+        for b in streams:
+            if not b.running and not b.finished:
+                f = b._pending if prepared else b.next_feed()
+                if f is not None:
+                    feeds.append((b, f))
+        if not feeds:
+            return []
+        dev = self.device
+        rows = torch.tensor([b._state_row(final) for b, (_, final) in feeds], dtype=torch.int32)
+        self.state.index_copy_(0, torch.tensor([b.slot for b, _ in feeds], dtype=torch.long).to(dev), rows.to(dev))
+        emb = self.emb_all[torch.tensor([i for _, (idx, _) in feeds for i in idx], dtype=torch.long).to(dev)]
+        cap = (self.dims.max_prefill_rows // 128) * 128
+        r0, grp = 0, []
+
+        def flush():
+            nonlocal grp
+            if grp:
+                n = len(grp)
+                a0 = grp[0][2]
+                arr = lambda v: (C.c_int32 * n)(*v)     # noqa: E731
+                part = emb[a0:a0 + sum(g[1] for g in grp)]
+                L.check(self.lib.cv2_llm_extend_batch(self.handle, n, arr([g[0].slot for g in grp]), arr([g[1] for g in grp]),
+                                                      arr([g[0].pos for g in grp]), L.ptr(part), L.stream_ptr()))
+                grp = []
+        for b, (idx, final) in feeds:
+            n = len(idx)
+            if n > cap:                                   # one feed beyond the GEMM path's capacity: 32 rows at a time
+                flush()
+                part = emb[r0:r0 + n]
+                L.check(self.lib.cv2_llm_extend(self.handle, b.slot, L.ptr(part), n, b.pos, L.stream_ptr()))
+            else:
+                if sum(g[1] for g in grp) + n > cap:
+                    flush()
+                grp.append((b, n, r0))
+            r0 += n
+        flush()
+        self._keep_rows = emb                            # alive until the stream has consumed it
+        for b, (idx, final) in feeds:
+            b._fed(len(idx), final)
+        return [b for b, _ in feeds]
+
+    def bi_burst(self, streams, n_steps, shared=False):
+        """n_steps decode steps over the running streams' slots (a slot that stops on a fill id inside the burst idles from there)."""
+        run = sorted(b.slot for b in streams if b.running)
+        if run and n_steps > 0:
+            self.step_rows(run, n_steps, shared=shared)
+            for b in streams:
+                if b.running and b.eta is not None:
+                    b.eta = max(0, b.eta - n_steps)
+
+    @staticmethod
+    def bi_burst_len(streams, burst=16):
+        """Steps worth enqueueing before the next poll: up to the earliest known stop (the forced fill, llm.py:796-798) or the earliest
+        point a consumer waits for; 0 when every running stream is expected to have stopped already."""
+        run = [b for b in streams if b.running]
+        if not run or all(b.eta == 0 for b in run):
+            return 0
+        c = [b.eta for b in run if b.eta] + [b.want for b in run if b.want is not None and b.want > 0]
+        return max(1, min(c + [burst]))
+
     def bistream(self, slot, text, prompt_text, prompt_speech_token, mode=MODE_GREEDY, seed=0, mix_ratio=(5, 15), burst=16,
                  n_seqs=None, on_device=None):
         """Qwen2LM.inference_bistream on slot `slot`: `text` is an iterable of int tensors [1, n] arriving over time; yields speech
         token ids as the reference generator does.  The LM input interleaves mix_ratio[0] text tokens with mix_ratio[1] speech
-        tokens; the device stops the slot on the fill id (k_sample, CV2_ST_WAIT) and this loop feeds the next text block with
-        cv2_llm_extend, exactly where the reference breaks out of its inner `while True` (llm.py:807-808).
-
-        Same bookkeeping as the reference, including its quirks: the stale `lm_input` is replaced by the text block after a fill
-        but fed again in front of the remaining text + task id at the end (llm.py:817).  `on_device(fn)` runs fn() under the
-        caller's device lock / stream (the scheduler passes one); `n_seqs` = slots covered by a decode step (default slot + 1)."""
-        n_text, n_speech = mix_ratio
-        dev = self.device
-        run = on_device or (lambda fn: fn())          # every device operation below goes through run()
-        S = {'pos': 0, 'n_read': 0, 'started': False}     # KV rows fed so far / entries of the device's out_tokens already seen
-        outs = []                                     # the reference's out_tokens (fill / EOS included)
-
-        def emb(ids):
-            return self.text_emb[ids.reshape(-1).to(dev).long()]
-
-        def feed(rows, final=False):
-            rows = rows.contiguous()
-            if not S['started']:
-                self.state[slot, L.ST_BIMODE], self.state[slot, L.ST_NEXTFILL] = 1, -1
-                S['started'] = True
-            self.state[slot, L.ST_DONE], self.state[slot, L.ST_WAIT], self.state[slot, L.ST_BIMODE] = 0, 0, (2 if final else 1)
-            L.check(self.lib.cv2_llm_extend(self.handle, slot, L.ptr(rows), rows.shape[0], S['pos'], L.stream_ptr()))
-            self._keep_rows = rows                    # keep the rows alive until the stream has consumed them
-
-        def poll():
-            st = self.state[slot].cpu()
-            n = min(int(st[L.ST_NOUT]), self.max_out)
-            new = self.out_tokens[slot, S['n_read']:n].cpu().tolist()
-            S['n_read'], S['pos'] = n, int(st[L.ST_POS])
-            return new, bool(st[L.ST_DONE]), int(st[L.ST_ERR])
-
-        def init():
-            self._init_state(slot, 0, self.max_out, mode, seed, False)
-            return (self.speech_emb[prompt_speech_token.reshape(-1).to(dev).long()], self.llm_emb[0:1], emb(prompt_text))
-        sp_left, lm_input, text_cache = run(init)
-
-        def decode_until_stop():
-            """the inner `while True` of llm.py:787-811 / 819-832: yields emitted ids until fill (mid) or EOS (final)."""
-            nonlocal lm_input
-            while True:
-                new, done, err = run(poll)
-                for t in new:
-                    outs.append(t)
-                    if t < EOS:
-                        yield t
-                if err in (1, 3):
-                    raise self._err(err)
-                if err == 2:
-                    raise ValueError('should not get token {}'.format(outs[-1]))
-                real = [t for t in new if t < EOS]
-                if real:                              # lm_input = speech_embedding[last emitted id] (llm.py:811)
-                    last = real[-1]
-                    lm_input = run(lambda: self.speech_emb[last:last + 1])
-                if done:
-                    return
-                run(lambda: self.step((n_seqs() if callable(n_seqs) else n_seqs) or slot + 1, burst))
-
-        for this_text in text:
-            def block():
-                nonlocal sp_left, lm_input, text_cache
-                text_cache = torch.cat([text_cache, emb(this_text)], dim=0)
-                while sp_left.shape[0] != 0:                               # llm.py:766-774
-                    if text_cache.shape[0] >= n_text:
-                        lm_input = torch.cat([lm_input, text_cache[:n_text], sp_left[:n_speech]], dim=0)
-                        text_cache, sp_left = text_cache[n_text:], sp_left[n_speech:]
-                    else:
-                        break
-                if sp_left.shape[0] != 0:
-                    return False
-                last_fill = len(outs) != 0 and outs[-1] == EOS + 2         # llm.py:776-786
-                if last_fill or (len(outs) == 0 and lm_input.shape[0] == 1):
-                    if text_cache.shape[0] < n_text:
-                        return False
-                    lm_input = text_cache[:n_text] if last_fill else torch.cat([lm_input, text_cache[:n_text]], dim=0)
-                    text_cache = text_cache[n_text:]
-                feed(lm_input)
-                return True
-            if run(block):
-                yield from decode_until_stop()
-
-        def final():
-            feed(torch.cat([lm_input, text_cache, self.llm_emb[1:2]], dim=0), final=True)     # llm.py:817
-        run(final)
-        yield from decode_until_stop()
+        tokens; the device stops the slot on the fill id (k_sample, CV2_ST_WAIT) and the next text block is fed exactly where the
+        reference breaks out of its inner `while True` (llm.py:807-808).  The bookkeeping lives in BiStream (shared with the
+        scheduler's rounds over several calls, cosyvoice/cli/model.py); `on_device(fn)` runs fn() under the caller's device lock /
+        stream; the next piece of `text` is only pulled when the slot has nothing left to feed, as the reference's `for` does."""
+        run = on_device or (lambda fn: fn())
+        bs = self.new_bistream(slot, prompt_text, prompt_speech_token, mode, seed, mix_ratio)
+        it = iter(text)
+        while not bs.finished:
+            if bs.running:
+                run(lambda: self.bi_poll([bs]))
+                yield from bs.take()
+                if bs.err is not None:
+                    raise bs.err
+                if bs.running:
+                    run(lambda: self.bi_burst([bs], self.bi_burst_len([bs], burst)))
+                continue
+            if run(lambda: self.bi_feed([bs])):
+                n = self.bi_burst_len([bs], burst)
+                if n:
+                    run(lambda: self.bi_burst([bs], n))
+                continue
+            try:
+                bs.push(next(it))
+            except StopIteration:
+                bs.close()
 
     def generate_fixed(self, requests, n_tokens, mode=MODE_RAS, seed=0):
         """Synthetic-weights mode: exactly n_tokens per request, EOS never drawn, no host sync inside the
@@ -329,3 +391,116 @@ class LLMEngine:
         st, toks = self.read(n)
         assert bool(st[:, L.ST_DONE].all()) and all(len(t) == n_tokens for t in toks)
         return toks, (e0, e1)
+
+
+class BiStream:
+    """Host half of one Qwen2LM.inference_bistream call (llm.py:721-834): the text cache, the prompt speech tokens still to interleave,
+    the pending LM input and the reference's `out_tokens` list, all as plain id lists (indices into LLMEngine.emb_all); the device
+    half is the slot's state machine in k_sample.  No method touches the device: LLMEngine.bi_poll / bi_feed / bi_burst do, for one
+    stream or for all the streams of a scheduler round at once."""
+
+    def __init__(self, eng, slot, prompt_text, prompt_speech_token, mode, seed, mix_ratio=(5, 15)):
+        import collections
+        self.eng, self.slot, self.mode, self.seed, self.mix = eng, slot, mode, seed, tuple(mix_ratio)
+        self.text_cache = [int(t) for t in prompt_text.reshape(-1).tolist()]                       # llm.py:750-757
+        self.sp_left = [eng.IDX_SPEECH + int(t) for t in prompt_speech_token.reshape(-1).tolist()]
+        self.lm_input = [eng.IDX_SOS]                                                              # llm.py:743
+        self.outs = []                        # the reference's out_tokens (fill / EOS entries included)
+        self.pieces, self.text_done = collections.deque(), False
+        self.n_read, self.pos = 0, 0          # entries of the device's out_tokens already seen / KV rows fed so far
+        self.started = self.running = self.finished = self.final_fed = False
+        self.eta = None                       # expected decode steps until the slot stops (None: unknown)
+        self.want = None                      # tokens a consumer is waiting for (scheduler hint for the burst length)
+        self.err = None
+        self._row = None                      # the slot's state record at the last poll
+        self._new = []                        # emitted ids not yet taken
+        self._pending = None
+
+    # ---- text side (any thread; the scheduler serialises these with its own lock) ----
+    def push(self, piece):
+        self.pieces.append([int(t) for t in piece.reshape(-1).tolist()])
+
+    def close(self):
+        self.text_done = True
+
+    def take(self):
+        """the ids emitted since the last take (what the reference generator has yielded in the meantime)"""
+        new, self._new = self._new, []
+        return new
+
+    # ---- llm.py:759-786, 817 for an idle slot ----
+    def next_feed(self):
+        """(indices of the next input rows, final) or None while the call waits for text.  Consumes text pieces exactly as the
+        reference's `for this_text in text` does: one piece at a time until one of them leads to a decode."""
+        if self._pending is not None:
+            return self._pending
+        n_text, n_speech = self.mix
+        fill = EOS + 2
+        while self.pieces:
+            self.text_cache += self.pieces.popleft()
+            while self.sp_left:                                                                    # llm.py:766-774
+                if len(self.text_cache) < n_text:
+                    break
+                self.lm_input = self.lm_input + self.text_cache[:n_text] + self.sp_left[:n_speech]
+                self.text_cache, self.sp_left = self.text_cache[n_text:], self.sp_left[n_speech:]
+            if self.sp_left:
+                continue
+            last_fill = bool(self.outs) and self.outs[-1] == fill                                  # llm.py:776-786
+            if last_fill or (not self.outs and len(self.lm_input) == 1):
+                if len(self.text_cache) < n_text:
+                    continue
+                self.lm_input = self.text_cache[:n_text] if last_fill else self.lm_input + self.text_cache[:n_text]
+                self.text_cache = self.text_cache[n_text:]
+            self._pending = (list(self.lm_input), False)
+            return self._pending
+        if self.text_done:                                                                         # llm.py:817 (the stale lm_input goes in again)
+            self._pending = (self.lm_input + self.text_cache + [self.eng.IDX_TASK], True)
+            return self._pending
+        return None
+
+    def _state_row(self, final):
+        """the slot's state record for the feed: a fresh one for the first feed, the polled one with the stop flags cleared afterwards"""
+        if not self.started:
+            eng, seed = self.eng, self.seed
+            row = [0] * L.STATE_STRIDE
+            row[L.ST_MINLEN], row[L.ST_MAXLEN], row[L.ST_MODE] = 0, eng.max_out, self.mode
+            row[L.ST_SEED_LO] = (seed & 0x7FFFFFFF) - (seed & 0x80000000)
+            row[L.ST_SEED_HI] = ((seed >> 32) & 0x7FFFFFFF) - ((seed >> 32) & 0x80000000)
+            row[L.ST_NEXTFILL] = -1
+        else:
+            row = list(self._row)
+        row[L.ST_DONE], row[L.ST_WAIT], row[L.ST_BIMODE] = 0, 0, (2 if final else 1)
+        return row
+
+    def _fed(self, n_rows, final):
+        last_fill = bool(self.outs) and self.outs[-1] == EOS + 2
+        self.started = self.running = True
+        self.final_fed = final
+        self.pos += n_rows
+        self._pending = None
+        # after a fill the next one is forced mix[1] + 1 entries later (llm.py:796-804): the feed draws the first of them
+        self.eta = None if final else (self.mix[1] if last_fill else 0)
+
+    def _polled(self, row, new):
+        self._row = row
+        self.n_read += len(new)
+        self.pos = row[L.ST_POS]
+        for t in new:
+            self.outs.append(t)
+            if t < EOS:
+                self._new.append(t)
+        real = [t for t in new if t < EOS]
+        if real:                                          # lm_input = speech_embedding[last emitted id] (llm.py:811)
+            self.lm_input = [self.eng.IDX_SPEECH + real[-1]]
+        err = row[L.ST_ERR]
+        if err in (1, 3):
+            self.err = self.eng._err(err)
+        elif err == 2:
+            self.err = ValueError('should not get token {}'.format(self.outs[-1]))
+        if row[L.ST_DONE] or self.err is not None:        # stopped: on the fill id (waits for text), on EOS, on an error or out of room
+            self.running = False
+            self.eta = None
+            if self.final_fed or self.err is not None or not row[L.ST_WAIT]:
+                self.finished = True
+        elif self.eta == 0:
+            self.eta = None                               # did not stop where expected: poll at the default cadence

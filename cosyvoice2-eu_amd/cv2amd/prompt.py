@@ -57,6 +57,18 @@ def _sinc_kernel(orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
     return k.astype(np.float32), width, orig, new
 
 
+def _on_own_device(fn):
+    """run the method with the object's device current: L.stream_ptr() is the current device's stream, and a rank that lives on
+    cuda:k must not launch on cuda:0's"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class PromptFeatures:
     """feat_extractor + resampler of the reference frontend on one device."""
 
@@ -82,6 +94,7 @@ class PromptFeatures:
         self._cfg = MelCfg(n_fft, hop, n_mels, n_fft // 2 + 1, t['window'].data_ptr(), t['tw'].data_ptr(), t['fb'].data_ptr(),
                            t['lo'].data_ptr(), t['hi'].data_ptr(), 1e-5)
 
+    @_on_own_device
     def resample(self, speech):
         """[1, n] at the source rate -> [1, ceil(up n / down)] (device)."""
         x = speech.reshape(-1).to(self.device, torch.float32).contiguous()
@@ -92,6 +105,7 @@ class PromptFeatures:
                                       n_out, L.stream_ptr()))
         return out.unsqueeze(0)
 
+    @_on_own_device
     def mel(self, speech_24k):
         """[1, n] -> log-mel [1, frames, n_mels] time-major (the layout of prompt_speech_feat), device."""
         x = speech_24k.reshape(-1).to(self.device, torch.float32).contiguous()
@@ -167,11 +181,13 @@ class SpeechFeatures:
         self._kaldi = FrameFeatCfg(512, 400, 160, 257, 80, w.data_ptr(), tw.data_ptr(), fb.data_ptr(), lo.data_ptr(), hi.data_ptr(), 0, 1, 0.97, 0,
                                    float(np.finfo(np.float32).eps))
 
+    @_on_own_device
     def _run(self, cfg, x, frames):
         out = torch.empty(frames, cfg.n_mels, dtype=torch.float32, device=self.device)
         L.check(self.lib.cv2_framefeat(C.byref(cfg), x.data_ptr(), x.numel(), out.data_ptr(), frames, L.stream_ptr()))
         return out
 
+    @_on_own_device
     def whisper_log_mel(self, speech_16k):
         """[1, n] -> [1, 128, n // 160] (device), the tensor the reference hands to speech_tokenizer_v2.onnx."""
         x = speech_16k.reshape(-1).to(self.device, torch.float32).contiguous()
@@ -183,6 +199,7 @@ class SpeechFeatures:
         L.check(self.lib.cv2_whisper_post(raw.data_ptr(), out.data_ptr(), frames, 128, L.stream_ptr()))
         return out.unsqueeze(0)
 
+    @_on_own_device
     def kaldi_fbank(self, speech_16k, subtract_mean=True):
         """[1, n] -> [1 + (n - 400) // 160, 80] (device); subtract_mean: the `feat - feat.mean(dim=0)` of frontend.py:278."""
         x = speech_16k.reshape(-1).to(self.device, torch.float32).contiguous()

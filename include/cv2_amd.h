@@ -120,12 +120,18 @@ int cv2_llm_prefill_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int
  * (embeds fp32 [len][hidden], device), then one draw from the last row under state[seq] (CV2_ST_BIMODE, CV2_ST_NEXTFILL).  In
  * bistream modes out_tokens receives EVERY drawn id (fill and EOS included), as the reference's out_tokens list does. */
 int cv2_llm_extend(cv2_llm* h, int32_t seq, const float* embeds, int32_t len, int32_t pos0, void* stream);
+/* The same for n slots in one pass over the weights (the matrix-core path of cv2_llm_prefill_batch): the text blocks that concurrent
+ * inference_bistream calls (cli/model.py:120-128 x the streams of BASELINE configs[4]) are waiting to feed.  slots / lens / pos0 are HOST
+ * arrays of n entries (distinct slots), embeds = the slots' rows concatenated, fp32 [sum(lens)][hidden] on the device; one draw per slot
+ * from its last row under state[slot].  sum(lens) rounded up to 128 must fit max_prefill_rows. */
+int cv2_llm_extend_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int32_t* lens, const int32_t* pos0, const float* embeds, void* stream);
 /* n_steps iterations of the decode loop for slots 0..n_seqs-1 in lock step (one hipGraph replay per step);
  * finished slots idle.  No host synchronisation inside.
  * n_seqs == 1: a step is ONE launch (k_step, csrc/chain.h: every layer's Q / attention / O / gate-up / down roles and the head
  * as blocks of one grid in dependency order, activations handed over as epoch-tagged granules) followed by the sampler; the
  * environment variable CV2_LLM_CHAIN=0 (read at create) selects the five launches per layer used for 2..16 rows instead.
- * CV2_ST_ERR = 3 reports a hand-off that timed out. */
+ * CV2_ST_ERR = 3 reports a hand-off that timed out: that step (and every later step of the call) commits nothing -- state, tokens and the
+ * KV positions are the ones before it -- so the caller clears the flag and repeats the steps with CV2_DECODE_SHARED (the launches). */
 int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream);
 /* The same with flags.  CV2_DECODE_SHARED: other streams' kernels run beside these steps (the streaming scheduler overlaps a decode
  * burst with the previous chunk's flow + HiFT): use the launches even at one row -- k_step's resident polling waves cost the
@@ -140,6 +146,9 @@ int cv2_llm_decode_rows(cv2_llm* h, const int32_t* slots, int32_t n_rows, int32_
 /* 1 when one-row decode steps of this engine run as one launch (k_step), 0 when they run as launches (dims outside k_step's
  * limits, or CV2_LLM_CHAIN=0). */
 int cv2_llm_one_launch_step(const cv2_llm* h);
+/* test hook: from now on Q-role block `q_block` of layer `layer` of every one-launch step does not publish its results (layer < 0: off),
+ * so the blocks behind it end in their bounded waits and the step reports CV2_ST_ERR = 3 without committing anything. */
+int cv2_llm_debug_skip_publish(cv2_llm* h, int32_t layer, int32_t q_block);
 /* test / diagnostic hook: device addresses of the decode workspaces and the granule layout (16 values; tools/dbg_chain_vals.py) */
 int cv2_llm_debug_ptrs(cv2_llm* h, uint64_t* out);
 

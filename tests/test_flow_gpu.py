@@ -11,6 +11,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+from _bars import bar
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -158,7 +159,7 @@ def test_large_batch_tile_configurations_agree_with_single(dev, flow_sd):
         single = big.inference_batch([utts[i]])[0]
         torch.cuda.synchronize()
         assert single.shape == batch[i].shape and torch.isfinite(batch[i]).all()
-        assert rel(batch[i].cpu(), single.cpu()) < 3e-2, f'utterance {i}: {rel(batch[i].cpu(), single.cpu()):.3e}'
+        bar(f'flow batch-of-8 vs single, utterance {i}', rel(batch[i].cpu(), single.cpu()), 3e-2)
 
 
 def test_oracle_full_size_estimator_random(eng, dev, flow_sd):
@@ -174,7 +175,7 @@ def test_oracle_full_size_estimator_random(eng, dev, flow_sd):
     y = eng.forward_estimator(x.to(dev).contiguous(), torch.ones(2, 1, T, device=dev), mu.to(dev), t.to(dev), spks.to(dev), cond.to(dev))
     torch.cuda.synchronize()
     ref = OF.estimator(flow_sd, x, torch.ones(2, 1, T), mu, t, spks, cond, False)
-    assert rel(y.cpu(), ref) < 4e-2
+    bar('flow estimator T=150 vs oracle (max of range)', rel(y.cpu(), ref), 4e-2)
 
 
 def _record(name, **vals):
@@ -270,7 +271,7 @@ def test_cached_chunks_equal_the_recompute_of_the_whole_prefix(eng):
         assert first == 2 * off, (first, off)
         assert got.shape == ref.shape and torch.isfinite(got).all()
         worst = max(worst, rel(got.cpu(), ref.cpu()))
-        assert rel(got.cpu(), ref.cpu()) < 3e-2, f'call at offset {off}: {rel(got.cpu(), ref.cpu()):.3e}'
+        bar(f'flow cached chunk vs recompute, offset {off}', rel(got.cpu(), ref.cpu()), 3e-2)
     assert cache.n_cached == 2 * (P + N) and cache.gen == len(calls)
     # a cache that sits out some calls (the scheduler only uses it when that pays) stays valid for the frames it holds: the next
     # cached call computes everything after them
@@ -284,7 +285,7 @@ def test_cached_chunks_equal_the_recompute_of_the_whole_prefix(eng):
         (got, first), = eng.inference_chunk_batch([u], [lazy], finalize=fin)
         torch.cuda.synchronize()
         assert first == max(before - 2 * P, 0) and first <= 2 * off and got.shape[2] == full.shape[2] - first
-        assert rel(got.cpu(), full[:, :, first:].cpu()) < 3e-2
+        bar('flow cached chunk vs full recompute (regrown cache)', rel(got.cpu(), full[:, :, first:].cpu()), 3e-2)
     _record('cached_chunks_vs_recompute', worst_rel=worst, calls=len(calls))
 
 
@@ -332,7 +333,7 @@ def test_cached_chunks_of_streams_in_different_phases_share_a_batch(eng):
             for k, (m, first) in zip(grp, outs):
                 ref = alone[k][pos[k]]
                 assert m.shape == ref.shape
-                assert rel(m.cpu(), ref.cpu()) < 3e-2, f'stream {k} call {pos[k]}: {rel(m.cpu(), ref.cpu()):.3e}'
+                bar(f'flow cached chunks of 3 streams, stream {k} call {pos[k]}', rel(m.cpu(), ref.cpu()), 3e-2)
                 pos[k] += 1
         rnd += 1
 
@@ -358,6 +359,6 @@ def test_stream_started_from_a_prompt_cache(eng):
         (mb, fb), = eng.inference_chunk_batch([u], [b], finalize=False)
         torch.cuda.synchronize()
         assert fa == fb and ma.shape == mb.shape
-        assert rel(mb.cpu(), ma.cpu()) < 3e-2, f'offset {off}: {rel(mb.cpu(), ma.cpu()):.3e}'
+        bar(f'flow prompt-cache start vs recompute, offset {off}', rel(mb.cpu(), ma.cpu()), 3e-2)
     assert a.n_cached == b.n_cached
     assert eng.prompt_cache(inp['prompt_token'][:, :20], inp['prompt_feat'][:, :40], inp['embedding']) is None

@@ -358,3 +358,115 @@ def test_serving_wire_formats_match_protobuf_and_pcm():
         assert [np.frombuffer(c, dtype=np.int16).tolist() for c in chunks] == [[8192] * 4, [-8192] * 2]
     finally:
         server.stop(0)
+
+
+class _SimBistreamEngine:
+    """The device half of cv2amd.llm's bistream rounds simulated on the CPU: k_sample's state machine (csrc/llm.hip: fill id stops the
+    slot, forced fill every mix[1] + 1 entries, final decode ends on EOS) over the oracle's backbone, greedy harness.  Only the methods
+    LLMEngine.bistream() calls on `self` exist; BiStream and the generator loop are the product's own code."""
+
+    def __init__(self, sd, max_out=512):
+        from cv2amd.llm import LLMEngine
+        from oracle import llm as OL
+        self.OL, self.sd, self.d, self.max_out = OL, sd, OL.LLMDims(sd), max_out
+        n_text, vocab = sd['llm.model.model.embed_tokens.weight'].shape[0], sd['speech_embedding.weight'].shape[0]
+        self.emb_all = torch.cat([sd['llm.model.model.embed_tokens.weight'], sd['speech_embedding.weight'], sd['llm_embedding.weight']], 0)
+        self.IDX_SPEECH, self.IDX_SOS, self.IDX_TASK = n_text, n_text + vocab, n_text + vocab + 1
+        self.slots = {}
+        self.feeds = []                                 # (slot, n rows, final) of every feed, in order
+        for name in ('new_bistream', 'bistream', 'bi_burst_len'):
+            setattr(self, name, getattr(LLMEngine, name).__get__(self) if name != 'bi_burst_len' else LLMEngine.bi_burst_len)
+
+    def _err(self, code):
+        return RuntimeError(f'err {code}')
+
+    def _draw(self, s, x):
+        from cv2amd import lib as L
+        OL, st = self.OL, s['st']
+        y = OL.qwen2_step(self.sd, self.d, x, s['cache'])
+        logp = torch.nn.functional.linear(y[-1], self.sd['llm_decoder.weight'], self.sd['llm_decoder.bias']).log_softmax(dim=-1)
+        nout, fill = st[L.ST_NOUT], OL.FILL_TOKEN
+        if st[L.ST_BIMODE] == 1 and st[L.ST_NEXTFILL] != -1 and nout == st[L.ST_NEXTFILL]:
+            top = fill
+        else:
+            top = OL.greedy_ids(logp, st[L.ST_BIMODE] == 1)
+        if top == fill:
+            st[L.ST_NEXTFILL] = nout + 16
+        s['out'].append(top)
+        st[L.ST_NOUT], st[L.ST_LAST] = nout + 1, top
+        if top >= OL.SPEECH_TOKEN_SIZE:
+            st[L.ST_DONE] = 1
+            if st[L.ST_BIMODE] == 1 and top == fill:
+                st[L.ST_WAIT] = 1
+            elif not (st[L.ST_BIMODE] == 2 and top == OL.SPEECH_TOKEN_SIZE):
+                st[L.ST_ERR] = 2
+
+    def bi_feed(self, streams, prepared=False):
+        from cv2amd import lib as L
+        fed = []
+        for b in streams:
+            if b.running or b.finished:
+                continue
+            f = b.next_feed()
+            if f is None:
+                continue
+            idx, final = f
+            s = self.slots.setdefault(b.slot, {'cache': [None] * self.d.layers, 'out': [], 'st': None})
+            s['st'] = b._state_row(final)
+            assert (s['st'][L.ST_POS] if b.started else 0) == b.pos
+            self._draw(s, self.emb_all[torch.tensor(idx)])
+            s['st'][L.ST_POS] = b.pos + len(idx)
+            self.feeds.append((b.slot, len(idx), final))
+            b._fed(len(idx), final)
+            fed.append(b)
+        return fed
+
+    def bi_burst(self, streams, n_steps, shared=False):
+        from cv2amd import lib as L
+        for b in streams:
+            if not b.running:
+                continue
+            s = self.slots[b.slot]
+            for _ in range(n_steps):
+                if s['st'][L.ST_DONE]:
+                    break
+                self._draw(s, self.sd['speech_embedding.weight'][s['st'][L.ST_LAST]][None])
+                if not s['st'][L.ST_DONE] or s['st'][L.ST_WAIT]:
+                    s['st'][L.ST_POS] += 1
+            if b.eta is not None:
+                b.eta = max(0, b.eta - n_steps)
+
+    def bi_poll(self, streams):
+        for b in streams:
+            if b.running:
+                s = self.slots[b.slot]
+                b._polled(list(s['st']), s['out'][b.n_read:])
+
+
+def test_bistream_host_bookkeeping_matches_the_oracle():
+    """cv2amd.llm.BiStream + LLMEngine.bistream (the host half of inference_bistream, llm.py:721-834: text cache, 5 : 15 interleave with the
+    prompt speech tokens, the feed after a fill id, the stale lm_input in front of the final feed) drive a SIMULATED device (the oracle's
+    backbone under k_sample's state machine): emitted ids and the out_tokens list equal oracle.llm.inference_bistream, for text arriving in
+    uneven pieces, with and without prompt speech tokens, and for every burst length (a burst may overshoot a stop)."""
+    from cv2amd import synth
+    from oracle import llm as OL
+    sd = synth.make_llm(layers=1)
+    b = sd['llm_decoder.bias'].clone()
+    b[6563] += 6.0; b[6561] += 14.0; b[6562] = -30.0
+    sd['llm_decoder.bias'] = b
+    for seed, P, cuts, burst in ((1, 31, (0, 3, 10, 15, 23), 16), (2, 0, (0, 5, 6, 17), 16), (3, 45, (0, 12, 13, 14, 30), 3), (4, 30, (0, 2, 4, 9), 1)):
+        inp = synth.synthetic_inputs(seed=seed, text_len=cuts[-1], prompt_len=max(P, 1), prompt_text_len=6)
+        ptok = inp['prompt_token'][:, :P]
+        pieces = [inp['text'][:, a:b2] for a, b2 in zip(cuts[:-1], cuts[1:])]
+        want, want_out = OL.inference_bistream(sd, pieces, inp['prompt_text'], ptok)
+        eng = _SimBistreamEngine(sd)
+        pulled = []
+
+        def text():
+            for p in pieces:
+                pulled.append(len(eng.feeds))          # feeds issued before this piece was asked for
+                yield p
+        got = list(eng.bistream(2, text(), inp['prompt_text'], ptok, burst=burst))
+        assert got == want and eng.slots[2]['out'] == want_out, (seed, got[:8], want[:8])
+        assert eng.feeds[-1][2] and sum(1 for f in eng.feeds if f[2]) == 1             # exactly one final feed, the last one
+        assert pulled == sorted(pulled) and pulled[0] == 0                              # pieces are pulled lazily, never ahead of a feed they enable

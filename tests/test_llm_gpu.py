@@ -138,6 +138,63 @@ def test_one_launch_step_at_a_long_context(dev, small):
     assert got[0] == OL.inference(sdr, *req, force_len=14)
 
 
+def test_one_launch_step_with_more_head_blocks_than_layer_blocks(dev, monkeypatch):
+    """Small dims the one-launch gate accepts (hidden 256, inter 512, 4 / 2 heads: ~100 blocks per layer) with the 6564-id vocabulary
+    (411 head blocks): the head's blocks follow the layers' in the grid and must index their logits rows by their distance from the
+    last layer block, not modulo the per-layer count.  ids of k_step == the launches (CV2_LLM_CHAIN=0) == the oracle; every logit row
+    of the last step agrees between the two paths."""
+    from cv2amd import synth, weights as W
+    from cv2amd.llm import LLMEngine
+    from oracle import llm as OL
+    sd = synth.make_llm(layers=2, hidden=256, inter=512, n_q=4, n_kv=2, vocab=2048)
+    sdr = W.round_llm_sd(sd)
+    inp = synth.synthetic_inputs(seed=5, text_len=7, prompt_len=20, prompt_text_len=3)
+    req = (inp['text'] % 2048, inp['prompt_text'] % 2048, inp['prompt_token'])
+    want = OL.inference(sdr, *req, force_len=20)
+    eng = LLMEngine(sd, dev, max_seqs=2, max_pos=256, max_out=64)
+    assert eng.lib.cv2_llm_one_launch_step(eng.handle) == 1
+    got = eng.generate([req], force_len=20)[0]
+    lg1 = eng.logits[0, :eng.vocab].cpu()
+    monkeypatch.setenv('CV2_LLM_CHAIN', '0')
+    eng0 = LLMEngine(sd, dev, max_seqs=2, max_pos=256, max_out=64)
+    assert eng0.lib.cv2_llm_one_launch_step(eng0.handle) == 0
+    got0 = eng0.generate([req], force_len=20)[0]
+    lg0 = eng0.logits[0, :eng0.vocab].cpu()
+    assert got == want and got0 == want
+    assert torch.isfinite(lg1).all() and (lg1 - lg0).abs().max().item() < 2e-4 * lg0.abs().max().item()
+
+
+def test_hand_off_timeout_commits_nothing_and_the_steps_are_repeated_on_the_launches(dev, small, caplog):
+    """A hand-off inside the one-launch step that never arrives (test hook: one Q-role block of layer 1 keeps its q values to itself):
+    every wait behind it is bounded (0.2 s, csrc/chain.h), the step reports CV2_ST_ERR = 3 and k_sample commits NOTHING for it or for
+    the steps enqueued behind it.  The host clears the flag, repeats the steps on the launches (the engine stays on them) and the
+    request finishes with the ids of an undisturbed run; another engine in the process is not affected."""
+    import logging
+    from cv2amd import lib as L
+    from cv2amd.llm import LLMEngine
+    sd, sdr, _ = small
+    eng = LLMEngine(sd, dev, max_seqs=2, max_pos=512, max_out=64)
+    assert eng.lib.cv2_llm_one_launch_step(eng.handle) == 1
+    req = _requests(1, seed=11)[0]
+    want = eng.generate([req], force_len=20)[0]
+    assert eng.handoff_recoveries == 0 and not eng.chain_broken
+    L.check(eng.lib.cv2_llm_debug_skip_publish(eng.handle, 1, 3))
+    try:
+        # the prefill draws token 0; the first burst's k_step times out: state as after the prefill, error flag set
+        eng.add_requests([0], [eng.build_lm_input(*req)], [(20, 20)], 0, 0, True)
+        eng.step(1, 3)
+        torch.cuda.synchronize()
+        st = eng.state[0].cpu()
+        assert int(st[L.ST_ERR]) == 3 and int(st[L.ST_STEP]) == 1 and int(st[L.ST_NOUT]) == 1 and int(st[L.ST_DONE]) == 0
+        with caplog.at_level(logging.WARNING):
+            got = eng.generate([req], force_len=20)[0]
+    finally:
+        L.check(eng.lib.cv2_llm_debug_skip_publish(eng.handle, -1, 0))
+    assert got == want
+    assert eng.handoff_recoveries == 1 and eng.chain_broken and any('hand-off' in r.message for r in caplog.records)
+    assert eng.generate([req], force_len=20)[0] == want          # stays on the launches, still correct
+
+
 def test_many_row_decode_path(small):
     """More than 16 sequences per step take the prepared-operand kernels (k_prep + PRE variants): ids still equal the oracle's."""
     from oracle import llm as OL
