@@ -89,6 +89,11 @@ class CosyVoice2Model:
         self._bi_calls, self._bi_thread, self._bi_gen = [], None, 0
         self.bistream_coalesce_ms = 3.0        # calls that start together are fed together (one pass over the weights for all first feeds)
         self.bistream_burst = 16
+        # chunks of one wave: the hub wakes every consumer whose tokens arrived with the same poll; their chunk submissions are a few
+        # hundred microseconds apart (thread wake-ups under the GIL), so the first submitter waits up to `chunk_wave_ms` for the others
+        # instead of running the flow for a batch of one and leaving the rest to a second round
+        self._chunk_wave, self.chunk_wave_ms = None, 2.0
+        self._sched_log = None                 # diagnostics (tools/bench_bistream.py): list receiving (t, kind, info) of hub / chunk rounds
         self._mode = threading.Condition()     # shared (streams, one LLM slot each) / exclusive (a batch) use of the engines
         self._n_shared, self._excl, self._excl_waiting = 0, False, 0
         self._slot_free, self._active_slots = [], set()
@@ -397,12 +402,19 @@ class CosyVoice2Model:
         c.done, c.speech, c.exc, c.cap_hint, c.pkey = False, None, None, cap_hint, pkey
         with self.lock:
             self._chunk_q.append(c)
+        wave = self._chunk_wave
+        if wave is not None and stream and not finalize:                      # (n consumers woken together, deadline)
+            while not c.done and len(self._chunk_q) < wave[0] and time.perf_counter() < wave[1]:
+                time.sleep(0.0001)
         with self.run_lock:
             if not c.done:
                 with self.lock:
                     batch = self._chunk_q[:self.max_batch]
                     del self._chunk_q[:len(batch)]
+                t0 = time.perf_counter()
                 self._run_chunks(batch)
+                if self._sched_log is not None:
+                    self._sched_log.append((t0, 'chunks', dict(n=len(batch), final=sum(1 for b in batch if b.finalize), ms=round((time.perf_counter() - t0) * 1e3, 2))))
         if c.exc is not None:
             raise c.exc
         return c.speech
@@ -715,6 +727,9 @@ class CosyVoice2Model:
                     if fed or n:
                         ev = torch.cuda.Event()
                         ev.record(self.llm_stream)
+                    if self._sched_log is not None:
+                        self._sched_log.append((time.perf_counter(), 'hub', dict(fed=len(fed), rows=sum(len(b._last_feed) for b in fed), burst=n,
+                                                                                 running=sum(1 for b in streams if b.running))))
                 if ev is not None:
                     ev.synchronize()                                          # the round's device work, outside the lock
                 else:
@@ -732,15 +747,21 @@ class CosyVoice2Model:
 
     def _bi_publish(self, calls):
         with self._bi_cv:
+            woken = 0
             for c in calls:
                 new = c.bs.take()
                 if new:
+                    before = len(c.toks)
                     c.toks.extend(new)
+                    if before < c.want_total <= len(c.toks):
+                        woken += 1
                 if c.bs.err is not None and c.exc is None:
                     c.exc = c.bs.err
                 if c.bs.finished and not c.ended:
                     c.ended = True
                     self.llm_end_dict[c.uuid] = True
+            if woken > 1:
+                self._chunk_wave = (woken, time.perf_counter() + self.chunk_wave_ms * 1e-3)
             self._bi_cv.notify_all()
 
     def _tts_pulled(self, text, prompt_text, llm_ptok, source_speech_token, fpt, feat, femb, this_uuid, stream, speed, vc):

@@ -325,6 +325,7 @@ class LLMEngine:
         flush()
         self._keep_rows = emb                            # alive until the stream has consumed it
         for b, (idx, final) in feeds:
+            b._last_feed = idx
             b._fed(len(idx), final)
         return [b for b, _ in feeds]
 
@@ -415,6 +416,7 @@ class BiStream:
         self._row = None                      # the slot's state record at the last poll
         self._new = []                        # emitted ids not yet taken
         self._pending = None
+        self._last_feed = ()
 
     # ---- text side (any thread; the scheduler serialises these with its own lock) ----
     def push(self, piece):

@@ -4,7 +4,8 @@ captured from the real reference (tests/golden/make_golden.py).  Run with -m gpu
 Tolerances: the HIP path multiplies bf16 operands (weights and activations rounded to bf16, fp32 accumulate, fp32
 softmax / LayerNorm / residual stream), the oracle is fp32.  Per GEMM the rounding error is ~2^-9 relative per operand;
 over the 56-block estimator it accumulates to ~1e-2 of the output range, so whole-network checks use
-max|err| <= 4e-2 * max|ref| and a mean-relative bound, while single-GEMM checks against fp64 on the SAME rounded
+max|err| <= 2e-2 * max|ref| (measured 1.2e-2 .. 1.5e-2; every bar goes through tests/_bars.py, which records the measured value
+beside its limit in gpurun_out/bars.jsonl) and a mean-relative bound, while single-GEMM checks against fp64 on the SAME rounded
 operands are tight (1e-5).  The reference's own precedent for this network is rtol 1e-2 (bin/export_onnx.py:133).
 """
 import ctypes as C
@@ -159,7 +160,7 @@ def test_large_batch_tile_configurations_agree_with_single(dev, flow_sd):
         single = big.inference_batch([utts[i]])[0]
         torch.cuda.synchronize()
         assert single.shape == batch[i].shape and torch.isfinite(batch[i]).all()
-        bar(f'flow batch-of-8 vs single, utterance {i}', rel(batch[i].cpu(), single.cpu()), 3e-2)
+        bar(f'flow batch-of-8 vs single, utterance {i}', rel(batch[i].cpu(), single.cpu()), 1e-2)        # measured 3.4e-3 (other tile shapes at other row counts)
 
 
 def test_oracle_full_size_estimator_random(eng, dev, flow_sd):
@@ -175,7 +176,7 @@ def test_oracle_full_size_estimator_random(eng, dev, flow_sd):
     y = eng.forward_estimator(x.to(dev).contiguous(), torch.ones(2, 1, T, device=dev), mu.to(dev), t.to(dev), spks.to(dev), cond.to(dev))
     torch.cuda.synchronize()
     ref = OF.estimator(flow_sd, x, torch.ones(2, 1, T), mu, t, spks, cond, False)
-    bar('flow estimator T=150 vs oracle (max of range)', rel(y.cpu(), ref), 4e-2)
+    bar('flow estimator T=150 vs oracle (max of range)', rel(y.cpu(), ref), 2e-2)                    # measured 1.5e-2: the estimator family's bar
 
 
 def _record(name, **vals):
@@ -271,7 +272,7 @@ def test_cached_chunks_equal_the_recompute_of_the_whole_prefix(eng):
         assert first == 2 * off, (first, off)
         assert got.shape == ref.shape and torch.isfinite(got).all()
         worst = max(worst, rel(got.cpu(), ref.cpu()))
-        bar(f'flow cached chunk vs recompute, offset {off}', rel(got.cpu(), ref.cpu()), 3e-2)
+        bar(f'flow cached chunk vs recompute, offset {off}', rel(got.cpu(), ref.cpu()), 2e-3)        # measured 0.0 (bit-identical)
     assert cache.n_cached == 2 * (P + N) and cache.gen == len(calls)
     # a cache that sits out some calls (the scheduler only uses it when that pays) stays valid for the frames it holds: the next
     # cached call computes everything after them
@@ -285,7 +286,7 @@ def test_cached_chunks_equal_the_recompute_of_the_whole_prefix(eng):
         (got, first), = eng.inference_chunk_batch([u], [lazy], finalize=fin)
         torch.cuda.synchronize()
         assert first == max(before - 2 * P, 0) and first <= 2 * off and got.shape[2] == full.shape[2] - first
-        bar('flow cached chunk vs full recompute (regrown cache)', rel(got.cpu(), full[:, :, first:].cpu()), 3e-2)
+        bar('flow cached chunk vs full recompute (regrown cache)', rel(got.cpu(), full[:, :, first:].cpu()), 2e-3)
     _record('cached_chunks_vs_recompute', worst_rel=worst, calls=len(calls))
 
 
@@ -333,7 +334,7 @@ def test_cached_chunks_of_streams_in_different_phases_share_a_batch(eng):
             for k, (m, first) in zip(grp, outs):
                 ref = alone[k][pos[k]]
                 assert m.shape == ref.shape
-                bar(f'flow cached chunks of 3 streams, stream {k} call {pos[k]}', rel(m.cpu(), ref.cpu()), 3e-2)
+                bar(f'flow cached chunks of 3 streams, stream {k} call {pos[k]}', rel(m.cpu(), ref.cpu()), 2e-3)
                 pos[k] += 1
         rnd += 1
 
@@ -359,6 +360,6 @@ def test_stream_started_from_a_prompt_cache(eng):
         (mb, fb), = eng.inference_chunk_batch([u], [b], finalize=False)
         torch.cuda.synchronize()
         assert fa == fb and ma.shape == mb.shape
-        bar(f'flow prompt-cache start vs recompute, offset {off}', rel(mb.cpu(), ma.cpu()), 3e-2)
+        bar(f'flow prompt-cache start vs recompute, offset {off}', rel(mb.cpu(), ma.cpu()), 2e-3)
     assert a.n_cached == b.n_cached
     assert eng.prompt_cache(inp['prompt_token'][:, :20], inp['prompt_feat'][:, :40], inp['embedding']) is None

@@ -6,7 +6,7 @@ configs[1]  B=1, P=255 prompt tokens, 50 text tokens, 250 forced tokens: 24-laye
             reference itself (tests/golden/fullsize.npz, tests/golden/make_golden.py gen_fullsize)
 configs[2]  B=32 FR (P=255) + DE (P=310): ids of all 32 slots vs the oracle, the packed flow batch vs the oracle
 configs[4]  8 concurrent streams at P=255: every chunk vs the reference's chunk / cache / cross-fade logic restated on the oracle
-Bars: ids bit-exact; flow mel <= 5e-2 of range and 2e-2 mean-relative (bf16 operands, precedent rtol 1e-2 bin/export_onnx.py:133);
+Bars: ids bit-exact; flow mel <= 1.5e-2 of range and 1.2e-2 mean-relative (bf16 operands, precedent rtol 1e-2 bin/export_onnx.py:133);
 HiFT waveform 5e-4 abs / source 2e-3 abs with identical mel and injected noise (fp32 MFMA vs torch CPU fp32).
 """
 import json
@@ -195,8 +195,8 @@ def test_b32_flow_batch_vs_oracle(dev):
         ref = OF.inference(fsd, tok, inp['prompt_token'], inp['prompt_feat'], inp['embedding'], False, True)
         got = mels[b].cpu()
         assert got.shape == ref.shape and torch.isfinite(got).all()
-        bar(f'flow B=32 batch vs oracle, utterance {b} (max of range)', rel(got, ref), 5e-2)
-        bar(f'flow B=32 batch vs oracle, utterance {b} (mean relative)', ((got - ref).abs().mean() / ref.abs().mean()).item(), 2e-2)
+        bar(f'flow B=32 batch vs oracle, utterance {b} (max of range)', rel(got, ref), 1.5e-2)               # measured 6.7e-3
+        bar(f'flow B=32 batch vs oracle, utterance {b} (mean relative)', ((got - ref).abs().mean() / ref.abs().mean()).item(), 1.2e-2)   # measured 7.6e-3
 
 
 # ------------------------------------------------------------------------------------------------ configs[0] / [4]: the product API
@@ -339,7 +339,7 @@ def test_config4_eight_streams_every_chunk_vs_reference_logic(cv_from_disk):
         for k, (tc, tr_) in enumerate(zip(c_trace, r_trace)):
             assert tc[1] == tr_[1] and tc[2] == tr_[2] and tc[0].shape == tr_[0].shape
             a, b = tc[0][:, :, 2 * tc[1]:], tr_[0][:, :, 2 * tr_[1]:]
-            bar(f'scheduler: cached flow vs recompute, chunk {k}', rel(a, b), 3e-2)
+            bar(f'scheduler: cached flow vs recompute, chunk {k}', rel(a, b), 2e-3)       # measured 0.0
             assert c_chunks[k].shape == r_chunks[k].shape
         mdl._trace = []
         out, errs, uuid_of, tl = [None] * len(calls), [], {}, threading.local()
@@ -384,7 +384,7 @@ def test_config4_eight_streams_every_chunk_vs_reference_logic(cv_from_disk):
             assert err < 1e-3, f'stream {i} ({calls[i]}) chunk {c}: max abs err {err:.3e}'
             m_alone, m_conc = a_trace[c][0][:, :, 2 * tr[c][1]:], tr[c][0][:, :, 2 * tr[c][1]:]     # the frames token2wav keeps (what lies before them depends on which frames the call's flow cache held)
             assert m_alone.shape == m_conc.shape
-            bar(f'scheduler: concurrent vs solo flow mel, stream {i} chunk {c}', rel(m_conc, m_alone), 3e-2)
+            bar(f'scheduler: concurrent vs solo flow mel, stream {i} chunk {c}', rel(m_conc, m_alone), 1e-2)   # measured 2.6e-3 (batched vs single tile shapes)
     assert sorted(mdl._slot_free) == list(range(mdl.max_batch)) and not mdl._active_slots and not mdl.hift_cache_dict and not mdl._hift_pin
     assert not mdl._flow_caches
 
@@ -586,7 +586,7 @@ def test_flow_cache_policy_and_regrowth(cv_from_disk):
     assert len(chunks) == len(ref_chunks) and [c.shape for c in chunks] == [c.shape for c in ref_chunks]
     for k, (a, b) in enumerate(zip(trace, ref_trace)):
         assert a[1] == b[1] and a[2] == b[2]
-        bar(f'scheduler: flow cache policy, chunk {k}', rel(a[0][:, :, 2 * a[1]:], b[0][:, :, 2 * b[1]:]), 3e-2)
+        bar(f'scheduler: flow cache policy, chunk {k}', rel(a[0][:, :, 2 * a[1]:], b[0][:, :, 2 * b[1]:]), 2e-3)
     assert not mdl._flow_caches
 
 
@@ -649,5 +649,5 @@ def test_second_wave_of_streams_starts_from_the_prompt_cache(cv_from_disk):
     assert [len(x) for x in o1] == [len(x) for x in o2]
     for a, b in zip(t1[0], t2[0]):                                 # greedy tokens: every call of a wave sees the same chunks
         assert a[1] == b[1] and a[2] == b[2] and a[0].shape == b[0].shape
-        bar('scheduler: second wave from the prompt cache', rel(b[0][:, :, 2 * b[1]:], a[0][:, :, 2 * a[1]:]), 3e-2)
+        bar('scheduler: second wave from the prompt cache', rel(b[0][:, :, 2 * b[1]:], a[0][:, :, 2 * a[1]:]), 2e-3)
     assert not mdl._flow_caches

@@ -127,9 +127,8 @@ def test_heavy_tailed_flow_error_is_explained_by_operand_rounding(dev, streaming
     _record('flow_heavy_estimator_' + ('chunk' if streaming else 'full'), hip_vs_fp32_max=hm, hip_vs_fp32_mean=hn, rounded_vs_fp32_max=rm,
             rounded_vs_fp32_mean=rn, out_range=float(ref32.abs().max()))
     assert torch.isfinite(y).all()
-    # the MEAN is the robust statistic (1.25 x, as on the Gaussian fixture); the max is one element of a field that this checkpoint amplifies:
-    # a pure re-association of the FF2 sum (round 3: four chains + tree) moved it from 1.17 x to 1.29 x of the rounded-operand max while the
-    # mean moved by 3 %, so the max gets 1.5 x here
-    bar(f'heavy-tail flow ({"chunk" if streaming else "full"}): HIP-vs-fp32 max / rounded-operand max', hm / rm, 1.5)
+    # HIP-vs-fp32 within 1.25 x (mean) / 1.3 x (max) of what bf16 operand rounding alone produces in the oracle (measured round 4: full context
+    # 0.94 / 1.00, chunk masks 1.14 / 1.29 -- the max is one element of a field this checkpoint amplifies)
+    bar(f'heavy-tail flow ({"chunk" if streaming else "full"}): HIP-vs-fp32 max / rounded-operand max', hm / rm, 1.3)
     bar(f'heavy-tail flow ({"chunk" if streaming else "full"}): HIP-vs-fp32 mean / rounded-operand mean', hn / rn, 1.25)
-    assert hn < 1.25 * rn and hm < 1.5 * rm, f'HIP vs fp32 (max {hm:.3e}, mean {hn:.3e}) exceeds what operand rounding explains (max {rm:.3e}, mean {rn:.3e})'
+    assert hn < 1.25 * rn and hm < 1.3 * rm, f'HIP vs fp32 (max {hm:.3e}, mean {hn:.3e}) exceeds what operand rounding explains (max {rm:.3e}, mean {rn:.3e})'
