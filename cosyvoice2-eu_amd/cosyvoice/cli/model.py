@@ -87,12 +87,15 @@ class CosyVoice2Model:
         self.llm_lock = threading.Lock()
         self._bi_cv = threading.Condition()    # guards _bi_calls and every BiStream's text side; signalled on new text / tokens / calls
         self._bi_calls, self._bi_thread, self._bi_gen = [], None, 0
-        self.bistream_coalesce_ms = 3.0        # calls that start together are fed together (one pass over the weights for all first feeds)
+        self.bistream_coalesce_ms = 8.0        # calls that start together are fed together (one pass over the weights for all first feeds)
         self.bistream_burst = 16
-        # chunks of one wave: the hub wakes every consumer whose tokens arrived with the same poll; their chunk submissions are a few
-        # hundred microseconds apart (thread wake-ups under the GIL), so the first submitter waits up to `chunk_wave_ms` for the others
-        # instead of running the flow for a batch of one and leaving the rest to a second round
-        self._chunk_wave, self.chunk_wave_ms = None, 2.0
+        # chunks of one round: concurrent streams come back from a chunk round (or are woken by the hub's poll) a few hundred
+        # microseconds apart (thread wake-ups under the GIL).  The first submitter waits until the queue has stopped growing for
+        # `chunk_quiet_ms` (at most `chunk_wave_ms`, and never when it is the only stream) instead of running the flow for a batch
+        # of a few and leaving the rest to a second round (measured, 8 generator-text streams: rounds of 4 + 4 chunks at 67 ms each
+        # instead of one of 8)
+        self.chunk_wave_ms, self.chunk_quiet_ms = 3.0, 1.0
+        self._bi_incoming = 0                  # generator-text calls that have entered tts() but not yet joined the hub
         self._sched_log = None                 # diagnostics (tools/bench_bistream.py): list receiving (t, kind, info) of hub / chunk rounds
         self._mode = threading.Condition()     # shared (streams, one LLM slot each) / exclusive (a batch) use of the engines
         self._n_shared, self._excl, self._excl_waiting = 0, False, 0
@@ -402,9 +405,18 @@ class CosyVoice2Model:
         c.done, c.speech, c.exc, c.cap_hint, c.pkey = False, None, None, cap_hint, pkey
         with self.lock:
             self._chunk_q.append(c)
-        wave = self._chunk_wave
-        if wave is not None and stream and not finalize:                      # (n consumers woken together, deadline)
-            while not c.done and len(self._chunk_q) < wave[0] and time.perf_counter() < wave[1]:
+        n_streams = min(self._n_shared, self.max_batch)
+        if n_streams > 1 and self.chunk_wave_ms > 0:
+            t_last = time.perf_counter()
+            t_end, last = t_last + self.chunk_wave_ms * 1e-3, len(self._chunk_q)
+            while not c.done:
+                n, now = len(self._chunk_q), time.perf_counter()
+                if n >= n_streams or now >= t_end:
+                    break
+                if n != last:
+                    last, t_last = n, now
+                elif now - t_last > self.chunk_quiet_ms * 1e-3:
+                    break
                 time.sleep(0.0001)
         with self.run_lock:
             if not c.done:
@@ -654,6 +666,7 @@ class CosyVoice2Model:
                     self._bi_cv.notify_all()
         with self._bi_cv:
             self._bi_calls.append(c)
+            self._bi_incoming -= 1
             self._bi_gen += 1
             if self._bi_thread is None or not self._bi_thread.is_alive():
                 self._bi_thread = threading.Thread(target=self._bi_loop, daemon=True, name='cv2-bistream-hub')
@@ -702,11 +715,10 @@ class CosyVoice2Model:
                     while time.perf_counter() < t_end:
                         gen = self._bi_gen
                         self._bi_cv.wait(0.0005)
-                        if self._bi_gen == gen and all(c.bs.started or c.bs.next_feed() is not None for c in self._bi_calls if not c.closed):
+                        if self._bi_gen == gen and self._bi_incoming <= 0 and all(c.bs.started or c.bs.next_feed() is not None
+                                                                                   for c in self._bi_calls if not c.closed):
                             break
                     calls = [c for c in self._bi_calls if not c.closed]
-                for c in calls:
-                    c.bs.want = max(0, c.want_total - len(c.toks)) if c.want_total else None
             if not calls:
                 continue
             try:
@@ -714,13 +726,18 @@ class CosyVoice2Model:
                 with self.llm_lock, torch.cuda.stream(self.llm_stream):
                     eng = self.llm
                     streams = [c.bs for c in calls if not c.closed]
+                    t_r0 = time.perf_counter()
                     eng.bi_poll(streams)
+                    t_r1 = time.perf_counter()
                     self._bi_publish(calls)
                     with self._bi_cv:                                         # text pieces are pushed under this lock: consume them under it,
+                        for c in calls:                                       # (tokens the consumers still wait for, after this poll's ids)
+                            c.bs.want = max(0, c.want_total - len(c.toks)) if c.want_total else None
                         for b in streams:                                     # feed outside it (the consumers' pull() takes it too)
                             if not b.running and not b.finished:
                                 b.next_feed()
                     fed = eng.bi_feed(streams, prepared=True)
+                    t_r2 = time.perf_counter()
                     n = eng.bi_burst_len(streams, self.bistream_burst)
                     if n:
                         eng.bi_burst(streams, n, shared=True)
@@ -728,8 +745,9 @@ class CosyVoice2Model:
                         ev = torch.cuda.Event()
                         ev.record(self.llm_stream)
                     if self._sched_log is not None:
-                        self._sched_log.append((time.perf_counter(), 'hub', dict(fed=len(fed), rows=sum(len(b._last_feed) for b in fed), burst=n,
-                                                                                 running=sum(1 for b in streams if b.running))))
+                        self._sched_log.append((t_r0, 'hub', dict(fed=len(fed), rows=sum(len(b._last_feed) for b in fed), burst=n,
+                                                                  running=sum(1 for b in streams if b.running), poll_ms=round((t_r1 - t_r0) * 1e3, 2),
+                                                                  feed_ms=round((t_r2 - t_r1) * 1e3, 2), burst_ms=round((time.perf_counter() - t_r2) * 1e3, 2))))
                 if ev is not None:
                     ev.synchronize()                                          # the round's device work, outside the lock
                 else:
@@ -747,21 +765,15 @@ class CosyVoice2Model:
 
     def _bi_publish(self, calls):
         with self._bi_cv:
-            woken = 0
             for c in calls:
                 new = c.bs.take()
                 if new:
-                    before = len(c.toks)
                     c.toks.extend(new)
-                    if before < c.want_total <= len(c.toks):
-                        woken += 1
                 if c.bs.err is not None and c.exc is None:
                     c.exc = c.bs.err
                 if c.bs.finished and not c.ended:
                     c.ended = True
                     self.llm_end_dict[c.uuid] = True
-            if woken > 1:
-                self._chunk_wave = (woken, time.perf_counter() + self.chunk_wave_ms * 1e-3)
             self._bi_cv.notify_all()
 
     def _tts_pulled(self, text, prompt_text, llm_ptok, source_speech_token, fpt, feat, femb, this_uuid, stream, speed, vc):
@@ -769,16 +781,19 @@ class CosyVoice2Model:
         speech tokens of the source utterance ARE the tokens) and generator text (inference_bistream, llm.py:721-834: the call owns
         one LLM slot, the hub above drives it together with every other generator-text call).  The chunk arithmetic is model.py:351-394."""
         hop, la = self.token_hop_len, self.flow.pre_lookahead_len
-        slot = None if vc else self._enter_shared()
+        incoming = not vc                                                      # counted in _bi_incoming until the call has joined the hub
+        slot = None
         toks = self.tts_speech_token_dict[this_uuid]
         call = None
         try:
+            slot = None if vc else self._enter_shared()
             if vc:
                 toks.extend(source_speech_token.flatten().tolist())
                 self.llm_end_dict[this_uuid] = True
             else:
                 self.seed += 1
                 call = self._bi_register(self.llm.new_bistream(slot, prompt_text, llm_ptok, mode=self.sampling_mode, seed=self.seed), this_uuid, text)
+                incoming = False
 
             def pull(n_total):
                 """wait until the call holds n_total tokens or its LLM has ended (the reference polls the shared list, model.py:353-366)"""
@@ -812,6 +827,9 @@ class CosyVoice2Model:
                     speech = self.token2wav(this_tok, fpt, feat, femb, 0, this_uuid, finalize=True, speed=speed).cpu()
                 yield {'tts_speech': speech}
         finally:
+            if incoming:
+                with self._bi_cv:
+                    self._bi_incoming -= 1
             if call is not None:
                 self._bi_unregister(call)
             if slot is not None:
@@ -848,10 +866,19 @@ class CosyVoice2Model:
         with self.lock:
             self.tts_speech_token_dict[this_uuid], self.llm_end_dict[this_uuid] = [], False
             self.hift_cache_dict[this_uuid] = None
+        if bistream and not vc:
+            with self._bi_cv:                                                 # the hub waits (briefly) for calls on their way in before its first feed
+                self._bi_incoming += 1
         dev = self.device
-        fpt = flow_prompt_speech_token.to(dev)
-        feat = prompt_speech_feat.to(dev)
-        femb = flow_embedding.to(dev)
+        try:
+            fpt = flow_prompt_speech_token.to(dev)
+            feat = prompt_speech_feat.to(dev)
+            femb = flow_embedding.to(dev)
+        except BaseException:
+            if bistream and not vc:
+                with self._bi_cv:
+                    self._bi_incoming -= 1
+            raise
         if vc or bistream:
             yield from self._tts_pulled(text, prompt_text, llm_prompt_speech_token, source_speech_token, fpt, feat, femb, this_uuid,
                                         stream, speed, vc)

@@ -346,6 +346,10 @@ class LLMEngine:
         if not run or all(b.eta == 0 for b in run):
             return 0
         c = [b.eta for b in run if b.eta] + [b.want for b in run if b.want is not None and b.want > 0]
+        # a stream that has not shown its first fill id yet stops at an unknown step (a trained model: when the prompt's last 15-token
+        # block is complete, see _fed): half bursts until then, so that few steps run behind the stop
+        if any(b.eta is None and not b.final_fed and not b.seen_fill for b in run):
+            c.append(max(1, burst // 2))
         return max(1, min(c + [burst]))
 
     def bistream(self, slot, text, prompt_text, prompt_speech_token, mode=MODE_GREEDY, seed=0, mix_ratio=(5, 15), burst=16,
@@ -405,6 +409,7 @@ class BiStream:
         self.eng, self.slot, self.mode, self.seed, self.mix = eng, slot, mode, seed, tuple(mix_ratio)
         self.text_cache = [int(t) for t in prompt_text.reshape(-1).tolist()]                       # llm.py:750-757
         self.sp_left = [eng.IDX_SPEECH + int(t) for t in prompt_speech_token.reshape(-1).tolist()]
+        self.n_prompt_speech, self.seen_fill = len(self.sp_left), False
         self.lm_input = [eng.IDX_SOS]                                                              # llm.py:743
         self.outs = []                        # the reference's out_tokens (fill / EOS entries included)
         self.pieces, self.text_done = collections.deque(), False
@@ -481,7 +486,14 @@ class BiStream:
         self.pos += n_rows
         self._pending = None
         # after a fill the next one is forced mix[1] + 1 entries later (llm.py:796-804): the feed draws the first of them
-        self.eta = None if final else (self.mix[1] if last_fill else 0)
+        # the FIRST feed ends inside the prompt's last block: a model trained on the 5 : 15 interleave completes that block (the prompt's
+        # speech tokens modulo 15 are in it) and then asks for text; if it does not stop there the poll says so and eta becomes unknown
+        if final:
+            self.eta = None
+        elif last_fill:
+            self.eta = self.mix[1]
+        else:
+            self.eta = (self.mix[1] - self.n_prompt_speech % self.mix[1]) % self.mix[1]
 
     def _polled(self, row, new):
         self._row = row
@@ -491,6 +503,8 @@ class BiStream:
             self.outs.append(t)
             if t < EOS:
                 self._new.append(t)
+            elif t == EOS + 2:
+                self.seen_fill = True
         real = [t for t in new if t < EOS]
         if real:                                          # lm_input = speech_embedding[last emitted id] (llm.py:811)
             self.lm_input = [self.eng.IDX_SPEECH + real[-1]]
