@@ -95,6 +95,7 @@ class CosyVoice2Model:
         # of a few and leaving the rest to a second round (measured, 8 generator-text streams: rounds of 4 + 4 chunks at 67 ms each
         # instead of one of 8)
         self.chunk_wave_ms, self.chunk_quiet_ms = 3.0, 1.0
+        self._chunks_active = 0                # chunk rounds (flow + HiFT) in progress: decode bursts beside them take the launches
         self._bi_incoming = 0                  # generator-text calls that have entered tts() but not yet joined the hub
         self._sched_log = None                 # diagnostics (tools/bench_bistream.py): list receiving (t, kind, info) of hub / chunk rounds
         self._mode = threading.Condition()     # shared (streams, one LLM slot each) / exclusive (a batch) use of the engines
@@ -424,7 +425,11 @@ class CosyVoice2Model:
                     batch = self._chunk_q[:self.max_batch]
                     del self._chunk_q[:len(batch)]
                 t0 = time.perf_counter()
-                self._run_chunks(batch)
+                self._chunks_active += 1
+                try:
+                    self._run_chunks(batch)
+                finally:
+                    self._chunks_active -= 1
                 if self._sched_log is not None:
                     self._sched_log.append((t0, 'chunks', dict(n=len(batch), final=sum(1 for b in batch if b.finalize), ms=round((time.perf_counter() - t0) * 1e3, 2))))
         if c.exc is not None:
@@ -739,8 +744,8 @@ class CosyVoice2Model:
                     fed = eng.bi_feed(streams, prepared=True)
                     t_r2 = time.perf_counter()
                     n = eng.bi_burst_len(streams, self.bistream_burst)
-                    if n:
-                        eng.bi_burst(streams, n, shared=True)
+                    if n:                                                     # beside a chunk round: the launches; alone: the one-launch step
+                        eng.bi_burst(streams, n, shared=bool(self._chunk_q) or self._chunks_active > 0)
                     if fed or n:
                         ev = torch.cuda.Event()
                         ev.record(self.llm_stream)

@@ -321,7 +321,9 @@ __device__ __host__ constexpr int r1_smem_bytes(int nks) { return R1_STAGE_BYTES
 // 512 threads = NWR x NWK waves; every wave's weight fragments (<= MAXKS) are requested first.
 struct R1NoHook { __device__ __forceinline__ void operator()() const {} };
 // `issued` runs right after the weight requests: the place for a role's own dependent loads (Q: position -> RoPE table).
-template <int NWR, int NWK, int MAXKS, bool NORM, class OP, class HOOK = R1NoHook>
+// NT: the weight fragments are read once per step (one row: non-temporal loads keep them out of L2); false when several rows' blocks
+// stream the same tile one after the other on one XCD (k_step<true>): the first brings it into that L2, the siblings hit there.
+template <int NWR, int NWK, int MAXKS, bool NORM, bool NT, class OP, class HOOK = R1NoHook>
 __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int tile0, int tstride, int KS, int K, int ks0, int ks1, OP& op,
                                            const float* norm_w, float eps, char* smem, HOOK issued = HOOK()) {
     static_assert(NWR * NWK == 8, "row1_core: 512 threads");
@@ -349,8 +351,10 @@ __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int t
     s16x8 abuf[MAXKS];
     const int nw = w1 - w0;
 #pragma unroll
-    for (int i = 0; i < MAXKS; i++)
-        abuf[i] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wbase + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024 + wlane));
+    for (int i = 0; i < MAXKS; i++) {
+        const s16x8* wp_ = reinterpret_cast<const s16x8*>(wbase + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024 + wlane);
+        abuf[i] = NT ? __builtin_nontemporal_load(wp_) : *wp_;
+    }
     __builtin_amdgcn_sched_barrier(0);
     issued();
     f32x8 v = op.finish(k, wave, nitems, active, xch);

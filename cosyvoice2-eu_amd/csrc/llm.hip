@@ -551,6 +551,7 @@ __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
 }
 
 // ------------------------------------------------------------------ k_step: a whole one-row decode step in one launch (chain.h)
+#define CH_MAX_ROWS 8                            // rows of one k_step launch (decode steps of 2..8 sequences: k_step<true>)
 struct StepLayer { const uint16_t *wqkv, *wo, *wgu, *wdown; const float *bqkv, *ln1, *ln2; float *kc, *vc; };
 struct StepArgs {
     const StepLayer* layers; int n_layers;
@@ -564,6 +565,12 @@ struct StepArgs {
     int per;                                     // blocks per layer: Q, A, O, GU, D in this order
     unsigned gl, off_dg, off_qg, off_kv, off_ag, off_hg;     // granules per layer; offsets of the buffers inside a layer (x_mid at 0)
     int dbg_layer;
+    // several rows (k_step<true>): every row is a chain of its own (own granule buffers, own slot: state record, KV cache, pending input);
+    // the rows' blocks are interleaved in the grid so that the rows of one weight tile run on one XCD, one after the other
+    int n_rows; const int* row_slots;            // row -> slot (null: identity)
+    unsigned row_gran;                           // granules per row (n_layers * gl)
+    long kv_slot;                                // floats between two slots of a layer's cache (n_kv * max_pos * 64)
+    int ldl, head_blocks;                        // logits row stride (vocab_pad), head blocks per row (vocab_pad / 16)
     const int* dbg_skip;                         // test hook (cv2_llm_debug_skip_publish): block index + 1 of a Q-role block that does not publish; 0 = none
 };
 #ifdef CV2_STAMPS
@@ -731,12 +738,34 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
     }
 }
 
+// MULTI: n_rows > 1.  Block order: layer by layer (then the head); inside a layer the role blocks go in groups of 8, a group's blocks
+// once per row: position = group * 8 R + row * 8 + (block % 8).  Consecutive block ids go round the 8 XCDs, so the R blocks that stream
+// one weight tile (one per row) share an XCD and follow each other within 8 R dispatches: one HBM read, R - 1 L2 hits.  A block still
+// waits only for lower block ids (its own row's earlier roles), so the forward-progress argument of chain.h holds unchanged.
+template <bool MULTI>
 __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int gb = blockIdx.x;
-    const int layer = min(gb / a.per, a.n_layers);           // the head's blocks (vocab_pad / 16 of them, possibly more than `per`) follow the layers
-    int r = gb - layer * a.per;
+    int layer, r, row = 0;
+    if (!MULTI) {
+        layer = min(gb / a.per, a.n_layers);                 // the head's blocks (vocab_pad / 16 of them, possibly more than `per`) follow the layers
+        r = gb - layer * a.per;
+    } else {
+        const int R = a.n_rows, lb = a.per * R;
+        layer = min(gb / lb, a.n_layers);
+        const int q = gb - layer * lb;
+        const int nb = layer < a.n_layers ? a.per : a.head_blocks, full = nb >> 3, g8 = q / (8 * R);
+        if (g8 < full) { const int rem = q - g8 * 8 * R; row = rem >> 3; r = g8 * 8 + (rem & 7); }
+        else { const int rem = q - full * 8 * R, m = nb - full * 8; row = rem / m; r = full * 8 + rem - row * m; }
+        const int slot = a.row_slots ? a.row_slots[row] : row;
+        a.gran += (size_t)row * a.row_gran;
+        a.state += slot * ST; a.err += slot * ST;
+        a.xin += (size_t)row * a.H;
+        a.logits += (size_t)row * a.ldl;
+        a.kv_slot *= slot;
+    }
+    constexpr bool NT = !MULTI;
     const int H = a.H;
     const int nQ = 2 * (a.n_q + 2 * a.n_kv), nA = a.ntiles * a.n_kv, nO = H / 16, nGU = a.inter / 16;
     const bool dbg = layer == a.dbg_layer;
@@ -748,11 +777,12 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     const unsigned gp = layer > 0 ? (unsigned)(layer - 1) * a.gl : 0u;      // the previous layer's
     if (layer >= a.n_layers) {      // head: final norm -> llm_decoder (+ bias) -> logits (read by k_sample, the next launch)
         OpFold op{&G, gl, gl + a.off_dg, H, nullptr, -1, gl + a.off_dg + H - 1};
-        const float out = row1_core<1, 8, 4, true>(a.wdec, r, 0, H / 32, H, 0, H / 32, op, a.final_norm, a.eps, smem);
+        const float out = row1_core<1, 8, 4, true, NT>(a.wdec, r, 0, H / 32, H, 0, H / 32, op, a.final_norm, a.eps, smem);
         if (tid < 16) a.logits[r * 16 + tid] = out + a.bdec[r * 16 + tid];
         return;
     }
-    const StepLayer L = a.layers[layer];
+    StepLayer L = a.layers[layer];
+    if (MULTI) { L.kc += a.kv_slot; L.vc += a.kv_slot; }
     OpFold xin{&G, gp, gp + a.off_dg, H, layer == 0 ? a.xin : nullptr, od, gp + a.off_hg + a.inter - 1};
     if (r < nQ) {                   // ---- Q: RMSNorm -> QKV -> + bias -> RoPE -> q granules / key, value granules + cache rows
         const int head = r >> 1, half = r & 1;
@@ -762,7 +792,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
         const float bias = L.bqkv[head * 64 + f];
         float c, sn;
         auto hook = [&]() { c = a.cosT[pos * 32 + (f & 31)]; sn = a.sinT[pos * 32 + (f & 31)]; };
-        float v = row1_core<2, 4, 7, true>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin, L.ln1, a.eps, smem, hook) + bias;
+        float v = row1_core<2, 4, 7, true, NT>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin, L.ln1, a.eps, smem, hook) + bias;
         const float vp = __shfl(v, (tid & 63) ^ 16);
         if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);      // rotate-half RoPE on q and k heads
         CH_T(1);
@@ -797,7 +827,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     if (r < nO) {                   // ---- O: attention combine -> O projection -> + residual -> x_mid granules
         const int pos = a.state[CV2_ST_POS];
         OpAtt op{&G, gl + a.off_ag, a.n_kv, a.rep, (pos + AT_TILE - 1) / AT_TILE, od, &xin, r * 16, gl + a.off_qg, gl + a.off_kv};
-        const float o = row1_core<1, 8, 4, false>(L.wo, r, 0, a.NQ / 32, a.NQ, 0, a.NQ / 32, op, nullptr, 0.f, smem);
+        const float o = row1_core<1, 8, 4, false, NT>(L.wo, r, 0, a.NQ / 32, a.NQ, 0, a.NQ / 32, op, nullptr, 0.f, smem);
         CH_T(1);
         if (tid < 16) G.store(gl + r * 16 + tid, reinterpret_cast<const float*>(smem + R1_STAGE_BYTES(a.NQ / 32))[1200 + tid] + o);
         CH_T(2);
@@ -806,7 +836,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     r -= nO;
     if (r < nGU) {                  // ---- GU: RMSNorm -> gate / up -> SiLU(g) * u -> h granules
         OpGran<4> op{&G, gl, gl + 15, 0, od};
-        const float v = row1_core<2, 4, 7, true>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, op, L.ln2, a.eps, smem);
+        const float v = row1_core<2, 4, 7, true, NT>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, op, L.ln2, a.eps, smem);
         const float u = __shfl(v, (tid & 15) + 16);            // threads 0..15 hold gate, 16..31 up (wave 0)
         CH_T(1);
         if (tid < 16) G.store(gl + a.off_hg + r * 16 + tid, (v / (1.f + __expf(-v))) * u);
@@ -819,7 +849,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
         const int KS = a.inter / 32;
         const int ks0 = (int)(((unsigned)KS * sp) / CH_NP), ks1 = (int)(((unsigned)KS * (sp + 1)) / CH_NP);
         OpGran<8> op{&G, gl + a.off_hg, gl + a.off_hg + ks0 * 32 + 15, 0, od};
-        const float v = row1_core<1, 8, 10, false>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op, nullptr, 0.f, smem);
+        const float v = row1_core<1, 8, 10, false, NT>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op, nullptr, 0.f, smem);
         CH_T(1);
         if (tid < 16) G.store(gl + a.off_dg + sp * H + tile * 16 + tid, v);
         CH_T(2);
@@ -1578,7 +1608,8 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
         // [tiles][n_kv][AT_GSTRIDE], h [inter]
         const size_t ntiles = (d.max_pos + AT_TILE - 1) / AT_TILE;
         const size_t gl = (size_t)d.hidden * (1 + CH_NP) + (size_t)d.n_q * 64 + (size_t)2 * d.n_kv * 64 + ntiles * d.n_kv * AT_GSTRIDE + d.inter;
-        p = take((size_t)d.layers * gl * 8); if (h) { h->gran = (u64*)p; h->gran_bytes = (unsigned)((size_t)d.layers * gl * 8); }
+        const int grows = d.max_seqs < CH_MAX_ROWS ? d.max_seqs : CH_MAX_ROWS;      // one set of hand-off buffers per row of a k_step launch
+        p = take((size_t)grows * d.layers * gl * 8); if (h) { h->gran = (u64*)p; h->gran_bytes = (unsigned)((size_t)d.layers * gl * 8); }
         p = take((size_t)d.layers * sizeof(StepLayer)); if (h) h->step_layers = (StepLayer*)p;
     }
     if (h) h->chain_bytes = off - h->chain_off;
@@ -1664,6 +1695,8 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
         a.off_ag = a.off_kv + 2 * d->n_kv * 64; a.off_hg = a.off_ag + ntiles * d->n_kv * AT_GSTRIDE; a.gl = a.off_hg + d->inter;
         a.dbg_layer = -1;
         a.dbg_skip = (const int*)(h->epoch + 16);
+        a.n_rows = 1; a.row_slots = nullptr; a.row_gran = (unsigned)((size_t)d->layers * a.gl);
+        a.kv_slot = (long)d->n_kv * d->max_pos * 64; a.ldl = d->vocab_pad; a.head_blocks = d->vocab_pad / 16;
         h->step_blocks = d->layers * a.per + d->vocab_pad / 16;
     }
     *out = h;
@@ -2041,7 +2074,11 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGra
 #ifdef CV2_STAMPS
                 a.dbg_layer = 12;
 #endif
-                hipLaunchKernelGGL(k_step, dim3(h->step_blocks), dim3(R1_THREADS), sm, cs, a);
+                if (n_seqs == 1 && !mapped) hipLaunchKernelGGL(k_step<false>, dim3(h->step_blocks), dim3(R1_THREADS), sm, cs, a);
+                else {                       // rows = slots 0 .. n - 1, or the live slots of cv2_llm_decode_rows (row -> slot map, inputs by row)
+                    a.n_rows = n_seqs; a.row_slots = mapped ? h->row_slots : nullptr; a.xin = xin;
+                    hipLaunchKernelGGL(k_step<true>, dim3(h->step_blocks * n_seqs), dim3(R1_THREADS), sm, cs, a);
+                }
                 if (hipGetLastError() != hipSuccess) rc = cv2_fail("k_step launch failed");
             } else
             rc = n_seqs <= 16 ? run_layers<1>(h, n_seqs, xin, rm, cs) : run_layers_pre(h, n_seqs, xin, rm, cs);
@@ -2068,7 +2105,7 @@ extern "C" int cv2_llm_decode_ex(cv2_llm* h, int32_t n_seqs, int32_t n_steps, in
     CV2_CHECK(h, "cv2_llm_decode: null handle");
     // one row and the device to itself: the whole step is one launch (k_step); CV2_DECODE_SHARED asks for the launches instead -- k_step
     // keeps ~1000 polling waves resident, which slows kernels of other streams running beside it more than the launches do
-    const bool one_launch = n_seqs == 1 && h->use_chain && !(flags & CV2_DECODE_SHARED);
+    const bool one_launch = n_seqs <= CH_MAX_ROWS && h->use_chain && !(flags & CV2_DECODE_SHARED);
     CV2_CHECK(n_seqs >= 1 && n_seqs <= h->d.max_seqs, "cv2_llm_decode: n_seqs %d out of range", n_seqs);
     if (init_attrs_once()) return -1;
     hipStream_t s = (hipStream_t)stream;
@@ -2108,8 +2145,8 @@ extern "C" int cv2_llm_decode_rows(cv2_llm* h, const int32_t* slots, int32_t n_r
         seen |= 1u << slots[r];
         sa.slots[r] = slots[r];
     }
-    if (n_rows == 1 && slots[0] == 0) return cv2_llm_decode_ex(h, 1, n_steps, flags, stream);      // slot 0 alone: the one-launch step
-    (void)flags;
+    if (n_rows == 1 && slots[0] == 0) return cv2_llm_decode_ex(h, 1, n_steps, flags, stream);      // slot 0 alone: the one-row form of the one-launch step
+    const bool one_launch = n_rows <= CH_MAX_ROWS && h->use_chain && !(flags & CV2_DECODE_SHARED);
     if (init_attrs_once()) return -1;
     hipStream_t s = (hipStream_t)stream;
     sa.n = n_rows; sa.dst = h->row_slots; sa.xnext = h->xnext; sa.xrows = h->xrows; sa.hidden = h->d.hidden;
@@ -2119,11 +2156,11 @@ extern "C" int cv2_llm_decode_rows(cv2_llm* h, const int32_t* slots, int32_t n_r
     hipGraphExec_t g8 = nullptr, g1 = nullptr;
     int i = 0;
     if (n_steps >= UNROLL) {
-        if (get_graph(h, n_rows, UNROLL, false, &g8, true)) return -1;
+        if (get_graph(h, n_rows, UNROLL, one_launch, &g8, true)) return -1;
         for (; i + UNROLL <= n_steps; i += UNROLL) CV2_HIP(hipGraphLaunch(g8, s));
     }
     if (i < n_steps) {
-        if (get_graph(h, n_rows, 1, false, &g1, true)) return -1;
+        if (get_graph(h, n_rows, 1, one_launch, &g1, true)) return -1;
         for (; i < n_steps; i++) CV2_HIP(hipGraphLaunch(g1, s));
     }
     return 0;

@@ -16,12 +16,17 @@ eng.step(32, 8)
 out = []
 for n in (32, 28, 24, 20, 17, 16, 12, 8, 6, 4, 3, 2, 1):
     slots = list(range(32 - n, 32))
-    eng.step_rows(slots, 16)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    eng.step_rows(slots, 64)
-    e1.record()
-    torch.cuda.synchronize()
-    out.append((n, e0.elapsed_time(e1) / 64 * 1e3))
-    print(f'rows {n:2d}: {out[-1][1]:7.1f} us / step', flush=True)
+    res = []
+    for shared in ((False, True) if n <= 8 else (False,)):         # <= 8 rows: the one-launch step (k_step, rows interleaved), and the launches beside it
+        eng.step_rows(slots, 16, shared=shared)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        eng.step_rows(slots, 64, shared=shared)
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 64 * 1e3)
+    out.append((n, res))
+    print(f'rows {n:2d}: ' + (f'{res[0]:7.1f} us / step (one launch)   {res[1]:7.1f} us / step (launches)' if len(res) == 2 else f'{res[0]:7.1f} us / step (launches)'), flush=True)
+st = eng.state.cpu()
+assert not int(st[:, 10].any()), 'a slot reports an error'
