@@ -43,10 +43,14 @@ __device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(flo
 
 struct Gran {                 // all granule buffers of the engine behind one buffer descriptor (32-bit byte offsets)
     __amdgpu_buffer_rsrc_t rsrc; u64* base; unsigned epoch; int* err;
-    __device__ __forceinline__ void init(u64* b, unsigned bytes, unsigned ep, int* e) {
+    bool spec;                // several rows per launch: most blocks are dispatched AFTER their operand was published -- sweep once before
+                              // any sentinel wait (one round trip instead of two when the operand is there, one wasted sweep when not)
+    __device__ __forceinline__ void init(u64* b, unsigned bytes, unsigned ep, int* e, bool sp = false) {
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)bytes, 0x00020000);
-        base = b; epoch = ep; err = e;
+        base = b; epoch = ep; err = e; spec = sp;
     }
+    template <class F>
+    __device__ __forceinline__ bool try_once(F f) const { return spec && __all(f()); }
     // idx = granule index from the start of the buffer
     __device__ __forceinline__ void store(unsigned idx, float v) const {
         __hip_atomic_store((gu64*)(base + idx), ((u64)epoch << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -162,9 +166,7 @@ struct OpFold {
         if (plain) {
             if (active) v = *reinterpret_cast<const f32x4*>(plain + k);
         } else {
-            G->wait(arm, 0, 1);                                     // armed: the previous layer's h has been published (the partials follow ~2 us later);
-                                                                    // from here the sweep itself polls (few consumer blocks: Q 36, head 411 once per step)
-            G->sweep([&]() {
+            auto body = [&]() {
                 bool ok = true;
                 if (active) {
                     f32x4 p[CH_NP];
@@ -175,7 +177,12 @@ struct OpFold {
                     for (int i = 0; i < CH_NP; i++) v += p[i];
                 }
                 return ok;
-            });
+            };
+            if (!G->try_once(body)) {
+                G->wait(arm, 0, 1);                                 // armed: the previous layer's h has been published (the partials follow ~2 us later);
+                                                                    // from here the sweep itself polls (few consumer blocks: Q 36, head 411 once per step)
+                G->sweep(body);
+            }
         }
         r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3];
         return r;
@@ -197,19 +204,17 @@ struct OpGran {
         if (threadIdx.x == 0) *armed = 0;
         __syncthreads();
         if (wave * 64 >= nitems) return v;
+        f32x4 q = {0.f, 0.f, 0.f, 0.f};
+        auto body = [&]() { return !active ? true : (IW == 8 ? G->ld8(g0 + k, v) : G->ld4(g0 + k, q)); };
+        const bool have = G->try_once(body);
         if (wave == 0) {                 // (two to four staggered polling waves per block measured the same: 363.5 / 364.0 / 362.8 / 363.6 us per step --
-            G->wait(sentinel, 0, 1);     //  the arming is off the critical path, the sweep's own retries are what follows the last producer)
+            if (!have) G->wait(sentinel, 0, 1);     //  the arming is off the critical path, the sweep's own retries are what follows the last producer)
             if ((threadIdx.x & 63) == 0) *armed = 1;
-        } else {
+        } else if (!have) {
             while (*armed == 0) __builtin_amdgcn_s_sleep(2);
         }
-        if (IW == 8) {
-            G->sweep([&]() { return active ? G->ld8(g0 + k, v) : true; });
-        } else {
-            f32x4 q = {0.f, 0.f, 0.f, 0.f};
-            G->sweep([&]() { return active ? G->ld4(g0 + k, q) : true; });
-            v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-        }
+        if (!have) G->sweep(body);
+        if (IW != 8) { v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
         return v;
     }
 };
@@ -243,7 +248,7 @@ struct OpAtt {
         {
             f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4, v4 = q4;
             float rv = 0.f;
-            G->wait(kvg + 2 * n_kv * 64 - 1, 0, 1);
+            if (!G->spec) G->wait(kvg + 2 * n_kv * 64 - 1, 0, 1);        // (spec: the sweep below polls by itself)
             G->sweep([&]() {
                 bool ok = true;
                 if (act) {
@@ -274,7 +279,7 @@ struct OpAtt {
             M = sc * 0.125f; den = 1.f; acc = v4;
         }
         asm volatile("" : "+v"(M), "+v"(acc));                     // (done before the wait below, not sunk behind it)
-        G->wait(ag + rep * 64, AT_GSTRIDE, O_WAIT_ALL ? cnt * n_kv : 1);   // every live (tile, head) pair's (max, sum) granule, or only the first tile's (then the sweep polls)
+        if (!G->spec) G->wait(ag + rep * 64, AT_GSTRIDE, O_WAIT_ALL ? cnt * n_kv : 1);   // every live (tile, head) pair's (max, sum) granule, or only the first tile's (then the sweep polls)
         for (int s0 = 0; s0 < cnt; s0 += AT_CHUNK) {               // (block-uniform trip count)
             f32x4 o[AT_CHUNK]; float m[AT_CHUNK], l[AT_CHUNK];
             G->sweep([&]() {
@@ -433,3 +438,4 @@ __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int t
     }
     return out;
 }
+

@@ -551,7 +551,10 @@ __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
 }
 
 // ------------------------------------------------------------------ k_step: a whole one-row decode step in one launch (chain.h)
-#define CH_MAX_ROWS 8                            // rows of one k_step launch (decode steps of 2..8 sequences: k_step<true>)
+// rows of one k_step launch (k_step<true>: 2 .. 6 sequences as interleaved chains).  Measured on MI355X, us per step, one launch / launches
+// (profiles/r4_rows_sweep.txt): 2 rows 503 / 639, 3: 541 / 736, 4: 632 / 769, 6: 787 / 838, 8: 938 / 890 -- every row adds its ~12 000 blocks
+// to a grid of which 512 are resident (2 blocks of 512 threads per CU at 109 VGPRs), ~75 us per row; the launches add ~42 us per row.
+#define CH_MAX_ROWS 6
 struct StepLayer { const uint16_t *wqkv, *wo, *wgu, *wdown; const float *bqkv, *ln1, *ln2; float *kc, *vc; };
 struct StepArgs {
     const StepLayer* layers; int n_layers;
@@ -571,6 +574,7 @@ struct StepArgs {
     unsigned row_gran;                           // granules per row (n_layers * gl)
     long kv_slot;                                // floats between two slots of a layer's cache (n_kv * max_pos * 64)
     int ldl, head_blocks;                        // logits row stride (vocab_pad), head blocks per row (vocab_pad / 16)
+    int spec;                                    // Gran::spec for k_step<true>
     const int* dbg_skip;                         // test hook (cv2_llm_debug_skip_publish): block index + 1 of a Q-role block that does not publish; 0 = none
 };
 #ifdef CV2_STAMPS
@@ -742,7 +746,7 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
 // once per row: position = group * 8 R + row * 8 + (block % 8).  Consecutive block ids go round the 8 XCDs, so the R blocks that stream
 // one weight tile (one per row) share an XCD and follow each other within 8 R dispatches: one HBM read, R - 1 L2 hits.  A block still
 // waits only for lower block ids (its own row's earlier roles), so the forward-progress argument of chain.h holds unchanged.
-template <bool MULTI>
+template <bool MULTI, bool NT = !MULTI>
 __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -765,14 +769,13 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
         a.logits += (size_t)row * a.ldl;
         a.kv_slot *= slot;
     }
-    constexpr bool NT = !MULTI;
     const int H = a.H;
     const int nQ = 2 * (a.n_q + 2 * a.n_kv), nA = a.ntiles * a.n_kv, nO = H / 16, nGU = a.inter / 16;
     const bool dbg = layer == a.dbg_layer;
     const int r_dbg = r, od = dbg ? r : -1; (void)r_dbg; (void)dbg;
     CH_T(0);
     Gran G;
-    G.init(a.gran, a.gran_bytes, *a.epoch, a.err);
+    G.init(a.gran, a.gran_bytes, *a.epoch, a.err, MULTI && a.spec != 0);
     const unsigned gl = (unsigned)min(layer, a.n_layers - 1) * a.gl;        // this layer's granules (head: the last layer's)
     const unsigned gp = layer > 0 ? (unsigned)(layer - 1) * a.gl : 0u;      // the previous layer's
     if (layer >= a.n_layers) {      // head: final norm -> llm_decoder (+ bias) -> logits (read by k_sample, the next launch)
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
         const int tile = r / a.n_kv, g = r - tile * a.n_kv;
         const int pos = a.state[CV2_ST_POS];
         if (tile * AT_TILE >= pos) return;              // no cached key in this tile: the consumer derives the live count from pos too
-        if (layer > 0) G.wait(gp + a.off_dg + H - 1, H, CH_NP);   // armed: the previous layer's down projection has published
+        if (layer > 0 && !G.spec) G.wait(gp + a.off_dg + H - 1, H, CH_NP);   // armed: the previous layer's down projection has published
         attn_role(G, L.kc + (size_t)g * a.max_pos * 64, L.vc + (size_t)g * a.max_pos * 64, pos, tile * AT_TILE, a.rep,
                   gl + a.off_qg + g * a.rep * 64, gl + a.off_ag + (unsigned)r * AT_GSTRIDE, smem, od);
         CH_T(2);
@@ -2074,10 +2077,14 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGra
 #ifdef CV2_STAMPS
                 a.dbg_layer = 12;
 #endif
-                if (n_seqs == 1 && !mapped) hipLaunchKernelGGL(k_step<false>, dim3(h->step_blocks), dim3(R1_THREADS), sm, cs, a);
+                if (n_seqs == 1 && !mapped) hipLaunchKernelGGL((k_step<false, true>), dim3(h->step_blocks), dim3(R1_THREADS), sm, cs, a);
                 else {                       // rows = slots 0 .. n - 1, or the live slots of cv2_llm_decode_rows (row -> slot map, inputs by row)
                     a.n_rows = n_seqs; a.row_slots = mapped ? h->row_slots : nullptr; a.xin = xin;
-                    hipLaunchKernelGGL(k_step<true>, dim3(h->step_blocks * n_seqs), dim3(R1_THREADS), sm, cs, a);
+                    static const int spec_env = getenv("CV2_CHAIN_SPEC") ? atoi(getenv("CV2_CHAIN_SPEC")) : 1;       // A/B switches (diagnostics)
+                    static const int nt_env = getenv("CV2_CHAIN_NT") ? atoi(getenv("CV2_CHAIN_NT")) : 0;
+                    a.spec = n_seqs >= 2 ? spec_env : 0;
+                    if (nt_env || n_seqs == 1) hipLaunchKernelGGL((k_step<true, true>), dim3(h->step_blocks * n_seqs), dim3(R1_THREADS), sm, cs, a);
+                    else hipLaunchKernelGGL((k_step<true, false>), dim3(h->step_blocks * n_seqs), dim3(R1_THREADS), sm, cs, a);
                 }
                 if (hipGetLastError() != hipSuccess) rc = cv2_fail("k_step launch failed");
             } else

@@ -14,7 +14,7 @@ for b in range(32):
     eng.add_request(b, eng.build_lm_input(inp['text'], inp['prompt_text'], inp['prompt_token']), 5000, 5000, force_len=True)
 eng.step(32, 8)
 out = []
-for n in (32, 28, 24, 20, 17, 16, 12, 8, 6, 4, 3, 2, 1):
+for n in (32, 28, 24, 20, 17, 16, 12, 8, 7, 6, 5, 4, 3, 2, 1):
     slots = list(range(32 - n, 32))
     res = []
     for shared in ((False, True) if n <= 8 else (False,)):         # <= 8 rows: the one-launch step (k_step, rows interleaved), and the launches beside it
@@ -28,5 +28,12 @@ for n in (32, 28, 24, 20, 17, 16, 12, 8, 6, 4, 3, 2, 1):
         res.append(e0.elapsed_time(e1) / 64 * 1e3)
     out.append((n, res))
     print(f'rows {n:2d}: ' + (f'{res[0]:7.1f} us / step (one launch)   {res[1]:7.1f} us / step (launches)' if len(res) == 2 else f'{res[0]:7.1f} us / step (launches)'), flush=True)
+# slot 0 alone: the one-row form (k_step<false>: no row -> slot lookup, non-temporal weight loads)
+eng.step(1, 16)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); eng.step(1, 64); e1.record()
+torch.cuda.synchronize()
+print(f'rows  1 (slot 0, one-row kernel): {e0.elapsed_time(e1) / 64 * 1e3:7.1f} us / step', flush=True)
 st = eng.state.cpu()
 assert not int(st[:, 10].any()), 'a slot reports an error'
