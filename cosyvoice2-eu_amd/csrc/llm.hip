@@ -551,10 +551,16 @@ __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
 }
 
 // ------------------------------------------------------------------ k_step: a whole one-row decode step in one launch (chain.h)
-// rows of one k_step launch (k_step<true>: 2 .. 6 sequences as interleaved chains).  Measured on MI355X, us per step, one launch / launches
-// (profiles/r4_rows_sweep.txt): 2 rows 503 / 639, 3: 541 / 736, 4: 632 / 769, 6: 787 / 838, 8: 938 / 890 -- every row adds its ~12 000 blocks
-// to a grid of which 512 are resident (2 blocks of 512 threads per CU at 109 VGPRs), ~75 us per row; the launches add ~42 us per row.
-#define CH_MAX_ROWS 6
+// Rows of one k_step launch (k_step<true>: the rows as interleaved chains).  Measured on MI355X at the configs[1] context (positions
+// 323 .. 387), us per step, one launch / launches (profiles/r4_rows_sweep.txt): 1 row 331 / 600, 2: 443 / 643, 3: 497 / 734, 4: 588 / 767,
+// 5: 673 / 792, 6: 746 / 822, 8: ~890 / 886 -- every row adds its ~12 000 blocks to a grid of which 512 are resident (2 blocks of 512 threads
+// per CU at 109 VGPRs): ~80 us per row against ~42 us per row for the launches, so the one-launch step is taken up to CH_ROWS_DEFAULT rows.
+#define CH_MAX_ROWS 8                            // hand-off buffer sets carved per engine
+#define CH_ROWS_DEFAULT 6
+static int chain_rows() {                        // CV2_CHAIN_ROWS = 1 .. 8: A/B switch (diagnostics)
+    static const int v = [] { const char* e = getenv("CV2_CHAIN_ROWS"); const int x = e ? atoi(e) : CH_ROWS_DEFAULT; return x < 1 ? 1 : (x > CH_MAX_ROWS ? CH_MAX_ROWS : x); }();
+    return v;
+}
 struct StepLayer { const uint16_t *wqkv, *wo, *wgu, *wdown; const float *bqkv, *ln1, *ln2; float *kc, *vc; };
 struct StepArgs {
     const StepLayer* layers; int n_layers;
@@ -2077,7 +2083,8 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGra
 #ifdef CV2_STAMPS
                 a.dbg_layer = 12;
 #endif
-                if (n_seqs == 1 && !mapped) hipLaunchKernelGGL((k_step<false, true>), dim3(h->step_blocks), dim3(R1_THREADS), sm, cs, a);
+                static const bool force_multi = getenv("CV2_CHAIN_FORCE_MULTI") != nullptr;       // diagnostics: one row through k_step<true>
+                if (n_seqs == 1 && !mapped && !force_multi) hipLaunchKernelGGL((k_step<false, true>), dim3(h->step_blocks), dim3(R1_THREADS), sm, cs, a);
                 else {                       // rows = slots 0 .. n - 1, or the live slots of cv2_llm_decode_rows (row -> slot map, inputs by row)
                     a.n_rows = n_seqs; a.row_slots = mapped ? h->row_slots : nullptr; a.xin = xin;
                     static const int spec_env = getenv("CV2_CHAIN_SPEC") ? atoi(getenv("CV2_CHAIN_SPEC")) : 1;       // A/B switches (diagnostics)
@@ -2112,7 +2119,7 @@ extern "C" int cv2_llm_decode_ex(cv2_llm* h, int32_t n_seqs, int32_t n_steps, in
     CV2_CHECK(h, "cv2_llm_decode: null handle");
     // one row and the device to itself: the whole step is one launch (k_step); CV2_DECODE_SHARED asks for the launches instead -- k_step
     // keeps ~1000 polling waves resident, which slows kernels of other streams running beside it more than the launches do
-    const bool one_launch = n_seqs <= CH_MAX_ROWS && h->use_chain && !(flags & CV2_DECODE_SHARED);
+    const bool one_launch = n_seqs <= chain_rows() && h->use_chain && !(flags & CV2_DECODE_SHARED);
     CV2_CHECK(n_seqs >= 1 && n_seqs <= h->d.max_seqs, "cv2_llm_decode: n_seqs %d out of range", n_seqs);
     if (init_attrs_once()) return -1;
     hipStream_t s = (hipStream_t)stream;
@@ -2153,7 +2160,7 @@ extern "C" int cv2_llm_decode_rows(cv2_llm* h, const int32_t* slots, int32_t n_r
         sa.slots[r] = slots[r];
     }
     if (n_rows == 1 && slots[0] == 0) return cv2_llm_decode_ex(h, 1, n_steps, flags, stream);      // slot 0 alone: the one-row form of the one-launch step
-    const bool one_launch = n_rows <= CH_MAX_ROWS && h->use_chain && !(flags & CV2_DECODE_SHARED);
+    const bool one_launch = n_rows <= chain_rows() && h->use_chain && !(flags & CV2_DECODE_SHARED);
     if (init_attrs_once()) return -1;
     hipStream_t s = (hipStream_t)stream;
     sa.n = n_rows; sa.dst = h->row_slots; sa.xnext = h->xnext; sa.xrows = h->xrows; sa.hidden = h->d.hidden;

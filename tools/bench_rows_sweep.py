@@ -9,31 +9,36 @@ from cv2amd.llm import LLMEngine
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 255
 eng = LLMEngine(synth.make_llm(layers=24), 'cuda:0', max_seqs=32, max_pos=2048, max_out=2048)
+xs = []
 for b in range(32):
     inp = synth.synthetic_inputs(seed=b, text_len=50, prompt_len=P)
-    eng.add_request(b, eng.build_lm_input(inp['text'], inp['prompt_text'], inp['prompt_token']), 5000, 5000, force_len=True)
-eng.step(32, 8)
-out = []
+    xs.append(eng.build_lm_input(inp['text'], inp['prompt_text'], inp['prompt_token']))
+
+
+def reset(slots):
+    """fresh requests in `slots`: every measurement runs at the same context (prompt + 16 .. 80 generated positions)"""
+    eng.park()
+    eng.add_requests(slots, [xs[b] for b in slots], [(2000, 2000)] * len(slots), 1, 0, True)
+
+
+def timed(fn):
+    fn(16)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); fn(64); e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 64 * 1e3
+
+
+print(f'decode step against the number of live rows, P = {P} prompt tokens + 50 text tokens, positions {P + 52 + 16} .. {P + 52 + 80} (us per step)')
 for n in (32, 28, 24, 20, 17, 16, 12, 8, 7, 6, 5, 4, 3, 2, 1):
     slots = list(range(32 - n, 32))
     res = []
-    for shared in ((False, True) if n <= 8 else (False,)):         # <= 8 rows: the one-launch step (k_step, rows interleaved), and the launches beside it
-        eng.step_rows(slots, 16, shared=shared)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        eng.step_rows(slots, 64, shared=shared)
-        e1.record()
-        torch.cuda.synchronize()
-        res.append(e0.elapsed_time(e1) / 64 * 1e3)
-    out.append((n, res))
-    print(f'rows {n:2d}: ' + (f'{res[0]:7.1f} us / step (one launch)   {res[1]:7.1f} us / step (launches)' if len(res) == 2 else f'{res[0]:7.1f} us / step (launches)'), flush=True)
-# slot 0 alone: the one-row form (k_step<false>: no row -> slot lookup, non-temporal weight loads)
-eng.step(1, 16)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); eng.step(1, 64); e1.record()
-torch.cuda.synchronize()
-print(f'rows  1 (slot 0, one-row kernel): {e0.elapsed_time(e1) / 64 * 1e3:7.1f} us / step', flush=True)
+    for shared in ((False, True) if n <= 8 else (False,)):         # <= 6 rows: the one-launch step (k_step<true>, rows interleaved), and the launches beside it
+        reset(slots)
+        res.append(timed(lambda k: eng.step_rows(slots, k, shared=shared)))
+    print(f'rows {n:2d}: ' + (f'{res[0]:7.1f} (one launch up to 6 rows)   {res[1]:7.1f} (launches)' if len(res) == 2 else f'{res[0]:7.1f} (launches)'), flush=True)
+reset([0])
+print(f'rows  1 (slot 0, one-row kernel k_step<false>): {timed(lambda k: eng.step(1, k)):7.1f}', flush=True)
 st = eng.state.cpu()
 assert not int(st[:, 10].any()), 'a slot reports an error'
