@@ -133,7 +133,7 @@ class CosyVoice2Model:
         self.flow_cache_min_group, self.flow_cache_min_frames, self.flow_cache_min_first = 2, 1500, 4
         import collections
         self._prompt_caches = collections.OrderedDict()    # prompt key -> FlowCache of the prompt alone (LRU), touched under run_lock
-        self._prompt_building = set()
+        self._prompt_building, self._builds_due = set(), []
         self.prompt_cache_max = int(os.environ.get('CV2_PROMPT_CACHES', '4'))       # 1.15 GB per 10 s prompt; 0 disables
         self.flow_cache_headroom = 0.5         # capacity beyond the chunk at hand when the caller's estimate is smaller
         if llm_sd is not None:
@@ -265,7 +265,7 @@ class CosyVoice2Model:
 
     # ---- chunks of concurrent streams: one ragged flow batch for every chunk that is ready -------------------------------
     class _Chunk:
-        __slots__ = ('token', 'fpt', 'feat', 'femb', 'offset', 'uuid', 'stream', 'finalize', 'done', 'speech', 'exc', 'cap_hint', 'pkey')
+        __slots__ = ('token', 'fpt', 'feat', 'femb', 'offset', 'uuid', 'stream', 'finalize', 'done', 'speech', 'exc', 'cap_hint', 'pkey', 'taken')
 
     def _flow_cache_for(self, c):
         """The call's flow cache, large enough for this chunk.  Capacity: the caller's estimate of the utterance (frames), at least
@@ -321,8 +321,8 @@ class CosyVoice2Model:
             if len(grp) >= self.flow_cache_min_group and self.prompt_cache_max > 0:
                 for c in grp:                                                  # several streams at once and a prompt not seen before:
                     if c.offset == 0 and c.pkey is not None and c.pkey not in self._prompt_caches and c.pkey not in self._prompt_building:
-                        self._prompt_building.add(c.pkey)                      # prepare it for the calls to come (after this round)
-                        threading.Thread(target=self._build_prompt_cache, args=(c.pkey, c.fpt, c.feat, c.femb), daemon=True).start()
+                        self._prompt_building.add(c.pkey)                      # prepare it for the calls to come: started when this round
+                        self._builds_due.append((c.pkey, c.fpt, c.feat, c.femb))   # has delivered (its waiters are in line for the device first)
         if cached:
             res = self.flow.inference_chunk_batch([utts[i] for i in cached], [self._flow_cache_for(grp[i]) for i in cached], finalize=False)
             for i, r in zip(cached, res):
@@ -393,6 +393,9 @@ class CosyVoice2Model:
         finally:
             for c in batch:
                 c.done = True
+            due, self._builds_due = self._builds_due, []
+            for args in due:
+                threading.Thread(target=self._build_prompt_cache, args=args, daemon=True).start()
 
     def _next_pin(self):
         self._pin_rr = (self._pin_rr + 1) % len(self.hift_pool.engines)
@@ -403,14 +406,14 @@ class CosyVoice2Model:
         queued chunks as one ragged batch (streams that share decode steps become ready together), then HiFT per chunk."""
         c = self._Chunk()
         c.token, c.fpt, c.feat, c.femb, c.offset, c.uuid, c.stream, c.finalize = token, fpt, feat, femb, offset, this_uuid, stream, finalize
-        c.done, c.speech, c.exc, c.cap_hint, c.pkey = False, None, None, cap_hint, pkey
+        c.done, c.speech, c.exc, c.cap_hint, c.pkey, c.taken = False, None, None, cap_hint, pkey, False
         with self.lock:
             self._chunk_q.append(c)
         n_streams = min(self._n_shared, self.max_batch)
         if n_streams > 1 and self.chunk_wave_ms > 0:
             t_last = time.perf_counter()
             t_end, last = t_last + self.chunk_wave_ms * 1e-3, len(self._chunk_q)
-            while not c.done:
+            while not c.done and not c.taken:                                 # (taken: a leader has this chunk in its round already -- get in line)
                 n, now = len(self._chunk_q), time.perf_counter()
                 if n >= n_streams or now >= t_end:
                     break
@@ -424,6 +427,8 @@ class CosyVoice2Model:
                 with self.lock:
                     batch = self._chunk_q[:self.max_batch]
                     del self._chunk_q[:len(batch)]
+                    for b in batch:
+                        b.taken = True
                 t0 = time.perf_counter()
                 self._chunks_active += 1
                 try:

@@ -7,8 +7,9 @@ import torch
 from cv2amd import synth
 from cosyvoice.cli.model import CosyVoice2Model
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-R = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+_a = [x for x in sys.argv[1:] if not x.startswith('--')]
+N = int(_a[0]) if len(_a) > 0 else 8
+R = int(_a[1]) if len(_a) > 1 else 4
 m = CosyVoice2Model(synth.make_llm(), synth.make_flow(), synth.make_hift(), max_text=128, max_prompt_tokens=320, max_new_tokens=1100,
                     max_batch=8)
 m.stream_live_rows = os.environ.get('CV2_STREAM_LOCKSTEP', '0') != '1'      # A/B switch
@@ -34,6 +35,18 @@ def run(n):
 
 
 run(1); run(N)                                   # warm-up (graphs for 1..N slots)
+if '--trace' in sys.argv:                        # one round of N streams with a prompt the model has not seen, with the scheduler's log
+    for new_prompt in (False, True):
+        if new_prompt:
+            m._prompt_caches.clear()
+        m._sched_log = []
+        t0 = time.perf_counter()
+        f, audio, dt = run(N)
+        log, m._sched_log = m._sched_log, None
+        print(f'--- {N} streams, {"new" if new_prompt else "served"} prompt: first chunks (ms) {sorted(round(x * 1e3) for x in f)}')
+        for t, kind, info in sorted(log):
+            print(f'{(t - t0) * 1e3:8.2f} ms  {kind:6s} {info}')
+    sys.exit(0)
 for n in (1, N):
     firsts = []
     for _ in range(R):
