@@ -42,12 +42,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
 
 struct Gran {                 // all granule buffers of the engine behind one buffer descriptor (32-bit byte offsets)
-    __amdgpu_buffer_rsrc_t rsrc; u64* base; unsigned epoch; int* err;
+    __amdgpu_buffer_rsrc_t rsrc; u64* base; unsigned epoch; int* err; int* err2;      // err2: the slot of a block's second row (k_step2), else == err
     bool spec;                // several rows per launch: most blocks are dispatched AFTER their operand was published -- sweep once before
                               // any sentinel wait (one round trip instead of two when the operand is there, one wasted sweep when not)
     __device__ __forceinline__ void init(u64* b, unsigned bytes, unsigned ep, int* e, bool sp = false) {
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)bytes, 0x00020000);
-        base = b; epoch = ep; err = e; spec = sp;
+        base = b; epoch = ep; err = err2 = e; spec = sp;
     }
     template <class F>
     __device__ __forceinline__ bool try_once(F f) const { return spec && __all(f()); }
@@ -76,7 +76,12 @@ struct Gran {                 // all granule buffers of the engine behind one bu
         v[2] = u2f(x1[0]); v[3] = u2f(x1[2]);
         return x0[1] == epoch && x0[3] == epoch && x1[1] == epoch && x1[3] == epoch;
     }
-    __device__ __forceinline__ void fail() const { if ((threadIdx.x & 63) == 0) __hip_atomic_store((__attribute__((address_space(1))) int*)err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void fail() const {
+        if ((threadIdx.x & 63) == 0) {
+            __hip_atomic_store((__attribute__((address_space(1))) int*)err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((__attribute__((address_space(1))) int*)err2, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // a wait gives up when its own time is over OR when any block of the launch has given up (the flag is re-read every 16 polls):
     // one broken dependency then costs one timeout, not one per block behind it
     __device__ __forceinline__ bool give_up(u64 t0) const {
@@ -193,6 +198,8 @@ template <int IW_>
 struct OpGran {
     static constexpr int IW = IW_;
     const Gran* G; unsigned g0, sentinel, sstride; int dbg;     // sentinel: one granule of the FIRST producer of this vector
+    int grp = 0;                                                 // k_step2: which half of the block runs this provider (own arming word; `wave` is the wave within the half)
+    bool nobar = false;                                          // k_step2: the caller has cleared the arming words behind a barrier of its own
     __device__ __forceinline__ void issue(int, int, bool) {}
     __device__ __forceinline__ f32x8 finish(int k, int wave, int nitems, bool active, char* xch_) {
         f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -200,9 +207,11 @@ struct OpGran {
         // producers finish within ~0.6 us of each other, so this costs one or two extra sweeps and saves the round trip that a
         // wait for the LAST producer's granule would put in front of the sweep.  ONE wave per block polls the arming word (hundreds
         // of blocks wait for the same 128-byte line: every poll of it goes to the same memory channel); the others watch an LDS word.
-        volatile int* armed = reinterpret_cast<volatile int*>(xch_);
-        if (threadIdx.x == 0) *armed = 0;
-        __syncthreads();
+        volatile int* armed = reinterpret_cast<volatile int*>(xch_) + grp;
+        if (!nobar) {
+            if (wave == 0 && (threadIdx.x & 63) == 0) *armed = 0;
+            __syncthreads();
+        }
         if (wave * 64 >= nitems) return v;
         f32x4 q = {0.f, 0.f, 0.f, 0.f};
         auto body = [&]() { return !active ? true : (IW == 8 ? G->ld8(g0 + k, v) : G->ld4(g0 + k, q)); };
@@ -210,8 +219,12 @@ struct OpGran {
         if (wave == 0) {                 // (two to four staggered polling waves per block measured the same: 363.5 / 364.0 / 362.8 / 363.6 us per step --
             if (!have) G->wait(sentinel, 0, 1);     //  the arming is off the critical path, the sweep's own retries are what follows the last producer)
             if ((threadIdx.x & 63) == 0) *armed = 1;
-        } else if (!have) {
-            while (*armed == 0) __builtin_amdgcn_s_sleep(2);
+        } else if (!have) {               // (bounded like every other wait: a leader that never arms must not hang the block)
+            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            for (unsigned spin = 0; *armed == 0; spin++) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((spin & 1023) == 1023 && G->give_up(t0)) break;
+            }
         }
         if (!have) G->sweep(body);
         if (IW != 8) { v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
@@ -233,12 +246,13 @@ struct OpAtt {
     const Gran* G; unsigned ag; int n_kv, rep, cnt; int dbg;      // cnt = live tiles
     const OpFold* fold; int col0;                                  // the block's 16 residual columns, fetched by 16 idle lanes beside the first chunk
     unsigned qg, kvg;                                              // q [n_q * 64] and the new token's key / value rows [2][n_kv][64] of this layer
+    int t0 = 0, grp = 0;                                           // k_step2: first thread of the half that runs this provider, its residual slot
     __device__ __forceinline__ void issue(int, int, bool) {}
     __device__ __forceinline__ f32x8 finish(int k, int, int, bool act, char* xch_) {
-        const int tid = threadIdx.x;
+        const int tid = (int)threadIdx.x - t0;
         const int hd = k >> 6, g = hd / rep, hh = hd - g * rep;
         const bool res = tid >= 240;                               // nitems = 224: the last 32 lanes own no item
-        float* xch = reinterpret_cast<float*>(xch_);
+        float* xch = reinterpret_cast<float*>(xch_) + grp * 16;
         // the new token attends to itself: score = q . k_new / 8 per head, value v_new -- one more partial {o = v_new, max = score,
         // sum = 1}.  Its three vectors (and the block's 16 residual columns) were published by the Q role ~2 us before the first
         // attention tile: they are fetched and folded FIRST, behind a sentinel of their own (the last value granule), so that the
@@ -439,3 +453,135 @@ __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int t
     return out;
 }
 
+
+// ---- two rows per block (k_step2): the rows are columns 0 and 1 of the MFMA's B operand, so one pass over the block's weight fragments
+// and one set of MFMAs serve both.  SPLIT (operands of <= 256 items: Q, O, gate/up, head): the two halves of the block fetch and stage
+// the two rows' operands at the same time (op0 by threads 0..255, op1 by 256..511, wave index relative to the half); otherwise (down
+// projection, 304 items) all threads fetch row 0, then row 1.  Returns feature f of row c in thread c * NWR * 16 + f.  Per row the
+// arithmetic (order of every sum) is row1_core's.
+#define R2_STAGE_BYTES(nks) ((nks) * 256)
+__device__ __host__ constexpr int r2_smem_bytes(int nks) { return R2_STAGE_BYTES(nks) + R1_XCH_BYTES + 32 + 2 * 8 * 4 * 16; }
+template <int NWR, int NWK, int MAXKS, bool NORM, bool SPLIT, class OP, class HOOK = R1NoHook>
+__device__ __forceinline__ float row2_core(const uint16_t* __restrict__ W, int tile0, int tstride, int KS, int K, int ks0, int ks1, OP& op0, OP& op1,
+                                           const float* norm_w, float eps, char* smem, HOOK issued = HOOK()) {
+    static_assert(NWR * NWK == 8, "row2_core: 512 threads");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave % NWR, wk = wave / NWR;
+    const int nks = ks1 - ks0;
+    const int w0 = ks0 + (nks * wk) / NWK, w1 = ks0 + (nks * (wk + 1)) / NWK;
+    constexpr int IW = OP::IW;
+    const int nitems = nks * (32 / IW);                           // per row
+    const int half = SPLIT ? (wave >> 2) : 0;                     // (wave-uniform)
+    const int tl = SPLIT ? (tid & 255) : tid, hw = SPLIT ? (wave & 3) : wave;
+    const bool active = tl < nitems;
+    const int k = ks0 * 32 + tl * IW;
+    char* stage = smem;
+    char* xch = smem + R2_STAGE_BYTES(nks);
+    float* sqs = reinterpret_cast<float*>(xch + R1_XCH_BYTES);     // [8] per-wave sums of squares (SPLIT: waves 0..3 row 0, 4..7 row 1)
+    float* red = reinterpret_cast<float*>(xch + R1_XCH_BYTES + 32);   // [2 rows][NWK][NWR][4 quarters][4]
+    f32x8 g0 = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (NORM && active) {
+        if (IW == 8) g0 = *reinterpret_cast<const f32x8*>(norm_w + k);
+        else { const f32x4 g4 = *reinterpret_cast<const f32x4*>(norm_w + k); g0[0] = g4[0]; g0[1] = g4[1]; g0[2] = g4[2]; g0[3] = g4[3]; }
+    }
+    const char* wbase = reinterpret_cast<const char*>(W) + ((size_t)(tile0 + wr * tstride) * KS + w0) * 1024;
+    const unsigned wlane = lane * 16;
+    s16x8 abuf[MAXKS];
+    const int nw = w1 - w0;
+#pragma unroll
+    for (int i = 0; i < MAXKS; i++)
+        abuf[i] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wbase + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024 + wlane));
+    __builtin_amdgcn_sched_barrier(0);
+    issued();
+    if (tid < 2) reinterpret_cast<volatile int*>(xch)[tid] = 0;     // the providers' arming words (OpGran::nobar)
+    __syncthreads();
+    auto put = [&](f32x8 v, int col) {                            // the row's hi / lo planes into column `col` of the operand stage
+        if (!active) return;
+        if (NORM) v = g0 * v;
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        if (IW == 8) {
+            bf16x8* dst = reinterpret_cast<bf16x8*>(stage + (size_t)(tl >> 2) * 256 + col * 64) + (tl & 3);
+            dst[0] = hi;
+            dst[8] = lo;
+        } else {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4* dst = reinterpret_cast<bf16x4*>(stage + (size_t)(tl >> 3) * 256 + col * 64) + (tl & 7);
+            dst[0] = __builtin_shufflevector(hi, hi, 0, 1, 2, 3);
+            dst[16] = __builtin_shufflevector(lo, lo, 0, 1, 2, 3);
+        }
+    };
+    auto sumsq = [&](const f32x8& v) {
+        float sq = 0.f;
+        if (active) {
+            sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            if (IW == 8) sq += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
+        }
+        return wave_sum(sq);
+    };
+    if constexpr (SPLIT) {
+        f32x8 v = half == 0 ? op0.finish(k, hw, nitems, active, xch) : op1.finish(k, hw, nitems, active, xch);
+        if (NORM) { const float sq = sumsq(v); if (lane == 0) sqs[wave] = sq; }
+        put(v, half);
+    } else {
+        static_assert(SPLIT || !NORM, "row2_core: the serial form carries no RMSNorm");
+        // both rows' vectors were published by the same producer blocks at the same time: one attempt with both rows' loads in flight
+        // together (one round trip); a wave whose attempt fails fetches them one after the other the blocking way
+        f32x8 v0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        bool both = false;
+        if (IW == 8 && op0.G->spec) {
+            bool ok = true;
+            if (active) { ok = op0.G->ld8(op0.g0 + k, v0); ok &= op1.G->ld8(op1.g0 + k, v1); }
+            both = __all(ok) && hw * 64 < nitems;
+        }
+        if (both) {                       // (the leader wave arms both words for the waves that go the blocking way)
+            if (hw == 0 && lane == 0) { volatile int* aw = reinterpret_cast<volatile int*>(xch); aw[op0.grp] = 1; aw[op1.grp] = 1; }
+        } else { v0 = op0.finish(k, hw, nitems, active, xch); v1 = op1.finish(k, hw, nitems, active, xch); }
+        put(v0, 0);
+        put(v1, 1);
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int GRP = MAXKS <= 7 ? MAXKS : (MAXKS + 1) / 2;
+    const int bcol = (lane & 15) == 1 ? 64 : 0;                   // B operand: column n = lane & 15 -> row n (columns >= 2 read row 0, results unused)
+#pragma unroll
+    for (int gg = 0; gg < MAXKS; gg += GRP) {
+        bf16x8 bh[GRP], bl[GRP];
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            const int i = gg + j;
+            if (i < MAXKS) {
+                const int s_ = (w0 + i < w1 ? w0 + i : w1 - 1) - ks0;
+                const bf16x8* xb = reinterpret_cast<const bf16x8*>(stage + (size_t)s_ * 256 + bcol) + (lane >> 4);
+                bh[j] = xb[0];
+                bl[j] = xb[8];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            const int i = gg + j;
+            if (i < MAXKS) {
+                const bf16x8 a_ = __builtin_bit_cast(bf16x8, w0 + i < w1 ? abuf[i] : zero8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, bh[j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, bl[j], acc, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if ((lane & 15) < 2) *reinterpret_cast<f32x4*>(red + (lane & 15) * (NWK * NWR * 16) + ((wk * NWR + wr) * 4 + (lane >> 4)) * 4) = acc;
+    __syncthreads();
+    float out = 0.f;
+    if (tid < 2 * NWR * 16) {
+        const int c = tid / (NWR * 16), t = tid - c * (NWR * 16);
+        const int wr_ = t >> 4, q = (t >> 2) & 3, r_ = t & 3;
+        const float* rc = red + c * (NWK * NWR * 16);
+        out = rc[((0 * NWR + wr_) * 4 + q) * 4 + r_];
+#pragma unroll
+        for (int j = 1; j < NWK; j++) out += rc[((j * NWR + wr_) * 4 + q) * 4 + r_];
+        if (NORM) out *= rsqrtf(((sqs[4 * c] + sqs[4 * c + 1]) + (sqs[4 * c + 2] + sqs[4 * c + 3])) / (float)K + eps);
+    }
+    return out;
+}

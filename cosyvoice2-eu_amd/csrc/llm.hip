@@ -551,12 +551,20 @@ __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
 }
 
 // ------------------------------------------------------------------ k_step: a whole one-row decode step in one launch (chain.h)
-// Rows of one k_step launch (k_step<true>: the rows as interleaved chains).  Measured on MI355X at the configs[1] context (positions
-// 323 .. 387), us per step, one launch / launches (profiles/r4_rows_sweep.txt): 1 row 331 / 600, 2: 443 / 643, 3: 497 / 734, 4: 588 / 767,
-// 5: 673 / 792, 6: 746 / 822, 8: ~890 / 886 -- every row adds its ~12 000 blocks to a grid of which 512 are resident (2 blocks of 512 threads
-// per CU at 109 VGPRs): ~80 us per row against ~42 us per row for the launches, so the one-launch step is taken up to CH_ROWS_DEFAULT rows.
+// Rows of one decode-step launch.  Two forms (both keep every sum of a row in k_step's order, so ids do not depend on the form):
+//   k_step<true>  every row is a chain of k_step's blocks of its own, the rows' chains interleaved in the grid so that the blocks that
+//                 stream one weight tile (one per row) share an XCD and its L2;
+//   k_step2       the rows in pairs: one chain per pair, every GEMV block serves both rows as MFMA columns 0 / 1 (row2_core).
+// Measured on MI355X at the configs[1] context (positions 323 .. 387), us per step (profiles/r4_rows_sweep.txt):
+//   rows            1     2     3     4     5     6     7     8
+//   k_step<true>   332   445   496   590   673   746   814   903
+//   k_step2         -    428   564   564   637   638   731   732
+//   launches       599   643   734   767   793   823   866   888
+// Every chain adds its ~12 600 blocks to a grid of which 512 are resident (2 blocks of 512 threads per CU at 109 VGPRs): ~80 us per
+// one-row chain, ~100 us per pair.  Policy: pairs, except 3 rows (one chain per row); the launches beside other streams' kernels
+// (CV2_DECODE_SHARED) and from 9 rows on.
 #define CH_MAX_ROWS 8                            // hand-off buffer sets carved per engine
-#define CH_ROWS_DEFAULT 6
+#define CH_ROWS_DEFAULT 8
 static int chain_rows() {                        // CV2_CHAIN_ROWS = 1 .. 8: A/B switch (diagnostics)
     static const int v = [] { const char* e = getenv("CV2_CHAIN_ROWS"); const int x = e ? atoi(e) : CH_ROWS_DEFAULT; return x < 1 ? 1 : (x > CH_MAX_ROWS ? CH_MAX_ROWS : x); }();
     return v;
@@ -862,6 +870,119 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
         CH_T(1);
         if (tid < 16) G.store(gl + a.off_dg + sp * H + tile * 16 + tid, v);
         CH_T(2);
+    }
+}
+
+// ------------------------------------------------------------------ k_step2: 2 .. CH_MAX_ROWS rows in one launch, two rows per block
+// The rows are taken in PAIRS: a pair is one chain of k_step's blocks in which every GEMV block serves both rows at once -- the rows are
+// columns 0 and 1 of the MFMA's B operand (row2_core, chain.h), the block's weight fragments are fetched once, the two rows' operands are
+// gathered by the two halves of the block side by side; hand-off buffers, slot (state record, KV cache, pending input) and epilogue are
+// per row.  The attention role has no weights to share: its tiles stay one block per (row, tile, kv head).  ceil(R / 2) pairs are
+// interleaved in the grid like the rows of k_step<true> (an odd row count: the last pair's second column repeats its first row and is
+// not published).  Per row every sum runs in k_step's order, so the ids do not depend on which kernel served a row.
+__global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, gb = blockIdx.x, R = a.n_rows, P = (R + 1) >> 1, H = a.H;
+    const int nQ = 2 * (a.n_q + 2 * a.n_kv), nA1 = a.ntiles * a.n_kv, nA = 2 * nA1, nO = H / 16, nGU = a.inter / 16;
+    const int per = a.per + nA1;
+    const int lb = per * P;
+    const int layer = min(gb / lb, a.n_layers);
+    int r, chain;
+    {
+        const int q = gb - layer * lb;
+        const int nb = layer < a.n_layers ? per : a.head_blocks, full = nb >> 3, g8 = q / (8 * P);
+        if (g8 < full) { const int rem = q - g8 * 8 * P; chain = rem >> 3; r = g8 * 8 + (rem & 7); }
+        else { const int rem = q - full * 8 * P, m = nb - full * 8; chain = rem / m; r = full * 8 + rem - chain * m; }
+    }
+    const bool two = 2 * chain + 1 < R;
+    const int row0 = 2 * chain, row1 = two ? row0 + 1 : row0;
+    const int slot0 = a.row_slots ? a.row_slots[row0] : row0, slot1 = a.row_slots ? a.row_slots[row1] : row1;
+    const unsigned go0 = (unsigned)row0 * a.row_gran, go1 = (unsigned)row1 * a.row_gran;
+    Gran G;
+    G.init(a.gran, a.gran_bytes * (unsigned)R, *a.epoch, a.err + slot0 * ST, a.spec != 0);
+    G.err2 = a.err + slot1 * ST;
+    const unsigned gl = (unsigned)min(layer, a.n_layers - 1) * a.gl;
+    const unsigned gp = layer > 0 ? (unsigned)(layer - 1) * a.gl : 0u;
+    const int c32 = (tid >> 5) & 1, c16 = (tid >> 4) & 1;          // the row of an epilogue thread: 32 (NWR = 2) / 16 (NWR = 1) features per row
+    if (layer >= a.n_layers) {      // head
+        OpFold op0{&G, go0 + gl, go0 + gl + a.off_dg, H, nullptr, -1, go0 + gl + a.off_dg + H - 1};
+        OpFold op1{&G, go1 + gl, go1 + gl + a.off_dg, H, nullptr, -1, go1 + gl + a.off_dg + H - 1};
+        const float out = row2_core<1, 8, 4, true, true>(a.wdec, r, 0, H / 32, H, 0, H / 32, op0, op1, a.final_norm, a.eps, smem);
+        if (tid < 32 && (c16 == 0 || two)) a.logits[(size_t)(c16 ? row1 : row0) * a.ldl + r * 16 + (tid & 15)] = out + a.bdec[r * 16 + (tid & 15)];
+        return;
+    }
+    const StepLayer L = a.layers[layer];
+    OpFold xin0{&G, go0 + gp, go0 + gp + a.off_dg, H, layer == 0 ? a.xin + (size_t)row0 * H : nullptr, -1, go0 + gp + a.off_hg + a.inter - 1};
+    OpFold xin1{&G, go1 + gp, go1 + gp + a.off_dg, H, layer == 0 ? a.xin + (size_t)row1 * H : nullptr, -1, go1 + gp + a.off_hg + a.inter - 1};
+    if (r < nQ) {                   // ---- Q
+        const int head = r >> 1, half = r & 1;
+        const int slot = c32 ? slot1 : slot0;
+        const int pos = a.state[slot * ST + CV2_ST_POS];
+        const int f = half * 16 + ((tid >> 4) & 1) * 32 + (tid & 15);
+        const float bias = L.bqkv[head * 64 + f];
+        float c, sn;
+        auto hook = [&]() { c = a.cosT[pos * 32 + (f & 31)]; sn = a.sinT[pos * 32 + (f & 31)]; };
+        float v = row2_core<2, 4, 7, true, true>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin0, xin1, L.ln1, a.eps, smem, hook) + bias;
+        const float vp = __shfl(v, (tid & 63) ^ 16);
+        if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);
+        if (tid < 64 && (c32 == 0 || two)) {
+            const unsigned o = (c32 ? go1 : go0) + gl;
+            if (head < a.n_q) G.store(o + a.off_qg + head * 64 + f, v);
+            else if (head < a.n_q + a.n_kv) {
+                const int kvh = head - a.n_q;
+                G.store(o + a.off_kv + kvh * 64 + f, v);
+                L.kc[(size_t)slot * a.kv_slot + ((size_t)kvh * a.max_pos + pos) * 64 + f] = v;
+            } else {
+                const int kvh = head - a.n_q - a.n_kv;
+                G.store(o + a.off_kv + (a.n_kv + kvh) * 64 + f, v);
+                L.vc[(size_t)slot * a.kv_slot + ((size_t)kvh * a.max_pos + pos) * 64 + f] = v;
+            }
+        }
+        return;
+    }
+    r -= nQ;
+    if (r < nA) {                   // ---- A: one tile of one kv head of one row
+        const int c = r / nA1, rr = r - c * nA1;
+        if (c == 1 && !two) return;
+        const int tile = rr / a.n_kv, g = rr - tile * a.n_kv;
+        const int slot = c ? slot1 : slot0;
+        const int pos = a.state[slot * ST + CV2_ST_POS];
+        if (tile * AT_TILE >= pos) return;
+        if (c) G.err = G.err2;
+        const unsigned o = c ? go1 : go0;
+        if (layer > 0 && !G.spec) G.wait(o + gp + a.off_dg + H - 1, H, CH_NP);
+        attn_role(G, L.kc + (size_t)slot * a.kv_slot + (size_t)g * a.max_pos * 64, L.vc + (size_t)slot * a.kv_slot + (size_t)g * a.max_pos * 64, pos,
+                  tile * AT_TILE, a.rep, o + gl + a.off_qg + g * a.rep * 64, o + gl + a.off_ag + (unsigned)rr * AT_GSTRIDE, smem, -1);
+        return;
+    }
+    r -= nA;
+    if (r < nO) {                   // ---- O
+        const int pos0 = a.state[slot0 * ST + CV2_ST_POS], pos1 = a.state[slot1 * ST + CV2_ST_POS];
+        OpAtt op0{&G, go0 + gl + a.off_ag, a.n_kv, a.rep, (pos0 + AT_TILE - 1) / AT_TILE, -1, &xin0, r * 16, go0 + gl + a.off_qg, go0 + gl + a.off_kv, 0, 0};
+        OpAtt op1{&G, go1 + gl + a.off_ag, a.n_kv, a.rep, (pos1 + AT_TILE - 1) / AT_TILE, -1, &xin1, r * 16, go1 + gl + a.off_qg, go1 + gl + a.off_kv, 256, 1};
+        const float ov = row2_core<1, 8, 4, false, true>(L.wo, r, 0, a.NQ / 32, a.NQ, 0, a.NQ / 32, op0, op1, nullptr, 0.f, smem);
+        if (tid < 32 && (c16 == 0 || two))
+            G.store((c16 ? go1 : go0) + gl + r * 16 + (tid & 15), reinterpret_cast<const float*>(smem + R2_STAGE_BYTES(a.NQ / 32))[1200 + c16 * 16 + (tid & 15)] + ov);
+        return;
+    }
+    r -= nO;
+    if (r < nGU) {                  // ---- GU
+        OpGran<4> op0{&G, go0 + gl, go0 + gl + 15, 0, -1, 0, true};
+        OpGran<4> op1{&G, go1 + gl, go1 + gl + 15, 0, -1, 1, true};
+        const float v = row2_core<2, 4, 7, true, true>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, op0, op1, L.ln2, a.eps, smem);
+        const float u = __shfl(v, (tid & 15) + 16 + 32 * c32);     // threads 0..15 hold gate, 16..31 up of row 0; 32..47 / 48..63 of row 1 (wave 0)
+        if (tid < 64 && (tid & 31) < 16 && (c32 == 0 || two)) G.store((c32 ? go1 : go0) + gl + a.off_hg + r * 16 + (tid & 15), (v / (1.f + __expf(-v))) * u);
+        return;
+    }
+    r -= nGU;
+    {                               // ---- D
+        const int sp = r / nO, tile = r - sp * nO;
+        const int KS = a.inter / 32;
+        const int ks0 = (int)(((unsigned)KS * sp) / CH_NP), ks1 = (int)(((unsigned)KS * (sp + 1)) / CH_NP);
+        OpGran<8> op0{&G, go0 + gl + a.off_hg, go0 + gl + a.off_hg + ks0 * 32 + 15, 0, -1, 0, true};
+        OpGran<8> op1{&G, go1 + gl + a.off_hg, go1 + gl + a.off_hg + ks0 * 32 + 15, 0, -1, 1, true};     // (own arming word: no barrier separates the two fetches)
+        const float v = row2_core<1, 8, 10, false, false>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op0, op1, nullptr, 0.f, smem);
+        if (tid < 32 && (c16 == 0 || two)) G.store((c16 ? go1 : go0) + gl + a.off_dg + sp * H + tile * 16 + (tid & 15), v);
     }
 }
 
@@ -2089,7 +2210,13 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGra
                     a.n_rows = n_seqs; a.row_slots = mapped ? h->row_slots : nullptr; a.xin = xin;
                     static const int spec_env = getenv("CV2_CHAIN_SPEC") ? atoi(getenv("CV2_CHAIN_SPEC")) : 1;       // A/B switches (diagnostics)
                     static const int nt_env = getenv("CV2_CHAIN_NT") ? atoi(getenv("CV2_CHAIN_NT")) : 0;
+                    static const bool inter_env = getenv("CV2_CHAIN_MULTI") && getenv("CV2_CHAIN_MULTI")[0] == 'i';     // "inter": one chain per row (k_step<true>)
                     a.spec = n_seqs >= 2 ? spec_env : 0;
+                    if (n_seqs >= 2 && n_seqs != 3 && !inter_env) {  // pairs of rows: two MFMA columns per block (3 rows: one chain per row is faster)
+                        const int P = (n_seqs + 1) / 2;
+                        const size_t sm2 = std::max((size_t)r2_smem_bytes(nks_max), (size_t)AT_SMEM_FLOATS * sizeof(float));
+                        hipLaunchKernelGGL(k_step2, dim3((d.layers * (a.per + a.ntiles * d.n_kv) + d.vocab_pad / 16) * P), dim3(R1_THREADS), sm2, cs, a);
+                    } else
                     if (nt_env || n_seqs == 1) hipLaunchKernelGGL((k_step<true, true>), dim3(h->step_blocks * n_seqs), dim3(R1_THREADS), sm, cs, a);
                     else hipLaunchKernelGGL((k_step<true, false>), dim3(h->step_blocks * n_seqs), dim3(R1_THREADS), sm, cs, a);
                 }

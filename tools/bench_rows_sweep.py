@@ -34,10 +34,10 @@ print(f'decode step against the number of live rows, P = {P} prompt tokens + 50 
 for n in (32, 28, 24, 20, 17, 16, 12, 8, 7, 6, 5, 4, 3, 2, 1):
     slots = list(range(32 - n, 32))
     res = []
-    for shared in ((False, True) if n <= 8 else (False,)):         # <= 6 rows: the one-launch step (k_step<true>, rows interleaved), and the launches beside it
+    for shared in ((False, True) if n <= 8 else (False,)):         # <= 8 rows: the one-launch step (k_step2 pairs / k_step<true>), and the launches beside it
         reset(slots)
         res.append(timed(lambda k: eng.step_rows(slots, k, shared=shared)))
-    print(f'rows {n:2d}: ' + (f'{res[0]:7.1f} (one launch up to 6 rows)   {res[1]:7.1f} (launches)' if len(res) == 2 else f'{res[0]:7.1f} (launches)'), flush=True)
+    print(f'rows {n:2d}: ' + (f'{res[0]:7.1f} (one launch)   {res[1]:7.1f} (launches)' if len(res) == 2 else f'{res[0]:7.1f} (launches)'), flush=True)
 reset([0])
 print(f'rows  1 (slot 0, one-row kernel k_step<false>): {timed(lambda k: eng.step(1, k)):7.1f}', flush=True)
 st = eng.state.cpu()
