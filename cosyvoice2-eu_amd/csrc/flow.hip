@@ -861,6 +861,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         t.xf = h->xf; t.out_ln = GB(h->lnb, 256); t.ldo_ln = 256; t.out_x = xout; t.ldo_x = ldx;
         t.seq = c.L->tab(); t.M_valid = M;
         t.part = h->tail_part; t.ticket = h->tail_ticket;
+        t.row0 = c.inc && M > INC_LEAD ? INC_LEAD : 0;           // (cached chunks: skip the lead panels, see TailArgs::row0)
         return (long)(M / 64) < tail_rows_min ? tail_panel_go(t, M, c.s) : tail_rows_go(t, M, c.s);
     }
     {

@@ -525,6 +525,8 @@ struct TailArgs {
     uint16_t* out_x; long ldo_x;                             // gn == null: x as bf16
     SeqTable seq; int M_valid;
     float* part; int* ticket;                                // k_tail_panel<S > 1>: partial FF2 tiles [panels][S][16][256] and the panels' arrival counters (zero between launches)
+    int row0;                                                // k_tail_panel: first row of the launch (cached streaming chunks: the 128 lead rows in front of the first sequence
+                                                             // hold nothing but the convolution tails -- 8 padding panels that pushed 8 streams' 128 real panels over the S = 2 limit)
 };
 // S > 1: S workgroups share a panel, each takes 1024 / S hidden columns of the feed-forward (its slice of W1 and of W2's K range: one
 // workgroup ingests ~100 GB/s, and at few rows the 1.25 MB of weights per panel were the launch: 64 panels = 64 CUs busy for 20 us).
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(1024) void k_tail_panel(TailArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = S > 1 ? (int)blockIdx.x : 0;
     constexpr int TPW = 4 / S, KS2P = KS2 / S;              // hidden column tiles per wave / k-steps of FF2 of one part
-    const int m0 = blockIdx.y * 16, m = m0 + wave, n = lane * 4;
+    const int m0 = a.row0 + blockIdx.y * 16, m = m0 + wave, n = lane * 4;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     {   // attention panel: piece kb = 16 rows x 32 k, one per wave
         const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 5) << 1);

@@ -64,7 +64,7 @@ static int tail_panel_go(const TailArgs& a, int M, hipStream_t s) {
     }
     // fewer panels than CUs: split the feed-forward's hidden columns over 2 or 4 workgroups per panel (needs the scratch of TailArgs)
     static const int split_env = getenv("CV2_FLOW_TAIL_SPLIT") ? atoi(getenv("CV2_FLOW_TAIL_SPLIT")) : -1;      // A/B switch (diagnostics): 1 / 2 / 4
-    const int panels = M / 16;
+    const int panels = (M - a.row0) / 16;
     int S = a.part ? (panels <= 64 ? 4 : (panels <= 128 ? 2 : 1)) : 1;
     // the scratch holds 128 panels x 4 parts and 128 tickets: a forced split only where it fits, else the default for this panel count
     if (split_env > 0 && a.part && (split_env == 1 || ((split_env == 2 || split_env == 4) && panels <= 128))) S = split_env;

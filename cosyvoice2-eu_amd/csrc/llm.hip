@@ -2246,7 +2246,8 @@ extern "C" int cv2_llm_decode_ex(cv2_llm* h, int32_t n_seqs, int32_t n_steps, in
     CV2_CHECK(h, "cv2_llm_decode: null handle");
     // one row and the device to itself: the whole step is one launch (k_step); CV2_DECODE_SHARED asks for the launches instead -- k_step
     // keeps ~1000 polling waves resident, which slows kernels of other streams running beside it more than the launches do
-    const bool one_launch = n_seqs <= chain_rows() && h->use_chain && !(flags & CV2_DECODE_SHARED);
+    static const bool shared_one = getenv("CV2_SHARED_ONE_LAUNCH") != nullptr;        // A/B switch (diagnostics): the one-launch step also beside other streams' kernels
+    const bool one_launch = n_seqs <= chain_rows() && h->use_chain && (shared_one || !(flags & CV2_DECODE_SHARED));
     CV2_CHECK(n_seqs >= 1 && n_seqs <= h->d.max_seqs, "cv2_llm_decode: n_seqs %d out of range", n_seqs);
     if (init_attrs_once()) return -1;
     hipStream_t s = (hipStream_t)stream;
@@ -2287,7 +2288,8 @@ extern "C" int cv2_llm_decode_rows(cv2_llm* h, const int32_t* slots, int32_t n_r
         sa.slots[r] = slots[r];
     }
     if (n_rows == 1 && slots[0] == 0) return cv2_llm_decode_ex(h, 1, n_steps, flags, stream);      // slot 0 alone: the one-row form of the one-launch step
-    const bool one_launch = n_rows <= chain_rows() && h->use_chain && !(flags & CV2_DECODE_SHARED);
+    static const bool shared_one = getenv("CV2_SHARED_ONE_LAUNCH") != nullptr;
+    const bool one_launch = n_rows <= chain_rows() && h->use_chain && (shared_one || !(flags & CV2_DECODE_SHARED));
     if (init_attrs_once()) return -1;
     hipStream_t s = (hipStream_t)stream;
     sa.n = n_rows; sa.dst = h->row_slots; sa.xnext = h->xnext; sa.xrows = h->xrows; sa.hidden = h->d.hidden;
