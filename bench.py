@@ -228,7 +228,7 @@ def pmc_decode_traffic(desc):
     pj = pmc_stage_file('decode')
     if pj is not None and 'k_step' in desc:
         for r in pj['kernels']:
-            if r['kernel'] == 'k_step' and r.get('hbm_read_MB_per_rep') is not None:
+            if r['kernel'].startswith('k_step') and r.get('hbm_read_MB_per_rep') is not None:
                 per = (r['hbm_read_MB_per_rep'] + r['hbm_write_MB_per_rep']) * 1e6 / r['launches_per_rep']
                 return int(per), f'{pj["_file"]}, k_step {note}; NOT measured in this run'
     for name in ('r2_pmc_decode.json', 'r1_pmc_decode.json'):

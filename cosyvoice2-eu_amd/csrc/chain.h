@@ -461,7 +461,7 @@ __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int t
 // arithmetic (order of every sum) is row1_core's.
 #define R2_STAGE_BYTES(nks) ((nks) * 256)
 __device__ __host__ constexpr int r2_smem_bytes(int nks) { return R2_STAGE_BYTES(nks) + R1_XCH_BYTES + 32 + 2 * 8 * 4 * 16; }
-template <int NWR, int NWK, int MAXKS, bool NORM, bool SPLIT, class OP, class HOOK = R1NoHook>
+template <int NWR, int NWK, int MAXKS, bool NORM, bool SPLIT, bool NT, class OP, class HOOK = R1NoHook>
 __device__ __forceinline__ float row2_core(const uint16_t* __restrict__ W, int tile0, int tstride, int KS, int K, int ks0, int ks1, OP& op0, OP& op1,
                                            const float* norm_w, float eps, char* smem, HOOK issued = HOOK()) {
     static_assert(NWR * NWK == 8, "row2_core: 512 threads");
@@ -490,8 +490,10 @@ __device__ __forceinline__ float row2_core(const uint16_t* __restrict__ W, int t
     s16x8 abuf[MAXKS];
     const int nw = w1 - w0;
 #pragma unroll
-    for (int i = 0; i < MAXKS; i++)
-        abuf[i] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wbase + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024 + wlane));
+    for (int i = 0; i < MAXKS; i++) {
+        const s16x8* wp_ = reinterpret_cast<const s16x8*>(wbase + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024 + wlane);
+        abuf[i] = NT ? __builtin_nontemporal_load(wp_) : *wp_;       // several pairs: the sibling chains' blocks of this tile follow on this XCD -> keep it in L2
+    }
     __builtin_amdgcn_sched_barrier(0);
     issued();
     if (tid < 2) reinterpret_cast<volatile int*>(xch)[tid] = 0;     // the providers' arming words (OpGran::nobar)

@@ -556,16 +556,17 @@ __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
 //                 stream one weight tile (one per row) share an XCD and its L2;
 //   k_step2       the rows in pairs: one chain per pair, every GEMV block serves both rows as MFMA columns 0 / 1 (row2_core).
 // Measured on MI355X at the configs[1] context (positions 323 .. 387), us per step (profiles/r4_rows_sweep.txt):
-//   rows            1     2     3     4     5     6     7     8
-//   k_step<true>   332   445   496   590   673   746   814   903
-//   k_step2         -    428   564   564   637   638   731   732
-//   launches       599   643   734   767   793   823   866   888
+//   rows            1     2     3     4     6     8    10    12    14    16
+//   k_step<true>   332   445   496   590   746   903
+//   k_step2         -    430   564   554   616   708   822   877   971  1076
+//   launches       599   643   734   767   823   888  1000  1064  1120  1162
 // Every chain adds its ~12 600 blocks to a grid of which 512 are resident (2 blocks of 512 threads per CU at 109 VGPRs): ~80 us per
-// one-row chain, ~100 us per pair.  Policy: pairs, except 3 rows (one chain per row); the launches beside other streams' kernels
-// (CV2_DECODE_SHARED) and from 9 rows on.
-#define CH_MAX_ROWS 8                            // hand-off buffer sets carved per engine
-#define CH_ROWS_DEFAULT 8
-static int chain_rows() {                        // CV2_CHAIN_ROWS = 1 .. 8: A/B switch (diagnostics)
+// one-row chain, ~92 us per pair (the pairs' weight loads are plain loads so that the sibling chains hit the XCD's L2; one pair alone:
+// non-temporal).  Policy: pairs up to 16 rows, except 3 rows (one chain per row); the launches beside other streams' kernels
+// (CV2_DECODE_SHARED) and from 17 rows on.
+#define CH_MAX_ROWS 16                           // hand-off buffer sets carved per engine
+#define CH_ROWS_DEFAULT 16
+static int chain_rows() {                        // CV2_CHAIN_ROWS = 1 .. 16: A/B switch (diagnostics)
     static const int v = [] { const char* e = getenv("CV2_CHAIN_ROWS"); const int x = e ? atoi(e) : CH_ROWS_DEFAULT; return x < 1 ? 1 : (x > CH_MAX_ROWS ? CH_MAX_ROWS : x); }();
     return v;
 }
@@ -880,6 +881,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
 // per row.  The attention role has no weights to share: its tiles stay one block per (row, tile, kv head).  ceil(R / 2) pairs are
 // interleaved in the grid like the rows of k_step<true> (an odd row count: the last pair's second column repeats its first row and is
 // not published).  Per row every sum runs in k_step's order, so the ids do not depend on which kernel served a row.
+template <bool NT>
 __global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, gb = blockIdx.x, R = a.n_rows, P = (R + 1) >> 1, H = a.H;
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
     if (layer >= a.n_layers) {      // head
         OpFold op0{&G, go0 + gl, go0 + gl + a.off_dg, H, nullptr, -1, go0 + gl + a.off_dg + H - 1};
         OpFold op1{&G, go1 + gl, go1 + gl + a.off_dg, H, nullptr, -1, go1 + gl + a.off_dg + H - 1};
-        const float out = row2_core<1, 8, 4, true, true>(a.wdec, r, 0, H / 32, H, 0, H / 32, op0, op1, a.final_norm, a.eps, smem);
+        const float out = row2_core<1, 8, 4, true, true, NT>(a.wdec, r, 0, H / 32, H, 0, H / 32, op0, op1, a.final_norm, a.eps, smem);
         if (tid < 32 && (c16 == 0 || two)) a.logits[(size_t)(c16 ? row1 : row0) * a.ldl + r * 16 + (tid & 15)] = out + a.bdec[r * 16 + (tid & 15)];
         return;
     }
@@ -922,7 +924,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
         const float bias = L.bqkv[head * 64 + f];
         float c, sn;
         auto hook = [&]() { c = a.cosT[pos * 32 + (f & 31)]; sn = a.sinT[pos * 32 + (f & 31)]; };
-        float v = row2_core<2, 4, 7, true, true>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin0, xin1, L.ln1, a.eps, smem, hook) + bias;
+        float v = row2_core<2, 4, 7, true, true, NT>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin0, xin1, L.ln1, a.eps, smem, hook) + bias;
         const float vp = __shfl(v, (tid & 63) ^ 16);
         if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);
         if (tid < 64 && (c32 == 0 || two)) {
@@ -960,7 +962,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
         const int pos0 = a.state[slot0 * ST + CV2_ST_POS], pos1 = a.state[slot1 * ST + CV2_ST_POS];
         OpAtt op0{&G, go0 + gl + a.off_ag, a.n_kv, a.rep, (pos0 + AT_TILE - 1) / AT_TILE, -1, &xin0, r * 16, go0 + gl + a.off_qg, go0 + gl + a.off_kv, 0, 0};
         OpAtt op1{&G, go1 + gl + a.off_ag, a.n_kv, a.rep, (pos1 + AT_TILE - 1) / AT_TILE, -1, &xin1, r * 16, go1 + gl + a.off_qg, go1 + gl + a.off_kv, 256, 1};
-        const float ov = row2_core<1, 8, 4, false, true>(L.wo, r, 0, a.NQ / 32, a.NQ, 0, a.NQ / 32, op0, op1, nullptr, 0.f, smem);
+        const float ov = row2_core<1, 8, 4, false, true, NT>(L.wo, r, 0, a.NQ / 32, a.NQ, 0, a.NQ / 32, op0, op1, nullptr, 0.f, smem);
         if (tid < 32 && (c16 == 0 || two))
             G.store((c16 ? go1 : go0) + gl + r * 16 + (tid & 15), reinterpret_cast<const float*>(smem + R2_STAGE_BYTES(a.NQ / 32))[1200 + c16 * 16 + (tid & 15)] + ov);
         return;
@@ -969,7 +971,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
     if (r < nGU) {                  // ---- GU
         OpGran<4> op0{&G, go0 + gl, go0 + gl + 15, 0, -1, 0, true};
         OpGran<4> op1{&G, go1 + gl, go1 + gl + 15, 0, -1, 1, true};
-        const float v = row2_core<2, 4, 7, true, true>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, op0, op1, L.ln2, a.eps, smem);
+        const float v = row2_core<2, 4, 7, true, true, NT>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, op0, op1, L.ln2, a.eps, smem);
         const float u = __shfl(v, (tid & 15) + 16 + 32 * c32);     // threads 0..15 hold gate, 16..31 up of row 0; 32..47 / 48..63 of row 1 (wave 0)
         if (tid < 64 && (tid & 31) < 16 && (c32 == 0 || two)) G.store((c32 ? go1 : go0) + gl + a.off_hg + r * 16 + (tid & 15), (v / (1.f + __expf(-v))) * u);
         return;
@@ -981,7 +983,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
         const int ks0 = (int)(((unsigned)KS * sp) / CH_NP), ks1 = (int)(((unsigned)KS * (sp + 1)) / CH_NP);
         OpGran<8> op0{&G, go0 + gl + a.off_hg, go0 + gl + a.off_hg + ks0 * 32 + 15, 0, -1, 0, true};
         OpGran<8> op1{&G, go1 + gl + a.off_hg, go1 + gl + a.off_hg + ks0 * 32 + 15, 0, -1, 1, true};     // (own arming word: no barrier separates the two fetches)
-        const float v = row2_core<1, 8, 10, false, false>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op0, op1, nullptr, 0.f, smem);
+        const float v = row2_core<1, 8, 10, false, false, NT>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op0, op1, nullptr, 0.f, smem);
         if (tid < 32 && (c16 == 0 || two)) G.store((c16 ? go1 : go0) + gl + a.off_dg + sp * H + tile * 16 + (tid & 15), v);
     }
 }
@@ -2215,7 +2217,9 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGra
                     if (n_seqs >= 2 && n_seqs != 3 && !inter_env) {  // pairs of rows: two MFMA columns per block (3 rows: one chain per row is faster)
                         const int P = (n_seqs + 1) / 2;
                         const size_t sm2 = std::max((size_t)r2_smem_bytes(nks_max), (size_t)AT_SMEM_FLOATS * sizeof(float));
-                        hipLaunchKernelGGL(k_step2, dim3((d.layers * (a.per + a.ntiles * d.n_kv) + d.vocab_pad / 16) * P), dim3(R1_THREADS), sm2, cs, a);
+                        const dim3 grid2((d.layers * (a.per + a.ntiles * d.n_kv) + d.vocab_pad / 16) * P);
+                        if (P == 1 || nt_env) hipLaunchKernelGGL(k_step2<true>, grid2, dim3(R1_THREADS), sm2, cs, a);      // one pair: every weight byte is read once
+                        else hipLaunchKernelGGL(k_step2<false>, grid2, dim3(R1_THREADS), sm2, cs, a);
                     } else
                     if (nt_env || n_seqs == 1) hipLaunchKernelGGL((k_step<true, true>), dim3(h->step_blocks * n_seqs), dim3(R1_THREADS), sm, cs, a);
                     else hipLaunchKernelGGL((k_step<true, false>), dim3(h->step_blocks * n_seqs), dim3(R1_THREADS), sm, cs, a);
