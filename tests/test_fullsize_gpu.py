@@ -484,6 +484,79 @@ def test_generator_text_and_vc_through_the_scheduler(dev):
     assert sorted(mdl._slot_free) == [0, 1] and not mdl.tts_speech_token_dict
 
 
+def test_hub_mixed_calls_failing_text_and_abandoned_stream(dev):
+    """The scheduler's bistream hub under the cases a server sees: generator-text calls (hub-driven slots) and tensor-text streaming
+    calls (caller-driven slots) at the same time on one model; a text generator that raises in the middle fails ITS call only; a
+    consumer that walks away after the first chunk frees its slot for later calls.  Token ids of every completed call equal the oracle's
+    (inference_bistream for generator text, inference for tensor text); 2-layer LLM, full-size flow and HiFT."""
+    from cv2amd import synth, weights as W
+    from cosyvoice.cli.model import CosyVoice2Model
+    from oracle import llm as OL
+    sd = _bistream_sd(2)
+    sdr = W.round_llm_sd(sd)
+    mdl = CosyVoice2Model(sd, synth.make_flow(), synth.make_hift(), max_batch=6, max_text=64, max_prompt_tokens=64, max_new_tokens=512, sampling='greedy')
+    inp = synth.synthetic_inputs(seed=1, text_len=23, prompt_len=31, prompt_text_len=6)
+    cuts = (0, 3, 10, 15, 23)
+    pieces = [inp['text'][:, a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    want_bi, _ = OL.inference_bistream(sdr, pieces, inp['prompt_text'], inp['prompt_token'])
+    want_uni = OL.inference(sdr, inp['text'], inp['prompt_text'], inp['prompt_token'], max_ratio=20)
+    kw = dict(flow_embedding=inp['embedding'], llm_embedding=inp['embedding'], prompt_text=inp['prompt_text'],
+              llm_prompt_speech_token=inp['prompt_token'], flow_prompt_speech_token=inp['prompt_token'], prompt_speech_feat=inp['prompt_feat'])
+
+    class Boom(Exception):
+        pass
+
+    def bad_text():
+        yield pieces[0]
+        yield pieces[1]
+        raise Boom('the upstream text source failed')
+
+    mdl._token_log = {}
+    uuid_of, tl = {}, threading.local()
+    mdl._on_call = lambda u: uuid_of.__setitem__(tl.i, u)
+    res, errs = {}, {}
+
+    def work(i, kind):
+        tl.i = i
+        try:
+            if kind == 'bi':
+                res[i] = sum(o['tts_speech'].shape[1] for o in mdl.tts(text=(p for p in pieces), stream=True, **kw))
+            elif kind == 'uni':
+                res[i] = sum(o['tts_speech'].shape[1] for o in mdl.tts(text=inp['text'], stream=True, **kw))
+            elif kind == 'bad':
+                res[i] = sum(o['tts_speech'].shape[1] for o in mdl.tts(text=bad_text(), stream=True, **kw))
+            else:                                   # walks away after the first chunk
+                g = mdl.tts(text=(p for p in pieces), stream=True, **kw)
+                res[i] = next(g)['tts_speech'].shape[1]
+                g.close()
+        except Exception as e:      # noqa: BLE001
+            errs[i] = e
+    kinds = ['bi', 'uni', 'bad', 'bi', 'uni', 'quit']
+    ths = [threading.Thread(target=work, args=(i, k)) for i, k in enumerate(kinds)]
+    [t.start() for t in ths]
+    [t.join(600) for t in ths]
+    assert not any(t.is_alive() for t in ths), 'a call hangs'
+    assert set(errs) == {2} and isinstance(errs[2], Boom), errs
+    log = mdl._token_log
+    for i, k in enumerate(kinds):
+        if k == 'bi':
+            assert log[uuid_of[i]] == want_bi and res[i] == 960 * len(want_bi), f'call {i}'
+        elif k == 'uni':
+            assert res[i] == 960 * len(want_uni), f'call {i}'
+    # every slot is free again: six more generator-text calls start together and finish
+    mdl._token_log, mdl._on_call = {}, None
+    res2 = {}
+
+    def again(i):
+        res2[i] = sum(o['tts_speech'].shape[1] for o in mdl.tts(text=(p for p in pieces), stream=True, **kw))
+    ths = [threading.Thread(target=again, args=(i,)) for i in range(6)]
+    [t.start() for t in ths]
+    [t.join(600) for t in ths]
+    assert all(res2.get(i) == 960 * len(want_bi) for i in range(6)), res2
+    assert all(t == want_bi for t in mdl._token_log.values())
+    mdl._token_log, mdl._on_call = None, None
+
+
 def test_config4_eight_generator_text_streams_vs_oracle_bistream(dev):
     """BASELINE configs[4] as it is worded ("bistream LLM + chunk-CFM, batch=8"): EIGHT concurrent streaming calls whose text is a
     Python generator (llm_job's bistream branch, cli/model.py:120-128 x 8) on one model.  Every stream owns one LLM slot; the eight

@@ -68,7 +68,7 @@ def test_heavy_tailed_llm_activations_are_heavy_tailed(heavy_llm):
     assert float(gains.min()) <= 0.06 and float(gains.max()) >= 25.0
 
 
-@pytest.mark.parametrize('n_req', [1, 3])
+@pytest.mark.parametrize('n_req', [1, 2, 3, 4])          # one-row k_step; one pair (k_step2); three chains (k_step<true>); two pairs
 def test_heavy_tailed_llm_greedy_ids_vs_oracle(heavy_llm, n_req):
     from cv2amd import synth
     from oracle import llm as OL
@@ -82,7 +82,7 @@ def test_heavy_tailed_llm_greedy_ids_vs_oracle(heavy_llm, n_req):
         want, logps = OL.inference(sdr, *req, force_len=60, return_logp=True)
         margins = np.array([float(lp.topk(2).values[0] - lp.topk(2).values[1]) for lp in logps])
         first = next((k for k, (a, b) in enumerate(zip(ids, want)) if a != b), -1)
-        _record(f'llm_heavy_ids_{n_req}req_{i}', path='one-launch step' if n_req == 1 else 'launches', min_margin=float(margins.min()),
+        _record(f'llm_heavy_ids_{n_req}req_{i}', path={1: 'k_step', 2: 'k_step2 (one pair)', 3: 'k_step<true> (three chains)'}.get(n_req, 'k_step2'), min_margin=float(margins.min()),
                 median_margin=float(np.median(margins)), first_difference=first)
         assert ids == want, f'request {i}: first difference at step {first}, margin there {margins[first]:.2e}, min margin {margins.min():.2e}'
 

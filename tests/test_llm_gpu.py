@@ -195,6 +195,32 @@ def test_hand_off_timeout_commits_nothing_and_the_steps_are_repeated_on_the_laun
     assert eng.generate([req], force_len=20)[0] == want          # stays on the launches, still correct
 
 
+@pytest.mark.parametrize('n', [2, 3, 4, 7, 8, 11, 16])
+def test_one_launch_rows_equal_the_launches_and_the_oracle(small, n):
+    """Decode steps of 2 .. 16 rows as ONE launch (k_step2: the rows in pairs as two MFMA columns per block, an odd count leaves the
+    last pair half empty; 3 rows: k_step<true>, one chain of blocks per row) against the same steps on the launches (CV2_DECODE_SHARED)
+    and the oracle: prompts of different lengths (every row has its own position, KV cache and attention-tile count), greedy and RAS.
+    Per row every sum runs in the one-row kernel's order, so the two forms agree id for id."""
+    from cv2amd.llm import MODE_RAS
+    from oracle import llm as OL
+    sd, sdr, eng = small
+    reqs = _requests(n, seed=40 + n)
+    xs = [eng.build_lm_input(*r) for r in reqs]
+    out = {}
+    for shared in (False, True):
+        for mode in (0, MODE_RAS):
+            eng.park()
+            eng.add_requests(list(range(n)), xs, [(24, 24)] * n, mode, 99, True)
+            eng.step(n, 23, shared=shared)
+            st, toks = eng.read(n)
+            assert bool(st[:, 3].all()) and all(len(t) == 24 for t in toks)
+            out[(shared, mode)] = toks
+    assert out[(False, 0)] == out[(True, 0)] and out[(False, MODE_RAS)] == out[(True, MODE_RAS)]
+    for r, ids in list(zip(reqs, out[(False, 0)]))[:3]:
+        assert ids == OL.inference(sdr, *r, force_len=24)
+    eng.park()
+
+
 def test_many_row_decode_path(small):
     """More than 16 sequences per step take the prepared-operand kernels (k_prep + PRE variants): ids still equal the oracle's."""
     from oracle import llm as OL
