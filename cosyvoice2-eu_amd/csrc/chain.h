@@ -164,6 +164,22 @@ struct OpFold {
         return v;
     }
     static constexpr int IW = 4;                 // operand columns per thread: 5 vectors x 4 granules in flight per lane
+    // one non-blocking look at the operand (k_step4: several rows' loads in flight together); false: not all there yet
+    __device__ __forceinline__ bool attempt(int k, bool active, f32x8& r) const {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        bool ok = true;
+        if (plain) { if (active) v = *reinterpret_cast<const f32x4*>(plain + k); }
+        else if (active) {
+            f32x4 p[CH_NP];
+            ok = G->ld4(xg + k, v);
+#pragma unroll
+            for (int i = 0; i < CH_NP; i++) ok &= G->ld4(dg + i * H + k, p[i]);
+#pragma unroll
+            for (int i = 0; i < CH_NP; i++) v += p[i];
+        }
+        r = (f32x8){v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f};
+        return ok;
+    }
     __device__ __forceinline__ f32x8 finish(int k, int wave, int nitems, bool active, char*) {
         f32x8 r = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (wave * 64 >= nitems) return r;
@@ -201,6 +217,15 @@ struct OpGran {
     int grp = 0;                                                 // k_step2: which half of the block runs this provider (own arming word; `wave` is the wave within the half)
     bool nobar = false;                                          // k_step2: the caller has cleared the arming words behind a barrier of its own
     __device__ __forceinline__ void issue(int, int, bool) {}
+    __device__ __forceinline__ bool attempt(int k, bool active, f32x8& v) const {
+        v = (f32x8){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (!active) return true;
+        if (IW == 8) return G->ld8(g0 + k, v);
+        f32x4 q = {0.f, 0.f, 0.f, 0.f};
+        const bool ok = G->ld4(g0 + k, q);
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+        return ok;
+    }
     __device__ __forceinline__ f32x8 finish(int k, int wave, int nitems, bool active, char* xch_) {
         f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // armed by the first producer (cheap one-word polls while the vector is still far away), then the sweep itself polls: the
@@ -577,6 +602,139 @@ __device__ __forceinline__ float row2_core(const uint16_t* __restrict__ W, int t
     __syncthreads();
     float out = 0.f;
     if (tid < 2 * NWR * 16) {
+        const int c = tid / (NWR * 16), t = tid - c * (NWR * 16);
+        const int wr_ = t >> 4, q = (t >> 2) & 3, r_ = t & 3;
+        const float* rc = red + c * (NWK * NWR * 16);
+        out = rc[((0 * NWR + wr_) * 4 + q) * 4 + r_];
+#pragma unroll
+        for (int j = 1; j < NWK; j++) out += rc[((j * NWR + wr_) * 4 + q) * 4 + r_];
+        if (NORM) out *= rsqrtf(((sqs[4 * c] + sqs[4 * c + 1]) + (sqs[4 * c + 2] + sqs[4 * c + 3])) / (float)K + eps);
+    }
+    return out;
+}
+
+// ---- four rows per block (k_step4): columns 0 .. 3 of the MFMA's B operand.  SPLIT (operands of <= 256 items): half h of the block
+// serves rows 2 h and 2 h + 1 -- one attempt with both rows' loads in flight (the rows' producers publish together), the blocking
+// providers one after the other where that fails; otherwise (down projection) all threads take rows (0, 1), then (2, 3) the same way.
+// ops[r].grp must be r (own arming word per row, cleared here), OpGran::nobar set.  Returns feature f of row c in thread c * NWR * 16 + f.
+#define R4_STAGE_BYTES(nks) ((nks) * 512)
+__device__ __host__ constexpr int r4_smem_bytes(int nks) { return R4_STAGE_BYTES(nks) + R1_XCH_BYTES + 64 + 4 * 8 * 4 * 16; }
+template <int NWR, int NWK, int MAXKS, bool NORM, bool SPLIT, bool NT, class OP, class HOOK = R1NoHook>
+__device__ __forceinline__ float row4_core(const uint16_t* __restrict__ W, int tile0, int tstride, int KS, int K, int ks0, int ks1, OP (&ops)[4],
+                                           const float* norm_w, float eps, char* smem, HOOK issued = HOOK()) {
+    static_assert(NWR * NWK == 8, "row4_core: 512 threads");
+    static_assert(SPLIT || !NORM, "row4_core: the serial form carries no RMSNorm");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave % NWR, wk = wave / NWR;
+    const int nks = ks1 - ks0;
+    const int w0 = ks0 + (nks * wk) / NWK, w1 = ks0 + (nks * (wk + 1)) / NWK;
+    constexpr int IW = OP::IW;
+    const int nitems = nks * (32 / IW);
+    const int half = SPLIT ? (wave >> 2) : 0;
+    const int tl = SPLIT ? (tid & 255) : tid, hw = SPLIT ? (wave & 3) : wave;
+    const bool active = tl < nitems;
+    const int k = ks0 * 32 + tl * IW;
+    char* stage = smem;
+    char* xch = smem + R4_STAGE_BYTES(nks);
+    float* sqs = reinterpret_cast<float*>(xch + R1_XCH_BYTES);     // [4 rows][4 waves of the row's half]
+    float* red = reinterpret_cast<float*>(xch + R1_XCH_BYTES + 64);   // [4 rows][NWK][NWR][4 quarters][4]
+    f32x8 g0 = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (NORM && active) {
+        if (IW == 8) g0 = *reinterpret_cast<const f32x8*>(norm_w + k);
+        else { const f32x4 g4 = *reinterpret_cast<const f32x4*>(norm_w + k); g0[0] = g4[0]; g0[1] = g4[1]; g0[2] = g4[2]; g0[3] = g4[3]; }
+    }
+    const char* wbase = reinterpret_cast<const char*>(W) + ((size_t)(tile0 + wr * tstride) * KS + w0) * 1024;
+    const unsigned wlane = lane * 16;
+    s16x8 abuf[MAXKS];
+    const int nw = w1 - w0;
+#pragma unroll
+    for (int i = 0; i < MAXKS; i++) {
+        const s16x8* wp_ = reinterpret_cast<const s16x8*>(wbase + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024 + wlane);
+        abuf[i] = NT ? __builtin_nontemporal_load(wp_) : *wp_;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issued();
+    volatile int* aw = reinterpret_cast<volatile int*>(xch);
+    if (tid < 4) aw[tid] = 0;
+    __syncthreads();
+    auto put = [&](f32x8 v, int col) {
+        if (!active) return;
+        if (NORM) v = g0 * v;
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        if (IW == 8) {
+            bf16x8* dst = reinterpret_cast<bf16x8*>(stage + (size_t)(tl >> 2) * 512 + col * 64) + (tl & 3);
+            dst[0] = hi;
+            dst[16] = lo;
+        } else {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4* dst = reinterpret_cast<bf16x4*>(stage + (size_t)(tl >> 3) * 512 + col * 64) + (tl & 7);
+            dst[0] = __builtin_shufflevector(hi, hi, 0, 1, 2, 3);
+            dst[32] = __builtin_shufflevector(lo, lo, 0, 1, 2, 3);
+        }
+    };
+    auto sumsq = [&](const f32x8& v) {
+        float sq = 0.f;
+        if (active) {
+            sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            if (IW == 8) sq += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
+        }
+        return wave_sum(sq);
+    };
+    auto pair = [&](OP& oa, OP& ob, int ra, int rb) {             // rows ra, rb of this thread group: fetch, (sum of squares), stage
+        f32x8 va, vb;                                             // (the providers by reference: a run-time index into ops[] puts the array in scratch)
+        bool both = false;
+        if (oa.G->spec) {
+            bool ok = oa.attempt(k, active, va);
+            ok &= ob.attempt(k, active, vb);
+            both = __all(ok) && hw * 64 < nitems;
+        }
+        if (both) { if (hw == 0 && lane == 0) { aw[ra] = 1; aw[rb] = 1; } }      // (the leader wave arms the rows' words for waves that go the blocking way)
+        else { va = oa.finish(k, hw, nitems, active, xch); vb = ob.finish(k, hw, nitems, active, xch); }
+        if (NORM) {
+            const float sa = sumsq(va), sb = sumsq(vb);
+            if (lane == 0) { sqs[ra * 4 + hw] = sa; sqs[rb * 4 + hw] = sb; }
+        }
+        put(va, ra);
+        put(vb, rb);
+    };
+    if constexpr (SPLIT) { if (half == 0) pair(ops[0], ops[1], 0, 1); else pair(ops[2], ops[3], 2, 3); }
+    else { pair(ops[0], ops[1], 0, 1); pair(ops[2], ops[3], 2, 3); }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int GRP = MAXKS <= 7 ? MAXKS : (MAXKS + 1) / 2;
+    const int bcol = ((lane & 15) < 4 ? (lane & 15) : 0) * 64;       // B operand: column n = lane & 15 -> row n (columns >= 4 read row 0, results unused)
+#pragma unroll
+    for (int gg = 0; gg < MAXKS; gg += GRP) {
+        bf16x8 bh[GRP], bl[GRP];
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            const int i = gg + j;
+            if (i < MAXKS) {
+                const int s_ = (w0 + i < w1 ? w0 + i : w1 - 1) - ks0;
+                const bf16x8* xb = reinterpret_cast<const bf16x8*>(stage + (size_t)s_ * 512 + bcol) + (lane >> 4);
+                bh[j] = xb[0];
+                bl[j] = xb[16];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            const int i = gg + j;
+            if (i < MAXKS) {
+                const bf16x8 a_ = __builtin_bit_cast(bf16x8, w0 + i < w1 ? abuf[i] : zero8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, bh[j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, bl[j], acc, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if ((lane & 15) < 4) *reinterpret_cast<f32x4*>(red + (lane & 15) * (NWK * NWR * 16) + ((wk * NWR + wr) * 4 + (lane >> 4)) * 4) = acc;
+    __syncthreads();
+    float out = 0.f;
+    if (tid < 4 * NWR * 16) {
         const int c = tid / (NWR * 16), t = tid - c * (NWR * 16);
         const int wr_ = t >> 4, q = (t >> 2) & 3, r_ = t & 3;
         const float* rc = red + c * (NWK * NWR * 16);

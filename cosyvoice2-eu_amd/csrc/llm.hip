@@ -551,22 +551,25 @@ __global__ __launch_bounds__(512) void k_gateup(GateUpArgs a) {
 }
 
 // ------------------------------------------------------------------ k_step: a whole one-row decode step in one launch (chain.h)
-// Rows of one decode-step launch.  Two forms (both keep every sum of a row in k_step's order, so ids do not depend on the form):
+// Rows of one decode-step launch.  Three forms (all keep every sum of a row in k_step's order, so ids do not depend on the form):
 //   k_step<true>  every row is a chain of k_step's blocks of its own, the rows' chains interleaved in the grid so that the blocks that
 //                 stream one weight tile (one per row) share an XCD and its L2;
-//   k_step2       the rows in pairs: one chain per pair, every GEMV block serves both rows as MFMA columns 0 / 1 (row2_core).
+//   k_step2       the rows in pairs: one chain per pair, every GEMV block serves both rows as MFMA columns 0 / 1 (row2_core);
+//   k_step4       the rows in fours: MFMA columns 0 .. 3 (row4_core; the O role stays two rows per block).
 // Measured on MI355X at the configs[1] context (positions 323 .. 387), us per step (profiles/r4_rows_sweep.txt):
-//   rows            1     2     3     4     6     8    10    12    14    16
+//   rows            1     2     3     4     6     8    10    12    16    20    24
 //   k_step<true>   332   445   496   590   746   903
-//   k_step2         -    430   564   554   616   708   822   877   971  1076
-//   launches       599   643   734   767   823   888  1000  1064  1120  1162
-// Every chain adds its ~12 600 blocks to a grid of which 512 are resident (2 blocks of 512 threads per CU at 109 VGPRs): ~80 us per
-// one-row chain, ~92 us per pair (the pairs' weight loads are plain loads so that the sibling chains hit the XCD's L2; one pair alone:
-// non-temporal).  Policy: pairs up to 16 rows, except 3 rows (one chain per row); the launches beside other streams' kernels
-// (CV2_DECODE_SHARED) and from 17 rows on.
-#define CH_MAX_ROWS 16                           // hand-off buffer sets carved per engine
-#define CH_ROWS_DEFAULT 16
-static int chain_rows() {                        // CV2_CHAIN_ROWS = 1 .. 16: A/B switch (diagnostics)
+//   k_step2         -    430   564   554   616   708   822   877  1076
+//   k_step4         -     -     -    561   691   709   801   826   921  1065  1175
+//   launches       599   643   734   767   823   888  1000  1064  1162  1181  1205
+// Every chain adds its ~12 600 blocks to a grid of which 512 are resident (2 blocks of 512 threads per CU at 109-125 VGPRs): ~80 us
+// per one-row chain, ~92 us per pair, ~120-150 us per four (their operand gathers are 2 / 4 x a row's: the Q role's x + 2 partials is
+// 86 KB at four rows against ~50 GB/s per workgroup).  Several chains read their weight tiles with plain loads (the sibling chains'
+// blocks follow on the same XCD and hit its L2), one chain alone with non-temporal ones.  Policy: pairs up to 8 rows (3 rows: one
+// chain per row), fours from 9 to 24, the launches beside other streams' kernels (CV2_DECODE_SHARED) and from 25 rows on.
+#define CH_MAX_ROWS 24                           // hand-off buffer sets carved per engine
+#define CH_ROWS_DEFAULT 24
+static int chain_rows() {                        // CV2_CHAIN_ROWS = 1 .. 24: A/B switch (diagnostics)
     static const int v = [] { const char* e = getenv("CV2_CHAIN_ROWS"); const int x = e ? atoi(e) : CH_ROWS_DEFAULT; return x < 1 ? 1 : (x > CH_MAX_ROWS ? CH_MAX_ROWS : x); }();
     return v;
 }
@@ -985,6 +988,139 @@ __global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
         OpGran<8> op1{&G, go1 + gl + a.off_hg, go1 + gl + a.off_hg + ks0 * 32 + 15, 0, -1, 1, true};     // (own arming word: no barrier separates the two fetches)
         const float v = row2_core<1, 8, 10, false, false, NT>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op0, op1, nullptr, 0.f, smem);
         if (tid < 32 && (c16 == 0 || two)) G.store((c16 ? go1 : go0) + gl + a.off_dg + sp * H + tile * 16 + (tid & 15), v);
+    }
+}
+
+// ------------------------------------------------------------------ k_step4: rows in groups of FOUR, four MFMA columns per GEMV block
+// As k_step2 with row4_core: one chain of blocks per four rows.  The Q / gate-up / head blocks serve the four rows with the block's
+// halves taking two rows each (both rows' operand loads in flight together), the down projection takes (0, 1) then (2, 3); the O role
+// keeps k_step2's two-row blocks (its provider merges attention tiles in several dependent sweeps: two blocks per chain, rows (0, 1)
+// and (2, 3), the second finds W_o in L2); attention tiles: one block per (row, tile, kv head).  A chain whose last rows do not exist
+// (row count not a multiple of 4) repeats its first row in the empty columns and does not publish them.
+template <bool NT>
+__global__ __launch_bounds__(R1_THREADS) void k_step4(StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, gb = blockIdx.x, R = a.n_rows, P = (R + 3) >> 2, H = a.H;
+    const int nQ = 2 * (a.n_q + 2 * a.n_kv), nA1 = a.ntiles * a.n_kv, nA = 4 * nA1, nO1 = H / 16, nO = 2 * nO1, nGU = a.inter / 16;
+    const int per = a.per + 3 * nA1 + nO1;
+    const int lb = per * P;
+    const int layer = min(gb / lb, a.n_layers);
+    int r, chain;
+    {
+        const int q = gb - layer * lb;
+        const int nb = layer < a.n_layers ? per : a.head_blocks, full = nb >> 3, g8 = q / (8 * P);
+        if (g8 < full) { const int rem = q - g8 * 8 * P; chain = rem >> 3; r = g8 * 8 + (rem & 7); }
+        else { const int rem = q - full * 8 * P, m = nb - full * 8; chain = rem / m; r = full * 8 + rem - chain * m; }
+    }
+    const int nv = min(4, R - 4 * chain);                        // rows of this chain that exist
+    int row[4], slot[4]; unsigned go[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        row[c] = 4 * chain + (c < nv ? c : 0);
+        slot[c] = a.row_slots ? a.row_slots[row[c]] : row[c];
+        go[c] = (unsigned)row[c] * a.row_gran;
+    }
+    Gran G;
+    G.init(a.gran, a.gran_bytes * (unsigned)R, *a.epoch, a.err + slot[0] * ST, a.spec != 0);
+    const unsigned gl = (unsigned)min(layer, a.n_layers - 1) * a.gl;
+    const unsigned gp = layer > 0 ? (unsigned)(layer - 1) * a.gl : 0u;
+    const int c32 = (tid >> 5) & 3, c16 = (tid >> 4) & 3;          // the row of an epilogue thread (NWR = 2: 32 features per row, NWR = 1: 16)
+    auto sel = [&](int c, auto& arr) { return c == 0 ? arr[0] : c == 1 ? arr[1] : c == 2 ? arr[2] : arr[3]; };
+    if (layer >= a.n_layers) {      // head
+        OpFold ops[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) ops[c] = OpFold{&G, go[c] + gl, go[c] + gl + a.off_dg, H, nullptr, -1, go[c] + gl + a.off_dg + H - 1};
+        const float out = row4_core<1, 8, 4, true, true, NT>(a.wdec, r, 0, H / 32, H, 0, H / 32, ops, a.final_norm, a.eps, smem);
+        if (tid < 64 && c16 < nv) a.logits[(size_t)sel(c16, row) * a.ldl + r * 16 + (tid & 15)] = out + a.bdec[r * 16 + (tid & 15)];
+        return;
+    }
+    const StepLayer L = a.layers[layer];
+    OpFold xin[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        xin[c] = OpFold{&G, go[c] + gp, go[c] + gp + a.off_dg, H, layer == 0 ? a.xin + (size_t)row[c] * H : nullptr, -1, go[c] + gp + a.off_hg + a.inter - 1};
+    if (r < nQ) {                   // ---- Q
+        const int head = r >> 1, half = r & 1;
+        const int sl = sel(c32, slot);
+        const int pos = a.state[sl * ST + CV2_ST_POS];
+        const int f = half * 16 + ((tid >> 4) & 1) * 32 + (tid & 15);
+        const float bias = L.bqkv[head * 64 + f];
+        float c, sn;
+        auto hook = [&]() { c = a.cosT[pos * 32 + (f & 31)]; sn = a.sinT[pos * 32 + (f & 31)]; };
+        float v = row4_core<2, 4, 7, true, true, NT>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin, L.ln1, a.eps, smem, hook) + bias;
+        const float vp = __shfl(v, (tid & 63) ^ 16);
+        if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);
+        if (tid < 128 && c32 < nv) {
+            const unsigned o = sel(c32, go) + gl;
+            if (head < a.n_q) G.store(o + a.off_qg + head * 64 + f, v);
+            else if (head < a.n_q + a.n_kv) {
+                const int kvh = head - a.n_q;
+                G.store(o + a.off_kv + kvh * 64 + f, v);
+                L.kc[(size_t)sl * a.kv_slot + ((size_t)kvh * a.max_pos + pos) * 64 + f] = v;
+            } else {
+                const int kvh = head - a.n_q - a.n_kv;
+                G.store(o + a.off_kv + (a.n_kv + kvh) * 64 + f, v);
+                L.vc[(size_t)sl * a.kv_slot + ((size_t)kvh * a.max_pos + pos) * 64 + f] = v;
+            }
+        }
+        return;
+    }
+    r -= nQ;
+    if (r < nA) {                   // ---- A: one tile of one kv head of one row
+        const int c = r / nA1, rr = r - c * nA1;
+        if (c >= nv) return;
+        const int tile = rr / a.n_kv, g = rr - tile * a.n_kv;
+        const int sl = sel(c, slot);
+        const int pos = a.state[sl * ST + CV2_ST_POS];
+        if (tile * AT_TILE >= pos) return;
+        G.err = G.err2 = a.err + sl * ST;
+        const unsigned o = sel(c, go);
+        if (layer > 0 && !G.spec) G.wait(o + gp + a.off_dg + H - 1, H, CH_NP);
+        attn_role(G, L.kc + (size_t)sl * a.kv_slot + (size_t)g * a.max_pos * 64, L.vc + (size_t)sl * a.kv_slot + (size_t)g * a.max_pos * 64, pos,
+                  tile * AT_TILE, a.rep, o + gl + a.off_qg + g * a.rep * 64, o + gl + a.off_ag + (unsigned)rr * AT_GSTRIDE, smem, -1);
+        return;
+    }
+    r -= nA;
+    if (r < nO) {                   // ---- O: rows (0, 1) or (2, 3) of the chain, two per block as in k_step2
+        const int pr = r / nO1, t = r - pr * nO1;
+        const int ca = 2 * pr, cb = 2 * pr + 1;
+        if (ca >= nv) return;
+        const bool two = cb < nv;
+        const int sa = sel(ca, slot), sb = sel(cb, slot);
+        const unsigned ga = sel(ca, go), gb_ = sel(cb, go);
+        G.err = a.err + sa * ST; G.err2 = a.err + sb * ST;
+        const int pos0 = a.state[sa * ST + CV2_ST_POS], pos1 = a.state[sb * ST + CV2_ST_POS];
+        OpFold& xa = ca == 0 ? xin[0] : xin[2];
+        OpFold& xb = cb == 1 ? xin[1] : xin[3];
+        OpAtt op0{&G, ga + gl + a.off_ag, a.n_kv, a.rep, (pos0 + AT_TILE - 1) / AT_TILE, -1, &xa, t * 16, ga + gl + a.off_qg, ga + gl + a.off_kv, 0, 0};
+        OpAtt op1{&G, gb_ + gl + a.off_ag, a.n_kv, a.rep, (pos1 + AT_TILE - 1) / AT_TILE, -1, &xb, t * 16, gb_ + gl + a.off_qg, gb_ + gl + a.off_kv, 256, 1};
+        const float ov = row2_core<1, 8, 4, false, true, NT>(L.wo, t, 0, a.NQ / 32, a.NQ, 0, a.NQ / 32, op0, op1, nullptr, 0.f, smem);
+        const int e = (tid >> 4) & 1;
+        if (tid < 32 && (e == 0 || two))
+            G.store((e ? gb_ : ga) + gl + t * 16 + (tid & 15), reinterpret_cast<const float*>(smem + R2_STAGE_BYTES(a.NQ / 32))[1200 + e * 16 + (tid & 15)] + ov);
+        return;
+    }
+    r -= nO;
+    G.err2 = a.err + sel(nv - 1, slot) * ST;
+    if (r < nGU) {                  // ---- GU
+        OpGran<4> ops[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) ops[c] = OpGran<4>{&G, go[c] + gl, go[c] + gl + 15, 0, -1, c, true};
+        const float v = row4_core<2, 4, 7, true, true, NT>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, ops, L.ln2, a.eps, smem);
+        const float u = __shfl(v, (tid & 15) + 16 + 32 * ((tid >> 5) & 1));     // within a wave: rows 2 w, 2 w + 1; gate in lanes 0..15 / 32..47, up in 16..31 / 48..63
+        if (tid < 128 && (tid & 31) < 16 && c32 < nv) G.store(sel(c32, go) + gl + a.off_hg + r * 16 + (tid & 15), (v / (1.f + __expf(-v))) * u);
+        return;
+    }
+    r -= nGU;
+    {                               // ---- D
+        const int sp = r / nO1, tile = r - sp * nO1;
+        const int KS = a.inter / 32;
+        const int ks0 = (int)(((unsigned)KS * sp) / CH_NP), ks1 = (int)(((unsigned)KS * (sp + 1)) / CH_NP);
+        OpGran<8> ops[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) ops[c] = OpGran<8>{&G, go[c] + gl + a.off_hg, go[c] + gl + a.off_hg + ks0 * 32 + 15, 0, -1, c, true};
+        const float v = row4_core<1, 8, 10, false, false, NT>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, ops, nullptr, 0.f, smem);
+        if (tid < 64 && c16 < nv) G.store(sel(c16, go) + gl + a.off_dg + sp * H + tile * 16 + (tid & 15), v);
     }
 }
 
@@ -2214,6 +2350,14 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGra
                     static const int nt_env = getenv("CV2_CHAIN_NT") ? atoi(getenv("CV2_CHAIN_NT")) : 0;
                     static const bool inter_env = getenv("CV2_CHAIN_MULTI") && getenv("CV2_CHAIN_MULTI")[0] == 'i';     // "inter": one chain per row (k_step<true>)
                     a.spec = n_seqs >= 2 ? spec_env : 0;
+                    static const int quad_from = getenv("CV2_CHAIN_QUADS") ? atoi(getenv("CV2_CHAIN_QUADS")) : 9;      // rows from which the chains take four rows (A/B switch)
+                    if (n_seqs >= quad_from && !inter_env) {
+                        const int P = (n_seqs + 3) / 4;
+                        const size_t sm4 = std::max((size_t)r4_smem_bytes(nks_max), (size_t)AT_SMEM_FLOATS * sizeof(float));
+                        const dim3 grid4((d.layers * (a.per + 3 * a.ntiles * d.n_kv + d.hidden / 16) + d.vocab_pad / 16) * P);
+                        if (P == 1 || nt_env) hipLaunchKernelGGL(k_step4<true>, grid4, dim3(R1_THREADS), sm4, cs, a);
+                        else hipLaunchKernelGGL(k_step4<false>, grid4, dim3(R1_THREADS), sm4, cs, a);
+                    } else
                     if (n_seqs >= 2 && n_seqs != 3 && !inter_env) {  // pairs of rows: two MFMA columns per block (3 rows: one chain per row is faster)
                         const int P = (n_seqs + 1) / 2;
                         const size_t sm2 = std::max((size_t)r2_smem_bytes(nks_max), (size_t)AT_SMEM_FLOATS * sizeof(float));

@@ -139,9 +139,10 @@ class LLMEngine:
     def decode_kernel_desc(self, n_seqs):
         """What one decode step launches (for bench.py's roofline record)."""
         L24 = self.dims.layers
-        if n_seqs <= 16 and self.lib.cv2_llm_one_launch_step(self.handle) and not self.chain_broken:
+        if n_seqs <= 24 and self.lib.cv2_llm_one_launch_step(self.handle) and not self.chain_broken:
             rows = ('' if n_seqs == 1 else f'; {n_seqs} rows = {n_seqs} interleaved chains sharing every weight tile through one L2' if n_seqs == 3 else
-                    f'; {n_seqs} rows = {(n_seqs + 1) // 2} interleaved chains of row PAIRS (k_step2: two MFMA columns per block)')
+                    f'; {n_seqs} rows = {(n_seqs + 1) // 2} interleaved chains of row PAIRS (k_step2: two MFMA columns per block)' if n_seqs <= 8 else
+                    f'; {n_seqs} rows = {(n_seqs + 3) // 4} interleaved chains of FOUR rows (k_step4: four MFMA columns per block)')
             return (f'LLM decode step = ONE launch k_step ({L24} x {{Q, attention, O, gate/up, down}} roles + head as blocks of one grid, granule '
                     f'hand-offs{rows}) + k_sample, {n_seqs} row(s)')
         if n_seqs <= 16:

@@ -195,10 +195,11 @@ def test_hand_off_timeout_commits_nothing_and_the_steps_are_repeated_on_the_laun
     assert eng.generate([req], force_len=20)[0] == want          # stays on the launches, still correct
 
 
-@pytest.mark.parametrize('n', [2, 3, 4, 7, 8, 11, 16])
+@pytest.mark.parametrize('n', [2, 3, 4, 7, 8, 9, 11, 16, 22])
 def test_one_launch_rows_equal_the_launches_and_the_oracle(small, n):
-    """Decode steps of 2 .. 16 rows as ONE launch (k_step2: the rows in pairs as two MFMA columns per block, an odd count leaves the
-    last pair half empty; 3 rows: k_step<true>, one chain of blocks per row) against the same steps on the launches (CV2_DECODE_SHARED)
+    """Decode steps of 2 .. 24 rows as ONE launch (up to 8 rows k_step2: the rows in pairs as two MFMA columns per block, an odd count
+    leaves the last pair half empty; 3 rows: k_step<true>, one chain of blocks per row; from 9 rows k_step4: four columns per block, the
+    last chain may hold 1 .. 3 rows) against the same steps on the launches (CV2_DECODE_SHARED)
     and the oracle: prompts of different lengths (every row has its own position, KV cache and attention-tile count), greedy and RAS.
     Per row every sum runs in the one-row kernel's order, so the two forms agree id for id."""
     from cv2amd.llm import MODE_RAS

@@ -31,10 +31,10 @@ def timed(fn):
 
 
 print(f'decode step against the number of live rows, P = {P} prompt tokens + 50 text tokens, positions {P + 52 + 16} .. {P + 52 + 80} (us per step)')
-for n in (32, 28, 24, 20, 17, 16, 14, 12, 10, 8, 7, 6, 5, 4, 3, 2, 1):
+for n in (32, 28, 24, 22, 20, 18, 17, 16, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1):
     slots = list(range(32 - n, 32))
     res = []
-    for shared in ((False, True) if n <= 16 else (False,)):         # <= 8 rows: the one-launch step (k_step2 pairs / k_step<true>), and the launches beside it
+    for shared in ((False, True) if n <= 24 else (False,)):         # <= 24 rows: the one-launch step (k_step2 pairs, k_step<true> at 3 rows, k_step4 from 9 rows), and the launches beside it
         reset(slots)
         res.append(timed(lambda k: eng.step_rows(slots, k, shared=shared)))
     print(f'rows {n:2d}: ' + (f'{res[0]:7.1f} (one launch)   {res[1]:7.1f} (launches)' if len(res) == 2 else f'{res[0]:7.1f} (launches)'), flush=True)
