@@ -134,18 +134,20 @@ __global__ __launch_bounds__(256) void k_pos_emb(uint16_t* out, int T, int rows_
     if (r < rows_pad) *reinterpret_cast<uint32_t*>(out + (size_t)r * 512 + 2 * i2) = pack_bf16x2(sv, cv);
 }
 
-// softmax over (ac[i][j] + bd[i][T-1-i+j]) / 8 with the chunk mask (attention.py:225-247 rel_shift, :297-330)
-struct RelSmArgs { const float* ac; const float* bd; uint16_t* probs; int T, Tp, P, chunk; };
+// softmax over (ac[i][j] + bd[i][T-1-ig+j]) / 8 with the chunk mask (attention.py:225-247 rel_shift, :297-330); the launch's query rows
+// i < n_new are positions ig = n0 + i of a sequence of T keys (n0 = 0, n_new = T: the whole sequence; cached streaming: the new rows)
+struct RelSmArgs { const float* ac; const float* bd; uint16_t* probs; int T, Mp, Tk, P, chunk, n0, n_new; };
 __global__ __launch_bounds__(256) void k_relsoftmax(RelSmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = reinterpret_cast<float*>(smem);
     __shared__ float red[8];
     const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
-    uint16_t* pr = a.probs + ((size_t)h * a.Tp + i) * a.Tp;
-    if (i >= a.T) { for (int j = tid; j < a.Tp; j += 256) pr[j] = 0; return; }
-    const int kmax = a.chunk > 0 ? min(a.T, (i / a.chunk + 1) * a.chunk) : a.T;
-    const float* acr = a.ac + ((size_t)h * a.Tp + i) * a.Tp;
-    const float* bdr = a.bd + ((size_t)h * a.Tp + i) * a.P + (a.T - 1 - i);
+    uint16_t* pr = a.probs + ((size_t)h * a.Mp + i) * a.Tk;
+    if (i >= a.n_new) { for (int j = tid; j < a.Tk; j += 256) pr[j] = 0; return; }
+    const int ig = a.n0 + i;
+    const int kmax = a.chunk > 0 ? min(a.T, (ig / a.chunk + 1) * a.chunk) : a.T;
+    const float* acr = a.ac + ((size_t)h * a.Mp + i) * a.Tk;
+    const float* bdr = a.bd + ((size_t)h * a.Mp + i) * a.P + (a.T - 1 - ig);
     float mx = -INFINITY;
     for (int j = tid; j < kmax; j += 256) { const float v = (acr[j] + bdr[j]) * 0.125f; sc[j] = v; mx = fmaxf(mx, v); }
     mx = wave_max(mx);
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void k_relsoftmax(RelSmArgs a) {
     if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
     __syncthreads();
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-    for (int j = tid; j < a.Tp; j += 256) pr[j] = j < kmax ? f2bf(sc[j] * inv) : (uint16_t)0;
+    for (int j = tid; j < a.Tk; j += 256) pr[j] = j < kmax ? f2bf(sc[j] * inv) : (uint16_t)0;
 }
 
 // F.normalize(embedding) -> Linear 192 -> 80 (flow.py:248-249), fp32; one block per utterance
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void k_euler_pack(PackArgs a) {
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(a.v + (size_t)(row + a.twin) * 80 + c);
                 x = x + a.dt * ((1.0f + a.cfg) * v0 - a.cfg * v1);
             }
-            const size_t mrow = a.mu_start ? (size_t)a.mu_start[s] + pt : (size_t)row;
+            const size_t mrow = a.mu_start ? (size_t)((long)a.mu_start[s] + pt) : (size_t)row;      // (mu_start may be negative: first mu row minus the cached frames)
             mu = *reinterpret_cast<const f32x4*>(a.mu + mrow * 80 + c);
             sp = *reinterpret_cast<const f32x4*>(a.spk + (size_t)s * 80 + c);
             if (pt < a.n_prompt[s]) cd = *reinterpret_cast<const f32x4*>(a.prompt[s] + (size_t)pt * 80 + c);
@@ -956,8 +958,73 @@ extern "C" int cv2_flow_estimator(cv2_flow* h, float* x, const float* mask, cons
     return 0;
 }
 
+// ------------------------------------------------------------------ streaming encoder cache (round 4)
+// With streaming masks the encoder is chunk-causal too (upsample_encoder.py:243-306: static chunks of 25 tokens / 50 frames, the
+// pre-lookahead conv reads 3 tokens ahead -- the call's look-ahead tokens --, every other convolution is causal), so the rows of
+// finished chunks never change.  Per stream, behind the estimator's part of the cache: for each of the 10 conformer layers the keys
+// K [cap][512] and values V^T [512][cap] of all positions so far (6 token-rate layers, cap = capT; 4 mel-rate layers, cap = capE),
+// and the last two input rows of the two causal convolutions (pre_lookahead conv2; the k = 5 conv behind the nearest-neighbour
+// upsampling, as the two token rows it repeats), double-buffered on the generation like the estimator's tails.
+#define ENC_LAYERS 10
+static long enc_capE(long frames) { return (frames + 127) / 128 * 128; }
+static long enc_capT(long frames) { return (frames / 2 + 127) / 128 * 128; }
+static size_t enc_layer_off(long frames, int l) {              // elements from the start of the encoder part
+    const size_t t = (size_t)enc_capT(frames) * 1024, e = (size_t)enc_capE(frames) * 1024;
+    return l < 6 ? l * t : 6 * t + (l - 6) * e;
+}
+static size_t enc_tail_off(long frames) { return enc_layer_off(frames, ENC_LAYERS); }
+static size_t enc_elems(long frames) { return enc_tail_off(frames) + (size_t)2 * 2 * 2 * 512; }      // + [gen][conv][2 rows][512]
+
+// this call's keys / values of one sequence -> its cache: K rows n0 .. n0 + n - 1, V^T columns likewise
+struct EncAppendArgs { const uint16_t* qkv; const uint16_t* vt; long vt_ld; int start, n, n0; uint16_t* K; uint16_t* VT; long cap; };
+__global__ __launch_bounds__(256) void k_enc_append(EncAppendArgs a) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.y == 0) {                                       // K: 64 x 16 B per row
+        if (idx >= (long)a.n * 64) return;
+        const long t = idx >> 6; const int c = (int)(idx & 63) * 8;
+        *reinterpret_cast<uint4*>(a.K + (a.n0 + t) * 512 + c) = *reinterpret_cast<const uint4*>(a.qkv + (a.start + t) * 1536 + 1024 + c);
+    } else {                                                     // V^T: one element per (feature, frame)
+        if (idx >= (long)a.n * 512) return;
+        const long c = idx / a.n, t = idx - c * a.n;
+        a.VT[c * a.cap + a.n0 + t] = a.vt[c * a.vt_ld + a.start + t];
+    }
+}
+// left context of a causal convolution: rows [start - nrep * 2, start) of `buf` <- the cached two rows (each repeated nrep times: the
+// upsampled signal repeats a token row twice), and this call's last two rows of `src` (bf16 `buf` itself, or the fp32 stage output) -> cache
+struct EncTailArgs { uint16_t* buf; const float* src_f32; const uint16_t* src_b16; long src_start; int start, n_src, n0, nrep; const uint16_t* rd; uint16_t* wr; };
+__global__ __launch_bounds__(256) void k_enc_tail(EncTailArgs a) {
+    for (int e = threadIdx.x; e < 2 * 512; e += 256) {
+        const int j = e >> 9, c = e & 511;
+        const uint16_t o = a.n0 > 0 ? a.rd[j * 512 + c] : (uint16_t)0;
+        for (int r = 0; r < a.nrep; r++) a.buf[(long)(a.start - 2 * a.nrep + j * a.nrep + r) * 512 + c] = o;
+        const int pos = a.n_src - 2 + j;                         // source row of the new tail (pos < 0: fewer than two new rows)
+        uint16_t v;
+        if (pos >= 0) v = a.src_f32 ? (uint16_t)(pack_bf16x2(a.src_f32[(a.src_start + pos) * 512 + c], 0.f) & 0xffffu) : a.src_b16[(a.src_start + pos) * 512 + c];     // (k_repeat2's conversion)
+        else v = pos == -1 && a.n0 > 0 ? a.rd[512 + c] : (uint16_t)0;
+        a.wr[j * 512 + c] = v;
+    }
+}
+struct EncCacheCopyArgs { const uint16_t* src; uint16_t* dst; long scap, dcap; int n; };
+__global__ __launch_bounds__(256) void k_enc_cache_copy(EncCacheCopyArgs a) {      // one layer: K rows [0, n), V^T columns [0, n)
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.y == 0) {
+        if (idx >= (long)a.n * 64) return;
+        *reinterpret_cast<uint4*>(a.dst + idx * 8) = *reinterpret_cast<const uint4*>(a.src + idx * 8);
+    } else {
+        if (idx >= (long)a.n * 512) return;
+        const long c = idx / a.n, t = idx - c * a.n;
+        a.dst[a.dcap * 512 + c * a.dcap + t] = a.src[a.scap * 512 + c * a.scap + t];
+    }
+}
+
 // ------------------------------------------------------------------ encoder
-struct EncCtx { cv2_flow* h; const Layout* L; int chunk; hipStream_t s; };
+struct EncInc {                                   // cached streaming: one entry per sequence of the call
+    std::vector<uint16_t*> base;                  // the encoder part of the sequence's cache
+    std::vector<long> frames;                     // its capacity in mel frames
+    std::vector<int> n0_tok;                      // tokens cached before this call
+    std::vector<int> gen;
+};
+struct EncCtx { cv2_flow* h; const Layout* L; int chunk; hipStream_t s; const EncInc* inc = nullptr; int layer = 0; int rate = 1; };
 
 static int enc_gemm(EncCtx& c, GemmArgs a, int cfg) {
     a.seq = c.L->tab(); a.mask = 1;
@@ -980,7 +1047,51 @@ static int conformer_layer(EncCtx& c, const cv2_conformer& cl) {
         if (enc_gemm(c, a, 0)) return -1;
     }
     int pos_T = -1;
-    for (int q = 0; q < c.L->S; q++) {
+    for (int q = 0; c.inc && q < c.L->S; q++) {
+        // cached streaming: the rows of the call are positions n0 .. T - 1 of the sequence; their keys / values join the cache and the
+        // attention runs over all of it (same products, same softmax row, same chunk mask as the whole-prefix form)
+        const int nn = c.L->len[q], r0 = c.L->start[q], Mp = pad_rows(nn);
+        const int n0 = c.inc->n0_tok[q] * c.rate, T = n0 + nn, Tk = (T + 127) / 128 * 128, P = (2 * T - 1 + 127) / 128 * 128;
+        const long fr = c.inc->frames[q], cap = c.rate == 2 ? enc_capE(fr) : enc_capT(fr);
+        uint16_t* Kc = c.inc->base[q] + enc_layer_off(fr, c.layer);
+        uint16_t* VTc = Kc + (size_t)cap * 512;
+        CV2_CHECK(Tk <= cap && (size_t)Mp * Tk <= (size_t)h->TPmax * h->TPmax && P <= h->Pmax, "flow: encoder cache capacity (T %d, cap %ld)", T, cap);
+        {
+            EncAppendArgs a{GB(h->e_qkv, 1536), h->e_vt + GUARD, RG, r0, nn, n0, Kc, VTc, cap};
+            hipLaunchKernelGGL(k_enc_append, dim3(((long)nn * 512 + 255) / 256, 2), dim3(256), 0, c.s, a);
+        }
+        if (T != pos_T) {
+            hipLaunchKernelGGL(k_pos_emb, dim3(P), dim3(256), 0, c.s, h->pos, T, P);
+            GemmArgs a = gemm_args(h->pos, 512, 0, cl.pos.w, P, 512, 512);
+            a.out_bf16 = h->posp; a.ldo16 = 512;
+            if (gemm_launch_cfg(a, 0, 1, true, c.s)) return -1;
+            pos_T = T;
+        }
+        const uint16_t* qkv = GB(h->e_qkv, 1536) + (size_t)r0 * 1536;
+        {   // ac[h] = (q + u) K^T over the cache
+            GemmArgs a = gemm_args(qkv, 1536, 0, Kc, Mp, Tk, 64);
+            a.a_bstride = 64; a.ldw = 512; a.w_bstride = 64;
+            a.out_f32 = h->ac; a.ldo = Tk; a.o_bstride = (long)Mp * Tk;
+            if (gemm_launch_cfg(a, 0, 8, false, c.s)) return -1;
+        }
+        {   // bd[h] = (q + v) p^T
+            GemmArgs a = gemm_args(qkv + 512, 1536, 0, h->posp, Mp, P, 64);
+            a.a_bstride = 64; a.ldw = 512; a.w_bstride = 64;
+            a.out_f32 = h->bd; a.ldo = P; a.o_bstride = (long)Mp * P;
+            if (gemm_launch_cfg(a, 0, 8, false, c.s)) return -1;
+        }
+        {
+            RelSmArgs a{h->ac, h->bd, h->probs, T, Mp, Tk, P, c.chunk, n0, nn};
+            hipLaunchKernelGGL(k_relsoftmax, dim3(Mp, 8), dim3(256), (size_t)Tk * 4, c.s, a);
+        }
+        {   // att[:, h*64:(h+1)*64] = probs[h] V[h] from the cache
+            GemmArgs a = gemm_args(h->probs, Tk, 0, VTc, Mp, 64, Tk);
+            a.a_bstride = (long)Mp * Tk; a.ldw = cap; a.w_bstride = 64 * cap;
+            a.out_bf16 = GB(h->e_att, 512) + (size_t)r0 * 512; a.ldo16 = 512; a.o16_bstride = 64;
+            if (gemm_launch_cfg(a, 2, 8, false, c.s)) return -1;
+        }
+    }
+    for (int q = 0; !c.inc && q < c.L->S; q++) {
         const int T = c.L->len[q], r0 = c.L->start[q], Tp = pad_rows(T), P = (2 * T - 1 + 127) / 128 * 128;
         if (T != pos_T) {       // linear_pos(pos_emb(T)) for this layer
             hipLaunchKernelGGL(k_pos_emb, dim3(P), dim3(256), 0, c.s, h->pos, T, P);
@@ -1003,7 +1114,7 @@ static int conformer_layer(EncCtx& c, const cv2_conformer& cl) {
             if (gemm_launch_cfg(a, 0, 8, false, c.s)) return -1;
         }
         {
-            RelSmArgs a{h->ac, h->bd, h->probs, T, Tp, P, c.chunk};
+            RelSmArgs a{h->ac, h->bd, h->probs, T, Tp, Tp, P, c.chunk, 0, T};
             hipLaunchKernelGGL(k_relsoftmax, dim3(Tp, 8), dim3(256), (size_t)Tp * 4, c.s, a);
         }
         {   // att[:, h*64:(h+1)*64] = probs[h] V[h]
@@ -1036,11 +1147,17 @@ static int conformer_layer(EncCtx& c, const cv2_conformer& cl) {
 // Token-rate bf16 input rows (e_a; with look-ahead context rows when LA.len = T + 3) -> mel-rate rows:
 //   final fp32 [rows2][512] after after_norm (out_f32, may be null) and/or bf16 (e_ln) for encoder_proj.
 // LA = layout with the embed-stage lengths, LT = token-rate layout (T), L2 = mel-rate layout (2T); same starts for LA/LT.
-static int encoder_core(cv2_flow* h, Layout& LA, Layout& LT, Layout& L2, int streaming, float* out_f32, hipStream_t s) {
+// inc != null (cached streaming): the layouts hold only the NEW tokens / frames of every sequence (after INC_LEAD lead rows), the rest
+// comes from the sequences' encoder caches.
+static int encoder_core(cv2_flow* h, Layout& LA, Layout& LT, Layout& L2, int streaming, float* out_f32, hipStream_t s, const EncInc* inc = nullptr) {
     const cv2_flow_weights& w = h->w;
     const float SQ = sqrtf(512.f);
-    EncCtx ca{h, &LA, streaming ? 25 : 0, s}, ct{h, &LT, streaming ? 25 : 0, s}, c2{h, &L2, streaming ? 50 : 0, s};
+    EncCtx ca{h, &LA, streaming ? 25 : 0, s}, ct{h, &LT, streaming ? 25 : 0, s, inc, 0, 1}, c2{h, &L2, streaming ? 50 : 0, s, inc, 6, 2};
     const int M = LT.rows;
+    auto tail = [&](int q, int kind, bool write) {      // the sequence's cached conv tail: [generation][conv][2 rows][512]
+        const int g = (inc->gen[q] + (write ? 1 : 0)) & 1;
+        return inc->base[q] + enc_tail_off(inc->frames[q]) + (size_t)((g * 2 + kind) * 2) * 512;
+    };
     {   // embed: Linear -> LayerNorm(1e-5) -> * sqrt(512)     subsampling.py:69-113, embedding.py:268
         GemmArgs a = gemm_args(GB(h->e_a, 512), 512, 0, w.embed.w, M, 512, 512);
         a.bias = w.embed.b; a.out_f32 = h->e_tmp; a.ldo = 512;
@@ -1051,14 +1168,22 @@ static int encoder_core(cv2_flow* h, Layout& LA, Layout& LT, Layout& L2, int str
         GemmArgs a = gemm_args(GB(h->e_b, 512), 512, 0, w.pre1.w, M, 512, 2048);
         a.bias = w.pre1.b; a.act = ACT_LRELU; a.act_slope = 0.01f; a.out_bf16 = GB(h->e_a, 512); a.ldo16 = 512;
         if (enc_gemm(ct, a, 0)) return -1;
+        for (int q = 0; inc && q < LT.S; q++) {      // conv2's left context: the previous call's last two conv1 outputs
+            EncTailArgs t{GB(h->e_a, 512), nullptr, GB(h->e_a, 512), LT.start[q], LT.start[q], LT.len[q], inc->n0_tok[q], 1, tail(q, 0, false), tail(q, 0, true)};
+            hipLaunchKernelGGL(k_enc_tail, dim3(1), dim3(256), 0, s, t);
+        }
         GemmArgs b = gemm_args(GB(h->e_a, 512), 512, -2, w.pre2.w, M, 512, 1536);
         b.bias = w.pre2.b; b.res = h->e_x; b.ldres = 512; b.out_f32 = h->e_x; b.ldo = 512;
         if (enc_gemm(ct, b, 0)) return -1;
     }
-    for (int i = 0; i < 6; i++) if (conformer_layer(ct, w.enc[i])) return -1;
+    for (int i = 0; i < 6; i++) { ct.layer = i; if (conformer_layer(ct, w.enc[i])) return -1; }
     {   // Upsample1D: nearest x2, left pad 4, conv k5   upsample_encoder.py:37-63 ; then up_embed
         RepeatArgs r{h->e_x, LT.tab(), L2.tab(), L2.rows, GB(h->e_a, 512)};
         hipLaunchKernelGGL(k_repeat2, dim3((L2.rows + 1) / 2), dim3(256), 0, s, r);
+        for (int q = 0; inc && q < LT.S; q++) {      // the k = 5 conv's left context: the previous call's last two token rows, each repeated twice
+            EncTailArgs t{GB(h->e_a, 512), h->e_x, nullptr, LT.start[q], L2.start[q], LT.len[q], inc->n0_tok[q], 2, tail(q, 1, false), tail(q, 1, true)};
+            hipLaunchKernelGGL(k_enc_tail, dim3(1), dim3(256), 0, s, t);
+        }
         GemmArgs a = gemm_args(GB(h->e_a, 512), 512, -4, w.up_conv.w, L2.rows, 512, 2560);
         a.bias = w.up_conv.b; a.out_bf16 = GB(h->e_b, 512); a.ldo16 = 512;
         if (enc_gemm(c2, a, 0)) return -1;
@@ -1067,7 +1192,7 @@ static int encoder_core(cv2_flow* h, Layout& LA, Layout& LT, Layout& L2, int str
         if (enc_gemm(c2, b, 0)) return -1;
         enc_ln(c2, h->e_tmp, w.up_embed_ln, 1e-5f, SQ, h->e_x, nullptr);
     }
-    for (int i = 0; i < 4; i++) if (conformer_layer(c2, w.up[i])) return -1;
+    for (int i = 0; i < 4; i++) { c2.layer = 6 + i; if (conformer_layer(c2, w.up[i])) return -1; }
     enc_ln(c2, h->e_x, w.after_norm, 1e-5f, 1.f, out_f32, GB(h->e_ln, 512));
     CV2_LAUNCH_CHECK();
     return 0;
@@ -1175,9 +1300,10 @@ extern "C" int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t
 static size_t inc_kv_elems(const cv2_flow* h, long frames) { return (size_t)2 * h->d.n_timesteps * INC_TBLOCKS * frames * 1024; }
 static size_t inc_tail_elems(const cv2_flow* h) { return (size_t)2 * 2 * h->d.n_timesteps * INC_CONVS * 1024; }
 
+static size_t enc_part_off(const cv2_flow* h, long frames) { return inc_kv_elems(h, frames) + inc_tail_elems(h); }     // elements in front of the encoder part
 extern "C" size_t cv2_flow_cache_bytes(const cv2_flow* h, int32_t frames) {
     if (!h || frames < 64 || frames % 64) return 0;
-    return (inc_kv_elems(h, frames) + inc_tail_elems(h)) * sizeof(uint16_t);
+    return (enc_part_off(h, frames) + enc_elems(frames)) * sizeof(uint16_t);
 }
 
 // first n frames of every slot (and the convolution tails) of one cache -> another cache of a different capacity: a stream that
@@ -1214,6 +1340,17 @@ extern "C" int cv2_flow_cache_copy(const cv2_flow* h, const void* src, int32_t s
     }
     CV2_HIP(hipMemcpyAsync((uint16_t*)dst + inc_kv_elems(h, dst_frames), (const uint16_t*)src + inc_kv_elems(h, src_frames),
                            inc_tail_elems(h) * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+    {   // the encoder part: keys / values of the first n_frames / 2 tokens (layers 0-5) and n_frames frames (layers 6-9), the conv tails
+        const uint16_t* se = (const uint16_t*)src + enc_part_off(h, src_frames);
+        uint16_t* de = (uint16_t*)dst + enc_part_off(h, dst_frames);
+        for (int l = 0; l < ENC_LAYERS && n_frames > 0; l++) {
+            const int n = l < 6 ? n_frames / 2 : n_frames;
+            EncCacheCopyArgs a{se + enc_layer_off(src_frames, l), de + enc_layer_off(dst_frames, l), l < 6 ? enc_capT(src_frames) : enc_capE(src_frames),
+                               l < 6 ? enc_capT(dst_frames) : enc_capE(dst_frames), n};
+            hipLaunchKernelGGL(k_enc_cache_copy, dim3(((long)n * 512 + 255) / 256, 2), dim3(256), 0, s, a);
+        }
+        CV2_HIP(hipMemcpyAsync(de + enc_tail_off(dst_frames), se + enc_tail_off(src_frames), (size_t)2 * 2 * 2 * 512 * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+    }
     CV2_LAUNCH_CHECK();
     return 0;
 }
@@ -1235,7 +1372,12 @@ extern "C" int cv2_flow_inference_chunk(cv2_flow* h, const cv2_flow_utt* utts, c
         CV2_CHECK(finalize || (2 * T) % 50 == 0, "cv2_flow_inference_chunk: utterance %d: a non-final call must end on a chunk boundary (%d frames)", u, 2 * T);
         lensT.push_back(T); lens2.push_back(2 * T); lensN.push_back(2 * T - nc);
     }
-    Layout LT = make_layout(lensT), L2 = make_layout(lens2);
+    // the encoder too runs over the new tokens only (its keys / values and conv tails of the prefix are in the cache) unless CV2_ENC_CACHE=0
+    static const bool enc_cache = !(getenv("CV2_ENC_CACHE") && getenv("CV2_ENC_CACHE")[0] == '0');
+    std::vector<int> lensTn;
+    for (int u = 0; u < U; u++) lensTn.push_back(lensT[u] - refs[u].n_cached / 2);
+    Layout LT = enc_cache ? make_layout(lensTn, INC_LEAD) : make_layout(lensT);
+    Layout L2 = enc_cache ? make_layout(lensN, INC_LEAD) : make_layout(lens2);
     Layout LA = LT;
     for (int u = 0; u < U; u++) LA.len[u] += la;
     Layout LI = make_layout(lensN, INC_LEAD);
@@ -1252,14 +1394,15 @@ extern "C" int cv2_flow_inference_chunk(cv2_flow* h, const cv2_flow_utt* utts, c
     std::vector<int> ints(9 * U);
     int maxn2 = 1;
     for (int u = 0; u < U; u++) {
-        ptrs[u] = utts[u].embedding; ptrs[U + u] = utts[u].prompt_feat; ptrs[2 * U + u] = utts[u].mel_out; ptrs[3 * U + u] = utts[u].tokens;
+        ptrs[u] = utts[u].embedding; ptrs[U + u] = utts[u].prompt_feat; ptrs[2 * U + u] = utts[u].mel_out;
+        ptrs[3 * U + u] = utts[u].tokens + (enc_cache ? refs[u].n_cached / 2 : 0);       // (the embedding kernel starts at the first new token)
         const long fr = refs[u].cache_frames;
         uint16_t* base = (uint16_t*)refs[u].cache;
         uint16_t* tails = base + inc_kv_elems(h, fr);
         ptrs[4 * U + u] = base; ptrs[5 * U + u] = base + inc_kv_elems(h, fr) / 2;
         ptrs[6 * U + u] = tails; ptrs[7 * U + u] = tails + inc_tail_elems(h) / 2;
         const int nc = refs[u].n_cached, skip = std::max(utts[u].n_prompt_feat - nc, 0);
-        ints[u] = utts[u].n_prompt_feat; ints[U + u] = skip; ints[2 * U + u] = L2.start[u];
+        ints[u] = utts[u].n_prompt_feat; ints[U + u] = skip; ints[2 * U + u] = enc_cache ? L2.start[u] - nc : L2.start[u];      // mu row of frame pt: this + pt
         ints[3 * U + u] = ints[4 * U + u] = nc;
         ints[5 * U + u] = ints[6 * U + u] = (int)fr;
         ints[7 * U + u] = ints[8 * U + u] = refs[u].gen;
@@ -1271,12 +1414,18 @@ extern "C" int cv2_flow_inference_chunk(cv2_flow* h, const cv2_flow_utt* utts, c
     CV2_HIP(hipStreamSynchronize(s));
     const void* const* dp = (const void* const*)h->ptab;
     IncTabs tabs{(uint16_t* const*)(dp + 4 * U), ibase + 5 * U, ibase + 3 * U, (uint16_t* const*)(dp + 6 * U), ibase + 7 * U};
-    // encoder over the whole prefix (2 % of the flow's work; its chunk masks make the rows of finished chunks reproduce exactly)
+    // encoder: over the new tokens with the per-stream cache (round 4), or over the whole prefix (its chunk masks make the rows of
+    // finished chunks reproduce exactly)
     SpkArgs sp{(const float* const*)dp, h->w.spk_w, h->w.spk_b, h->spk};
     hipLaunchKernelGGL(k_spk, dim3(U), dim3(128), 0, s, sp);
     EmbedPtrArgs ea{(const int* const*)(dp + 3 * U), h->w.input_embedding, LA.tab(), LA.rows, GB(h->e_a, 512)};
     hipLaunchKernelGGL(k_embed_tokens_ptr, dim3((LA.rows + 1) / 2), dim3(256), 0, s, ea);
-    if (encoder_core(h, LA, LT, L2, 1, nullptr, s)) return -1;
+    EncInc einc;
+    for (int u = 0; enc_cache && u < U; u++) {
+        einc.base.push_back((uint16_t*)refs[u].cache + enc_part_off(h, refs[u].cache_frames));
+        einc.frames.push_back(refs[u].cache_frames); einc.n0_tok.push_back(refs[u].n_cached / 2); einc.gen.push_back(refs[u].gen);
+    }
+    if (encoder_core(h, LA, LT, L2, 1, nullptr, s, enc_cache ? &einc : nullptr)) return -1;
     {
         GemmArgs a = gemm_args(GB(h->e_ln, 512), 512, 0, h->w.enc_proj.w, L2.rows, 128, 512);
         a.bias = h->w.enc_proj.b; a.out_f32 = h->mu; a.ldo = 80; a.n_store = 80; a.seq = L2.tab(); a.mask = 1;
