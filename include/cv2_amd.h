@@ -261,7 +261,9 @@ int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t n_utts, in
 /* Streaming calls with a per-stream cache.  The reference's token2wav re-runs flow.inference over the WHOLE prefix for every chunk
  * (cli/model.py:351-381, 300-311) and keeps mel[token_offset * 2:].  With streaming masks the estimator is chunk-causal (flow/decoder.py:
  * 439-441: static chunk of 50 frames; every convolution is causal), so the frames of finished chunks never change: this entry point
- * computes only the frames the cache does not hold yet and returns exactly those the recompute would have produced for them.
+ * computes only the frames the cache does not hold yet and returns exactly those the recompute would have produced for them.  The encoder
+ * (transformer/upsample_encoder.py:243-306) is chunk-causal in the same way; its per-layer keys / values and convolution tails live in the same
+ * cache, so a call's encoder pass covers the new tokens only (CV2_ENC_CACHE=0: recompute the prefix, diagnostics).
  *   cache         device memory of cv2_flow_cache_bytes(h, cache_frames) bytes, ZERO-initialised by the caller before the first call of a
  *                 stream, owned by the caller (one per stream); cache_frames = a multiple of 64 >= the longest prefix in frames
  *   n_cached      frames the cache holds = 2 * (n_tok - 3) of the stream's previous (non-final) call, 0 on the first call; a multiple of 50
