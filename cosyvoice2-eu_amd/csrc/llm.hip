@@ -930,6 +930,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
         float v = row2_core<2, 4, 7, true, true, NT>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin0, xin1, L.ln1, a.eps, smem, hook) + bias;
         const float vp = __shfl(v, (tid & 63) ^ 16);
         if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);
+        if (*a.dbg_skip == layer * a.per + r + 1) return;      // (test hook, as in k_step: Q block r of this layer keeps its results to itself)
         if (tid < 64 && (c32 == 0 || two)) {
             const unsigned o = (c32 ? go1 : go0) + gl;
             if (head < a.n_q) G.store(o + a.off_qg + head * 64 + f, v);

@@ -195,6 +195,30 @@ def test_hand_off_timeout_commits_nothing_and_the_steps_are_repeated_on_the_laun
     assert eng.generate([req], force_len=20)[0] == want          # stays on the launches, still correct
 
 
+def test_hand_off_timeout_in_a_two_row_step_fails_no_request(dev, small):
+    """The same broken hand-off inside k_step2 (two requests = one pair of rows per block): the waits behind it time out, BOTH rows'
+    slots report CV2_ST_ERR = 3 and commit nothing; generate() clears the flags, repeats the steps on the launches and both requests
+    finish with the ids of an undisturbed run."""
+    from cv2amd import lib as L
+    from cv2amd.llm import LLMEngine
+    sd, sdr, _ = small
+    eng = LLMEngine(sd, dev, max_seqs=2, max_pos=512, max_out=64)
+    reqs = _requests(2, seed=21)
+    want = eng.generate(reqs, force_len=18)
+    assert eng.handoff_recoveries == 0
+    L.check(eng.lib.cv2_llm_debug_skip_publish(eng.handle, 1, 2))
+    try:
+        eng.add_requests([0, 1], [eng.build_lm_input(*r) for r in reqs], [(18, 18)] * 2, 0, 0, True)
+        eng.step(2, 2)
+        torch.cuda.synchronize()
+        st = eng.state[:2].cpu()
+        assert st[:, L.ST_ERR].tolist() == [3, 3] and st[:, L.ST_STEP].tolist() == [1, 1] and st[:, L.ST_NOUT].tolist() == [1, 1]
+        got = eng.generate(reqs, force_len=18)
+    finally:
+        L.check(eng.lib.cv2_llm_debug_skip_publish(eng.handle, -1, 0))
+    assert got == want and eng.chain_broken and eng.handoff_recoveries >= 1
+
+
 @pytest.mark.parametrize('n', [2, 3, 4, 7, 8, 9, 11, 16, 22])
 def test_one_launch_rows_equal_the_launches_and_the_oracle(small, n):
     """Decode steps of 2 .. 24 rows as ONE launch (up to 8 rows k_step2: the rows in pairs as two MFMA columns per block, an odd count
