@@ -3,4 +3,4 @@
 set -e
 cd "$(dirname "$0")"
 SRC=cosyvoice2-eu_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $SRC/*.hip -o cosyvoice2-eu_amd/cv2amd/libcv2amd.so "$@"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form=1 $SRC/*.hip -o cosyvoice2-eu_amd/cv2amd/libcv2amd.so "$@"
