@@ -433,7 +433,7 @@ static void launch_attn(const AttnArgs& a, int rows, hipStream_t s) {
         else hipLaunchKernelGGL(k_attn<1>, grid, dim3(256), 0, s, a);
         return;
     }
-    if (nsub >= 4) hipLaunchKernelGGL(k_attn_m<4>, grid, dim3(1024), 0, s, a);
+    if (nsub >= 4) hipLaunchKernelGGL(k_attn<4>, grid, dim3(1024), 0, s, a);         // (256-key splits: the matrix-core form at 1024 threads spilled 10 VGPRs -- the scalar kernel serves them)
     else if (nsub == 2) hipLaunchKernelGGL(k_attn_m<2>, grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL(k_attn_m<1>, grid, dim3(256), 0, s, a);
 }
