@@ -127,11 +127,13 @@ int cv2_llm_extend(cv2_llm* h, int32_t seq, const float* embeds, int32_t len, in
 int cv2_llm_extend_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int32_t* lens, const int32_t* pos0, const float* embeds, void* stream);
 /* n_steps iterations of the decode loop for slots 0..n_seqs-1 in lock step (one hipGraph replay per step);
  * finished slots idle.  No host synchronisation inside.
- * n_seqs == 1: a step is ONE launch (k_step, csrc/chain.h: every layer's Q / attention / O / gate-up / down roles and the head
- * as blocks of one grid in dependency order, activations handed over as epoch-tagged granules) followed by the sampler; the
- * environment variable CV2_LLM_CHAIN=0 (read at create) selects the five launches per layer used for 2..16 rows instead.
- * CV2_ST_ERR = 3 reports a hand-off that timed out: that step (and every later step of the call) commits nothing -- state, tokens and the
- * KV positions are the ones before it -- so the caller clears the flag and repeats the steps with CV2_DECODE_SHARED (the launches). */
+ * Up to 24 sequences: a step is ONE launch followed by the sampler -- k_step (csrc/chain.h: every layer's Q / attention / O / gate-up /
+ * down roles and the head as blocks of one grid in dependency order, activations handed over as epoch-tagged granules) at one row;
+ * k_step2 / k_step4 at 2 .. 8 / 9 .. 24 rows (the rows in pairs / fours as columns of the blocks' MFMA operands, one chain of blocks per
+ * group; 3 rows: one chain per row).  From 25 rows on, and whenever the environment variable CV2_LLM_CHAIN=0 is set at create, a step is
+ * five to seven launches per layer.  CV2_ST_ERR = 3 reports a hand-off that timed out: that step (and every later step of the call)
+ * commits nothing -- state, tokens and the KV positions are the ones before it -- so the caller clears the flag and repeats the steps
+ * with CV2_DECODE_SHARED (the launches). */
 int cv2_llm_decode(cv2_llm* h, int32_t n_seqs, int32_t n_steps, void* stream);
 /* The same with flags.  CV2_DECODE_SHARED: other streams' kernels run beside these steps (the streaming scheduler overlaps a decode
  * burst with the previous chunk's flow + HiFT): use the launches even at one row -- k_step's resident polling waves cost the
@@ -143,8 +145,8 @@ int cv2_llm_decode_ex(cv2_llm* h, int32_t n_seqs, int32_t n_steps, int32_t flags
  * finished slots from the list at every poll, so a step costs what its live rows cost (the slots' state, caches and results are
  * the ones cv2_llm_decode uses: the two calls may alternate on the same slots). */
 int cv2_llm_decode_rows(cv2_llm* h, const int32_t* slots, int32_t n_rows, int32_t n_steps, int32_t flags, void* stream);
-/* 1 when one-row decode steps of this engine run as one launch (k_step), 0 when they run as launches (dims outside k_step's
- * limits, or CV2_LLM_CHAIN=0). */
+/* 1 when decode steps of up to 24 rows of this engine run as one launch (k_step / k_step2 / k_step4), 0 when they run as launches (dims
+ * outside k_step's limits, or CV2_LLM_CHAIN=0). */
 int cv2_llm_one_launch_step(const cv2_llm* h);
 /* test hook: from now on Q-role block `q_block` of layer `layer` of every one-launch step does not publish its results (layer < 0: off),
  * so the blocks behind it end in their bounded waits and the step reports CV2_ST_ERR = 3 without committing anything. */
