@@ -285,6 +285,9 @@ def test_bench_gpus2_spawns_ranks_and_gathers(tmp_path):
     # what a driver run needs to judge the line: the world the process group saw, its backend, every rank's own time and share
     assert out['ranks_seen'] == 2 and out['backend'] == 'gloo' and [r['rank'] for r in out['per_rank']] == [0, 1]
     assert all(r['utts_per_step'] == 5 and r['work_s'] >= 0 and r['wall_s'] > 0 for r in out['per_rank']) and out['imbalance'] >= 1.0
+    # the N > 1 line carries its own one-GPU reference: what every rank's shard ran at, and the committed N = 1 measurement of the same workload
+    ref = out['n1_reference']
+    assert ref['per_rank_shard_rate_median'] > 0 and ref['per_rank_shard_rate_min'] > 0 and ref['committed_n1_batch32']['value'] > 0
     # a launcher / flag mismatch fails loudly instead of reporting a 1-GPU number as N = 2's line
     env2 = dict(env, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env2, capture_output=True, text=True, timeout=120)
