@@ -87,8 +87,9 @@ class LLMEngine:
                                         nbytes, C.byref(h)))
         self.handle = h
         # a one-launch step whose in-launch hand-off timed out (CV2_ST_ERR = 3) commits nothing; the host clears the flag, repeats the
-        # steps and keeps this engine on the launches from then on (_recover_handoff)
-        self.chain_broken, self.handoff_recoveries = False, 0
+        # steps and keeps this engine on the launches for a while (_recover_handoff): 30 s after the first time-out, twice as long after
+        # every further one (up to an hour) -- contention that broke the step's forward progress once is given time to go away
+        self._chain_off_until, self._chain_backoff, self.handoff_recoveries = 0.0, 30.0, 0
         self.weight_bytes = sum(t.numel() * t.element_size() for t in keep if t.dtype == torch.int16)
 
     def __del__(self):
@@ -150,6 +151,12 @@ class LLMEngine:
         return (f'LLM decode step = one hipGraph replay ({L24} x {{k_prep, k_qkv, k_attn, k_prep, k_store(o)+norm2, k_gateup, k_store(down)}} + head + '
                 f'k_sample), {n_seqs} rows')
 
+    @property
+    def chain_broken(self):
+        """True while the engine keeps off the one-launch step after a hand-off time-out"""
+        import time
+        return time.monotonic() < self._chain_off_until
+
     def step(self, n_seqs, n_steps=1, shared=False):
         """shared: kernels of other streams run beside these steps (CV2_DECODE_SHARED: the launches instead of the one-launch step)."""
         L.check(self.lib.cv2_llm_decode_ex(self.handle, n_seqs, n_steps, 1 if (shared or self.chain_broken) else 0, L.stream_ptr()))
@@ -163,15 +170,17 @@ class LLMEngine:
         """CV2_ST_ERR = 3: a hand-off inside the one-launch step (k_step, csrc/chain.h) did not arrive within its bound -- the device
         was contended in a way that broke the step's forward progress.  k_sample commits nothing for such a step (nor for the steps
         enqueued behind it): tokens, positions and the pending input are those before it and the KV rows it wrote are rewritten by the
-        repeat.  The flag is cleared, the caller's loop issues the missing steps again, and from here on this engine runs every step
-        on the launches (the structure that needs no co-residency)."""
+        repeat.  The flag is cleared, the caller's loop issues the missing steps again, and for the next 30 s (doubling with every
+        further time-out, up to an hour) this engine runs every step on the launches (the structure that needs no co-residency)."""
         import logging
+        import time
         for s in slots:
             self.state[s, L.ST_ERR] = 0
-        self.chain_broken = True
+        self._chain_off_until = time.monotonic() + self._chain_backoff
         self.handoff_recoveries += 1
         logging.warning('LLM decode: an in-launch hand-off of the one-launch step timed out (slot %s); the step is repeated on the launches and '
-                        'this engine stays on them', list(slots))
+                        'this engine stays on them for %.0f s', list(slots), self._chain_backoff)
+        self._chain_backoff = min(2 * self._chain_backoff, 3600.0)
 
     ERR_MSG = 'sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!'      # llm.py:249
     ERR_HANDOFF = 'LLM decode: an in-launch hand-off (k_step) timed out; the device was too contended for the step to finish'

@@ -167,7 +167,7 @@ def test_one_launch_step_with_more_head_blocks_than_layer_blocks(dev, monkeypatc
 def test_hand_off_timeout_commits_nothing_and_the_steps_are_repeated_on_the_launches(dev, small, caplog):
     """A hand-off inside the one-launch step that never arrives (test hook: one Q-role block of layer 1 keeps its q values to itself):
     every wait behind it is bounded (0.2 s, csrc/chain.h), the step reports CV2_ST_ERR = 3 and k_sample commits NOTHING for it or for
-    the steps enqueued behind it.  The host clears the flag, repeats the steps on the launches (the engine stays on them) and the
+    the steps enqueued behind it.  The host clears the flag, repeats the steps on the launches (the engine stays on them for a back-off period) and the
     request finishes with the ids of an undisturbed run; another engine in the process is not affected."""
     import logging
     from cv2amd import lib as L
@@ -192,7 +192,9 @@ def test_hand_off_timeout_commits_nothing_and_the_steps_are_repeated_on_the_laun
         L.check(eng.lib.cv2_llm_debug_skip_publish(eng.handle, -1, 0))
     assert got == want
     assert eng.handoff_recoveries == 1 and eng.chain_broken and any('hand-off' in r.message for r in caplog.records)
-    assert eng.generate([req], force_len=20)[0] == want          # stays on the launches, still correct
+    assert eng.generate([req], force_len=20)[0] == want          # stays on the launches for now, still correct
+    eng._chain_off_until = 0.0                                   # ... and returns to the one-launch step once the back-off period (30 s, doubling) is over
+    assert not eng.chain_broken and eng.generate([req], force_len=20)[0] == want and eng.handoff_recoveries == 1
 
 
 def test_hand_off_timeout_in_a_two_row_step_fails_no_request(dev, small):
