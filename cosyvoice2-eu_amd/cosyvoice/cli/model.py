@@ -89,6 +89,9 @@ class CosyVoice2Model:
         self._bi_calls, self._bi_thread, self._bi_gen = [], None, 0
         self.bistream_coalesce_ms = 8.0        # calls that start together are fed together (one pass over the weights for all first feeds)
         self.bistream_burst = 16
+        # True: no decode burst beside a FIRST chunk's flow + HiFT round.  Measured with 8 generator-text calls: first chunk 139 instead of
+        # 142-148 ms, but 90.5 instead of 96-98 audio-s/s (the later chunks' tokens come 15-25 ms later): off by default
+        self.bistream_first_chunk_alone = os.environ.get('CV2_BI_FIRST_ALONE', '0') == '1'
         # chunks of one round: concurrent streams come back from a chunk round (or are woken by the hub's poll) a few hundred
         # microseconds apart (thread wake-ups under the GIL).  The first submitter waits until the queue has stopped growing for
         # `chunk_quiet_ms` (at most `chunk_wave_ms`, and never when it is the only stream) instead of running the flow for a batch
@@ -650,13 +653,14 @@ class CosyVoice2Model:
 
     # ---- llm_job's bistream branch (model.py:120-128) for ALL generator-text calls: one round loop -------------------------------
     class _BiCall:
-        __slots__ = ('bs', 'uuid', 'toks', 'want_total', 'closed', 'exc', 'ended')
+        __slots__ = ('bs', 'uuid', 'toks', 'want_total', 'closed', 'exc', 'ended', 'first_done')
 
     def _bi_register(self, bs, this_uuid, text):
         """A generator-text call joins the hub: its text generator is drained by a small pump thread (host only: the reference's
         llm_job thread iterates it the same way, model.py:118-128), the device side is driven by the hub thread for all calls."""
         c = self._BiCall()
         c.bs, c.uuid, c.toks, c.want_total, c.closed, c.exc, c.ended = bs, this_uuid, self.tts_speech_token_dict[this_uuid], 0, False, None, False
+        c.first_done = False                  # the call's first chunk has been delivered (until then its chunk round has the device to itself, see _bi_loop)
 
         def pump():
             try:
@@ -736,6 +740,7 @@ class CosyVoice2Model:
                 with self.llm_lock, torch.cuda.stream(self.llm_stream):
                     eng = self.llm
                     streams = [c.bs for c in calls if not c.closed]
+                    hold = False
                     t_r0 = time.perf_counter()
                     eng.bi_poll(streams)
                     t_r1 = time.perf_counter()
@@ -749,6 +754,11 @@ class CosyVoice2Model:
                     fed = eng.bi_feed(streams, prepared=True)
                     t_r2 = time.perf_counter()
                     n = eng.bi_burst_len(streams, self.bistream_burst)
+                    # a FIRST chunk is in its flow + HiFT round: no decode burst beside it (the latency that is felt; the bursts resume with
+                    # the round's end -- every later chunk's tokens are ready long before its round)
+                    if n and self.bistream_first_chunk_alone and self._chunks_active > 0 and any(
+                            not c.first_done and c.want_total and len(c.toks) >= c.want_total for c in calls):
+                        n, hold = 0, True
                     if n:                                                     # beside a chunk round: the launches; alone: the one-launch step
                         eng.bi_burst(streams, n, shared=bool(self._chunk_q) or self._chunks_active > 0)
                     if fed or n:
@@ -760,6 +770,8 @@ class CosyVoice2Model:
                                                                   feed_ms=round((t_r2 - t_r1) * 1e3, 2), burst_ms=round((time.perf_counter() - t_r2) * 1e3, 2))))
                 if ev is not None:
                     ev.synchronize()                                          # the round's device work, outside the lock
+                elif hold:
+                    time.sleep(0.001)
                 else:
                     with self._bi_cv:                                         # every slot waits for text (or has ended): sleep until something arrives
                         if all(not c.bs.running and (c.bs.finished or c.bs.next_feed() is None) for c in self._bi_calls):
@@ -825,6 +837,8 @@ class CosyVoice2Model:
                         break
                     this_tok = torch.tensor(toks[:token_offset + this_hop + la], dtype=torch.int32).unsqueeze(0)
                     speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, True, False)
+                    if call is not None:
+                        call.first_done = True
                     token_offset += this_hop
                     yield {'tts_speech': speech}
                 pull(1 << 30)
