@@ -63,6 +63,7 @@ struct QkvArgs {
     float* kc; float* vc;                       // this layer's cache: [max_seqs][n_kv][max_pos][64]
     int max_pos;
     RowMap rm;
+    const float* sq; int nsq; float eps;        // PRE operand left un-normalised by k_store<.., LAST>: rstd[r] = rsqrt(sum_b sq[r][b] / K + eps), as k_gateup
 };
 // block = (head, half): features {half*16 + i, half*16 + 32 + i : i < 16} so that the rotate-half partner is in-block
 template <int NB, bool PRE = false>
@@ -83,12 +84,27 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
     a.rm.get(min((int)threadIdx.x >> 5, a.rows - 1), seq0, pos0);
     pb0 = a.bias[head * 64 + f0];
     pb1 = a.bias[head * 64 + (f0 ^ 32)];
+    __shared__ float rs_s[SK_ROWS_CAP];
+    float sqt = 0.f;                                    // (PRE with sq) thread (row, i of 16): its stride of the row's shares, fixed order
     auto hook = [&]() {
         pc0 = a.cosT[pos0 * 32 + (f0 & 31)];
         ps0 = a.sinT[pos0 * 32 + (f0 & 31)];
+        if (PRE && a.sq) {
+            const int rr = min((int)threadIdx.x >> 4, a.rows - 1);
+            for (int b = threadIdx.x & 15; b < a.nsq; b += 16) sqt += a.sq[(size_t)rr * a.nsq + b];
+        }
     };
     float* res = skinny_core<NB, 2, 4, 8, false, PRE>(a.W, head * 4 + half + 2 * wr, a.KS, a.rows, a.K, a.X, smem, hook);
     const int ld = NB * 16 + 1;
+    const bool scaled = PRE && a.sq;
+    if (scaled) {
+        sqt += dpp_mov_f32<0xB1, 0xf>(0.f, sqt);
+        sqt += dpp_mov_f32<0x4E, 0xf>(0.f, sqt);
+        sqt += __shfl_xor(sqt, 4);
+        sqt += __shfl_xor(sqt, 8);
+        if ((threadIdx.x & 15) == 0 && (int)threadIdx.x < a.rows * 16) rs_s[threadIdx.x >> 4] = rsqrtf(sqt / (float)a.K + a.eps);
+        __syncthreads();
+    }
     for (int e = threadIdx.x; e < a.rows * 32; e += blockDim.x) {
         const int r = e >> 5, w = (e >> 4) & 1, i16 = e & 15;
         const int f = half * 16 + w * 32 + i16;           // feature within the head
@@ -99,9 +115,10 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
             b0 = a.bias[head * 64 + f];
             if (rot) { b1 = a.bias[head * 64 + (f ^ 32)]; c = a.cosT[pos * 32 + (f & 31)]; sn = a.sinT[pos * 32 + (f & 31)]; }
         }
-        float v = res[(w * 16 + i16) * ld + r] + b0;
+        const float rs = scaled ? rs_s[r] : 1.f;
+        float v = res[(w * 16 + i16) * ld + r] * rs + b0;
         if (rot) {                                         // rotate-half RoPE on q and k heads
-            const float vp = res[((1 - w) * 16 + i16) * ld + r] + b1;
+            const float vp = res[((1 - w) * 16 + i16) * ld + r] * rs + b1;
             v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);
         }
         if (head < a.n_q) a.q[(size_t)r * a.n_q * 64 + head * 64 + f] = v;
@@ -125,7 +142,38 @@ struct AttnArgs {
     int n_q, n_kv, max_pos, nsplit, keys_per_split;
     RowMap rm;
     int rep;                  // n_q / n_kv (<= 8), passed so that no block divides
+    // many-row launches (17..32 rows): the LAST split of a (row, kv head) to finish combines the splits and leaves the O projection's
+    // operand planes (what k_prep<true> did as a launch of its own).  arrive = [SK_ROWS_CAP][n_kv] counters, zero between launches
+    int* arrive; uint16_t* pre;
 };
+// Stores / loads that are coherent across the XCDs' L2s (sc1): what a last-arriving block reads of the other blocks' results
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// Block-uniform: has every one of the `n` blocks that share `cnt` (this one included) left its results?  The callers' result stores are
+// st_agent; they are complete (vmcnt) before the barrier, the counter is bumped after it.  The last block re-arms the counter.
+__device__ __forceinline__ bool last_arriver(int* cnt, int n) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == n - 1;
+        if (old == n - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+// element (row r, column c) of an operand in the layout the PRE kernels copy (skinny.h): [c / 32][r / 16][hi, lo][(c / 8) % 4][r % 16][c % 8]
+__device__ __forceinline__ void put_planes(uint16_t* pre, int r, int c, float v) {
+    uint16_t* d = pre + ((size_t)((c >> 5) * 2 + (r >> 4)) * 2) * 512 + (((c >> 3) & 3) * 16 + (r & 15)) * 8 + (c & 7);
+    const uint16_t hb = f2bf(v);
+    d[0] = hb;
+    d[512] = f2bf(v - bf2f(hb));
+}
 #define AT_KB 64
 // No LDS staging of K or V: thread (key, quarter) keeps its 16 dims of one key row in registers for the scores of all
 // heads of the group, thread (dim, head pair) keeps the V column of the tile in registers; one round of global loads.
@@ -278,7 +326,7 @@ __global__ __launch_bounds__(256 * NSUB) void k_attn(AttnArgs a) {
             const float* pp = &po_s[u][e];
             o += sc * (((pp[0] + pp[512]) + (pp[1024] + pp[1536])) + ((pp[2048] + pp[2560]) + (pp[3072] + pp[3584])));
         }
-        po[e] = o;
+        if (a.arrive) st_agent(&po[e], o); else po[e] = o;
     }
     if (tid < rep) {
         float M = run_m[0][tid], l = 0.f;
@@ -286,10 +334,41 @@ __global__ __launch_bounds__(256 * NSUB) void k_attn(AttnArgs a) {
         for (int u = 1; u < NSUB; u++) M = fmaxf(M, run_m[u][tid]);
 #pragma unroll
         for (int u = 0; u < NSUB; u++) l += (NSUB == 1 ? 1.f : __expf(run_m[u][tid] - M)) * run_l[u][tid];
-        ml[tid * 2] = M; ml[tid * 2 + 1] = l;
+        if (a.arrive) { st_agent(&ml[tid * 2], M); st_agent(&ml[tid * 2 + 1], l); }
+        else { ml[tid * 2] = M; ml[tid * 2 + 1] = l; }
     }
     SK_STAMP(6);
     SK_STAMP_FLUSH;
+    if (!a.arrive) return;
+    // the last split of this (row, kv head) to get here combines them (sk_finish_x's order: the same bits as k_prep<true>) and leaves
+    // the planes of the group's rep x 64 columns
+    const int ns = (L + a.keys_per_split - 1) / a.keys_per_split;
+    if (!last_arriver(a.arrive + r * a.n_kv + g, ns)) return;
+    for (int e = tid; e < rep * 64; e += 256 * NSUB) {
+        const int c = g * rep * 64 + e;
+        float mv[SK_MAXSPLIT], lv[SK_MAXSPLIT], ov[SK_MAXSPLIT];
+#pragma unroll
+        for (int s = 0; s < SK_MAXSPLIT; s++) {
+            if (s < a.nsplit) {
+                const float* mlp = a.part_ml + (((size_t)s * SK_ROWS_CAP + r) * a.n_q + (c >> 6)) * 2;
+                mv[s] = ld_agent(mlp); lv[s] = ld_agent(mlp + 1);
+                ov[s] = ld_agent(a.part_o + ((size_t)s * SK_ROWS_CAP + r) * a.n_q * 64 + c);
+            }
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < SK_MAXSPLIT; s++) if (s < ns) M = fmaxf(M, mv[s]);
+        float acc = 0.f, den = 0.f;
+#pragma unroll
+        for (int s = 0; s < SK_MAXSPLIT; s++) {
+            if (s < ns) {
+                const float w = __expf(mv[s] - M);
+                den += w * lv[s];
+                acc += w * ov[s];
+            }
+        }
+        put_planes(a.pre, r, c, acc * (1.f / den));
+    }
 }
 // The same kernel on the matrix cores (fp32 accuracy: three exact bf16 planes per operand, six products; see attn_role, the form inside
 // k_step).  Grid, split layout and outputs are k_attn's.  A 64-key tile group = 4 waves x 16 keys: K rows / V rows go global -> registers
@@ -458,35 +537,48 @@ struct StoreArgs {
     // planes of next_g . x_mid in the layout the PRE kernels copy, and this block's share of every row's sum of squares (the consumer
     // sums the N / 16 shares in a fixed order and scales its OUTPUTS by the row's rstd: W (g . x) rstd = W (g . x rstd))
     const float* resid; const float* next_g; float* x_out; uint16_t* next_pre; float* next_sq;
+    // LAST (many-row down projection, split-K over gridDim.y): the last K-slice block of a column tile to finish folds the slices in index
+    // order onto the residual stream and runs the NEXT epilogue for the following layer's QKV kernel (what k_prep<false> did as a launch
+    // of its own).  arrive = [N / 16] counters, zero between launches
+    int* arrive;
 };
-template <int NB, int MAXKS, bool ATT = false, bool PRE = false, bool NEXT = false>
+template <int NB, int MAXKS, bool ATT = false, bool PRE = false, bool NEXT = false, bool LAST = false>
 __global__ __launch_bounds__(256) void k_store(StoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* res = skinny_core<NB, 1, 4, MAXKS, ATT, PRE>(a.W, blockIdx.x, a.KS, a.rows, a.K, a.X, smem);
     const int ld = NB * 16 + 1;
     const int n0 = blockIdx.x * 16;
     float* out = a.out + (gridDim.y > 1 ? (size_t)blockIdx.y * SK_ROWS_CAP * a.N : 0);
+    auto next = [&](int r, int i, float v) {             // v = the finished residual stream at (row r, column n0 + i)
+        const int c = n0 + i;
+        a.x_out[(size_t)r * a.N + c] = v;
+        put_planes(a.next_pre, r, c, a.next_g[c] * v);
+        float sq = v * v;                                 // the row's 16 columns sit in 16 consecutive lanes
+        sq += dpp_mov_f32<0xB1, 0xf>(0.f, sq);            // quad_perm [1,0,3,2]
+        sq += dpp_mov_f32<0x4E, 0xf>(0.f, sq);            // quad_perm [2,3,0,1]
+        sq += __shfl_xor(sq, 4);
+        sq += __shfl_xor(sq, 8);
+        if (i == 0) a.next_sq[(size_t)r * gridDim.x + blockIdx.x] = sq;
+    };
     for (int e = threadIdx.x; e < a.rows * 16; e += blockDim.x) {
         const int r = e >> 4, i = e & 15;
         float v = res[i * ld + r];
         if (a.bias && blockIdx.y == 0) v += a.bias[n0 + i];
-        if (NEXT) {
-            const int c = n0 + i;
-            v += a.resid[(size_t)r * a.N + c];
-            a.x_out[(size_t)r * a.N + c] = v;
-            const float gx = a.next_g[c] * v;
-            uint16_t* d = a.next_pre + ((size_t)((c >> 5) * 2 + (r >> 4)) * 2) * 512 + (((c >> 3) & 3) * 16 + (r & 15)) * 8 + (c & 7);
-            const uint16_t hb = f2bf(gx);
-            d[0] = hb;
-            d[512] = f2bf(gx - bf2f(hb));
-            float sq = v * v;                                 // the row's 16 columns sit in 16 consecutive lanes
-            sq += dpp_mov_f32<0xB1, 0xf>(0.f, sq);            // quad_perm [1,0,3,2]
-            sq += dpp_mov_f32<0x4E, 0xf>(0.f, sq);            // quad_perm [2,3,0,1]
-            sq += __shfl_xor(sq, 4);
-            sq += __shfl_xor(sq, 8);
-            if (i == 0) a.next_sq[(size_t)r * gridDim.x + blockIdx.x] = sq;
-        } else {
-            out[(size_t)r * a.N + n0 + i] = v;
+        if (LAST) st_agent(&out[(size_t)r * a.N + n0 + i], v);
+        else if (NEXT) next(r, i, v + a.resid[(size_t)r * a.N + n0 + i]);
+        else out[(size_t)r * a.N + n0 + i] = v;
+    }
+    if (LAST) {
+        if (!last_arriver(a.arrive + blockIdx.x, gridDim.y)) return;
+        for (int e = threadIdx.x; e < a.rows * 16; e += blockDim.x) {
+            const int r = e >> 4, i = e & 15;
+            float v = a.resid[(size_t)r * a.N + n0 + i], pv[SK_MAXNP];
+#pragma unroll
+            for (int p = 0; p < SK_MAXNP; p++)           // all slices in flight together; folded in index order (k_prep<false>'s)
+                pv[p] = ld_agent(a.out + ((size_t)min(p, (int)gridDim.y - 1) * SK_ROWS_CAP + r) * a.N + n0 + i);
+#pragma unroll
+            for (int p = 0; p < SK_MAXNP; p++) if (p < (int)gridDim.y) v += pv[p];
+            next(r, i, v);
         }
     }
 }
@@ -1825,6 +1917,9 @@ struct cv2_llm {
     float *attc;               // [32][n_q*64] combined attention output (many-row path)
     uint16_t *xp2;             // prepared gate/up operand written by the O projection's epilogue (xp is still being read by that launch)
     float *sqp;                // [32][hidden / 16] shares of the rows' sums of squares
+    float *sqp2;               // the same for the next layer's QKV operand (left by the down projection's last arrivers)
+    int *arrive_att, *arrive_down;   // arrival counters of the many-row path's fused combines: [32][n_kv], [hidden / 16]
+    int pre_fuse;              // CV2_PRE_FUSE=1 at creation (run_layers_pre): bit 0 the attention's combine, bit 1 the down projection's
     uint16_t *xp, *xp_h;       // prepared operand planes [K/32][2][hi, lo][512]: k_prep output; SwiGLU output of k_gateup<2, true>
     int nsplit, keys_per_split;
     float *hbuf;               // [32][inter]
@@ -1868,11 +1963,14 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     p = take((size_t)(d.inter / 32) * 2 * 2 * 1024); if (h) h->xp_h = (uint16_t*)p;
     p = take((size_t)(d.inter / 32) * 2 * 2 * 1024); if (h) h->xp2 = (uint16_t*)p;
     p = take((size_t)32 * (d.hidden / 16) * 4); if (h) h->sqp = (float*)p;
+    p = take((size_t)32 * (d.hidden / 16) * 4); if (h) h->sqp2 = (float*)p;
     p = take((size_t)32 * d.hidden * 4); if (h) h->o = (float*)p;
     p = take((size_t)32 * d.inter * 4); if (h) h->hbuf = (float*)p;
     p = take((size_t)SK_MAXNP * 32 * d.hidden * 4); if (h) h->parts = (float*)p;
     if (h) h->chain_off = off;
     p = take(256); if (h) h->epoch = (unsigned*)p;
+    p = take((size_t)SK_ROWS_CAP * d.n_kv * 4); if (h) h->arrive_att = (int*)p;          // (zeroed at create, re-armed by their last arriver)
+    p = take((size_t)(d.hidden / 16) * 4); if (h) h->arrive_down = (int*)p;
     {   // per layer: x_mid [H], down partials [CH_NP][H], q [NQ], new key / value rows [2 n_kv 64], attention partials
         // [tiles][n_kv][AT_GSTRIDE], h [inter]
         const size_t ntiles = (d.max_pos + AT_TILE - 1) / AT_TILE;
@@ -1915,6 +2013,10 @@ extern "C" int cv2_llm_create(const cv2_llm_dims* d, const cv2_llm_weights* w, c
     h->d = *d;
     if (h->d.top_k == 0) { h->d.top_p = 0.8f; h->d.top_k = 25; h->d.win_size = 10; h->d.tau_r = 0.1f; }   // conf/cosyvoice2.yaml:33-37
     h->layers.assign(w->layers, w->layers + d->layers);
+    {
+        const char* e = getenv("CV2_PRE_FUSE");
+        h->pre_fuse = !e ? 0 : e[0] == '1' ? 3 : e[0] == 'a' ? 1 : e[0] == 'd' ? 2 : 0;
+    }
     h->w = *w;
     h->w.layers = h->layers.data();
     h->io = *io;
@@ -2091,8 +2193,16 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
     const cv2_llm_dims& d = h->d;
     const int H = d.hidden, KSH = H / 32, NQ = d.n_q * 64;
     const size_t cache_l = (size_t)d.max_seqs * d.n_kv * d.max_pos * 64;
+    // Default: 7 launches per layer, both operand preparations (k_prep) as launches of their own.  CV2_PRE_FUSE=1 / a / d at engine creation
+    // (diagnostics, kept for the A/B): the preparations done by the producers' last-arriving blocks, both / the attention's / the down
+    // projection's.  Measured on MI355X at 32 rows: 1474 / 1478 / 1287 us per step against 1292 -- the attention's seam inside the launch
+    // (drain the write-through stores, the counter's round trip, agent-coherent loads of the other splits' results, all behind the slowest
+    // split) costs ~12 us where the launch boundary with a 4.8 us k_prep costs less; the down projection's is worth what its launch was
+    // (profiles/r4_pre_fuse_ab.txt).
+    const bool fuse = h->pre_fuse & 1, fuse_d = h->pre_fuse & 2;      // ('a' / 'd': the attention's / the down projection's alone)
     const float* xcur = xin;
     int np = 0;
+    bool ready = false;                                  // the layer's QKV operand was left by the previous down projection (planes in xp, shares in sqp2, x1 written)
     auto prep = [&](const SkinnyX& X, int K, bool att) {
         if (att) hipLaunchKernelGGL(k_prep<true>, dim3(rows), dim3(256), 0, s, X, K, h->xp);
         else hipLaunchKernelGGL(k_prep<false>, dim3(rows), dim3(256), 0, s, X, K, h->xp);
@@ -2102,20 +2212,22 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
     for (int l = 0; l < d.layers; l++) {
         const cv2_llm_layer& L = h->layers[l];
         float* x1 = (xcur == h->xa) ? h->xb : h->xa;
-        prep(SkinnyX{xcur, h->parts, np, L.ln1, d.rms_eps, x1}, H, false);
+        if (!ready) prep(SkinnyX{xcur, h->parts, np, L.ln1, d.rms_eps, x1}, H, false);
         {
             QkvArgs a{};
             a.W = L.wqkv; a.bias = L.bqkv; a.X = pre;
             a.KS = KSH; a.rows = rows; a.K = H; a.n_q = d.n_q; a.n_kv = d.n_kv;
             a.cosT = h->w.rope_cos; a.sinT = h->w.rope_sin;
             a.q = h->q; a.kc = h->kc + l * cache_l; a.vc = h->vc + l * cache_l; a.max_pos = d.max_pos; a.rm = rm;
+            if (ready) { a.sq = h->sqp2; a.nsq = H / 16; a.eps = d.rms_eps; }
             { const size_t sm = skinny_smem_bytes<2, 2, 4>(KSH); hipLaunchKernelGGL((k_qkv<2, true>), dim3(2 * (d.n_q + 2 * d.n_kv), 1), dim3(512), sm, s, a); }
         }
-        {
+        {   // attention; the last split of a (row, kv head) combines the splits and leaves the O projection's operand planes
             AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm, d.n_q / d.n_kv};
+            if (fuse) { a.arrive = h->arrive_att; a.pre = h->xp; }
             launch_attn(a, rows, s);
         }
-        prep(SkinnyX{nullptr, h->att, h->nsplit, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt}, NQ, true);
+        if (!fuse) prep(SkinnyX{nullptr, h->att, h->nsplit, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt}, NQ, true);
         float* x2 = (x1 == h->xa) ? h->xb : h->xa;
         {   // O projection; its epilogue adds the residual and prepares the gate/up operand (no k_prep launch in between)
             StoreArgs a{};
@@ -2134,12 +2246,19 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
                 hipLaunchKernelGGL((k_gateup<2, true, 2>), dim3(d.inter / 32, 1), dim3(512), sm, s, a);
             } else { const size_t sm = skinny_smem_bytes<2, 2, 4>(KSH); hipLaunchKernelGGL((k_gateup<2, true>), dim3(d.inter / 16, 1), dim3(512), sm, s, a); }
         }
-        {
+        {   // down projection, split-K; before the last layer's, the last K-slice block of a column tile finishes the residual stream
+            // and prepares the next layer's QKV operand (no k_prep launch in between)
             StoreArgs a{};
             SkinnyX preh{};
             preh.pre = h->xp_h;
             a.W = L.wdown; a.X = preh; a.KS = d.inter / 32; a.rows = rows; a.K = d.inter; a.N = H; a.out = h->parts;
-            { const size_t sm = skinny_smem_bytes<2, 1, 4>(cdiv(a.KS, SK_MAXNP) + 1); hipLaunchKernelGGL((k_store<2, 10, false, true>), dim3(H / 16, SK_MAXNP), dim3(256), sm, s, a); }
+            const size_t sm = skinny_smem_bytes<2, 1, 4>(cdiv(a.KS, SK_MAXNP) + 1);
+            ready = fuse_d && l + 1 < d.layers;
+            if (ready) {
+                a.resid = x2; a.next_g = h->layers[l + 1].ln1; a.x_out = (x2 == h->xa) ? h->xb : h->xa; a.next_pre = h->xp; a.next_sq = h->sqp2;
+                a.arrive = h->arrive_down;
+                hipLaunchKernelGGL((k_store<2, 10, false, true, false, true>), dim3(H / 16, SK_MAXNP), dim3(256), sm, s, a);
+            } else hipLaunchKernelGGL((k_store<2, 10, false, true>), dim3(H / 16, SK_MAXNP), dim3(256), sm, s, a);
         }
         xcur = x2;
         np = SK_MAXNP;
@@ -2163,11 +2282,12 @@ static int set_smem(F f, size_t bytes) {
 static int init_attrs_once() {
     static std::atomic<bool> done{false};   // idempotent: a concurrent first call repeats the attribute calls rather than launch before they are in place
     if (done) return 0;
-    const size_t big = 160 * 1024;
+    const size_t big = 159 * 1024;                 // (dynamic + the kernels' few static words <= 160 KB)
     if (set_smem(k_qkv<1>, big) || set_smem(k_qkv<2>, big) || set_smem(k_gateup<1>, big) || set_smem(k_gateup<2>, big) ||
         set_smem((k_store<1, 8>), big) || set_smem((k_store<2, 8>), big) || set_smem((k_store<1, 8, true>), big) || set_smem((k_store<2, 8, true>), big) || set_smem((k_store<1, 10>), big) ||
         set_smem((k_store<2, 10>), big) || set_smem((k_qkv<2, true>), big) || set_smem((k_gateup<2, true>), big) || set_smem((k_gateup<2, true, 2>), big) ||
-        set_smem((k_store<2, 8, false, true>), big) || set_smem((k_store<2, 8, false, true, true>), big) || set_smem((k_store<2, 10, false, true>), big))
+        set_smem((k_store<2, 8, false, true>), big) || set_smem((k_store<2, 8, false, true, true>), big) || set_smem((k_store<2, 10, false, true>), big) ||
+        set_smem((k_store<2, 10, false, true, false, true>), big))
         return -1;
     done = true;
     return 0;

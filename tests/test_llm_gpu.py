@@ -258,6 +258,36 @@ def test_many_row_decode_path(small):
         assert ids == OL.inference(sdr, text, ptxt, ptok, force_len=8)
 
 
+def test_many_row_launches_with_fused_combines_are_reproducible(dev, small, monkeypatch):
+    """The measured-and-rejected form of the 17 .. 32-row step, kept behind CV2_PRE_FUSE=1 for the A/B (llm.hip, run_layers_pre): 5
+    launches per layer -- the attention's last split of a (row, kv head) combines the splits and leaves the O projection's operand; the
+    down projection's last K-slice block of a column tile finishes the residual stream and leaves the next QKV operand (arrival counters,
+    results read back with agent-coherent loads).  Prompts of different lengths (every row has its own split count).  Ids equal the
+    oracle's and the default form's; two runs agree bit for bit in ids AND logits (a stale read of another block's result would not)."""
+    from cv2amd.llm import LLMEngine, MODE_RAS
+    from oracle import llm as OL
+    sd, sdr, eng0 = small
+    monkeypatch.setenv('CV2_PRE_FUSE', '1')
+    eng = LLMEngine(sd, dev, max_seqs=32, max_pos=512, max_out=64)
+    monkeypatch.delenv('CV2_PRE_FUSE')
+    n = 30
+    reqs = _requests(n, seed=700)
+    xs = [eng.build_lm_input(*r) for r in reqs]
+    runs = []
+    for e, mode in ((eng, 0), (eng, 0), (eng, MODE_RAS), (eng0, 0), (eng0, MODE_RAS)):
+        e.park()
+        e.add_requests(list(range(n)), xs, [(48, 48)] * n, mode, 99, True)
+        e.step(n, 47, shared=True)
+        st, toks = e.read(n)
+        assert bool(st[:, 3].all()) and all(len(t) == 48 for t in toks)
+        runs.append((toks, e.logits[:n, :e.vocab].clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][0] == runs[3][0] and runs[2][0] == runs[4][0]
+    for r, ids in list(zip(reqs, runs[0][0]))[::7]:
+        assert ids == OL.inference(sdr, *r, force_len=48)
+    eng0.park()
+
+
 def test_live_row_decode_equals_lockstep_and_oracle(small):
     """Requests of one batch end at different lengths: generate() drops the finished slots from the decode rows at every poll
     (cv2_llm_decode_rows, rows != slots, passing through the 17..32-row, 2..16-row and one-row kernels).  The ids equal those of the

@@ -1,5 +1,5 @@
 """Decode step time against the number of live rows (cv2_llm_decode_rows over slots 1..n, so that one row also takes the launches):
-python tools/bench_rows_sweep.py [prompt_len]"""
+python tools/bench_rows_sweep.py [prompt_len]      (CV2_SWEEP_ROWS=32,24,17: those row counts only)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cosyvoice2-eu_amd'))
@@ -31,7 +31,8 @@ def timed(fn):
 
 
 print(f'decode step against the number of live rows, P = {P} prompt tokens + 50 text tokens, positions {P + 52 + 16} .. {P + 52 + 80} (us per step)')
-for n in (32, 28, 24, 22, 20, 18, 17, 16, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1):
+ROWS = tuple(int(v) for v in os.environ['CV2_SWEEP_ROWS'].split(',')) if os.environ.get('CV2_SWEEP_ROWS') else (32, 28, 24, 22, 20, 18, 17, 16, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1)
+for n in ROWS:
     slots = list(range(32 - n, 32))
     res = []
     for shared in ((False, True) if n <= 24 else (False,)):         # <= 24 rows: the one-launch step (k_step2 pairs, k_step<true> at 3 rows, k_step4 from 9 rows), and the launches beside it
