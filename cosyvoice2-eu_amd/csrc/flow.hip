@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <map>
 #include <math.h>
+#include <atomic>
 #include <vector>
 
 #define GUARD 128
@@ -345,7 +346,13 @@ struct AttnEstArgs {
 #define AK_LD 72    // K tile row stride (bf16 elements): 64 + 8
 #define AV_LD 68    // V^T tile row stride: 64 + 4
 // one 64-key tile of the flash loop: scores, running softmax, O^T update (Kt / Vt = the staged tile in LDS)
-template <int QS>
+// SWZ: the tile was written by LDS DMA (k_attn_est_dma): rows of 128 B without padding; chunk c (16 B) of V^T row d sits in slot c ^ (d & 7),
+// chunk c of K row r in slot c ^ att_kswz-of-its-score-row.  The score rows are a permutation of the tile's keys, chosen so that the eight
+// P entries a lane holds per key-pair tile are eight consecutive keys: the V^T operand of the second product is then ONE 16-byte read
+// (the register-staged form reads two 8-byte halves 16 keys apart and moves them together).  Same products, another order inside a
+// matrix-core k group: the two forms agree to fp32 round-off, not bit for bit.
+__device__ __forceinline__ int att_kswz(int i) { return (i >> 2) * 2 + ((i >> 1) & 1); }      // i = score row (0 .. 15): two rows per value
+template <int QS, bool SWZ = false>
 __device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t* Vt, const bf16x8 (&qf)[QS][2], f32x4 (&o)[QS][4],
                                              float (&mrun)[QS], float (&lrun)[QS], const int (&kmax_q)[QS], int kt, int q16, int g) {
         // S^T: 4 key tiles x (d = 64 in two k-steps), K fragments shared by the QS query sub-tiles
@@ -356,7 +363,10 @@ __device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t*
             for (int u = 0; u < QS; u++) sacc[u][k4] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kt[(16 * k4 + q16) * AK_LD + ks * 32 + g * 8]);
+                // SWZ: score row i = q16 of key tile k4 is key 32 (k4 / 2) + 8 (i / 4) + 4 (k4 % 2) + i % 4 (see the V^T read below)
+                const bf16x8 kf = SWZ ? *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Kt) + (k4 >> 1) * 4096 + (k4 & 1) * 512 +
+                                                                         (((8 * (q16 >> 2) + (q16 & 3)) * 128 + ((g ^ att_kswz(q16)) << 4)) ^ (ks << 6)))
+                                      : *reinterpret_cast<const bf16x8*>(&Kt[(16 * k4 + q16) * AK_LD + ks * 32 + g * 8]);
 #pragma unroll
                 for (int u = 0; u < QS; u++) sacc[u][k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][k4], 0, 0, 0);
             }
@@ -373,15 +383,19 @@ __device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t*
                 for (int k4 = 0; k4 < 4; k4++)
 #pragma unroll
                     for (int r = 0; r < 4; r++)
-                        if (kt * 64 + 16 * k4 + 4 * g + r >= kmax_q[u]) sacc[u][k4][r] = -INFINITY;
+                        if (kt * 64 + (SWZ ? 32 * (k4 >> 1) + 8 * g + 4 * (k4 & 1) : 16 * k4 + 4 * g) + r >= kmax_q[u]) sacc[u][k4][r] = -INFINITY;
             }
-            float mloc = fmaxf(fmaxf(fmaxf(sacc[u][0][0], sacc[u][0][1]), fmaxf(sacc[u][0][2], sacc[u][0][3])),
-                               fmaxf(fmaxf(sacc[u][1][0], sacc[u][1][1]), fmaxf(sacc[u][1][2], sacc[u][1][3])));
-            mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(sacc[u][2][0], sacc[u][2][1]), fmaxf(sacc[u][2][2], sacc[u][2][3])),
-                                     fmaxf(fmaxf(sacc[u][3][0], sacc[u][3][1]), fmaxf(sacc[u][3][2], sacc[u][3][3]))));
+            // 16 scores -> one maximum as a chain of three-operand maxima (8 v_max3_f32; a balanced tree of pairs compiled to 23 instructions)
+            float mloc = fmaxf(fmaxf(sacc[u][0][0], sacc[u][0][1]), sacc[u][0][2]);
+            mloc = fmaxf(fmaxf(mloc, sacc[u][0][3]), sacc[u][1][0]);
+            mloc = fmaxf(fmaxf(mloc, sacc[u][1][1]), sacc[u][1][2]);
+            mloc = fmaxf(fmaxf(mloc, sacc[u][1][3]), sacc[u][2][0]);
+            mloc = fmaxf(fmaxf(mloc, sacc[u][2][1]), sacc[u][2][2]);
+            mloc = fmaxf(fmaxf(mloc, sacc[u][2][3]), sacc[u][3][0]);
+            mloc = fmaxf(fmaxf(mloc, sacc[u][3][1]), sacc[u][3][2]);
+            mloc = fmaxf(mloc, sacc[u][3][3]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            const float mnew = fmaxf(mrun[u], mloc);                   // raw-score domain
+            const float mnew = fmaxf(fmaxf(mrun[u], mloc), __shfl_xor(mloc, 32));      // raw-score domain
             const float msafe = mnew == -INFINITY ? 0.f : mnew;
             const float mc = msafe * SC;
             const float alpha = __builtin_amdgcn_exp2f((mrun[u] - msafe) * SC);     // mrun = -inf -> 0
@@ -409,10 +423,15 @@ __device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t*
         for (int kp = 0; kp < 2; kp++)
 #pragma unroll
             for (int dt = 0; dt < 4; dt++) {
-                const uint16_t* vrow = &Vt[(16 * dt + q16) * AV_LD + 32 * kp + 4 * g];
-                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                bf16x8 vf;
+                if (SWZ) {                       // the lane's eight P entries of key-pair tile kp are the CONSECUTIVE keys 32 kp + 8 g .. + 7: one 16-byte chunk
+                    vf = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Vt) + dt * 2048 + ((q16 * 128 + ((g ^ (q16 & 7)) << 4)) ^ (kp << 6)));
+                } else {
+                    const uint16_t* vrow = &Vt[(16 * dt + q16) * AV_LD + 32 * kp + 4 * g];
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+                    vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                }
 #pragma unroll
                 for (int u = 0; u < QS; u++) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][kp], o[u][dt], 0, 0, 0);
             }
@@ -605,6 +624,126 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
         g_stamps[60][6] = ntiles; g_stamps[60][7] = gridDim.x * gridDim.y;
     }
 #endif
+}
+
+// The same attention with the K / V^T tiles going global -> LDS by DMA (4 waves, one key group): no staging registers (k_attn_est keeps
+// two tiles = 64 VGPRs in flight per thread and stores them to LDS itself), three LDS stages of 16 KB, two tiles in flight.  A wave's DMA
+// instruction writes 1 KiB = 8 rows of 128 B; lane l fetches chunk (l & 7) ^ (l >> 3) of row l >> 3, so the chunk c of row r lands in
+// slot c ^ (r & 7) and the fragment reads (att_est_tile<.., true>) are conflict-free without padding.  Same MFMA sequence: same bits.
+template <int QS, bool CACHE = false>
+__global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
+    constexpr int NW = 4, RB = 16 * NW;
+    __shared__ __attribute__((aligned(1024))) uint16_t Ks[3][64 * 64];
+    __shared__ __attribute__((aligned(1024))) uint16_t Vs[3][64 * 64];
+    const int lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CV2_NO_XCD
+    const int lin_ = blockIdx.x + 8 * blockIdx.y, mt_ = gridDim.y;
+    const int m0 = (lin_ % mt_) * RB * QS, h = lin_ / mt_;
+#else
+    const int m0 = blockIdx.y * RB * QS, h = blockIdx.x;
+#endif
+    const int q16 = lane & 15, g = lane >> 4;
+    const int s = a.seq.tile_seq[m0 >> 6];
+    uint16_t* orow[QS];
+#pragma unroll
+    for (int u = 0; u < QS; u++) orow[u] = a.out + (size_t)(m0 + RB * u + 16 * w + q16) * 512 + h * 64 + 4 * g;
+    const int start = s < 0 ? 0 : a.seq.seq_start[s], len = s < 0 ? 0 : a.seq.seq_len[s];
+    const int t0 = m0 - start;
+    if (s < 0 || (CACHE && t0 >= len)) {               // padding tile / padding rows of the sequence's last tile(s): zeros
+#pragma unroll
+        for (int u = 0; u < QS; u++)
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) *reinterpret_cast<uint2*>(orow[u] + 16 * dt) = make_uint2(0u, 0u);
+        return;
+    }
+    const int p0 = CACHE ? a.pos0[s] : 0;
+    const int klen = p0 + len;
+    int tq[QS], kmax_q[QS];
+#pragma unroll
+    for (int u = 0; u < QS; u++) {
+        tq[u] = t0 + RB * u + 16 * w + q16;
+        kmax_q[u] = a.chunk > 0 ? min(klen, ((p0 + tq[u]) / a.chunk + 1) * a.chunk) : klen;
+    }
+    const int kmax_blk = a.chunk > 0 ? min(klen, ((p0 + t0 + RB * QS - 1) / a.chunk + 1) * a.chunk) : klen;
+    const int ntiles = (kmax_blk + 63) / 64;
+    // this lane's two K and two V^T DMA sources of tile 0 (wave w, instruction j: rows 8 (w + 4 j) .. + 7 of the tile); a tile further on is
+    // 64 key rows (K) / 64 keys (V^T) further
+    const int rr = lane >> 3, gc = (lane & 7) ^ rr;
+    const uint16_t* ksrc[2]; const uint16_t* vsrc[2];
+    long kstep;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int r = 8 * (w + 4 * j) + rr;
+        // key r of the tile is score row 4 ((r >> 3) & 3) + (r & 3) of its key tile (att_est_tile): its chunks are swizzled by that row's value
+        const int gck = (lane & 7) ^ att_kswz(4 * ((r >> 3) & 3) + (r & 3));
+        if (CACHE) {
+            const long fr = a.kv_frames[s];
+            ksrc[j] = a.kv[s] + a.slot * fr * 1024 + h * 64 + (long)r * 512 + gck * 8;
+            vsrc[j] = a.kv[s] + a.slot * fr * 1024 + fr * 512 + (long)(h * 64 + r) * fr + gc * 8;
+        } else {
+            ksrc[j] = a.qk + (size_t)(start + r) * 1024 + 512 + h * 64 + gck * 8;
+            vsrc[j] = a.vt + (size_t)(h * 64 + r) * a.R + start + gc * 8;
+        }
+    }
+    kstep = CACHE ? 64 * 512 : 64 * 1024;
+    // The DMA instructions are inline asm on purpose: hipcc orders every LDS read that may alias the destination of a DMA builtin behind
+    // vmcnt(0) (here: each tile's fragment reads behind the DMA issued just before them, i.e. no tile in flight).  Written this way the
+    // compiler knows nothing of the LDS writes and the waits below are the only ones; m0 is used by nothing else in this kernel.
+    auto dma = [&](int kt, int st) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const unsigned kd = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(&Ks[st][(w + 4 * j) * 512]);
+            const unsigned vd = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(&Vs[st][(w + 4 * j) * 512]);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(kd), "v"(ksrc[j] + (long)kt * kstep) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(vd), "v"(vsrc[j] + (long)kt * 64) : "memory");
+        }
+    };
+    f32x4 o[QS][4];
+    float mrun[QS], lrun[QS];
+#pragma unroll
+    for (int u = 0; u < QS; u++) {
+        mrun[u] = -INFINITY; lrun[u] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) o[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int last = ntiles - 1;
+    dma(0, 0);
+    dma(min(1, last), 1);
+    // q fragments: loaded AFTER the first DMAs and consumed (empty asm) before the loop, so that the compiler's own wait for these loads sits
+    // here -- placed at their first use inside the loop it would be a vmcnt(0) in every iteration, i.e. a wait for the DMA just issued
+    bf16x8 qf[QS][2];
+#pragma unroll
+    for (int u = 0; u < QS; u++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+            qf[u][ks] = *reinterpret_cast<const bf16x8*>(a.qk + (size_t)(m0 + RB * u + 16 * w + q16) * 1024 + h * 64 + ks * 32 + g * 8);
+#pragma unroll
+    for (int u = 0; u < QS; u++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) asm volatile("" : "+v"(qf[u][ks]));
+    int st = 0;
+    for (int kt = 0; kt < ntiles; kt++) {
+        // four DMA instructions per tile and wave, always (a tile index past the end re-fetches the last tile): tile kt has landed when at
+        // most the four of tile kt + 1 are outstanding; the barrier makes that true for every wave's share and says that every wave is
+        // done with tile kt - 1 (its fragment reads have returned: lgkmcnt), whose stage the next DMA overwrites
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // (no fence: __syncthreads() would add waits of its own)
+        dma(min(kt + 2, last), st >= 1 ? st - 1 : 2);
+        att_est_tile<QS, true>(Ks[st], Vs[st], qf, o, mrun, lrun, kmax_q, kt, q16, g);
+        st = st == 2 ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the look-ahead DMAs target this block's LDS: they land before it is released)
+#pragma unroll
+    for (int u = 0; u < QS; u++) {
+        float l = lrun[u];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = (tq[u] < len && l > 0.f) ? 1.f / l : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+            *reinterpret_cast<uint2*>(orow[u] + 16 * dt) = make_uint2(pack_bf16x2(o[u][dt][0] * inv, o[u][dt][1] * inv), pack_bf16x2(o[u][dt][2] * inv, o[u][dt][3] * inv));
+    }
 }
 
 // =========================================================================== host side
@@ -821,6 +960,11 @@ static int est_resnet(EstCtx& c, const cv2_resnet& rn, int ridx, uint16_t* A, in
     return 0;
 }
 
+// test hook: 1 / 0 = the four-wave estimator attention with / without LDS DMA staging (same MFMA sequence: the outputs must agree bit for
+// bit), -1 = the default (CV2_ATT_DMA)
+static std::atomic<int> g_att_dma{-1};
+extern "C" int cv2_flow_debug_attn_dma(int32_t on) { g_att_dma = on < 0 ? -1 : (on != 0); return 0; }
+
 // transformer block; next_ln == null: last of its group -> bf16 copy of x goes to (xout, ldx)
 static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, uint16_t* xout, long ldx) {
     cv2_flow* h = c.h; const int M = c.L->rows;
@@ -841,13 +985,17 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
             CV2_CHECK(bi < INC_TBLOCKS, "flow: transformer block counter overflow");
             a.kv = c.inc->kv; a.kv_frames = c.inc->kv_frames; a.pos0 = c.inc->pos0; a.slot = (long)c.step * INC_TBLOCKS + bi;
         }
+        // the four-wave forms stage their tiles by LDS DMA (k_attn_est_dma); CV2_ATT_DMA=0 (A/B, diagnostics): through registers as the two-group form
+        static const bool dma_env = !(getenv("CV2_ATT_DMA") && getenv("CV2_ATT_DMA")[0] == '0');
+        const int dma_dbg = g_att_dma.load();
+        const bool dma = dma_dbg < 0 ? dma_env : dma_dbg != 0;
         if (c.inc) {
-            if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4, 1, true>), dim3(8, M / 128), dim3(256), 0, c.s, a);
-            else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4, 1, true>), dim3(8, M / 64), dim3(256), 0, c.s, a);
+            if (M / 128 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<2, true>), dim3(8, M / 128), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<2, 4, 1, true>), dim3(8, M / 128), dim3(256), 0, c.s, a); }
+            else if (M / 64 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<1, true>), dim3(8, M / 64), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<1, 4, 1, true>), dim3(8, M / 64), dim3(256), 0, c.s, a); }
             else hipLaunchKernelGGL((k_attn_est<1, 2, 2, true>), dim3(8, M / 32), dim3(256), 0, c.s, a);
         }
-        else if (M / 128 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(8, M / 128), dim3(256), 0, c.s, a);   // enough blocks to fill the chip twice
-        else if (M / 64 * 8 >= 512) hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(8, M / 64), dim3(256), 0, c.s, a);
+        else if (M / 128 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<2>), dim3(8, M / 128), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(8, M / 128), dim3(256), 0, c.s, a); }   // enough blocks to fill the chip twice
+        else if (M / 64 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<1>), dim3(8, M / 64), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(8, M / 64), dim3(256), 0, c.s, a); }
         else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(8, M / 32), dim3(256), 0, c.s, a);       // one utterance: split keys over two wave groups
     }
     static const bool tail_rows_off = getenv("CV2_FLOW_TAIL_ROWS") && getenv("CV2_FLOW_TAIL_ROWS")[0] == '0';     // A/B switch (diagnostics)

@@ -2,11 +2,20 @@
 #pragma once
 #include "gemm.h"
 
-template <int BM, int BN, int WM, int WN, bool SPLITA = false, int NSTAGE = 2>
+// a GEMM whose epilogue only stores bf16: k_gemm's EPI = 1 (CV2_GEMM_PLAIN=0, diagnostics: the general epilogue everywhere)
+static bool gemm_plain(const GemmArgs& a) {
+    static const bool off = getenv("CV2_GEMM_PLAIN") && getenv("CV2_GEMM_PLAIN")[0] == '0';
+    return !off && !a.bias && !a.ln1_g && !a.ln2_g && a.act == ACT_NONE && !a.rowadd && !a.res && !a.out_f32 && a.out_bf16 && !a.kvc;
+}
+template <int BM, int BN, int WM, int WN, bool SPLITA = false, int NSTAGE = 2, bool PLAIN_OK = false>
 static int gemm_go(const GemmArgs& a, int batch, bool packed, hipStream_t s) {
     constexpr size_t sm = gemm_smem_bytes<BM, BN, SPLITA, NSTAGE>();
     dim3 grid(a.N / BN, a.M / BM, batch), block(WM * WN * 64);
-    if (packed) {
+    if (PLAIN_OK && packed && gemm_plain(a)) {
+        static std::atomic<bool> once{false};
+        if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, true, SPLITA, NSTAGE, PLAIN_OK ? 1 : 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true, SPLITA, NSTAGE, PLAIN_OK ? 1 : 0>), grid, block, sm, s, a);
+    } else if (packed) {
         static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
         if (!once) { CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, true, SPLITA, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm)); once = true; }
         hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true, SPLITA, NSTAGE>), grid, block, sm, s, a);
@@ -82,9 +91,9 @@ static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, h
     if (cfg == 0) { CV2_CHECK(a.N % 128 == 0, "gemm cfg0: N=%d %% 128", a.N); 
         // fewer blocks than ~1.5 per CU: 16 waves per block spread the LDS-DMA issue cost (phase stamps: the K loop runs at ~2x the per-CU
         // vector-memory bound of 64 B/clk whatever the number of stages in flight); otherwise 8 waves and two blocks per CU
-        if ((long)(a.N / 128) * (a.M / 128) * batch < 200) return gemm_go<64, 128, 2, 4>(a, batch, packed, s);      // < 1 block per CU: halve the tile, the row epilogue (GELU, V^T) is VALU-bound
-        if ((long)(a.N / 128) * (a.M / 128) * batch < 400) return gemm_go<128, 128, 4, 4>(a, batch, packed, s);
-        return gemm_go<128, 128, 2, 4>(a, batch, packed, s);
+        if ((long)(a.N / 128) * (a.M / 128) * batch < 200) return gemm_go<64, 128, 2, 4, false, 2, true>(a, batch, packed, s);      // < 1 block per CU: halve the tile, the row epilogue (GELU, V^T) is VALU-bound
+        if ((long)(a.N / 128) * (a.M / 128) * batch < 400) return gemm_go<128, 128, 4, 4, false, 2, true>(a, batch, packed, s);
+        return gemm_go<128, 128, 2, 4, false, 2, true>(a, batch, packed, s);
     }
     if (cfg == 1) {
         CV2_CHECK(a.N % 256 == 0, "gemm cfg1: N=%d %% 256", a.N);

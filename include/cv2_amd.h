@@ -284,6 +284,10 @@ int cv2_flow_inference_chunk(cv2_flow* h, const cv2_flow_utt* utts, const cv2_fl
  * same `gen` as the source.  The source must hold exactly n_frames (its tails belong to that position). */
 int cv2_flow_cache_copy(const cv2_flow* h, const void* src, int32_t src_frames, void* dst, int32_t dst_frames, int32_t n_frames, void* stream);
 
+/* Test hook: 1 / 0 = the estimator attention of large batches (>= 4096 rows) with / without LDS DMA staging of its key / value tiles
+ * (same matrix-core sequence: outputs agree bit for bit), -1 = the default. */
+int cv2_flow_debug_attn_dma(int32_t on);
+
 /* The estimator alone behind the reference's TensorRT seam (flow_matching.py:125-150): six contiguous device
  * tensors x(2,80,T) mask(2,1,T) mu(2,80,T) t(2,) spks(2,80) cond(2,80,T), result written in place into x. */
 int cv2_flow_estimator(cv2_flow* h, float* x, const float* mask, const float* mu, const float* t, const float* spks,

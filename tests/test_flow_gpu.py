@@ -163,6 +163,58 @@ def test_large_batch_tile_configurations_agree_with_single(dev, flow_sd):
         bar(f'flow batch-of-8 vs single, utterance {i}', rel(batch[i].cpu(), single.cpu()), 1e-2)        # measured 3.4e-3 (other tile shapes at other row counts)
 
 
+def test_attention_with_dma_staged_tiles_agrees_with_the_register_staged_form(dev, flow_sd):
+    """Batches of >= 4096 / 8192 rows run the estimator attention with its key / value tiles staged by LDS DMA (k_attn_est_dma<1> / <2>:
+    swizzled 128-byte rows, three stages, inline-asm DMA with hand-counted waits, the keys of a tile permuted among the score rows so that
+    the V^T operand is one 16-byte read).  Same products as the register-staged form (test hook cv2_flow_debug_attn_dma), another order
+    inside a matrix-core k group: the mels agree to round-off amplified by the 10 Euler steps -- the class of the batch-vs-single test
+    above -- in full context, under chunk masks, and in the cached streaming form (keys / values from the streams' caches, second call at
+    pos0 > 0)."""
+    from cv2amd import synth, lib as L
+    from cv2amd.flow import FlowEngine
+    big = FlowEngine(flow_sd, dev, max_utts=16, max_len=1200)
+
+    def utt(i, n, p):
+        inp = synth.synthetic_inputs(seed=170 + i, prompt_len=p)
+        g = torch.Generator().manual_seed(300 + i)
+        return dict(token=torch.randint(0, 6561, (1, n), generator=g, dtype=torch.int32), prompt_token=inp['prompt_token'],
+                    prompt_feat=inp['prompt_feat'], embedding=inp['embedding'])
+
+    def both(fn):
+        out = []
+        for on in (1, 0):
+            L.check(L.lib().cv2_flow_debug_attn_dma(on))
+            try:
+                out.append(fn())
+                torch.cuda.synchronize()
+            finally:
+                L.check(L.lib().cv2_flow_debug_attn_dma(-1))
+        return out
+
+    for n_utts in (8, 3):                                   # 8 x 2 x ~1000 rows: the 128-row query tiles; 3: the 64-row ones
+        utts = [utt(i, 430 + 11 * i, 35 + 4 * i) for i in range(n_utts)]
+        for streaming in (False, True):
+            a, b = both(lambda: [m.clone() for m in big.inference_batch(utts, streaming=streaming)])
+            assert all(torch.isfinite(x).all() for x in a)
+            bar(f'flow DMA-staged vs register-staged attention, {n_utts} utterances, {"chunk" if streaming else "full"}',
+                max(rel(x.cpu(), y.cpu()) for x, y in zip(a, b)), 1e-2)
+    for n_streams in (16, 10):
+        P, N = 37, 90
+        us = [utt(40 + i, N, P) for i in range(n_streams)]
+        calls = _stream_calls(P, N)[:2]
+
+        def run():
+            caches = [big.new_cache(2 * (P + N)) for _ in range(n_streams)]
+            res = []
+            for n, off, fin in calls:
+                cur = [dict(u, token=u['token'][:, :n]) for u in us]
+                res += [g.clone() for g, _ in big.inference_chunk_batch(cur, caches, finalize=fin)]
+            return res
+        a, b = both(run)
+        assert len(a) == 2 * n_streams and all(torch.isfinite(x).all() for x in a)
+        bar(f'flow DMA-staged vs register-staged attention, {n_streams} cached streams', max(rel(x.cpu(), y.cpu()) for x, y in zip(a, b)), 1e-2)
+
+
 def test_oracle_full_size_estimator_random(eng, dev, flow_sd):
     """Against the oracle itself (not only the stored vectors) at a tile-crossing length, weights bf16-rounded on both sides."""
     from oracle import flow as OF

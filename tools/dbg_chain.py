@@ -17,6 +17,7 @@ inp = synth.synthetic_inputs(seed=0, text_len=50, prompt_len=255)
 x = eng.build_lm_input(inp['text'], inp['prompt_text'], inp['prompt_token'])
 eng.add_request(0, x, 2000, 2000, mode=1, seed=7, force_len=True)
 nQ, nA, nO, nGU, nD = 36, 32, 56, 304, 112
+DUMP = sys.argv[sys.argv.index('--dump') + 1] if '--dump' in sys.argv else None
 roles = (('Q', nQ), ('A', nA), ('O', nO), ('gate/up', nGU), ('down', nD))
 for rep in range(3):
     eng.step(1, 64)
@@ -39,6 +40,11 @@ for rep in range(3):
         if t0 is None:
             t0 = r[:, 3].min() if (r[:, 3] > 0).any() else r[:, 0].min()
         us = (r - t0) / 100.0
+        if DUMP and rep == 2:                     # every block of the role: index in the role, XCD of its grid position, stamps
+            idx = np.nonzero(m)[0]
+            with open(DUMP, 'a') as fdump:
+                for i, u in zip(idx, us):
+                    fdump.write(f'{name} {i:3d} start {u[0]:7.2f} operand {u[3]:7.2f} staged {u[4]:7.2f} mfma {u[5]:7.2f} reduced {u[6]:7.2f} result {u[1]:7.2f} published {u[2]:7.2f}\n')
         f = lambda a: f'min {a.min():7.2f} med {np.median(a):7.2f} max {a.max():7.2f}'
         print(f'  {name:8s} n={len(r):3d} start [{f(us[:, 0])}]  operand [{f(us[:, 3])}]  result [{f(us[:, 1])}]  published [{f(us[:, 2])}]')
         if name == 'A':

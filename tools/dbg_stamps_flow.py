@@ -10,12 +10,15 @@ import torch
 from cv2amd import synth, lib as L
 from cv2amd.flow import FlowEngine
 
-flow = FlowEngine(synth.make_flow(), 'cuda:0', max_utts=1, max_len=2 * (320 + 512))
-inp = synth.synthetic_inputs(seed=1986, text_len=50, prompt_len=255, prompt_text_len=20)
-utt = dict(token=torch.randint(0, 6561, (1, 250), dtype=torch.int32), prompt_token=inp['prompt_token'].to('cuda:0'),
-           prompt_feat=inp['prompt_feat'].to('cuda:0'), embedding=inp['embedding'].to('cuda:0'))
+NU = int(sys.argv[1]) if len(sys.argv) > 1 else 1          # utterances per batch (32: the configs[2] tile shapes)
+flow = FlowEngine(synth.make_flow(), 'cuda:0', max_utts=NU, max_len=2 * (320 + 512))
+utts = []
+for i in range(NU):
+    inp = synth.synthetic_inputs(seed=1986 + i, text_len=50, prompt_len=255 - (37 * i) % 100, prompt_text_len=20)
+    utts.append(dict(token=torch.randint(0, 6561, (1, 250 - (53 * i) % 100), dtype=torch.int32), prompt_token=inp['prompt_token'].to('cuda:0'),
+                     prompt_feat=inp['prompt_feat'].to('cuda:0'), embedding=inp['embedding'].to('cuda:0')))
 for rep in range(2):
-    flow.inference_batch([utt], streaming=False, finalize=True)
+    flow.inference_batch(utts, streaming=False, finalize=True)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * (64 * 8))()
 L.check(L.lib().cv2_debug_stamps_flow(buf))
