@@ -575,12 +575,13 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
         }
     }
     SK_STAMP(4);
-    if (KSP > 1) {
-        // merge: group 1 parks (m, l, O) in LDS (its own tile buffers are free now), group 0 folds them in
+    if constexpr (KSP > 1) {
+        // merge: the groups 1 .. KSP - 1 park (m, l, O) in LDS (each in its own tile buffers, free now), group 0 folds them in, in group order
         constexpr float SC = 0.125f * 1.4426950408889634f;
+        static_assert((size_t)64 * NW * QS * 18 * sizeof(float) <= sizeof(Ks_[0]), "a group's tile buffers hold its parked state");
         __syncthreads();
-        float* mg = reinterpret_cast<float*>(&Ks_[KSP - 1][0][0]);      // [NW*64 threads][QS][18]
-        if (kgrp == 1) {
+        if (kgrp != 0) {
+            float* mg = reinterpret_cast<float*>(&Ks_[kgrp][0][0]);      // [NW*64 threads][QS][18]
 #pragma unroll
             for (int u = 0; u < QS; u++) {
                 float* d = mg + ((size_t)tid * QS + u) * 18;
@@ -594,17 +595,22 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
         __syncthreads();
         if (kgrp != 0) return;
 #pragma unroll
-        for (int u = 0; u < QS; u++) {
-            const float* d = mg + ((size_t)tid * QS + u) * 18;
-            const float m1 = d[0], l1 = d[1];
-            const float M = fmaxf(mrun[u], m1);
-            const float ms = M == -INFINITY ? 0.f : M;
-            const float a0 = __builtin_amdgcn_exp2f((mrun[u] - ms) * SC), a1 = __builtin_amdgcn_exp2f((m1 - ms) * SC);
-            lrun[u] = lrun[u] * a0 + l1 * a1;
+        for (int gq = 1; gq < KSP; gq++) {
+            const float* mg = reinterpret_cast<const float*>(&Ks_[gq][0][0]);
 #pragma unroll
-            for (int dt = 0; dt < 4; dt++)
+            for (int u = 0; u < QS; u++) {
+                const float* d = mg + ((size_t)tid * QS + u) * 18;
+                const float m1 = d[0], l1 = d[1];
+                const float M = fmaxf(mrun[u], m1);
+                const float ms = M == -INFINITY ? 0.f : M;
+                const float a0 = __builtin_amdgcn_exp2f((mrun[u] - ms) * SC), a1 = __builtin_amdgcn_exp2f((m1 - ms) * SC);
+                lrun[u] = lrun[u] * a0 + l1 * a1;
+                mrun[u] = M;
 #pragma unroll
-                for (int e = 0; e < 4; e++) o[u][dt][e] = o[u][dt][e] * a0 + d[2 + dt * 4 + e] * a1;
+                for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[u][dt][e] = o[u][dt][e] * a0 + d[2 + dt * 4 + e] * a1;
+            }
         }
     }
 #pragma unroll
@@ -987,16 +993,22 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         }
         // the four-wave forms stage their tiles by LDS DMA (k_attn_est_dma); CV2_ATT_DMA=0 (A/B, diagnostics): through registers as the two-group form
         static const bool dma_env = !(getenv("CV2_ATT_DMA") && getenv("CV2_ATT_DMA")[0] == '0');
+        // below 4096 rows the keys are split over wave groups of one block: four groups of a 64-row block from 1024 rows on (one 10 s utterance:
+        // flow 26.5 -> 24.9 ms), two groups of a 32-row block below (a stream's chunk alone); CV2_ATT_KSP=2 (A/B, diagnostics): two everywhere
+        static const bool ksp4_env = !(getenv("CV2_ATT_KSP") && getenv("CV2_ATT_KSP")[0] == '2');
+        const bool ksp4 = ksp4_env && M >= 1024;
         const int dma_dbg = g_att_dma.load();
         const bool dma = dma_dbg < 0 ? dma_env : dma_dbg != 0;
         if (c.inc) {
             if (M / 128 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<2, true>), dim3(8, M / 128), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<2, 4, 1, true>), dim3(8, M / 128), dim3(256), 0, c.s, a); }
             else if (M / 64 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<1, true>), dim3(8, M / 64), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<1, 4, 1, true>), dim3(8, M / 64), dim3(256), 0, c.s, a); }
+            else if (ksp4) hipLaunchKernelGGL((k_attn_est<1, 4, 4, true>), dim3(8, M / 64), dim3(1024), 0, c.s, a);
             else hipLaunchKernelGGL((k_attn_est<1, 2, 2, true>), dim3(8, M / 32), dim3(256), 0, c.s, a);
         }
         else if (M / 128 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<2>), dim3(8, M / 128), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(8, M / 128), dim3(256), 0, c.s, a); }   // enough blocks to fill the chip twice
         else if (M / 64 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<1>), dim3(8, M / 64), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(8, M / 64), dim3(256), 0, c.s, a); }
-        else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(8, M / 32), dim3(256), 0, c.s, a);       // one utterance: split keys over two wave groups
+        else if (ksp4) hipLaunchKernelGGL((k_attn_est<1, 4, 4>), dim3(8, M / 64), dim3(1024), 0, c.s, a);   // one utterance: the keys split over four wave groups of a 64-row block
+        else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(8, M / 32), dim3(256), 0, c.s, a);       // (over two groups of a 32-row block)
     }
     static const bool tail_rows_off = getenv("CV2_FLOW_TAIL_ROWS") && getenv("CV2_FLOW_TAIL_ROWS")[0] == '0';     // A/B switch (diagnostics)
     static const long tail_rows_min = getenv("CV2_FLOW_TAIL_ROWS_MIN") ? atol(getenv("CV2_FLOW_TAIL_ROWS_MIN")) : 96;    // 64-row tiles from which the 64-row blocks are used (8 streaming chunks: 192 -> 184 ms first chunk)
