@@ -169,6 +169,46 @@ def request(seed, prompt_len, text_len, dev, prompt_text_len=PROMPT_TEXT_LEN):
                 flow_embedding=inp['embedding'].to(d), llm_embedding=inp['embedding'].to(d))
 
 
+class CallerPool:
+    """The callers of concurrent tts() calls: persistent worker threads, as in the reference's harness and servers (a ThreadPoolExecutor in
+    evaluation/cosyvoice_synthesizer.py:260 and runtime/python/grpc/server.py).  A thread's FIRST device copy pays the per-thread HIP
+    initialisation (20-40 ms on this image, during which it holds the GIL): with fresh threads per round that lands inside every first
+    chunk (8 streams: p50 146 ms against 108 ms on the same box).  fresh=True (--fresh-threads) starts new threads per round instead."""
+    fresh = False
+    _inst = None
+
+    def __init__(self):
+        import queue
+        self._queue, self.q, self.done = queue, [], queue.Queue()
+
+    @classmethod
+    def run(cls, fn, n):
+        if cls.fresh:
+            ths = [threading.Thread(target=fn, args=(i,)) for i in range(n)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            return
+        if cls._inst is None:
+            cls._inst = cls()
+        self = cls._inst
+        while len(self.q) < n:
+            q = self._queue.Queue()
+            self.q.append(q)
+            threading.Thread(target=self._loop, args=(q, len(self.q) - 1), daemon=True).start()
+        for i in range(n):
+            self.q[i].put(fn)
+        for _ in range(n):
+            self.done.get()
+
+    def _loop(self, q, i):
+        while True:
+            fn = q.get()
+            try:
+                fn(i)
+            finally:
+                self.done.put(i)
+
+
 def run_calls(model, reqs, forces, stream=False, chunk_times=None):
     """The evaluation harness pattern (evaluation/cosyvoice_synthesizer.py:219,260): one thread per utterance calling tts() on ONE
     model.  Returns (list of waveforms [1, n] CPU, list of first-yield times relative to the common start); chunk_times (a list of n
@@ -200,9 +240,7 @@ def run_calls(model, reqs, forces, stream=False, chunk_times=None):
             wavs[i] = outs[0] if len(outs) == 1 else torch.cat(outs, 1)
         except Exception as e:      # noqa: BLE001
             errs.append(e)
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(n)]
-    [t.start() for t in ths]
-    [t.join() for t in ths]
+    CallerPool.run(work, n)
     if errs:
         raise errs[0]
     return wavs, first
@@ -430,6 +468,16 @@ def extras(model, st, flow_t, hift_t, dev):
         firsts.sort()
         out[n] = {'first_chunk_ms_p50': round(firsts[len(firsts) // 2] * 1e3, 1), 'first_chunk_ms_max': round(firsts[-1] * 1e3, 1),
                   'audio_s_per_s': round(audio / dts, 1)}
+        if n == 8 and not CallerPool.fresh:           # the same with new caller threads per round (what rounds 1-3 of this bench measured)
+            CallerPool.fresh = True
+            try:
+                ff = []
+                for _ in range(3):
+                    ff += run_calls(model, [sreq] * n, [None] * n, stream=True)[1]
+                ff.sort()
+                out[n]['first_chunk_ms_p50_fresh_threads'] = round(ff[len(ff) // 2] * 1e3, 1)
+            finally:
+                CallerPool.fresh = False
     # first chunk when the prompt has NOT been seen before (no prompt flow cache to start from): the number a new voice gets
     if hasattr(model, '_prompt_caches'):
         keep_max = model.prompt_cache_max
@@ -493,9 +541,7 @@ def extras(model, st, flow_t, hift_t, dev):
                         audio[i] += o['tts_speech'].shape[1] / 24000.0
                 except Exception as e:      # noqa: BLE001
                     errs.append(e)
-            ths = [threading.Thread(target=work, args=(i,)) for i in range(n)]
-            [t.start() for t in ths]
-            [t.join() for t in ths]
+            CallerPool.run(work, n)
             if errs:
                 raise errs[0]
             return firsts, sum(audio), time.perf_counter() - t0
@@ -519,6 +565,9 @@ def extras(model, st, flow_t, hift_t, dev):
                                        '(first_chunk_ms_p50_new_prompt: without it)' if getattr(model, 'prompt_cache_max', 0) > 0 else 'off',
                        'workload': 'configs[4]: streaming (hop 25, look-ahead 3), P=255: the first chunk needs prefill + 48 tokens, chunk-masked flow at '
                                    'T=600, HiFT on 90 frames; time from the tts() call to its first yielded chunk, 3 rounds',
+                       'callers': ('new threads per round' if CallerPool.fresh else 'persistent worker threads (CallerPool: a server\'s / the evaluation harness\'s '
+                                   'thread pool); first_chunk_ms_p50_fresh_threads = the same calls from new threads per round, each paying its first '
+                                   'device copy\'s per-thread HIP initialisation (20-40 ms, GIL held) inside the first chunk'),
                        'streams_1': out[1], 'streams_8': out[8]}
     return ex
 
@@ -669,7 +718,9 @@ def main():
     ap.add_argument('--batch', type=int, default=1, help='N=1 only: utterances per step (1 = configs[1], 32 = configs[2])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='N=1: skip the configs[2] / configs[4] measurements')
+    ap.add_argument('--fresh-threads', action='store_true', help='concurrent calls from new threads per round instead of persistent workers (CallerPool)')
     args = ap.parse_args()
+    CallerPool.fresh = bool(args.fresh_threads)
     if args.steps is None:
         args.steps = 6 if args.gpus == 1 else 2
     if args.warmup is None:

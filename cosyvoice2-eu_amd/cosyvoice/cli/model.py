@@ -98,6 +98,7 @@ class CosyVoice2Model:
         # of a few and leaving the rest to a second round (measured, 8 generator-text streams: rounds of 4 + 4 chunks at 67 ms each
         # instead of one of 8)
         self.chunk_wave_ms, self.chunk_quiet_ms = 3.0, 1.0
+        self._joining, self.join_burst = set(), 8      # slots taken but not prefilled yet; decode burst length while there are any
         self._chunks_active = 0                # chunk rounds (flow + HiFT) in progress: decode bursts beside them take the launches
         self._bi_incoming = 0                  # generator-text calls that have entered tts() but not yet joined the hub
         self._sched_log = None                 # diagnostics (tools/bench_bistream.py): list receiving (t, kind, info) of hub / chunk rounds
@@ -412,6 +413,8 @@ class CosyVoice2Model:
         c.done, c.speech, c.exc, c.cap_hint, c.pkey, c.taken = False, None, None, cap_hint, pkey, False
         with self.lock:
             self._chunk_q.append(c)
+        if self._sched_log is not None:
+            self._sched_log.append((time.perf_counter(), 'submit', dict(queued=len(self._chunk_q), offset=offset)))
         n_streams = min(self._n_shared, self.max_batch)
         if n_streams > 1 and self.chunk_wave_ms > 0:
             t_last = time.perf_counter()
@@ -445,7 +448,7 @@ class CosyVoice2Model:
         return c.speech
 
     # ---- llm side: llm_job (model.py:118-139) as bursts on the LLM stream -------------------------------------------
-    def _enter_shared(self):
+    def _enter_shared(self, joining=True):
         """A streaming / serial call takes one LLM slot; waits while a coalesced batch runs (or waits to run) or no slot is free."""
         with self._mode:
             while self._excl or self._excl_waiting > 0 or not self._slot_free:
@@ -453,11 +456,14 @@ class CosyVoice2Model:
             self._n_shared += 1
             slot = self._slot_free.pop(0)
             self._active_slots.add(slot)
+            if joining:                                                       # (prefilled by _llm_start; the bistream hub feeds its slots itself)
+                self._joining.add(slot)
         return slot
 
     def _exit_shared(self, slot):
         with self._mode:
             self._active_slots.discard(slot)
+            self._joining.discard(slot)
             self._enq.pop(slot, None)
             self._slot_ready.pop(slot, None)
             self._slot_free.append(slot)
@@ -484,6 +490,8 @@ class CosyVoice2Model:
     def _llm_start(self, slot, text, prompt_text, llm_prompt_speech_token, force_len=None):
         """llm.py:684-719 step 0 (prefill + first draw) for one call.  Calls that start together are prefilled TOGETHER: the request
         is queued, whoever gets the device next runs one batched prefill (one pass over the weights) for every queued request."""
+        if self._sched_log is not None:
+            self._sched_log.append((time.perf_counter(), 'start', dict(slot=slot)))
         p = self._Prefill()
         p.slot, p.text, p.prompt_text, p.ptok, p.done, p.exc, p.force_len = slot, text, prompt_text, llm_prompt_speech_token, False, None, force_len
         with self.lock:
@@ -513,6 +521,9 @@ class CosyVoice2Model:
                         ev.record(self.llm_stream)
                     for b in batch:
                         self._slot_ready[b.slot], self._enq[b.slot] = ev, 1          # the prefill draws token 0
+                        self._joining.discard(b.slot)
+                    if self._sched_log is not None:
+                        self._sched_log.append((time.perf_counter(), 'prefill', dict(n=len(batch), rows=sum(x.shape[0] for x in xs))))
                 except BaseException as e:
                     for b in batch:
                         b.exc = e
@@ -531,6 +542,11 @@ class CosyVoice2Model:
             return
         with self._mode:
             act = sorted(self._active_slots)
+            # a call that has taken its slot but is not prefilled yet (it started a moment after the others): its prefill queues on the
+            # LLM stream behind whatever is enqueued now, so keep that short -- the caller's loop asks again (measured with 8 calls
+            # starting within 5 ms of each other: three of them missed the first prefill by < 1 ms and waited 41 ms behind a 47-step burst)
+            if self._joining:
+                n_steps = min(n_steps, self.join_burst)
         with self.llm_lock, torch.cuda.stream(self.llm_stream):
             if self.stream_live_rows:
                 self.llm.step_rows(act, n_steps, shared=shared)
@@ -543,6 +559,8 @@ class CosyVoice2Model:
         self._bursts.append(ev)
         for sl in act:
             self._enq[sl] = self._enq.get(sl, 0) + n_steps
+        if self._sched_log is not None:
+            self._sched_log.append((time.perf_counter(), 'burst', dict(rows=len(act), steps=n_steps, shared=bool(shared))))
 
     def _llm_poll(self, this_uuid, slot, need=None):
         """Publish the tokens of the slot so far (the reference's thread appends to the same list).  need = None: wait for all the
@@ -808,7 +826,7 @@ class CosyVoice2Model:
         toks = self.tts_speech_token_dict[this_uuid]
         call = None
         try:
-            slot = None if vc else self._enter_shared()
+            slot = None if vc else self._enter_shared(joining=False)
             if vc:
                 toks.extend(source_speech_token.flatten().tolist())
                 self.llm_end_dict[this_uuid] = True
@@ -884,7 +902,11 @@ class CosyVoice2Model:
         this_uuid = str(uuid.uuid1())
         # the current device is per thread and a new thread starts on device 0: callers run tts() from pool threads (the evaluation
         # harness, evaluation/cosyvoice_synthesizer.py:260) while the model may live on another GPU of the node (one rank per GPU)
+        if self._sched_log is not None:
+            self._sched_log.append((time.perf_counter(), 'call', {}))
         torch.cuda.set_device(self.device)
+        if self._sched_log is not None:
+            self._sched_log.append((time.perf_counter(), 'device', {}))
         if self._on_call is not None:
             self._on_call(this_uuid)
         with self.lock:
@@ -925,6 +947,8 @@ class CosyVoice2Model:
         slot = self._enter_shared()
         hop, la = self.token_hop_len, self.flow.pre_lookahead_len
         try:
+            if self._sched_log is not None:
+                self._sched_log.append((time.perf_counter(), 'slot', dict(slot=slot)))
             text_d, ptext_d, lptok_d = text.to(dev), prompt_text.to(dev), llm_prompt_speech_token.to(dev)
             if stream is True:
                 token_offset = 0

@@ -19,8 +19,38 @@ kw = dict(text=inp['text'], prompt_text=inp['prompt_text'], llm_prompt_speech_to
           llm_embedding=inp['embedding'])
 
 
+POOL = '--fresh-threads' not in sys.argv       # callers are the persistent workers of a server's pool (default); --fresh-threads: new threads per
+_pool = None                                   # round, whose first device copy costs ~20 ms of per-thread HIP initialisation on this image
+
+
+class _Pool:
+    def __init__(self, n):
+        import queue
+        self.q = [queue.Queue() for _ in range(n)]
+        self.done = queue.Queue()
+        self.ths = [threading.Thread(target=self._loop, args=(i,), daemon=True) for i in range(n)]
+        [t.start() for t in self.ths]
+
+    def _loop(self, i):
+        while True:
+            fn = self.q[i].get()
+            try:
+                fn(i)
+            finally:
+                self.done.put(i)
+
+    def run(self, fn, n):
+        for i in range(n):
+            self.q[i].put(fn)
+        for _ in range(n):
+            self.done.get()
+
+
 def run(n):
+    global _pool
     first, total = [None] * n, [0.0] * n
+    if POOL and _pool is None:
+        _pool = _Pool(N)
     t0 = time.perf_counter()
 
     def work(i):
@@ -28,9 +58,12 @@ def run(n):
             if first[i] is None:
                 first[i] = time.perf_counter() - t0
             total[i] += out['tts_speech'].shape[1] / 24000.0
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(n)]
-    [t.start() for t in ths]
-    [t.join() for t in ths]
+    if POOL:
+        _pool.run(work, n)
+    else:
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
     return first, sum(total), time.perf_counter() - t0
 
 
