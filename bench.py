@@ -197,16 +197,18 @@ class CallerPool:
             threading.Thread(target=self._loop, args=(q, len(self.q) - 1), daemon=True).start()
         for i in range(n):
             self.q[i].put(fn)
-        for _ in range(n):
-            self.done.get()
+        errs = [e for e in (self.done.get() for _ in range(n)) if e is not None]
+        if errs:
+            raise errs[0]
 
     def _loop(self, q, i):
-        while True:
+        while True:                                   # a worker survives a failing call: the round's first error is re-raised by run()
             fn = q.get()
             try:
                 fn(i)
-            finally:
-                self.done.put(i)
+                self.done.put(None)
+            except BaseException as e:      # noqa: BLE001
+                self.done.put(e)
 
 
 def run_calls(model, reqs, forces, stream=False, chunk_times=None):

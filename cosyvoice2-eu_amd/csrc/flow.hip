@@ -695,7 +695,8 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
     kstep = CACHE ? 64 * 512 : 64 * 1024;
     // The DMA instructions are inline asm on purpose: hipcc orders every LDS read that may alias the destination of a DMA builtin behind
     // vmcnt(0) (here: each tile's fragment reads behind the DMA issued just before them, i.e. no tile in flight).  Written this way the
-    // compiler knows nothing of the LDS writes and the waits below are the only ones; m0 is used by nothing else in this kernel.
+    // compiler knows nothing of the LDS writes and the waits below are the only ones; m0 is used by nothing else in this kernel (it is a
+    // reserved register: hipcc rejects it on a clobber list, and itself writes it only for DMA builtins, LDS-direct and GWS operations).
     auto dma = [&](int kt, int st) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {

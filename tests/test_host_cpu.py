@@ -473,3 +473,33 @@ def test_bistream_host_bookkeeping_matches_the_oracle():
         assert got == want and eng.slots[2]['out'] == want_out, (seed, got[:8], want[:8])
         assert eng.feeds[-1][2] and sum(1 for f in eng.feeds if f[2]) == 1             # exactly one final feed, the last one
         assert pulled == sorted(pulled) and pulled[0] == 0                              # pieces are pulled lazily, never ahead of a feed they enable
+
+
+def test_bench_caller_pool_runs_every_call_once_in_both_modes():
+    """bench.CallerPool: n calls on persistent worker threads (the same threads round after round) or on new threads per round; every index
+    runs exactly once per round and an exception inside a call does not lose the round."""
+    import threading
+    import bench
+    seen = []
+    lock = threading.Lock()
+
+    def fn(i):
+        with lock:
+            seen.append((i, threading.get_ident()))
+        if i == 1:
+            raise RuntimeError('a failing call')
+    keep = bench.CallerPool.fresh
+    try:
+        bench.CallerPool.fresh = False
+        for _ in range(3):
+            with pytest.raises(RuntimeError, match='a failing call'):     # re-raised once the whole round has run; the worker survives
+                bench.CallerPool.run(fn, 4)
+        assert sorted(i for i, _ in seen) == sorted(list(range(4)) * 3)
+        per_index = {i: {t for j, t in seen if j == i} for i in range(4)}
+        assert all(len(v) == 1 for v in per_index.values())            # index i always lands on worker i
+        seen.clear()
+        bench.CallerPool.fresh = True
+        bench.CallerPool.run(lambda i: fn(i) if i != 1 else None, 3)
+        assert sorted(i for i, _ in seen) == [0, 2]
+    finally:
+        bench.CallerPool.fresh = keep
