@@ -994,10 +994,9 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         }
         // the four-wave forms stage their tiles by LDS DMA (k_attn_est_dma); CV2_ATT_DMA=0 (A/B, diagnostics): through registers as the two-group form
         static const bool dma_env = !(getenv("CV2_ATT_DMA") && getenv("CV2_ATT_DMA")[0] == '0');
-        // below 4096 rows the keys are split over wave groups of one block: four groups of a 64-row block from 1024 rows on (one 10 s utterance:
-        // flow 26.5 -> 24.9 ms), two groups of a 32-row block below (a stream's chunk alone); CV2_ATT_KSP=2 (A/B, diagnostics): two everywhere
-        static const bool ksp4_env = !(getenv("CV2_ATT_KSP") && getenv("CV2_ATT_KSP")[0] == '2');
-        const bool ksp4 = ksp4_env && M >= 1024;
+        // below 4096 rows the keys are split over four wave groups of a 64-row block (one 10 s utterance: flow 26.5 -> 24.9 ms against two
+        // groups of a 32-row block; a stream's chunk alone: first chunk 51.3 -> 50.8 ms); CV2_ATT_KSP=2 (A/B, diagnostics): the two-group form
+        static const bool ksp4 = !(getenv("CV2_ATT_KSP") && getenv("CV2_ATT_KSP")[0] == '2');
         const int dma_dbg = g_att_dma.load();
         const bool dma = dma_dbg < 0 ? dma_env : dma_dbg != 0;
         if (c.inc) {
