@@ -1,5 +1,6 @@
 """First-chunk latency of N concurrent streaming calls on ONE model (BASELINE config 5: streaming, B = 8):
-python tools/bench_streams.py [streams] [rounds].  Each round starts N threads at once; reports p50 / max of t(first chunk)."""
+python tools/bench_streams.py [streams] [rounds] [--stagger MS] [--fresh-threads] [--trace].  Each round starts N calls at once (or within MS
+milliseconds of each other); reports p50 / max of the time from a call to its first chunk."""
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cosyvoice2-eu_amd'))
@@ -7,7 +8,7 @@ import torch
 from cv2amd import synth
 from cosyvoice.cli.model import CosyVoice2Model
 
-_a = [x for x in sys.argv[1:] if not x.startswith('--')]
+_a = [x for i, x in enumerate(sys.argv[1:]) if not x.startswith('--') and sys.argv[i] != '--stagger']
 N = int(_a[0]) if len(_a) > 0 else 8
 R = int(_a[1]) if len(_a) > 1 else 4
 m = CosyVoice2Model(synth.make_llm(), synth.make_flow(), synth.make_hift(), max_text=128, max_prompt_tokens=320, max_new_tokens=1100,
@@ -19,6 +20,9 @@ kw = dict(text=inp['text'], prompt_text=inp['prompt_text'], llm_prompt_speech_to
           llm_embedding=inp['embedding'])
 
 
+import random
+STAGGER = float(sys.argv[sys.argv.index('--stagger') + 1]) if '--stagger' in sys.argv else 0.0      # --stagger MS: random start offsets
+_rng = random.Random(1986)
 POOL = '--fresh-threads' not in sys.argv       # callers are the persistent workers of a server's pool (default); --fresh-threads: new threads per
 _pool = None                                   # round, whose first device copy costs ~20 ms of per-thread HIP initialisation on this image
 
@@ -54,9 +58,13 @@ def run(n):
     t0 = time.perf_counter()
 
     def work(i):
+        t_call = t0
+        if STAGGER > 0:                            # calls that do NOT start together: each waits a random 0 .. STAGGER ms first
+            time.sleep(_rng.random() * STAGGER * 1e-3)
+            t_call = time.perf_counter()
         for out in m.tts(**kw, stream=True):
             if first[i] is None:
-                first[i] = time.perf_counter() - t0
+                first[i] = time.perf_counter() - t_call
             total[i] += out['tts_speech'].shape[1] / 24000.0
     if POOL:
         _pool.run(work, n)
