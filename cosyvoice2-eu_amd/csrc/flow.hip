@@ -10,7 +10,8 @@
 //
 // Kernels (roofline that bounds each):
 //   k_gemm (gemm.h)        MFMA bf16   every Linear / Conv1d of the encoder and the estimator, fused epilogues
-//   k_attn_est             MFMA bf16   estimator self-attention, flash style (no T x T matrix in HBM)
+//   k_attn_est             MFMA bf16   estimator self-attention, flash style (no T x T matrix in HBM); below 4 096 rows four key groups per block
+//   k_attn_est_dma         MFMA bf16   the same from 4 096 rows on, key / value tiles by LDS DMA (three stages, three waves per SIMD)
 //   k_relsoftmax           HBM         conformer rel-pos softmax over explicit score matrices (encoder only, ~2 % of FLOPs)
 //   k_layernorm, k_pack, k_euler, ...  HBM   small row-wise kernels
 #include "gemm_launch.h"
