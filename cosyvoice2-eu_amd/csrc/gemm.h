@@ -50,6 +50,9 @@ struct GemmArgs {
     // slot -- K rows [frames][512] for features [kvc_k0, vt_n0), V^T [512][frames] for features >= vt_n0 -- at frames pos0[s] + t
     // (what a separate k_kv_append launch per transformer block did: 7.5 us x 560 per chunk round)
     uint16_t* const* kvc; const int* kvc_frames; const int* kvc_pos0; long kvc_slot; int kvc_k0;
+    // split-K as a batch (the one-prompt prefill's down projection: blockIdx.z = K slice, a_bstride = w.r.t. columns, o_bstride = one
+    // partial matrix): the packed W's row-tile stride in k blocks stays that of the WHOLE K
+    int w_ks;                                                       // 0: K / 32
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -157,8 +160,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
     const int m0 = by_ * BM, n0 = bx_ * BN;
     const uint16_t* A = a.A + (size_t)blockIdx.z * a.a_bstride;
     const uint16_t* W = a.W + (size_t)blockIdx.z * a.w_bstride;
-    const int KS = a.K / 32;                                                  // 32-wide k blocks in the packed W
+    const int KS = a.w_ks > 0 ? a.w_ks : a.K / 32;                            // 32-wide k blocks in the packed W
     const int nk = a.K / 64;
+    const uint16_t* A_lo = SPLITA ? a.A_lo + (size_t)blockIdx.z * a.a_bstride : nullptr;
 
     // per-lane source coordinates of an LDS-DMA piece (lane writes LDS byte lane*16 of the sub-tile)
     const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 5) << 1);
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmArgs a) {
             const void* src;
             if (p < NAP) {                                // wave-uniform
                 const int pp = SPLITA ? p % NA : p, sub = pp >> 1, ks = pp & 1;
-                const uint16_t* Ab = (SPLITA && p >= NA) ? a.A_lo : A;
+                const uint16_t* Ab = (SPLITA && p >= NA) ? A_lo : A;
                 src = Ab + ((long)(m0 + sub * 16 + srow) + a.a_row_off) * a.lda + kt * 64 + ks * 32 + schunk * 8;
             } else {
                 const int q = p - NAP, sub = q >> 1, ks = q & 1;

@@ -106,9 +106,9 @@ static int gemm_launch_cfg(const GemmArgs& a, int cfg, int batch, bool packed, h
         return gemm_go<64, 256, 2, 4>(a, batch, packed, s);
     }
     if (cfg == 4) {
-        CV2_CHECK(a.N % 128 == 0 && a.A_lo && batch == 1, "gemm cfg4: N=%d %% 128, A_lo required", a.N);
+        CV2_CHECK(a.N % 128 == 0 && a.A_lo, "gemm cfg4: N=%d %% 128, A_lo required", a.N);
         // one utterance's prefill (3 row tiles of 128): the N = 896 / 1152 layers give 21-27 blocks; 64-row tiles double them
-        if ((long)(a.N / 128) * (a.M / 128) < 128) return gemm_go<64, 128, 2, 4, true>(a, batch, packed, s);
+        if ((long)(a.N / 128) * (a.M / 128) * batch < 128) return gemm_go<64, 128, 2, 4, true>(a, batch, packed, s);
         return gemm_go<128, 128, 2, 4, true>(a, batch, packed, s);
     }
     CV2_CHECK(a.N % 64 == 0, "gemm cfg2: N=%d %% 64", a.N);

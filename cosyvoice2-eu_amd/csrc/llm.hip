@@ -1658,13 +1658,23 @@ sample_done:
 __device__ __forceinline__ uint32_t pk2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
 
 // RMSNorm + hi/lo split: x fp32 [M][H] -> bf16 planes; one wave per row; rows >= M_valid -> 0
-__global__ __launch_bounds__(256) void k_rms_split(const float* x, const float* g, float eps, uint16_t* hi, uint16_t* lo, int M_valid, int Mp, int H) {
+// parts != null: x += parts[0] + .. + parts[np - 1] first (the split-K partials of the previous layer's down projection, index order), written back
+__global__ __launch_bounds__(256) void k_rms_split(float* x, const float* g, float eps, uint16_t* hi, uint16_t* lo, int M_valid, int Mp, int H,
+                                                   const float* parts = nullptr, int np = 0, long pstride = 0) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= Mp) return;
     const int per = H / 64;                                   // 14 for hidden 896
     float v[16];
     float sq = 0.f;
-    for (int i = 0; i < per; i++) { v[i] = row < M_valid ? x[(size_t)row * H + lane * per + i] : 0.f; sq += v[i] * v[i]; }
+    for (int i = 0; i < per; i++) {
+        const size_t o = (size_t)row * H + lane * per + i;
+        v[i] = row < M_valid ? x[o] : 0.f;
+        if (parts && row < M_valid) {
+            for (int p = 0; p < np; p++) v[i] += parts[p * pstride + o];
+            x[o] = v[i];
+        }
+        sq += v[i] * v[i];
+    }
     const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
     for (int i = 0; i < per; i += 2) {
         const int c = lane * per + i;
@@ -1894,6 +1904,14 @@ __global__ __launch_bounds__(256) void k_swiglu_split(const float* gu, uint16_t*
     const uint16_t hb = f2bf(v);
     hi[idx] = hb; lo[idx] = f2bf(v - bf2f(hb));
 }
+// x += parts[0] + .. + parts[np - 1] (after the last layer of a split-K prefill)
+__global__ void k_fold_parts(float* x, const float* parts, int np, long pstride, long n) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    float v = x[idx];
+    for (int p = 0; p < np; p++) v += parts[p * pstride + idx];
+    x[idx] = v;
+}
 __global__ void k_gather_rows(const float* x, const int* rows, float* out, int n, int H) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx < n * H) out[idx] = x[(size_t)rows[idx / H] * H + idx % H];
@@ -1928,6 +1946,7 @@ struct cv2_llm {
     int pf_rows;
     float *pf_x, *pf_qkv, *pf_q, *pf_gu, *pf_last;
     uint16_t *pf_hi, *pf_lo;
+    float *pf_parts;           // [PF_SPLITK][PF_SPLIT_ROWS][hidden] split-K partials of the down projection (prefills of <= PF_SPLIT_ROWS rows)
     int* pf_int;               // row_seq[pf_rows], row_pos[pf_rows], seq tables 5 x 32
     u64* gran;                 // k_step hand-off granules [layers][gl]
     unsigned gran_bytes;
@@ -1941,6 +1960,11 @@ struct cv2_llm {
     hipStream_t cap_stream;    // private stream used only to capture the decode-step graph (the caller's may be the null stream)
 };
 
+// One prompt's prefill: the down projection (N = hidden, K = inter) is 35 blocks of 64 x 128 with a 76-step K loop each -- 159 MFLOP on one
+// CU while 220 idle.  Up to PF_SPLIT_ROWS rows its K is split PF_SPLITK ways as a batch of GEMMs into partial matrices, which the next
+// layer's k_rms_split (or k_fold_parts after the last layer) adds to the residual stream in index order.
+#define PF_SPLITK 4
+#define PF_SPLIT_ROWS 512
 static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return base ? base + o : (char*)nullptr; };
@@ -1992,6 +2016,7 @@ static size_t carve(const cv2_llm_dims& d, cv2_llm* h, char* base) {
         p = take(R * d.inter * 2); if (h) h->pf_hi = (uint16_t*)p;
         p = take(R * d.inter * 2); if (h) h->pf_lo = (uint16_t*)p;
         p = take((2 * R + 6 * 32) * 4); if (h) h->pf_int = (int*)p;
+        p = take((size_t)PF_SPLITK * PF_SPLIT_ROWS * d.hidden * 4); if (h) h->pf_parts = (float*)p;
     }
     return off;
 }
@@ -2379,9 +2404,15 @@ static int rows_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int32_t
     CV2_CHECK(H % 128 == 0 || H % 64 == 0, "prefill: hidden %% 64");
     CV2_CHECK(NQKV % 128 == 0 && H % 128 == 0 && (2 * I) % 128 == 0 && NQ % 64 == 0 && I % 64 == 0, "cv2_llm_prefill_batch: dims must be multiples of 128 / 64 for the GEMM tiles");
     const size_t cache_l = (size_t)d.max_seqs * d.n_kv * d.max_pos * 64;
+    static const bool splitk_env = !(getenv("CV2_PREFILL_SPLITK") && getenv("CV2_PREFILL_SPLITK")[0] == '0');      // A/B switch (diagnostics)
+    const bool splitk = splitk_env && Mp <= PF_SPLIT_ROWS && I % (PF_SPLITK * 64) == 0;
+    const long pstride = (long)Mp * H;
+    bool pending = false;                                  // the previous layer's down projection left partials
     for (int l = 0; l < d.layers; l++) {
         const cv2_llm_layer& L = h->layers[l];
-        hipLaunchKernelGGL(k_rms_split, dim3(Mp / 4), dim3(256), 0, s, (const float*)h->pf_x, L.ln1, d.rms_eps, h->pf_hi, h->pf_lo, M, Mp, H);
+        hipLaunchKernelGGL(k_rms_split, dim3(Mp / 4), dim3(256), 0, s, h->pf_x, L.ln1, d.rms_eps, h->pf_hi, h->pf_lo, M, Mp, H,
+                           pending ? (const float*)h->pf_parts : nullptr, PF_SPLITK, pstride);
+        pending = false;
         {
             GemmArgs g = gemm_args(h->pf_hi, H, 0, L.wqkv, Mp, NQKV, H);
             g.A_lo = h->pf_lo; g.bias = L.bqkv; g.out_f32 = h->pf_qkv; g.ldo = NQKV;
@@ -2401,19 +2432,26 @@ static int rows_batch(cv2_llm* h, int32_t n, const int32_t* slots, const int32_t
             g.A_lo = h->pf_lo; g.res = h->pf_x; g.ldres = H; g.out_f32 = h->pf_x; g.ldo = H;
             if (gemm_launch_cfg(g, 4, 1, true, s)) return -1;
         }
-        hipLaunchKernelGGL(k_rms_split, dim3(Mp / 4), dim3(256), 0, s, (const float*)h->pf_x, L.ln2, d.rms_eps, h->pf_hi, h->pf_lo, M, Mp, H);
+        hipLaunchKernelGGL(k_rms_split, dim3(Mp / 4), dim3(256), 0, s, h->pf_x, L.ln2, d.rms_eps, h->pf_hi, h->pf_lo, M, Mp, H, (const float*)nullptr, 0, 0L);
         {
             GemmArgs g = gemm_args(h->pf_hi, H, 0, L.wgu, Mp, 2 * I, H);
             g.A_lo = h->pf_lo; g.out_f32 = h->pf_gu; g.ldo = 2 * I;
             if (gemm_launch_cfg(g, 4, 1, true, s)) return -1;
         }
         hipLaunchKernelGGL(k_swiglu_split, dim3(((long)Mp * I + 255) / 256), dim3(256), 0, s, (const float*)h->pf_gu, h->pf_hi, h->pf_lo, M, Mp, I);
-        {
+        if (splitk) {
+            GemmArgs g = gemm_args(h->pf_hi, I, 0, L.wdown, Mp, H, I / PF_SPLITK);
+            g.A_lo = h->pf_lo; g.a_bstride = I / PF_SPLITK; g.w_ks = I / 32; g.w_bstride = (long)(I / PF_SPLITK / 32) * 512;
+            g.out_f32 = h->pf_parts; g.ldo = H; g.o_bstride = pstride;
+            if (gemm_launch_cfg(g, 4, PF_SPLITK, true, s)) return -1;
+            pending = true;
+        } else {
             GemmArgs g = gemm_args(h->pf_hi, I, 0, L.wdown, Mp, H, I);
             g.A_lo = h->pf_lo; g.res = h->pf_x; g.ldres = H; g.out_f32 = h->pf_x; g.ldo = H;
             if (gemm_launch_cfg(g, 4, 1, true, s)) return -1;
         }
     }
+    if (pending) hipLaunchKernelGGL(k_fold_parts, dim3(((long)M * H + 255) / 256), dim3(256), 0, s, h->pf_x, (const float*)h->pf_parts, PF_SPLITK, pstride, (long)M * H);
     // last row of every prompt -> final norm -> llm_decoder -> first draw
     hipLaunchKernelGGL(k_gather_rows, dim3((n * H + 255) / 256), dim3(256), 0, s, (const float*)h->pf_x, d_last, h->pf_last, n, H);
     {
