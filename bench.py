@@ -289,7 +289,7 @@ def counter_fields(pmc_flow, pmc_hift, hift_tf):
                           'cycles = kernel-trace duration x 2.4 GHz (util_counter) or GRBM_GUI_ACTIVE / 8 (util_counter_gui_active)'}
     if pmc_hift:
         tot = (pmc_hift['hbm_read_MB_per_rep'] + pmc_hift['hbm_write_MB_per_rep']) / 1e3
-        k6 = next((r for r in pmc_hift['kernels'] if r['kernel'] == 'k_conv6'), {})
+        k6 = max((r for r in pmc_hift['kernels'] if r['kernel'].startswith('k_conv6')), key=lambda r: r.get('us_per_rep') or 0, default={})     # (k_conv6<2>: the 128-frame form)
         hift = {'hbm_gbs': pmc_hift.get('hbm_GBs_over_kernel_time'), 'hbm_GB_per_10s_audio': round(tot, 3), 'survey_8d_GB_per_10s_audio': 0.28,
                 'k_conv6': {'hbm_gbs': k6.get('hbm_GBs'), 'mfma_util_counter': k6.get('mfma_util_wall'), 'avg_us': k6.get('avg_us')},
                 'measured_in_this_run': False, 'source': pmc_hift['_file'] + ' (500 mel frames = 10 s of audio per rep; FETCH_SIZE x 2 + WRITE_SIZE over the stage\'s kernel time); '

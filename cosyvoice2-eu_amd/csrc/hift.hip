@@ -169,15 +169,19 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #define C6_G 4                                        // 16-channel steps per weight register set (4 = one tap of the 64-channel chunk)
 #define C6_LD 72                                      // bf16 elements per line-buffer row (64 + 8: 144-B stride, conflict-free ds_read_b128)
 // (split3t / pack_hi: common.h)
+// FT = frame tiles of 32 per wave: 2 -> blocks of 128 frames (CV_BT), 1 -> blocks of 64 frames for convolutions whose 128-frame grid leaves
+// half the CUs idle (one utterance: the 256-channel stage is 32 x 4 = 128 blocks)
+template <int FT>
 __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
+    constexpr int BT = 64 * FT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     { const size_t zo = (size_t)blockIdx.z * a.zs; a.x += zo; a.out += zo; if (a.res) a.res += zo; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx_, by_;
     xcd_tile_yfast(bx_, by_);                                       // the output-channel tiles of one frame tile read the same input rows: one L2
-    const int t0 = bx_ * CV_BT, co0 = by_ * 64;
+    const int t0 = bx_ * BT, co0 = by_ * 64;
     const int span = (a.taps - 1) * a.dil;
-    const int rows = CV_BT + span;
+    const int rows = BT + span;
     uint16_t* xp[3];
     xp[0] = reinterpret_cast<uint16_t*>(smem); xp[1] = xp[0] + (size_t)rows * C6_LD; xp[2] = xp[1] + (size_t)rows * C6_LD;
     const int ntile = a.CoutP / 32;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
     const int li = lane & 31, lk = lane >> 5;
-    const int fw = wave >> 1, cw = wave & 1;                        // frame half (64 frames), 32-channel output tile
+    const int fw = wave >> 1, cw = wave & 1;                        // frame half (32 FT frames), 32-channel output tile
     const size_t kbstride = (size_t)ntile * 3 * 512;                // elements between consecutive 16-channel blocks of one tap
     for (int c0 = 0; c0 < a.CinP; c0 += CV_CK) {
         __syncthreads();
@@ -237,25 +241,25 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
 #define C6_MMA(SET, GI)                                                                                             \
         _Pragma("unroll") for (int g_ = 0; g_ < C6_G; g_++) {                                                         \
             const int si_ = (GI) * C6_G + g_;                                                                         \
-            const size_t xo_ = (size_t)(fw * 64 + li + (si_ >> 2) * a.dil) * C6_LD + (si_ & 3) * 16 + lk * 8;         \
+            const size_t xo_ = (size_t)(fw * (32 * FT) + li + (si_ >> 2) * a.dil) * C6_LD + (si_ & 3) * 16 + lk * 8;         \
             bf16x8 x0[3], x1[3];                                                                                      \
             _Pragma("unroll") for (int p = 0; p < 3; p++) {                                                           \
                 x0[p] = *reinterpret_cast<const bf16x8*>(xp[p] + xo_);                                                \
-                x1[p] = *reinterpret_cast<const bf16x8*>(xp[p] + xo_ + 32 * C6_LD);                                   \
+                if (FT == 2) x1[p] = *reinterpret_cast<const bf16x8*>(xp[p] + xo_ + 32 * C6_LD);                      \
             }                                                                                                       \
             const bf16x8 w0_ = SET[g_ * 3], w1_ = SET[g_ * 3 + 1], w2_ = SET[g_ * 3 + 2];                             \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[2], w0_, acc0, 0, 0, 0);                                \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[2], w0_, acc1, 0, 0, 0);                                \
+            if (FT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[2], w0_, acc1, 0, 0, 0);                                \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[1], w1_, acc0, 0, 0, 0);                                \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[1], w1_, acc1, 0, 0, 0);                                \
+            if (FT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[1], w1_, acc1, 0, 0, 0);                                \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[0], w2_, acc0, 0, 0, 0);                                \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w2_, acc1, 0, 0, 0);                                \
+            if (FT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w2_, acc1, 0, 0, 0);                                \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[1], w0_, acc0, 0, 0, 0);                                \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[1], w0_, acc1, 0, 0, 0);                                \
+            if (FT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[1], w0_, acc1, 0, 0, 0);                                \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[0], w1_, acc0, 0, 0, 0);                                \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w1_, acc1, 0, 0, 0);                                \
+            if (FT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w1_, acc1, 0, 0, 0);                                \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[0], w0_, acc0, 0, 0, 0);                                \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w0_, acc1, 0, 0, 0);                                \
+            if (FT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w0_, acc1, 0, 0, 0);                                \
         }
         static_assert(4 % C6_G == 0, "a register set must not straddle taps");
         const int ngroups = a.taps * 4 / C6_G;
@@ -275,13 +279,13 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
     }
     // epilogue: identical to k_conv
 #pragma unroll
-    for (int tile = 0; tile < 2; tile++) {
+    for (int tile = 0; tile < FT; tile++) {
         const int co = co0 + cw * 32 + li;
         if (co >= a.Cout_store) continue;
         const float b = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int t = t0 + fw * 64 + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int t = t0 + fw * (32 * FT) + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             if (t >= a.L_out) continue;
             float v = (tile == 0 ? acc0[r] : acc1[r]) + b;
             if (a.res) v += a.res[(size_t)t * a.ldres + co];
@@ -555,7 +559,8 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
     static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
     if (!once) {
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv6<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv6<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
     *out = h;
@@ -584,8 +589,17 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
     static const bool fp32_only = getenv("CV2_HIFT_FP32") && getenv("CV2_HIFT_FP32")[0] == '1';      // A/B switch: the fp32 matrix-core kernel everywhere
     if (cw.w3 && !fp32_only) {
         a.w3 = cw.w3;
+        // fewer 128-frame blocks than CUs (one utterance's 256- and 512-channel stages): 64-frame blocks; CV2_HIFT_BT64=0: A/B, diagnostics
+        static const bool bt64 = !(getenv("CV2_HIFT_BT64") && getenv("CV2_HIFT_BT64")[0] == '0');
+        const long blocks128 = (long)((L_out + CV_BT - 1) / CV_BT) * (cw.cout_pad / 64) * g_hz_n;
+        if (bt64 && blocks128 < 200) {
+            const size_t sm = (size_t)(64 + (cw.taps - 1) * cw.dil) * C6_LD * 2 * 3;
+            hipLaunchKernelGGL(k_conv6<1>, dim3((L_out + 63) / 64, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
+            CV2_LAUNCH_CHECK();
+            return 0;
+        }
         const size_t sm = (size_t)(CV_BT + (cw.taps - 1) * cw.dil) * C6_LD * 2 * 3;
-        hipLaunchKernelGGL(k_conv6, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
+        hipLaunchKernelGGL(k_conv6<2>, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
         CV2_LAUNCH_CHECK();
         return 0;
     }

@@ -27,8 +27,14 @@ elif what == 'hift':
     from cv2amd.hift import HiftEngine
     eng = HiftEngine(synth.make_hift(), dev, max_frames=512)
     mel = torch.randn(1, 80, 500, device=dev) * 0.5
-    for _ in range(reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for i in range(reps):                          # exactly `reps` calls; the last one is timed
+        if i == reps - 1:
+            e0.record()
         eng.inference(mel, None, seed=1)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f'hift, 500 frames: {e0.elapsed_time(e1):.3f} ms (last of {reps} calls)')
 else:
     from cv2amd.llm import LLMEngine
     eng = LLMEngine(synth.make_llm(layers=24), dev, max_seqs=1, max_pos=2048, max_out=2048)
