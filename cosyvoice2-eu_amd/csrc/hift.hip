@@ -592,7 +592,9 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
         // fewer 128-frame blocks than CUs (one utterance's 256- and 512-channel stages): 64-frame blocks; CV2_HIFT_BT64=0: A/B, diagnostics
         static const bool bt64 = !(getenv("CV2_HIFT_BT64") && getenv("CV2_HIFT_BT64")[0] == '0');
         const long blocks128 = (long)((L_out + CV_BT - 1) / CV_BT) * (cw.cout_pad / 64) * g_hz_n;
-        if (bt64 && blocks128 < 200) {
+        // (measured, 500 frames: below 200 blocks 4.61 ms, below 400 -- the 128-channel stage too -- 4.55, below 600 4.64; 5.34 without)
+        static const long bt64_max = getenv("CV2_HIFT_BT64_MAX") ? atol(getenv("CV2_HIFT_BT64_MAX")) : 200;
+        if (bt64 && blocks128 < bt64_max) {
             const size_t sm = (size_t)(64 + (cw.taps - 1) * cw.dil) * C6_LD * 2 * 3;
             hipLaunchKernelGGL(k_conv6<1>, dim3((L_out + 63) / 64, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
             CV2_LAUNCH_CHECK();
