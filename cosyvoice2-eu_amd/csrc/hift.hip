@@ -56,16 +56,19 @@ __device__ __forceinline__ float pre_apply(float v, int pre, float al, float slo
     return v;
 }
 
+// FT = frame tiles of 32 per wave (2: blocks of 128 frames = CV_BT; 1: of 64 frames, for grids that leave CUs idle; see k_conv6)
+template <int FT>
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+    constexpr int BT = 64 * FT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     { const size_t zo = (size_t)blockIdx.z * a.zs; a.x += zo; a.out += zo; if (a.res) a.res += zo; }
     float* xs = reinterpret_cast<float*>(smem);                     // [rows][CV_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx_, by_;
     xcd_tile_yfast(bx_, by_);                                       // the output-channel tiles of one frame tile read the same input rows: one L2
-    const int t0 = bx_ * CV_BT, co0 = by_ * 64;
+    const int t0 = bx_ * BT, co0 = by_ * 64;
     const int span = (a.taps - 1) * a.dil;
-    const int rows = CV_BT + span;
+    const int rows = BT + span;
     const int ntile = a.CoutP / 32;
     f32x16 acc0, acc1;
 #pragma unroll
@@ -117,11 +120,11 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         }
 #define CV_MMA(SET, GI)                                                                                             \
         {                                                                                                           \
-            const float* xr_ = xs + (fw * 64 + li + ((GI) / NG) * a.dil) * CV_LD + lk + 2 * ((GI) % NG) * GK;         \
+            const float* xr_ = xs + (fw * (32 * FT) + li + ((GI) / NG) * a.dil) * CV_LD + lk + 2 * ((GI) % NG) * GK;         \
             _Pragma("unroll") for (int u = 0; u < GK; u++) {                                                          \
-                const float av0 = xr_[2 * u], av1 = xr_[32 * CV_LD + 2 * u];                                          \
+                const float av0 = xr_[2 * u], av1 = FT == 2 ? xr_[32 * CV_LD + 2 * u] : 0.f;                          \
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, SET[u], acc0, 0, 0, 0);                              \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, SET[u], acc1, 0, 0, 0);                              \
+                if (FT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, SET[u], acc1, 0, 0, 0);                 \
             }                                                                                                       \
         }
         const int ngroups = a.taps * NG;                         // even (NG = 4)
@@ -141,13 +144,13 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     }
     // epilogue: lane holds channel co (li) of its output tile and 16 frames of each of its two frame tiles
 #pragma unroll
-    for (int tile = 0; tile < 2; tile++) {
+    for (int tile = 0; tile < FT; tile++) {
         const int co = co0 + cw * 32 + li;
         if (co >= a.Cout_store) continue;
         const float b = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int t = t0 + fw * 64 + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int t = t0 + fw * (32 * FT) + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             if (t >= a.L_out) continue;
             float v = (tile == 0 ? acc0[r] : acc1[r]) + b;
             if (a.res) v += a.res[(size_t)t * a.ldres + co];
@@ -558,7 +561,8 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
     if (d->lanes <= 1 && n_kept.fetch_add(1) < keep && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) h->cap_stream = nullptr;
     static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
     if (!once) {
-        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv6<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv6<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
@@ -605,8 +609,18 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
         CV2_LAUNCH_CHECK();
         return 0;
     }
+    {
+        static const bool bt64 = !(getenv("CV2_HIFT_BT64") && getenv("CV2_HIFT_BT64")[0] == '0');
+        const long blocks128 = (long)((L_out + CV_BT - 1) / CV_BT) * (cw.cout_pad / 64) * g_hz_n;
+        if (bt64 && blocks128 < 200) {                 // (the f0 predictor's 512-channel layers at one utterance: 4 x 8 blocks)
+            const size_t sm = (size_t)(64 + (cw.taps - 1) * cw.dil) * CV_LD * 4;
+            hipLaunchKernelGGL(k_conv<1>, dim3((L_out + 63) / 64, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
+            CV2_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const size_t sm = (size_t)(CV_BT + (cw.taps - 1) * cw.dil) * CV_LD * 4;
-    hipLaunchKernelGGL(k_conv, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
+    hipLaunchKernelGGL(k_conv<2>, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
     CV2_LAUNCH_CHECK();
     return 0;
 }
