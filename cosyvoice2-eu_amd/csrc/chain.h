@@ -42,13 +42,20 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
 
 struct Gran {                 // all granule buffers of the engine behind one buffer descriptor (32-bit byte offsets)
-    __amdgpu_buffer_rsrc_t rsrc; u64* base; unsigned epoch; int* err; int* err2;      // err2: the slot of a block's second row (k_step2), else == err
+    __amdgpu_buffer_rsrc_t rsrc; u64* base; unsigned epoch;
+    int* err;                 // the error word every wait of the chain re-reads (the chain's first slot)
+    int* err2;                // the slot of a block's second row (k_step2), else == err
+    int* errs[4];             // every slot the block's CHAIN serves (k_step4: up to four rows; else {err, err2, err, err2}): a block that gives up
+                              // flags them all -- its consumers see valid tags on whatever it published and never time out themselves, so a row the
+                              // block did not flag would draw from garbage logits and commit (k_sample checks CV2_ST_ERR per slot)
     bool spec;                // several rows per launch: most blocks are dispatched AFTER their operand was published -- sweep once before
                               // any sentinel wait (one round trip instead of two when the operand is there, one wasted sweep when not)
     __device__ __forceinline__ void init(u64* b, unsigned bytes, unsigned ep, int* e, bool sp = false) {
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)bytes, 0x00020000);
         base = b; epoch = ep; err = err2 = e; spec = sp;
+        errs[0] = errs[1] = errs[2] = errs[3] = e;
     }
+    __device__ __forceinline__ void set_err2(int* e2) { err2 = e2; errs[1] = errs[3] = e2; }
     template <class F>
     __device__ __forceinline__ bool try_once(F f) const { return spec && __all(f()); }
     // idx = granule index from the start of the buffer
@@ -80,6 +87,8 @@ struct Gran {                 // all granule buffers of the engine behind one bu
         if ((threadIdx.x & 63) == 0) {
             __hip_atomic_store((__attribute__((address_space(1))) int*)err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store((__attribute__((address_space(1))) int*)err2, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 4; i++) __hip_atomic_store((__attribute__((address_space(1))) int*)errs[i], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // a wait gives up when its own time is over OR when any block of the launch has given up (the flag is re-read every 16 polls):
@@ -742,6 +751,134 @@ __device__ __forceinline__ float row4_core(const uint16_t* __restrict__ W, int t
 #pragma unroll
         for (int j = 1; j < NWK; j++) out += rc[((j * NWR + wr_) * 4 + q) * 4 + r_];
         if (NORM) out *= rsqrtf(((sqs[4 * c] + sqs[4 * c + 1]) + (sqs[4 * c + 2] + sqs[4 * c + 3])) / (float)K + eps);
+    }
+    return out;
+}
+
+// ---- two row tiles per wave (k_step1: a QA block's query head, a gate/up block of two pairs): the eight waves are row1_core<2, 4, MAXKS>'s
+// 2 (wr) x 4 (wk) grid, wave (wr, wk) owns the row tiles tile0 + wr and tile0 + wr + 2 over its K quarter -- a block covers four consecutive
+// row tiles, feature i of tile q = wr + 2 j comes back in thread 16 q + i.  Per feature every sum runs in row1_core<2, 4, MAXKS>'s order
+// (the same fragments in the same k order per wave, the same fold of the four K quarters, the same sum of squares), so the values do not
+// depend on which of the two forms computed them.  Split in two so that a caller can put loads of its own (the QA role's cache rows)
+// between the weight requests and the operand wait.
+#define T2_RED_BYTES (4 * 4 * 4 * 4 * 4)                      // [4 K quarters][4 tiles][4 lane quarters][4] floats
+__device__ __host__ constexpr int t2_smem_bytes(int nks) { return R1_STAGE_BYTES(nks) + R1_XCH_BYTES + 32 + T2_RED_BYTES; }
+template <int MAXKS>
+struct T2W { s16x8 a0[MAXKS], a1[MAXKS]; };
+template <int MAXKS, bool NT>
+__device__ __forceinline__ void t2_issue(const uint16_t* __restrict__ W, int tile0, int KS, T2W<MAXKS>& w) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 1, wk = wave >> 1;
+    const int w0 = (KS * wk) / 4, w1 = (KS * (wk + 1)) / 4, nw = w1 - w0;
+    const char* b0 = reinterpret_cast<const char*>(W) + ((size_t)(tile0 + wr) * KS + w0) * 1024 + lane * 16;
+    const char* b1 = reinterpret_cast<const char*>(W) + ((size_t)(tile0 + wr + 2) * KS + w0) * 1024 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < MAXKS; i++) {
+        const size_t o = (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024;
+        const s16x8* p0 = reinterpret_cast<const s16x8*>(b0 + o);
+        const s16x8* p1 = reinterpret_cast<const s16x8*>(b1 + o);
+        w.a0[i] = NT ? __builtin_nontemporal_load(p0) : *p0;
+        w.a1[i] = NT ? __builtin_nontemporal_load(p1) : *p1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int MAXKS, bool NORM, class OP>
+__device__ __forceinline__ float t2_finish(const T2W<MAXKS>& w, int KS, int K, OP& op, const float* norm_w, float eps, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 1, wk = wave >> 1;
+    const int w0 = (KS * wk) / 4, w1 = (KS * (wk + 1)) / 4;
+    constexpr int IW = OP::IW;
+    const int nitems = KS * (32 / IW);
+    const bool active = tid < nitems;
+    const int k = tid * IW;
+    char* stage = smem;
+    char* xch = smem + R1_STAGE_BYTES(KS);
+    float* sqs = reinterpret_cast<float*>(xch + R1_XCH_BYTES);
+    float* red = reinterpret_cast<float*>(xch + R1_XCH_BYTES + 32);
+    f32x8 g0 = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (NORM && active) {
+        if (IW == 8) g0 = *reinterpret_cast<const f32x8*>(norm_w + k);
+        else { const f32x4 g4 = *reinterpret_cast<const f32x4*>(norm_w + k); g0[0] = g4[0]; g0[1] = g4[1]; g0[2] = g4[2]; g0[3] = g4[3]; }
+    }
+    f32x8 v = op.finish(k, wave, nitems, active, xch);
+    R1_T_OPERAND;
+    if (NORM) {
+        float sq = 0.f;
+        if (active) {
+            sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            if (IW == 8) sq += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
+        }
+        sq = wave_sum(sq);
+        if (lane == 0) sqs[wave] = sq;
+    }
+    if (active) {
+        if (NORM) v = g0 * v;
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        if (IW == 8) {
+            bf16x8* dst = reinterpret_cast<bf16x8*>(stage + (size_t)(tid >> 2) * 128) + (tid & 3);
+            dst[0] = hi;
+            dst[4] = lo;
+        } else {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4* dst = reinterpret_cast<bf16x4*>(stage + (size_t)(tid >> 3) * 128) + (tid & 7);
+            dst[0] = __builtin_shufflevector(hi, hi, 0, 1, 2, 3);
+            dst[8] = __builtin_shufflevector(lo, lo, 0, 1, 2, 3);
+        }
+    }
+    __syncthreads();
+    R1_T(4);
+    float rs = 1.f;
+    if (NORM) rs = rsqrtf((((sqs[0] + sqs[1]) + (sqs[2] + sqs[3])) + ((sqs[4] + sqs[5]) + (sqs[6] + sqs[7]))) / (float)K + eps);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // B operands in groups of GRP k-steps (row1_core's reason: requested together, then the group's MFMAs; all MAXKS at once would hold
+    // 8 MAXKS registers beside the 8 MAXKS of weight fragments)
+    constexpr int GRP = 4;
+#pragma unroll
+    for (int g = 0; g < MAXKS; g += GRP) {
+        bf16x8 bh[GRP], bl[GRP];
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            const int i = g + j;
+            if (i < MAXKS) {
+                const int s = (w0 + i < w1 ? w0 + i : w1 - 1);
+                const bf16x8* xb = reinterpret_cast<const bf16x8*>(stage + (size_t)s * 128) + (lane >> 4);
+                bh[j] = xb[0];
+                bl[j] = xb[4];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {                              // the two tiles' chains interleaved: independent accumulators
+            const int i = g + j;
+            if (i < MAXKS) {
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, w0 + i < w1 ? w.a0[i] : zero8);
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, w0 + i < w1 ? w.a1[i] : zero8);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bh[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bh[j], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bl[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bl[j], acc1, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    R1_T(5);
+    if ((lane & 15) == 0) {
+        *reinterpret_cast<f32x4*>(red + ((wk * 4 + wr) * 4 + (lane >> 4)) * 4) = acc0;
+        *reinterpret_cast<f32x4*>(red + ((wk * 4 + wr + 2) * 4 + (lane >> 4)) * 4) = acc1;
+    }
+    __syncthreads();
+    R1_T(6);
+    float out = 0.f;
+    if (tid < 64) {
+        const int q = tid >> 4, lq = (tid >> 2) & 3, r = tid & 3;
+        out = red[((0 * 4 + q) * 4 + lq) * 4 + r];
+#pragma unroll
+        for (int j = 1; j < 4; j++) out += red[((j * 4 + q) * 4 + lq) * 4 + r];
+        out *= rs;
     }
     return out;
 }

@@ -685,7 +685,7 @@ struct StepArgs {
     long kv_slot;                                // floats between two slots of a layer's cache (n_kv * max_pos * 64)
     int ldl, head_blocks;                        // logits row stride (vocab_pad), head blocks per row (vocab_pad / 16)
     int spec;                                    // Gran::spec for k_step<true>
-    const int* dbg_skip;                         // test hook (cv2_llm_debug_skip_publish): block index + 1 of a Q-role block that does not publish; 0 = none
+    const int* dbg_skip;                         // test hook (cv2_llm_debug_skip_publish): ((layer << 16) | r) + 1 of the Q-role block r of `layer` that does not publish; 0 = none (the same key in every one-launch form)
 };
 #ifdef CV2_STAMPS
 __device__ unsigned long long g_chain_t[1024][8] = {};      // per block of one layer: start, result, published, operand ready (100 MHz ticks)
@@ -720,16 +720,17 @@ extern "C" int cv2_debug_chain(unsigned long long* out_host) {
 //     permlane swaps), P planes, 24 MFMAs -> the wave's partial O[head][dim]; the eight partials are merged through LDS with their
 //     (max, sum) and published as the tile's granules (o unnormalised, max, sum -- what OpAtt merges across tiles).
 // The scalar form this replaces took 3.3-4.0 us from q to the published tile (scores 1.2-1.9, softmax 0.6, PV 1.15, merge 0.35).
-__device__ __forceinline__ void attn_role(const Gran& G, const float* K, const float* V, int pos, int j0, int rep,
-                                          unsigned qg, unsigned og, char* smem, int dbg_slot) {
-    float* qs = reinterpret_cast<float*>(smem);       // [16][AT_QLD]; rows >= rep stay zero
-    float* po = qs + 16 * AT_QLD;                     // [8 waves][8 heads][64]
-    float* wm = po + 8 * 8 * 64; float* wl = wm + 128;    // [8 waves][16 heads] max, sum
+// The role in three parts, so that k_step1's QA blocks can put their own q computation between the second and the third:
+//   att_prepare  cache rows -> registers -> planes (before q exists);   att_compute  q rows in LDS -> published tile.
+struct AttTile { bf16x8 ka[2][3]; s16x4 vb[4][3]; int n; };
+__device__ __forceinline__ void att_prepare(const float* K, const float* V, int pos, int j0, int nh, AttTile& T, char* smem) {
+    float* qs = reinterpret_cast<float*>(smem);       // [16][AT_QLD]; rows >= nh stay zero
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g4 = lane >> 4;
     const int kb = j0 + 16 * w;                        // the wave's first key
     const int n = max(0, min(16, pos - kb));           // its cached keys (rows past the length may hold anything)
+    T.n = n;
     f32x4 kr[4];
     float vr[16];
     {
@@ -742,51 +743,71 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
 #pragma unroll
             for (int j = 0; j < 4; j++) vr[4 * t + j] = vp[j * 64 + 16 * t];
     }
-    for (int e = rep * AT_QLD + tid; e < 16 * AT_QLD; e += R1_THREADS) qs[e] = 0.f;
-    bf16x8 ka[2][3];
-    s16x4 vb[4][3];
-    planes8(kr[0], kr[1], ka[0][0], ka[0][1], ka[0][2]);
-    planes8(kr[2], kr[3], ka[1][0], ka[1][1], ka[1][2]);
+    for (int e = nh * AT_QLD + tid; e < 16 * AT_QLD; e += R1_THREADS) qs[e] = 0.f;
+    planes8(kr[0], kr[1], T.ka[0][0], T.ka[0][1], T.ka[0][2]);
+    planes8(kr[2], kr[3], T.ka[1][0], T.ka[1][1], T.ka[1][2]);
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         f32x4 v4;
 #pragma unroll
         for (int j = 0; j < 4; j++) v4[j] = 4 * g4 + j < n ? vr[4 * t + j] : 0.f;
-        planes4(v4, vb[t][0], vb[t][1], vb[t][2]);
+        planes4(v4, T.vb[t][0], T.vb[t][1], T.vb[t][2]);
     }
     // the planes must be IN registers before the polling starts: left to itself the compiler sinks the loads (and what hangs on them)
     // to their first use, behind the q wait
 #pragma unroll
     for (int s = 0; s < 2; s++)
 #pragma unroll
-        for (int i = 0; i < 3; i++) asm volatile("" : "+v"(ka[s][i]));
+        for (int i = 0; i < 3; i++) asm volatile("" : "+v"(T.ka[s][i]));
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
-        for (int i = 0; i < 3; i++) asm volatile("" : "+v"(vb[t][i]));
+        for (int i = 0; i < 3; i++) asm volatile("" : "+v"(T.vb[t][i]));
     __builtin_amdgcn_sched_barrier(0);
-    // q is polled directly: a few blocks per layer, one 8-byte load per thread -- cheaper than a sentinel round trip in front of the
-    // sweep.  The poll starts once the previous layer's down projection has published (armed by the caller).
-    {
-        float q0 = 0.f;
-        const bool mine = tid < rep * 64;
-        G.sweep([&]() {
-            if (!mine) return true;
-            const u64 x0 = __hip_atomic_load((const gu64*)(G.base + qg + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q0 = __builtin_bit_cast(float, (unsigned)x0);
-            return (unsigned)(x0 >> 32) == G.epoch;
-        });
-        if (mine) qs[(tid >> 6) * AT_QLD + (tid & 63)] = q0;
-    }
-    AT_T(3);
+}
+// q rows [nh][64] sit in qs (written by this block's threads, not yet synchronised); the tile's o [nh * 64] go to granules og_o ..,
+// its (max, sum) pairs to og_ml + 2 h
+// PO_H: heads per wave in the partial-output area (8; k_step1's one-head blocks: 1).  LDSKV: the tile's cache rows were left in LDS by
+// att_dma_tile (kl / vl) instead of as planes in T -- they are turned into planes here, the keys first, the values behind the score products.
+template <int PO_H = 8, bool LDSKV = false>
+__device__ __forceinline__ void att_compute(const Gran& G, AttTile& T, int nh, unsigned og_o, unsigned og_ml, char* smem, int dbg_slot,
+                                            const char* kl = nullptr, const char* vl = nullptr) {
+    float* qs = reinterpret_cast<float*>(smem);
+    float* po = qs + 16 * AT_QLD;                     // [8 waves][PO_H heads][64]
+    float* wm = po + 8 * PO_H * 64; float* wl = wm + 128;    // [8 waves][16 heads] max, sum
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g4 = lane >> 4;
+    const int n = T.n;
     __syncthreads();
+    if constexpr (LDSKV) {                            // key rows: row 16 w + c, 16-byte chunks 2 g4, 2 g4 + 1, 8 + 2 g4, 9 + 2 g4 (slot = chunk ^ (row & 15))
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's own DMA (it reads only the rows it fetched): long landed, but say so
+        const char* kp = kl + (size_t)(16 * w + c) * 256;
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp + (((2 * g4) ^ c) << 4)), k1 = *reinterpret_cast<const f32x4*>(kp + (((2 * g4 + 1) ^ c) << 4));
+        const f32x4 k2 = *reinterpret_cast<const f32x4*>(kp + (((8 + 2 * g4) ^ c) << 4)), k3 = *reinterpret_cast<const f32x4*>(kp + (((9 + 2 * g4) ^ c) << 4));
+        planes8(k0, k1, T.ka[0][0], T.ka[0][1], T.ka[0][2]);
+        planes8(k2, k3, T.ka[1][0], T.ka[1][1], T.ka[1][2]);
+    }
     f32x4 sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         const float* qp = qs + c * AT_QLD + 32 * s + 8 * g4;
         bf16x8 qb[3];
         planes8(*reinterpret_cast<const f32x4*>(qp), *reinterpret_cast<const f32x4*>(qp + 4), qb[0], qb[1], qb[2]);
-        sc = mm6_32(sc, ka[s], qb);
+        sc = mm6_32(sc, T.ka[s], qb);
+    }
+    if constexpr (LDSKV) {                            // value rows 16 w + 4 g4 + j, dims 16 t + c (the products above are still running)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            f32x4 v4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = 4 * g4 + j;
+                const float v = *reinterpret_cast<const float*>(vl + (size_t)(16 * w + r) * 256 + (((4 * t + (c >> 2)) ^ r) << 4) + ((c & 3) << 2));
+                v4[j] = r < n ? v : 0.f;
+            }
+            planes4(v4, T.vb[t][0], T.vb[t][1], T.vb[t][2]);
+        }
     }
     AT_T(4);
     // sc[j] = score of key kb + 4 g4 + j against head c
@@ -807,49 +828,88 @@ __device__ __forceinline__ void attn_role(const Gran& G, const float* K, const f
 #pragma unroll
     for (int t = 0; t < 4; t++) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[2], vb[t][0], o[t], 0, 0, 0);
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[2], T.vb[t][0], o[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[1], vb[t][1], o[t], 0, 0, 0);
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[1], T.vb[t][1], o[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[0], vb[t][2], o[t], 0, 0, 0);
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[0], T.vb[t][2], o[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[1], vb[t][0], o[t], 0, 0, 0);
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[1], T.vb[t][0], o[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[0], vb[t][1], o[t], 0, 0, 0);
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[0], T.vb[t][1], o[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[0], vb[t][0], o[t], 0, 0, 0);
+    for (int t = 0; t < 4; t++) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa[0], T.vb[t][0], o[t], 0, 0, 0);
     // o[t][j] = head 4 g4 + j, dim 16 t + c
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int h = 4 * g4 + j;
-        if (h < rep) {
+        if (h < nh) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) po[(w * 8 + h) * 64 + 16 * t + c] = o[t][j];
+            for (int t = 0; t < 4; t++) po[(w * PO_H + h) * 64 + 16 * t + c] = o[t][j];
         }
     }
     if (g4 == 0) { wm[w * 16 + c] = mx; wl[w * 16 + c] = ls; }
     __syncthreads();
     AT_T(6);
-    if (tid < rep * 64) {
+    if (tid < nh * 64) {
         const int h = tid >> 6, d = tid & 63;
         float M = wm[h];
 #pragma unroll
         for (int i = 1; i < 8; i++) M = fmaxf(M, wm[i * 16 + h]);
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; i++) acc += __expf(wm[i * 16 + h] - M) * po[(i * 8 + h) * 64 + d];       // (wave 0 always holds a cached key: M is finite)
-        G.store(og + tid, acc);
+        for (int i = 0; i < 8; i++) acc += __expf(wm[i * 16 + h] - M) * po[(i * PO_H + h) * 64 + d];       // (wave 0 always holds a cached key: M is finite)
+        G.store(og_o + tid, acc);
     }
-    if (tid < rep) {
+    if (tid < nh) {
         float M = wm[tid];
 #pragma unroll
         for (int i = 1; i < 8; i++) M = fmaxf(M, wm[i * 16 + tid]);
         float l = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; i++) l += __expf(wm[i * 16 + tid] - M) * wl[i * 16 + tid];
-        G.store(og + rep * 64 + tid * 2, M);
-        G.store(og + rep * 64 + tid * 2 + 1, l);
+        G.store(og_ml + tid * 2, M);
+        G.store(og_ml + tid * 2 + 1, l);
     }
+}
+// k_step1's QA blocks: the tile's 128 key rows and 128 value rows (fp32, 256 B each) go to LDS by DMA and wait THERE for q -- as planes in
+// registers (att_prepare) they would sit beside the block's 14 weight fragments per wave: 168 VGPRs, one block per CU.  One instruction =
+// 1 KiB = four rows; lane l fetches chunk (l & 15) ^ (row & 15) of row l >> 4, so that chunk c of row r lands in slot c ^ (r & 15) and both
+// fragment reads of att_compute (16 lanes: one chunk of 16 rows; or four rows x 16 consecutive dwords) touch every bank once.
+__device__ __forceinline__ void att_dma_tile(const float* K, const float* V, int j0, char* kl, char* vl) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = 16 * w + 4 * i + (lane >> 4);
+        const size_t off = (size_t)(j0 + r) * 64 + (((lane & 15) ^ (r & 15)) << 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(K + off),
+                                         (__attribute__((address_space(3))) void*)(kl + (16 * w + 4 * i) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(V + off),
+                                         (__attribute__((address_space(3))) void*)(vl + (16 * w + 4 * i) * 256), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void attn_role(const Gran& G, const float* K, const float* V, int pos, int j0, int rep,
+                                          unsigned qg, unsigned og, char* smem, int dbg_slot) {
+    float* qs = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x;
+    AttTile T;
+    att_prepare(K, V, pos, j0, rep, T, smem);
+    // q is polled directly: a few blocks per layer, one 8-byte load per thread -- cheaper than a sentinel round trip in front of the
+    // sweep.  The poll starts once the previous layer's down projection has published (armed by the caller).
+    {
+        float q0 = 0.f;
+        const bool mine = tid < rep * 64;
+        G.sweep([&]() {
+            if (!mine) return true;
+            const u64 x0 = __hip_atomic_load((const gu64*)(G.base + qg + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q0 = __builtin_bit_cast(float, (unsigned)x0);
+            return (unsigned)(x0 >> 32) == G.epoch;
+        });
+        if (mine) qs[(tid >> 6) * AT_QLD + (tid & 63)] = q0;
+    }
+    AT_T(3);
+    att_compute(G, T, rep, og, og + rep * 64, smem, dbg_slot);
 }
 
 // MULTI: n_rows > 1.  Block order: layer by layer (then the head); inside a layer the role blocks go in groups of 8, a group's blocks
@@ -909,7 +969,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
         const float vp = __shfl(v, (tid & 63) ^ 16);
         if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);      // rotate-half RoPE on q and k heads
         CH_T(1);
-        if (skip == gb + 1) return;                    // (test hook: a hand-off that never arrives -> the consumers' bounded waits, CV2_ST_ERR = 3)
+        if (skip == ((layer << 16) | r) + 1) return;   // (test hook: a hand-off that never arrives -> the consumers' bounded waits, CV2_ST_ERR = 3)
         if (tid < 32) {
             if (head < a.n_q) G.store(gl + a.off_qg + head * 64 + f, v);
             else if (head < a.n_q + a.n_kv) {
@@ -969,6 +1029,169 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ k_step1: round-5 experiments on the one-row step (CV2_STEP1, default off)
+// k_step's chain is x -> Q -> A -> O -> GU -> D -> x: five all-to-all hand-offs per layer, each a fabric round trip behind the slowest
+// producer.  Two restructurings, both bit-identical to k_step (every sum keeps its order: t2_finish, chain.h) and both measured NOT to pay
+// (profiles/r5_decode_step_experiments.txt); kept behind the switch as the record of the A/B, like CV2_PRE_FUSE:
+//   QA   a block per (query head, 128-key tile) computes the head's 64 q values ITSELF (the 115 KB of W_q rows requested at dispatch like
+//        every weight fragment) and goes straight on to the tile's scores: no Q -> A hand-off, no wait for the slowest of 14 q blocks.  The
+//        key / value heads of the new token keep their Q-role blocks.  The tile's cache rows wait in LDS (att_dma_tile) -- as planes in
+//        registers beside 14 weight fragments per wave the kernel needs 168 VGPRs.  372 us per step against 342: the fused block's serial
+//        work costs what the hop did, and every live tile re-reads W_q.
+//   GU2  a gate/up block covers two (gate, up) tile pairs -- 152 blocks instead of 304 -- so that more than one layer of weight requests is
+//        resident: the down projection's blocks start 4 us earlier and no longer wait for their weights, the fatter gate/up blocks publish
+//        as much later.  342.5 us against 342.4.
+// Block order per layer: Q (QA: the 2 x 2 n_kv key / value blocks only), A (QA: ntiles x 16 slots, head fastest), O, GU, D.
+#define QA_HEADS 16
+#define QA_TILE_BYTES (AT_TILE * 64 * 4)
+#define QA_ATT_BYTES ((16 * AT_QLD + 8 * 64 + 2 * 8 * 16) * 4)
+__host__ __device__ constexpr size_t qa_smem_bytes(int nks) { return 2 * (size_t)QA_TILE_BYTES + ((size_t)t2_smem_bytes(nks) > (size_t)QA_ATT_BYTES ? (size_t)t2_smem_bytes(nks) : (size_t)QA_ATT_BYTES); }
+template <bool QA, bool GU2>
+__global__ __launch_bounds__(R1_THREADS) void k_step1(StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int gb = blockIdx.x;
+    const int H = a.H;
+    const int nKV = 2 * 2 * a.n_kv, nQ = QA ? nKV : 2 * (a.n_q + 2 * a.n_kv), nA = QA ? a.ntiles * QA_HEADS : a.ntiles * a.n_kv, nO = H / 16,
+              nGU = GU2 ? a.inter / 32 : a.inter / 16;
+    const int per = nQ + nA + nO + nGU + CH_NP * nO;
+    const int layer = min(gb / per, a.n_layers);
+    int r = gb - layer * per;
+    const bool dbg = layer == a.dbg_layer;
+    const int r_dbg = r, od = dbg ? r : -1; (void)r_dbg; (void)dbg;
+    CH_T(0);
+    Gran G;
+    G.init(a.gran, a.gran_bytes, *a.epoch, a.err, false);
+    const unsigned gl = (unsigned)min(layer, a.n_layers - 1) * a.gl;
+    const unsigned gp = layer > 0 ? (unsigned)(layer - 1) * a.gl : 0u;
+    if (layer >= a.n_layers) {      // head
+        OpFold op{&G, gl, gl + a.off_dg, H, nullptr, -1, gl + a.off_dg + H - 1};
+        const float out = row1_core<1, 8, 4, true, true>(a.wdec, r, 0, H / 32, H, 0, H / 32, op, a.final_norm, a.eps, smem);
+        if (tid < 16) a.logits[r * 16 + tid] = out + a.bdec[r * 16 + tid];
+        return;
+    }
+    const StepLayer L = a.layers[layer];
+    OpFold xin{&G, gp, gp + a.off_dg, H, layer == 0 ? a.xin : nullptr, od, gp + a.off_hg + a.inter - 1};
+    if (r < nQ) {                   // ---- Q (QA: only the new token's key / value heads)
+        const int head = (QA ? a.n_q : 0) + (r >> 1), half = r & 1;
+        const int pos = a.state[CV2_ST_POS];
+        const int skip = *a.dbg_skip;
+        const int f = half * 16 + ((tid >> 4) & 1) * 32 + (tid & 15);
+        const float bias = L.bqkv[head * 64 + f];
+        float c, sn;
+        auto hook = [&]() { c = a.cosT[pos * 32 + (f & 31)]; sn = a.sinT[pos * 32 + (f & 31)]; };
+        float v = row1_core<2, 4, 7, true, true>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin, L.ln1, a.eps, smem, hook) + bias;
+        const float vp = __shfl(v, (tid & 63) ^ 16);
+        if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);
+        CH_T(1);
+        if (skip == ((layer << 16) | r) + 1) return;
+        if (tid < 32) {
+            if (head < a.n_q) G.store(gl + a.off_qg + head * 64 + f, v);
+            else if (head < a.n_q + a.n_kv) {
+                const int kvh = head - a.n_q;
+                G.store(gl + a.off_kv + kvh * 64 + f, v);
+                L.kc[((size_t)kvh * a.max_pos + pos) * 64 + f] = v;
+            } else {
+                const int kvh = head - a.n_q - a.n_kv;
+                G.store(gl + a.off_kv + (a.n_kv + kvh) * 64 + f, v);
+                L.vc[((size_t)kvh * a.max_pos + pos) * 64 + f] = v;
+            }
+        }
+        CH_T(2);
+        return;
+    }
+    r -= nQ;
+    if (r < nA) {
+        const int pos = a.state[CV2_ST_POS];
+        if constexpr (QA) {         // ---- QA: query head `head` against the 128-key tile `tile` of its kv head
+            // QA_HEADS (16) block slots per tile, the last ones empty: the blocks of one head (one per live tile) are 16 apart in the grid, i.e.
+            // on ONE XCD (consecutive block ids go round the 8 XCDs) -- they all read the head's 115 KB of W_q rows, the first from HBM, the
+            // others from that XCD's L2 (plain loads; tile-major with n_q slots and non-temporal loads the step took 398 us against 342:
+            // +4.8 MB of weight traffic per layer)
+            const int tile = r / QA_HEADS, head = r - tile * QA_HEADS;
+            if (head >= a.n_q || (tile > 0 && tile * AT_TILE >= pos)) return;
+            const int g = head / a.rep, hh = head - g * a.rep;
+            // LDS: [key rows 32 K][value rows 32 K][work: the q computation's stage / exchange / reduction, then the attention's q rows / partials]
+            char* kl = smem; char* vl = smem + QA_TILE_BYTES; char* wk = smem + 2 * QA_TILE_BYTES;
+            T2W<7> w;
+            t2_issue<7, false>(L.wqkv, head * 4, H / 32, w);
+            const float c = a.cosT[pos * 32 + (tid & 31)], sn = a.sinT[pos * 32 + (tid & 31)];
+            const float bias = L.bqkv[head * 64 + (tid & 63)];
+            const bool keys = tile * AT_TILE < pos;                          // (tile 0 at position 0: q only)
+            if (keys) att_dma_tile(L.kc + (size_t)g * a.max_pos * 64, L.vc + (size_t)g * a.max_pos * 64, tile * AT_TILE, kl, vl);
+            float v = t2_finish<7, true>(w, H / 32, H, xin, L.ln1, a.eps, wk) + bias;
+            const float vp = __shfl(v, (tid & 63) ^ 32);                     // rotate-half partner: feature f ^ 32 sits in lane f ^ 32 of wave 0
+            {   // separately rounded products and sum, as the other forms' RoPE compiles (v_mul, v_mul, v_add / v_sub; here hipcc would
+                // contract the sum into one fma: 1-ulp differences in a fifth of the q values)
+                float vc = v * c, ps = vp * sn;
+                asm volatile("" : "+v"(vc), "+v"(ps));                       // (the products leave the expression: nothing to contract)
+                v = (tid & 32) ? vc + ps : vc - ps;
+            }
+            CH_T(1);
+            __syncthreads();                                                 // the q computation's LDS is free: it becomes the attention's
+            float* qs = reinterpret_cast<float*>(wk);
+            for (int e = tid; e < 16 * AT_QLD; e += R1_THREADS) qs[e] = e < 64 ? v : 0.f;      // q row 0 (thread f < 64 holds feature f), rows 1 .. 15 zero
+            if (tid < 64 && tile == 0) G.store(gl + a.off_qg + head * 64 + tid, v);             // the O role's new-token partial needs q too
+            if (!keys) return;
+            AttTile T;
+            {
+                const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+                T.n = max(0, min(16, pos - (tile * AT_TILE + 16 * w8)));
+            }
+            const unsigned og = gl + a.off_ag + (unsigned)(tile * a.n_kv + g) * AT_GSTRIDE;
+            att_compute<1, true>(G, T, 1, og + hh * 64, og + a.rep * 64 + hh * 2, wk, od, kl, vl);
+        } else {                    // ---- A: one tile of one kv head, all its query heads (k_step's role)
+            const int tile = r / a.n_kv, g = r - tile * a.n_kv;
+            if (tile * AT_TILE >= pos) return;
+            if (layer > 0) G.wait(gp + a.off_dg + H - 1, H, CH_NP);
+            attn_role(G, L.kc + (size_t)g * a.max_pos * 64, L.vc + (size_t)g * a.max_pos * 64, pos, tile * AT_TILE, a.rep,
+                      gl + a.off_qg + g * a.rep * 64, gl + a.off_ag + (unsigned)r * AT_GSTRIDE, smem, od);
+        }
+        CH_T(2);
+        return;
+    }
+    r -= nA;
+    if (r < nO) {                   // ---- O
+        const int pos = a.state[CV2_ST_POS];
+        OpAtt op{&G, gl + a.off_ag, a.n_kv, a.rep, (pos + AT_TILE - 1) / AT_TILE, od, &xin, r * 16, gl + a.off_qg, gl + a.off_kv};
+        const float o = row1_core<1, 8, 4, false, true>(L.wo, r, 0, a.NQ / 32, a.NQ, 0, a.NQ / 32, op, nullptr, 0.f, smem);
+        CH_T(1);
+        if (tid < 16) G.store(gl + r * 16 + tid, reinterpret_cast<const float*>(smem + R1_STAGE_BYTES(a.NQ / 32))[1200 + tid] + o);
+        CH_T(2);
+        return;
+    }
+    r -= nO;
+    if (r < nGU) {                  // ---- GU
+        OpGran<4> op{&G, gl, gl + 15, 0, od};
+        if constexpr (GU2) {        // tiles 4 r .. 4 r + 3 = (gate, up) of hidden columns [32 r, 32 r + 16) and [32 r + 16, 32 r + 32)
+            T2W<7> w;
+            t2_issue<7, true>(L.wgu, r * 4, H / 32, w);
+            const float v = t2_finish<7, true>(w, H / 32, H, op, L.ln2, a.eps, smem);
+            const float u = __shfl(v, (tid & 63) + 16);            // wave 0: lanes 0..15 gate a, 16..31 up a, 32..47 gate b, 48..63 up b
+            CH_T(1);
+            if (tid < 64 && (tid & 16) == 0) G.store(gl + a.off_hg + r * 32 + (tid >> 5) * 16 + (tid & 15), (v / (1.f + __expf(-v))) * u);
+        } else {
+            const float v = row1_core<2, 4, 7, true, true>(L.wgu, r * 2, 1, H / 32, H, 0, H / 32, op, L.ln2, a.eps, smem);
+            const float u = __shfl(v, (tid & 15) + 16);
+            CH_T(1);
+            if (tid < 16) G.store(gl + a.off_hg + r * 16 + tid, (v / (1.f + __expf(-v))) * u);
+        }
+        CH_T(2);
+        return;
+    }
+    r -= nGU;
+    {                               // ---- D
+        const int sp = r / nO, tile = r - sp * nO;
+        const int KS = a.inter / 32;
+        const int ks0 = (int)(((unsigned)KS * sp) / CH_NP), ks1 = (int)(((unsigned)KS * (sp + 1)) / CH_NP);
+        OpGran<8> op{&G, gl + a.off_hg, gl + a.off_hg + ks0 * 32 + 15, 0, od};
+        const float v = row1_core<1, 8, 10, false, true>(L.wdown, tile, 0, KS, a.inter, ks0, ks1, op, nullptr, 0.f, smem);
+        CH_T(1);
+        if (tid < 16) G.store(gl + a.off_dg + sp * H + tile * 16 + tid, v);
+        CH_T(2);
+    }
+}
+
 // ------------------------------------------------------------------ k_step2: 2 .. CH_MAX_ROWS rows in one launch, two rows per block
 // The rows are taken in PAIRS: a pair is one chain of k_step's blocks in which every GEMV block serves both rows at once -- the rows are
 // columns 0 and 1 of the MFMA's B operand (row2_core, chain.h), the block's weight fragments are fetched once, the two rows' operands are
@@ -997,7 +1220,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
     const unsigned go0 = (unsigned)row0 * a.row_gran, go1 = (unsigned)row1 * a.row_gran;
     Gran G;
     G.init(a.gran, a.gran_bytes * (unsigned)R, *a.epoch, a.err + slot0 * ST, a.spec != 0);
-    G.err2 = a.err + slot1 * ST;
+    G.set_err2(a.err + slot1 * ST);
     const unsigned gl = (unsigned)min(layer, a.n_layers - 1) * a.gl;
     const unsigned gp = layer > 0 ? (unsigned)(layer - 1) * a.gl : 0u;
     const int c32 = (tid >> 5) & 1, c16 = (tid >> 4) & 1;          // the row of an epilogue thread: 32 (NWR = 2) / 16 (NWR = 1) features per row
@@ -1022,7 +1245,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
         float v = row2_core<2, 4, 7, true, true, NT>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin0, xin1, L.ln1, a.eps, smem, hook) + bias;
         const float vp = __shfl(v, (tid & 63) ^ 16);
         if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);
-        if (*a.dbg_skip == layer * a.per + r + 1) return;      // (test hook, as in k_step: Q block r of this layer keeps its results to itself)
+        if (*a.dbg_skip == ((layer << 16) | r) + 1) return;    // (test hook, as in k_step: Q block r of this layer keeps its results to itself)
         if (tid < 64 && (c32 == 0 || two)) {
             const unsigned o = (c32 ? go1 : go0) + gl;
             if (head < a.n_q) G.store(o + a.off_qg + head * 64 + f, v);
@@ -1115,6 +1338,8 @@ __global__ __launch_bounds__(R1_THREADS) void k_step4(StepArgs a) {
     }
     Gran G;
     G.init(a.gran, a.gran_bytes * (unsigned)R, *a.epoch, a.err + slot[0] * ST, a.spec != 0);
+#pragma unroll
+    for (int c = 0; c < 4; c++) G.errs[c] = a.err + slot[c] * ST;      // a block that gives up flags every row of its chain (rows >= nv repeat slot[0])
     const unsigned gl = (unsigned)min(layer, a.n_layers - 1) * a.gl;
     const unsigned gp = layer > 0 ? (unsigned)(layer - 1) * a.gl : 0u;
     const int c32 = (tid >> 5) & 3, c16 = (tid >> 4) & 3;          // the row of an epilogue thread (NWR = 2: 32 features per row, NWR = 1: 16)
@@ -1143,6 +1368,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step4(StepArgs a) {
         float v = row4_core<2, 4, 7, true, true, NT>(L.wqkv, head * 4 + half, 2, H / 32, H, 0, H / 32, xin, L.ln1, a.eps, smem, hook) + bias;
         const float vp = __shfl(v, (tid & 63) ^ 16);
         if (head < a.n_q + a.n_kv) v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);
+        if (*a.dbg_skip == ((layer << 16) | r) + 1) return;    // (test hook, as in k_step)
         if (tid < 128 && c32 < nv) {
             const unsigned o = sel(c32, go) + gl;
             if (head < a.n_q) G.store(o + a.off_qg + head * 64 + f, v);
@@ -2115,7 +2341,7 @@ extern "C" int cv2_llm_debug_ptrs(cv2_llm* h, uint64_t* out) {
 // The blocks behind it run into their bounded waits: CV2_ST_ERR = 3, the step commits nothing (k_sample), the host re-runs it on the launches.
 extern "C" int cv2_llm_debug_skip_publish(cv2_llm* h, int32_t layer, int32_t q_block) {
     CV2_CHECK(h, "cv2_llm_debug_skip_publish: null handle");
-    const int v = layer < 0 ? 0 : layer * h->step.per + q_block + 1;
+    const int v = layer < 0 ? 0 : ((layer << 16) | q_block) + 1;
     CV2_HIP(hipDeviceSynchronize());
     CV2_HIP(hipMemcpy((void*)(h->epoch + 16), &v, sizeof(v), hipMemcpyHostToDevice));
     return 0;
@@ -2312,7 +2538,7 @@ static int init_attrs_once() {
         set_smem((k_store<1, 8>), big) || set_smem((k_store<2, 8>), big) || set_smem((k_store<1, 8, true>), big) || set_smem((k_store<2, 8, true>), big) || set_smem((k_store<1, 10>), big) ||
         set_smem((k_store<2, 10>), big) || set_smem((k_qkv<2, true>), big) || set_smem((k_gateup<2, true>), big) || set_smem((k_gateup<2, true, 2>), big) ||
         set_smem((k_store<2, 8, false, true>), big) || set_smem((k_store<2, 8, false, true, true>), big) || set_smem((k_store<2, 10, false, true>), big) ||
-        set_smem((k_store<2, 10, false, true, false, true>), big))
+        set_smem((k_store<2, 10, false, true, false, true>), big) || set_smem((k_step1<true, true>), big) || set_smem((k_step1<true, false>), big))
         return -1;
     done = true;
     return 0;
@@ -2502,6 +2728,20 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGra
                 a.dbg_layer = 12;
 #endif
                 static const bool force_multi = getenv("CV2_CHAIN_FORCE_MULTI") != nullptr;       // diagnostics: one row through k_step<true>
+                // one row: k_step, or with CV2_STEP1 = 1 / 2 / 3 k_step1 (round 5: bit 0 QA blocks that compute their query head themselves, bit 1
+                // gate/up blocks of two tile pairs -- same ids and logits bit for bit, measured slower / equal: profiles/r5_decode_step_experiments.txt)
+                const int step1_env = getenv("CV2_STEP1") ? atoi(getenv("CV2_STEP1")) : 0;      // (read at capture: a new engine takes the current value)
+                const int step1 = step1_env & ((d.inter / 16) % 2 == 0 ? 3 : 1) & (d.n_q <= QA_HEADS ? 3 : 2);
+                if (n_seqs == 1 && !mapped && !force_multi && step1) {
+                    const bool qa = step1 & 1, gu2 = step1 & 2;
+                    const int nO = d.hidden / 16;
+                    const int per1 = (qa ? 4 * d.n_kv + a.ntiles * QA_HEADS : 2 * (d.n_q + 2 * d.n_kv) + a.ntiles * d.n_kv) + nO + (gu2 ? d.inter / 32 : d.inter / 16) + CH_NP * nO;
+                    const size_t sm1 = std::max(sm, qa ? qa_smem_bytes(d.hidden / 32) : (size_t)t2_smem_bytes(d.hidden / 32));
+                    const dim3 grid1(d.layers * per1 + d.vocab_pad / 16);
+                    if (qa && gu2) hipLaunchKernelGGL((k_step1<true, true>), grid1, dim3(R1_THREADS), sm1, cs, a);
+                    else if (qa) hipLaunchKernelGGL((k_step1<true, false>), grid1, dim3(R1_THREADS), sm1, cs, a);
+                    else hipLaunchKernelGGL((k_step1<false, true>), grid1, dim3(R1_THREADS), sm1, cs, a);
+                } else
                 if (n_seqs == 1 && !mapped && !force_multi) hipLaunchKernelGGL((k_step<false, true>), dim3(h->step_blocks), dim3(R1_THREADS), sm, cs, a);
                 else {                       // rows = slots 0 .. n - 1, or the live slots of cv2_llm_decode_rows (row -> slot map, inputs by row)
                     a.n_rows = n_seqs; a.row_slots = mapped ? h->row_slots : nullptr; a.xin = xin;

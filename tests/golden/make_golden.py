@@ -14,6 +14,7 @@ What is pinned (reference symbol -> file):
   Qwen2LM.inference_bistream greedy (llm.py:721-834)          llm_bistream.npz    (24 layers; via the cache view of oracle/ref_harness.py)
   flow.inference at T=1010 + HiFTGenerator.inference on 500 frames     fullsize.npz        (BASELINE configs[1] shapes)
   nucleus_sampling candidate set (common.py:120-134)         sampler.npz
+  ras_sampling + TransformerLM.sampling_ids decisions (common.py:111-139, llm.py:235-250; injected uniforms)   sampler_ras.npz
 Each block also asserts that oracle/ reproduces the reference before writing.
 """
 import os
@@ -349,9 +350,120 @@ def gen_sampler():
     save('sampler.npz', logp=np.stack(logps), candidates=np.stack(cands))
 
 
+def gen_sampler_ras():
+    """The DECISION logic of the sampler, run through the reference's own functions: `ras_sampling` -> `nucleus_sampling` /
+    `random_sampling` (utils/common.py:111-139) under `TransformerLM.sampling_ids` (llm/llm.py:235-250: EOS re-draws while
+    ignore_eos, RuntimeError after 100).  Only the RNG is replaced: `Tensor.multinomial` draws by inverse CDF from a committed
+    table of uniforms (first index whose float64 cumulative sum exceeds u * total) -- the nucleus draw of trial t takes
+    u[t][0], the full-vocabulary re-draw of that trial (when the repetition rule fires) u[t][1] -- exactly like torch.rand /
+    randn_like are replaced for HiFT above.  Stored per case: logp, the decoded window, ignore_eos, the uniforms, and the id the
+    reference returned (-1: it raised the RuntimeError)."""
+    from cosyvoice.utils.common import ras_sampling
+    from cosyvoice.llm.llm import TransformerLM
+    EOS = 6561
+    lm = types.SimpleNamespace(sampling=ras_sampling, speech_token_size=EOS)
+    g = torch.Generator().manual_seed(1986)
+    real_multinomial = torch.Tensor.multinomial
+    state = {}
+
+    def inv_cdf_multinomial(self, num_samples, replacement=False, *, generator=None):
+        assert num_samples == 1 and self.dim() == 1
+        if self.numel() != 6564:                 # the nucleus draw opens a trial; the full-vocabulary draw belongs to the trial in progress
+            state['trial'] += 1
+        u = state['u'][state['trial'], 0 if self.numel() != 6564 else 1]
+        c = torch.cumsum(self.double(), 0)
+        i = int(torch.searchsorted(c, (u.double() * c[-1]).reshape(1), right=True))
+        state['draws'] += 1
+        return torch.tensor([min(i, self.numel() - 1)], dtype=torch.long)
+
+    def run(logp, window, ignore_eos, u):
+        state.update(trial=-1, u=u, draws=0)
+        torch.Tensor.multinomial = inv_cdf_multinomial
+        try:
+            try:
+                top = int(TransformerLM.sampling_ids(lm, logp, list(window), 25, ignore_eos))
+            except RuntimeError as e:
+                assert 'max_trials' in str(e)
+                top = -1
+        finally:
+            torch.Tensor.multinomial = real_multinomial
+        return top, state['trial'] + 1, state['draws']
+
+    cases = []
+
+    def add(kind, logp, window, ignore_eos, u=None):
+        u = torch.rand(102, 2, generator=g, dtype=torch.float64) if u is None else u
+        cases.append((kind, logp.float().log_softmax(0), list(window), bool(ignore_eos), u))
+
+    def peaked(ids, vals, base=-14.0, noise=0.3):
+        x = torch.full((6564,), base) + noise * torch.randint(-8, 9, (6564,), generator=g).float() / 4      # (few distinct values: the fixture compresses)
+        for i, v in zip(ids, vals):
+            x[i] = v
+        return x
+
+    # (a) broad logits, window without the likely candidates: the nucleus draw stands (kind 0)
+    for i in range(12):
+        add(0, torch.randn(6564, generator=g) * (0.8 + 0.4 * i), torch.randint(0, 6561, (int(torch.randint(0, 14, (1,), generator=g)),), generator=g).tolist(), i % 2)
+    # (b) a few dominant ids that fill the window: rep_num >= 1 -> the full-vocabulary re-draw decides (kind 1); windows shorter and longer than 10
+    for i in range(16):
+        ids = torch.randint(0, 6561, (3,), generator=g).tolist()
+        x = peaked(ids, [2.0, 1.5, 1.0])
+        far = torch.randint(0, 6561, (6,), generator=g).tolist()
+        window = ([ids[0]] * 12 + far if i % 4 == 3 else far + [ids[i % 3]] + ids[:(i % 4)])     # (i % 4 == 3: the hit lies OUTSIDE the last 10 -> no re-draw if the nucleus picks it)
+        add(1, x, window, i % 2)
+    # (c) EOS among the candidates while ignore_eos: re-draws until another id comes (kind 2); the same logits with ignore_eos False keep EOS
+    for i in range(16):
+        ids = torch.randint(0, 6561, (2,), generator=g).tolist()
+        x = peaked([EOS] + ids, [2.2 + 0.05 * i, 2.0, 1.0])
+        add(2, x, [ids[0]] if i % 3 == 0 else [], i % 4 != 3)
+    # (d) EOS (almost) certain while ignore_eos: 101 trials, then the RuntimeError (kind 3); one case escapes on a late trial through the full-vocabulary draw
+    for i in range(8):
+        x = peaked([EOS], [40.0], base=-40.0, noise=0.0)
+        u = torch.rand(102, 2, generator=g, dtype=torch.float64)
+        window = [EOS] if i >= 4 else []           # EOS in the window: every trial also takes the full-vocabulary draw (EOS again)
+        add(3, x, window, True, u)
+    for i in range(4):
+        x = peaked([EOS, 17 + i], [6.0, 0.0], base=-30.0, noise=0.0)        # EOS holds 0.9975 of the mass (> top_p: the only nucleus candidate) and sits in the window:
+        u = 0.5 + 0.5 * torch.rand(102, 2, generator=g, dtype=torch.float64)  # every trial goes to the full-vocabulary draw, which returns EOS for u >= 0.0025 ...
+        u[60 + 7 * i, 1] = 0.001                                              # ... except on one late trial (id 17 + i)
+        add(3, x, [EOS], True, u)
+    # (e) ties: equal top logits (the stable sort keeps the lower id first), exactly 25 candidates, one candidate holding > top_p (kind 4)
+    for i in range(8):
+        x = torch.full((6564,), -20.0)
+        if i < 3:
+            x[[100, 50, 3000, 7][: i + 2]] = 1.0
+        elif i < 6:
+            x[torch.randperm(6561, generator=g)[:40]] = 0.0
+        else:
+            x[1234] = 5.0
+        add(4, x, [50] if i == 1 else [], i % 2)
+    out = dict(logp=[], window=[], window_len=[], ignore_eos=[], uniforms=[], kind=[], top=[], trials=[], draws=[])
+    hist = {}
+    for kind, logp, window, ign, u in cases:
+        top, trials, draws = run(logp, window, ign, u)
+        uni = lambda s_, t_: (float(u[t_, 0]), float(u[t_, 1]))
+        try:
+            o = OL.sampling_ids(logp, list(window), ign, 'ras', uni, 0)
+        except RuntimeError:
+            o = -1
+        assert o == top, f'oracle != reference (sampler decision, kind {kind}): {o} vs {top}'
+        w = np.full(24, -1, dtype=np.int64)
+        w[:len(window)] = window
+        out['logp'].append(logp.numpy()); out['window'].append(w); out['window_len'].append(len(window)); out['ignore_eos'].append(int(ign))
+        out['uniforms'].append(u.numpy()); out['kind'].append(kind); out['top'].append(top); out['trials'].append(trials); out['draws'].append(draws)
+        hist.setdefault(kind, []).append((top, trials, draws))
+    # the cases cover what they were built for
+    assert all(t == 1 and d == 1 for _, t, d in hist[0])                          # no repetition: one trial, one draw
+    assert sum(1 for _, t, d in hist[1] if d == 2 * t) >= 8                       # the repetition rule fired
+    assert any(t > 1 for _, t, d in hist[2]) and any(top == EOS for top, _, _ in hist[2])
+    assert sum(1 for top, t, _ in hist[3] if top == -1 and t == 101) >= 8 and any(top >= 0 and t > 50 for top, t, _ in hist[3])
+    save('sampler_ras.npz', **{k: np.stack(v) if k in ('logp', 'window', 'uniforms') else np.asarray(v) for k, v in out.items()})
+    print('sampler_ras: kinds', {k: len(v) for k, v in hist.items()}, 'errors', sum(1 for v in out['top'] if v == -1))
+
+
 if __name__ == '__main__':
     assert R.available(), 'needs /root/reference'
     R.activate()
-    which = sys.argv[1:] or ['hift', 'flow', 'llm', 'llm_bf16w', 'bistream', 'fullsize', 'text', 'textnorm', 'sampler']
+    which = sys.argv[1:] or ['hift', 'flow', 'llm', 'llm_bf16w', 'bistream', 'fullsize', 'text', 'textnorm', 'sampler', 'sampler_ras']
     for w in which:
         globals()['gen_' + w]()

@@ -221,6 +221,61 @@ def test_hand_off_timeout_in_a_two_row_step_fails_no_request(dev, small):
     assert got == want and eng.chain_broken and eng.handoff_recoveries >= 1
 
 
+@pytest.mark.parametrize('n,q_block', [(3, 2), (9, 5), (11, 0)])
+def test_hand_off_timeout_flags_every_row_of_the_launch(dev, small, n, q_block):
+    """The broken hand-off in the other one-launch forms: 3 rows (k_step<true>, one chain per row) and 9 / 11 rows (k_step4: four rows per
+    block, the last chain of 11 holds three).  A block that gives up flags EVERY row its chain serves (csrc/chain.h Gran::errs) -- its
+    consumers see valid tags on whatever it published and would never time out themselves -- so every row reports CV2_ST_ERR = 3 and
+    commits nothing (step, output count and position as after the prefill); generate() repeats the steps on the launches and all requests
+    finish with the ids of an undisturbed run.  The hook's key is (layer, Q-role block) in every form."""
+    from cv2amd import lib as L
+    from cv2amd.llm import LLMEngine
+    sd, sdr, _ = small
+    eng = LLMEngine(sd, dev, max_seqs=12, max_pos=512, max_out=64)
+    reqs = _requests(n, seed=60 + n)
+    want = eng.generate(reqs, force_len=12)
+    assert eng.handoff_recoveries == 0
+    xs = [eng.build_lm_input(*r) for r in reqs]
+    eng.park()
+    eng.add_requests(list(range(n)), xs, [(12, 12)] * n, 0, 0, True)
+    torch.cuda.synchronize()
+    before = eng.state[:n].cpu().clone()
+    L.check(eng.lib.cv2_llm_debug_skip_publish(eng.handle, 1, q_block))
+    try:
+        eng.step(n, 2)
+        torch.cuda.synchronize()
+        st = eng.state[:n].cpu()
+        assert st[:, L.ST_ERR].tolist() == [3] * n
+        for col in (L.ST_STEP, L.ST_NOUT, L.ST_POS, L.ST_DONE):
+            assert st[:, col].tolist() == before[:, col].tolist(), f'state column {col} moved in a step that reported a hand-off time-out'
+        got = eng.generate(reqs, force_len=12)
+    finally:
+        L.check(eng.lib.cv2_llm_debug_skip_publish(eng.handle, -1, 0))
+    assert got == want and eng.chain_broken and eng.handoff_recoveries >= 1
+
+
+@pytest.mark.parametrize('mode', ['1', '2', '3'])
+def test_one_row_step_forms_give_the_same_ids(dev, small, monkeypatch, mode):
+    """k_step (the default one-row step) against the round-5 experiments kept behind CV2_STEP1 (k_step1; 1: QA blocks that compute their
+    query head themselves and keep the tile's cache rows in LDS, 2: gate/up blocks of two tile pairs, 3: both): every sum of a row runs in
+    k_step's order in all of them, so ids AND logits are equal bit for bit (profiles/r5_decode_step_experiments.txt has their timings)."""
+    from cv2amd.llm import LLMEngine, MODE_RAS
+    from oracle import llm as OL
+    sd, sdr, _ = small
+    req = _requests(3, seed=77)[2]
+    eng = LLMEngine(sd, dev, max_seqs=2, max_pos=512, max_out=64)
+    ids = eng.generate([req], force_len=40)[0]
+    lg = eng.logits[0, :eng.vocab].cpu().clone()
+    ras = eng.generate([req], force_len=40, mode=MODE_RAS, seed=5)[0]
+    assert ids == OL.inference(sdr, *req, force_len=40)
+    monkeypatch.setenv('CV2_STEP1', mode)
+    eng2 = LLMEngine(sd, dev, max_seqs=2, max_pos=512, max_out=64)
+    ids2 = eng2.generate([req], force_len=40)[0]
+    lg2 = eng2.logits[0, :eng2.vocab].cpu().clone()
+    assert ids2 == ids and torch.equal(lg, lg2)
+    assert eng2.generate([req], force_len=40, mode=MODE_RAS, seed=5)[0] == ras
+
+
 @pytest.mark.parametrize('n', [2, 3, 4, 7, 8, 9, 11, 16, 22])
 def test_one_launch_rows_equal_the_launches_and_the_oracle(small, n):
     """Decode steps of 2 .. 24 rows as ONE launch (up to 8 rows k_step2: the rows in pairs as two MFMA columns per block, an odd count

@@ -12,7 +12,8 @@ P = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 t0 = time.time()
 sd = synth.make_llm(layers=24)
 print('synth', time.time() - t0)
-eng = LLMEngine(sd, 'cuda:0', max_seqs=32, max_pos=2048, max_out=2048)
+MAXPOS = int(os.environ.get('CV2_MAXPOS', '2048'))      # (the product's engine at BASELINE configs[1]: 968 -> 8 attention tiles)
+eng = LLMEngine(sd, 'cuda:0', max_seqs=32, max_pos=MAXPOS, max_out=MAXPOS)
 print('engine', time.time() - t0, 'weight MB', eng.weight_bytes / 1e6)
 for b in range(B):
     inp = synth.synthetic_inputs(seed=b, text_len=50, prompt_len=P)

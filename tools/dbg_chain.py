@@ -12,13 +12,16 @@ from cv2amd import synth, lib as L
 from cv2amd.llm import LLMEngine
 
 sd = synth.make_llm(layers=24)
-eng = LLMEngine(sd, 'cuda:0', max_seqs=1, max_pos=2048, max_out=2048)
+MAXPOS = int(os.environ.get('CV2_MAXPOS', '2048'))
+NT = (MAXPOS + 127) // 128
+eng = LLMEngine(sd, 'cuda:0', max_seqs=1, max_pos=MAXPOS, max_out=MAXPOS)
 inp = synth.synthetic_inputs(seed=0, text_len=50, prompt_len=255)
 x = eng.build_lm_input(inp['text'], inp['prompt_text'], inp['prompt_token'])
-eng.add_request(0, x, 2000, 2000, mode=1, seed=7, force_len=True)
-nQ, nA, nO, nGU, nD = 36, 32, 56, 304, 112
+eng.add_request(0, x, MAXPOS - 400, MAXPOS - 400, mode=1, seed=7, force_len=True)
+step1 = int(os.environ.get('CV2_STEP1', '0'))        # the one-row form that runs (llm.hip get_graph): bit 0 QA blocks, bit 1 two-pair gate/up blocks
+nQ, nA, nO, nGU, nD = (8 if step1 & 1 else 36), (NT * 16 if step1 & 1 else NT * 2), 56, (152 if step1 & 2 else 304), 112
 DUMP = sys.argv[sys.argv.index('--dump') + 1] if '--dump' in sys.argv else None
-roles = (('Q', nQ), ('A', nA), ('O', nO), ('gate/up', nGU), ('down', nD))
+roles = (('KV' if step1 & 1 else 'Q', nQ), ('QA' if step1 & 1 else 'A', nA), ('O', nO), ('gate/up', nGU), ('down', nD))
 for rep in range(3):
     eng.step(1, 64)
     torch.cuda.synchronize()
@@ -47,7 +50,7 @@ for rep in range(3):
                     fdump.write(f'{name} {i:3d} start {u[0]:7.2f} operand {u[3]:7.2f} staged {u[4]:7.2f} mfma {u[5]:7.2f} reduced {u[6]:7.2f} result {u[1]:7.2f} published {u[2]:7.2f}\n')
         f = lambda a: f'min {a.min():7.2f} med {np.median(a):7.2f} max {a.max():7.2f}'
         print(f'  {name:8s} n={len(r):3d} start [{f(us[:, 0])}]  operand [{f(us[:, 3])}]  result [{f(us[:, 1])}]  published [{f(us[:, 2])}]')
-        if name == 'A':
+        if name in ('A', 'QA'):
             g = lambda a: f'{np.median(a):5.2f}/{a.max():5.2f}'
             print(f'           q arrived [{f(us[:, 3])}]  q->scores {g(us[:, 4] - us[:, 3])}  scores->softmax {g(us[:, 5] - us[:, 4])}  softmax->pv {g(us[:, 6] - us[:, 5])}  pv->published {g(us[:, 2] - us[:, 6])}')
         elif (r[:, 4] > 0).all():
