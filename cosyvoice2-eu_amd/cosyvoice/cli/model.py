@@ -88,6 +88,7 @@ class CosyVoice2Model:
         self._bi_cv = threading.Condition()    # guards _bi_calls and every BiStream's text side; signalled on new text / tokens / calls
         self._bi_calls, self._bi_thread, self._bi_gen = [], None, 0
         self.bistream_coalesce_ms = 8.0        # calls that start together are fed together (one pass over the weights for all first feeds)
+        self.bistream_text_ahead = 8           # text pieces a generator-text call may be pulled ahead of their consumption (the reference: the one in work)
         self.bistream_burst = 16
         # True: no decode burst beside a FIRST chunk's flow + HiFT round.  Measured with 8 generator-text calls: first chunk 139 instead of
         # 142-148 ms, but 90.5 instead of 96-98 audio-s/s (the later chunks' tokens come 15-25 ms later): off by default
@@ -99,6 +100,16 @@ class CosyVoice2Model:
         # instead of one of 8)
         self.chunk_wave_ms, self.chunk_quiet_ms = 3.0, 1.0
         self._joining, self.join_burst = set(), 8      # slots taken but not prefilled yet; decode burst length while there are any
+        self.open_burst, self.burst_piece = 16, 8      # burst length while slots are free; steps per completion event inside a burst
+        self.prefill_wave_ms = 3.0             # a prefill waits this long for calls that hold a slot but have not queued their prompt yet
+        # Calls that do NOT start together (a server's arrivals, 0-40 ms apart): the earliest stream's first chunk used to start a round of its
+        # own, and a round holds the device for ~40 ms -- the prefills and first bursts of the calls that arrived meanwhile waited behind it
+        # (8 calls within 40 ms: first chunk p50 151 ms, max 215-257 ms from each call's own start).  A FIRST chunk therefore waits while
+        # newcomers -- calls that hold a slot, started less than first_round_hold_ms ago and have not submitted their first chunk -- are on
+        # their way (their prefills and shared decode bursts run meanwhile, this stream's rows included).  0: off.
+        self.first_round_hold_ms = float(os.environ.get('CV2_FIRST_ROUND_HOLD_MS', '80'))
+        self.first_round_hold_cap = float(os.environ.get('CV2_FIRST_ROUND_HOLD_CAP', '1.5'))      # longest hold of one chunk, in units of first_round_hold_ms
+        self._first_pending = {}               # uuid -> time of the call, until its first chunk is submitted
         self._chunks_active = 0                # chunk rounds (flow + HiFT) in progress: decode bursts beside them take the launches
         self._bi_incoming = 0                  # generator-text calls that have entered tts() but not yet joined the hub
         self._sched_log = None                 # diagnostics (tools/bench_bistream.py): list receiving (t, kind, info) of hub / chunk rounds
@@ -415,6 +426,20 @@ class CosyVoice2Model:
             self._chunk_q.append(c)
         if self._sched_log is not None:
             self._sched_log.append((time.perf_counter(), 'submit', dict(queued=len(self._chunk_q), offset=offset)))
+        if stream and not finalize and offset == 0:
+            self._first_pending.pop(this_uuid, None)
+            hold = self.first_round_hold_ms * 1e-3
+            if hold > 0:
+                t_sub, held = time.perf_counter(), False
+                t_cap = t_sub + self.first_round_hold_cap * hold              # (arrivals that never stop must not hold a chunk for ever)
+                while not c.done and not c.taken:                             # (taken: a round has this chunk -- get in line)
+                    now = time.perf_counter()
+                    if now >= t_cap or not any(now - t0 < hold for t0 in list(self._first_pending.values())):
+                        break
+                    held = True
+                    time.sleep(0.0002)
+                if held and self._sched_log is not None:
+                    self._sched_log.append((time.perf_counter(), 'held', dict(ms=round((time.perf_counter() - t_sub) * 1e3, 1))))
         n_streams = min(self._n_shared, self.max_batch)
         if n_streams > 1 and self.chunk_wave_ms > 0:
             t_last = time.perf_counter()
@@ -498,6 +523,11 @@ class CosyVoice2Model:
             self._prefill_q.append(p)
         with self.run_lock:
             if not p.done:
+                # calls that have taken a slot but not queued their prompt yet (they are copying their inputs) join this prefill: one that
+                # misses it by a millisecond waits for the whole prefill + the bursts behind it (trace of 8 staggered calls: 26 ms)
+                t_end = time.perf_counter() + self.prefill_wave_ms * 1e-3
+                while len(self._prefill_q) < len(self._joining) and time.perf_counter() < t_end:
+                    time.sleep(0.0002)
                 with self.lock:
                     batch = self._prefill_q[:]
                     self._prefill_q.clear()
@@ -547,16 +577,29 @@ class CosyVoice2Model:
             # starting within 5 ms of each other: three of them missed the first prefill by < 1 ms and waited 41 ms behind a 47-step burst)
             if self._joining:
                 n_steps = min(n_steps, self.join_burst)
+            elif self._slot_free and self.max_batch > 1:
+                # slots are free: a call may arrive any moment, and its prefill waits for the device lock, which the stream that polls for
+                # this burst's tokens holds until the burst has run (trace of 8 staggered calls: two newcomers waited 17 and 24 ms behind a
+                # 39-step burst of the first two streams).  The caller's loop asks again.
+                n_steps = min(n_steps, self.open_burst)
+        evs = []
         with self.llm_lock, torch.cuda.stream(self.llm_stream):
-            if self.stream_live_rows:
-                self.llm.step_rows(act, n_steps, shared=shared)
-            else:
-                self.llm.step(act[-1] + 1, n_steps, shared=shared)   # slots 0 .. highest active, parked ones idle
-            ev = torch.cuda.Event()
-            ev.record(self.llm_stream)
+            # an event every `burst_piece` steps: a stream that needs 8 more tokens waits for 8 steps, not for the 25 another stream asked for
+            # in the same burst (the same trace: four newcomers 8 tokens short of their first chunk sat out a 25-step burst, 15 ms)
+            left = n_steps
+            while left > 0:
+                k = min(left, self.burst_piece) if left > self.burst_piece + 2 else left
+                if self.stream_live_rows:
+                    self.llm.step_rows(act, k, shared=shared)
+                else:
+                    self.llm.step(act[-1] + 1, k, shared=shared)     # slots 0 .. highest active, parked ones idle
+                ev = torch.cuda.Event()
+                ev.record(self.llm_stream)
+                evs.append(ev)
+                left -= k
         while self._bursts and self._bursts[0].query():                       # finished bursts nobody had to wait for
             self._bursts.pop(0)
-        self._bursts.append(ev)
+        self._bursts.extend(evs)
         for sl in act:
             self._enq[sl] = self._enq.get(sl, 0) + n_steps
         if self._sched_log is not None:
@@ -586,7 +629,7 @@ class CosyVoice2Model:
 
     # ---- coalesced non-streaming calls ---------------------------------------------------------------------------
     class _Pending:
-        __slots__ = ('text', 'prompt_text', 'llm_ptok', 'fpt', 'feat', 'femb', 'speed', 'uuid', 'done', 'speech', 'exc', 'force_len')
+        __slots__ = ('text', 'prompt_text', 'llm_ptok', 'fpt', 'feat', 'femb', 'speed', 'uuid', 'done', 'speech', 'exc', 'force_len', 'dev_out')
 
     def _run_batch(self, batch):
         """llm_job + token2wav(finalize=True) of model.py:118-139,300-334 for several queued calls at once.  Only the caller whose
@@ -629,7 +672,7 @@ class CosyVoice2Model:
             outs = self.hift_pool.inference_many(gm) if gm else []
             torch.cuda.synchronize(self.device)
             for (p, _), (wav, _s) in zip(good, outs):
-                p.speech = wav.cpu()
+                p.speech = wav.clone() if p.dev_out else wav.cpu()      # (device_output: the waveform stays in HBM for a device-side consumer)
         except BaseException as e:                                            # not attributable to one request
             for p in batch:
                 if p.speech is None and p.exc is None:
@@ -681,8 +724,22 @@ class CosyVoice2Model:
         c.first_done = False                  # the call's first chunk has been delivered (until then its chunk round has the device to itself, see _bi_loop)
 
         def pump():
+            # The reference pulls the next piece only when the previous one has been worked off (llm.py `for this_text in text`: a piece that
+            # leads to a decode holds the loop until the fill id).  Here: at most `bistream_text_ahead` pieces wait un-consumed, so the caller's
+            # generator sees the same back-pressure (within that margin) and is never drained ahead of the synthesis.
+            failed = False
             try:
-                for piece in text:
+                it = iter(text)
+                while True:
+                    with self._bi_cv:
+                        while not c.closed and len(bs.pieces) >= self.bistream_text_ahead:
+                            self._bi_cv.wait(0.05)
+                        if c.closed:
+                            return
+                    try:
+                        piece = next(it)
+                    except StopIteration:
+                        break
                     with self._bi_cv:
                         if c.closed:
                             return
@@ -690,12 +747,19 @@ class CosyVoice2Model:
                         self._bi_gen += 1
                         self._bi_cv.notify_all()
             except BaseException as e:      # noqa: BLE001 -- the caller's generator failed: the call fails with it
-                c.exc = e
-            finally:
-                with self._bi_cv:
-                    bs.close()
+                failed = True
+                with self._bi_cv:           # no final feed, no further decode for a call that will raise: the stream is over as it stands
+                    c.exc = e
+                    c.ended = True
+                    bs.finished = True
                     self._bi_gen += 1
                     self._bi_cv.notify_all()
+            finally:
+                if not failed:
+                    with self._bi_cv:
+                        bs.close()
+                        self._bi_gen += 1
+                        self._bi_cv.notify_all()
         with self._bi_cv:
             self._bi_calls.append(c)
             self._bi_incoming -= 1
@@ -706,6 +770,14 @@ class CosyVoice2Model:
             self._bi_cv.notify_all()
         threading.Thread(target=pump, daemon=True, name='cv2-bistream-text').start()
         return c
+
+    def _bi_next(self, bs):
+        """BiStream.next_feed() under _bi_cv; the text pumps are told when it consumed pieces (they pull the next ones)"""
+        n0 = len(bs.pieces)
+        r = bs.next_feed()
+        if len(bs.pieces) != n0:
+            self._bi_cv.notify_all()
+        return r
 
     def _bi_unregister(self, c):
         with self._bi_cv:
@@ -747,7 +819,7 @@ class CosyVoice2Model:
                     while time.perf_counter() < t_end:
                         gen = self._bi_gen
                         self._bi_cv.wait(0.0005)
-                        if self._bi_gen == gen and self._bi_incoming <= 0 and all(c.bs.started or c.bs.next_feed() is not None
+                        if self._bi_gen == gen and self._bi_incoming <= 0 and all(c.bs.started or self._bi_next(c.bs) is not None
                                                                                    for c in self._bi_calls if not c.closed):
                             break
                     calls = [c for c in self._bi_calls if not c.closed]
@@ -768,7 +840,7 @@ class CosyVoice2Model:
                             c.bs.want = max(0, c.want_total - len(c.toks)) if c.want_total else None
                         for b in streams:                                     # feed outside it (the consumers' pull() takes it too)
                             if not b.running and not b.finished:
-                                b.next_feed()
+                                self._bi_next(b)
                     fed = eng.bi_feed(streams, prepared=True)
                     t_r2 = time.perf_counter()
                     n = eng.bi_burst_len(streams, self.bistream_burst)
@@ -792,7 +864,7 @@ class CosyVoice2Model:
                     time.sleep(0.001)
                 else:
                     with self._bi_cv:                                         # every slot waits for text (or has ended): sleep until something arrives
-                        if all(not c.bs.running and (c.bs.finished or c.bs.next_feed() is None) for c in self._bi_calls):
+                        if all(not c.bs.running and (c.bs.finished or self._bi_next(c.bs) is None) for c in self._bi_calls):
                             self._bi_cv.wait(0.05)
             except BaseException as e:      # noqa: BLE001 -- not attributable to one call: all of this round's calls see it
                 with self._bi_cv:
@@ -891,9 +963,11 @@ class CosyVoice2Model:
             llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
             flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
             prompt_speech_feat=torch.zeros(1, 0, 80), source_speech_token=torch.zeros(1, 0, dtype=torch.int32), stream=False, speed=1.0,
-            force_len=None, **kwargs):
+            force_len=None, device_output=False, **kwargs):
         """force_len (an extension; the reference swallows unknown keywords in **kwargs): synthetic-weights mode of SURVEY.md §8(d) —
-        exactly that many speech tokens, EOS and fill ids never drawn — so that benchmark work is deterministic without a checkpoint."""
+        exactly that many speech tokens, EOS and fill ids never drawn — so that benchmark work is deterministic without a checkpoint.
+        device_output (an extension, non-streaming coalesced calls only): 'tts_speech' stays on the model's device instead of the reference's
+        CPU tensor -- for a caller that hands the waveform to a device-side consumer (cv2amd/shard.py: the RCCL gather of configs[3])."""
         from collections.abc import Generator
         vc = source_speech_token.shape[1] != 0                   # vc_job (model.py:141-143): the tokens are given, no LLM
         bistream = isinstance(text, Generator)                    # llm_job's bistream branch (model.py:120-128)
@@ -933,6 +1007,7 @@ class CosyVoice2Model:
             p = self._Pending()
             p.text, p.prompt_text, p.llm_ptok = text.to(dev), prompt_text.to(dev), llm_prompt_speech_token.to(dev)
             p.fpt, p.feat, p.femb, p.speed, p.uuid, p.force_len = fpt, feat, femb, speed, this_uuid, force_len
+            p.dev_out = bool(device_output)
             p.done, p.speech, p.exc = threading.Event(), None, None
             try:
                 yield {'tts_speech': self._tts_coalesced(p)}
@@ -944,6 +1019,7 @@ class CosyVoice2Model:
                 self._hift_pin.pop(this_uuid, None)
                 self._flow_caches.pop(this_uuid, None)
             return
+        t_call = time.perf_counter()
         slot = self._enter_shared()
         hop, la = self.token_hop_len, self.flow.pre_lookahead_len
         try:
@@ -960,6 +1036,7 @@ class CosyVoice2Model:
                 if self.flow_cache and self.prompt_cache_max > 0:              # identity of the prompt: tokens + checksums of mel and embedding
                     pkey = (tuple(flow_prompt_speech_token.flatten().tolist()), float(prompt_speech_feat.double().sum()),
                             float(flow_embedding.double().sum()))
+                self._first_pending[this_uuid] = t_call
                 self._llm_start(slot, text_d, ptext_d, lptok_d, force_len)     # prefill draws token 0; the first pass of the loop below
                 while True:                                                    # requests the rest of the first chunk's tokens
                     this_tok, finished = None, False
@@ -1008,6 +1085,7 @@ class CosyVoice2Model:
                 with torch.cuda.stream(self.llm_stream):
                     self.llm.park(slot)
                 self.llm_stream.synchronize()
+            self._first_pending.pop(this_uuid, None)
             self._exit_shared(slot)
             with self.lock:
                 self.tts_speech_token_dict.pop(this_uuid, None)

@@ -636,7 +636,8 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
 // The same attention with the K / V^T tiles going global -> LDS by DMA (4 waves, one key group): no staging registers (k_attn_est keeps
 // two tiles = 64 VGPRs in flight per thread and stores them to LDS itself), three LDS stages of 16 KB, two tiles in flight.  A wave's DMA
 // instruction writes 1 KiB = 8 rows of 128 B; lane l fetches chunk (l & 7) ^ (l >> 3) of row l >> 3, so the chunk c of row r lands in
-// slot c ^ (r & 7) and the fragment reads (att_est_tile<.., true>) are conflict-free without padding.  Same MFMA sequence: same bits.
+// slot c ^ (r & 7) and the fragment reads (att_est_tile<.., true>) are conflict-free without padding.  The tile's keys are permuted among the
+// score rows (att_est_tile): same products, another order inside a k group -- agreement with k_attn_est to fp32 round-off, not bit for bit.
 template <int QS, bool CACHE = false>
 __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
     constexpr int NW = 4, RB = 16 * NW;
@@ -968,8 +969,8 @@ static int est_resnet(EstCtx& c, const cv2_resnet& rn, int ridx, uint16_t* A, in
     return 0;
 }
 
-// test hook: 1 / 0 = the four-wave estimator attention with / without LDS DMA staging (same MFMA sequence: the outputs must agree bit for
-// bit), -1 = the default (CV2_ATT_DMA)
+// test hook: 1 / 0 = the four-wave estimator attention with / without LDS DMA staging (agreement to fp32 round-off, see k_attn_est_dma),
+// -1 = the default (CV2_ATT_DMA)
 static std::atomic<int> g_att_dma{-1};
 extern "C" int cv2_flow_debug_attn_dma(int32_t on) { g_att_dma = on < 0 ? -1 : (on != 0); return 0; }
 

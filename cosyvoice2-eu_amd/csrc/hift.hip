@@ -43,6 +43,10 @@ struct ConvArgs {
     const float* res; int ldres;
     int post, acc;
     long zs;                                // batched chunks (cv2_hift_inference_batch): lane blockIdx.z works zs floats further into the workspace
+    // flat windows (k_conv6 only; the source_downs, generator.py:468-479): ld_in > 0 -> input row t is the Cin consecutive floats starting at
+    // x[t * ld_in + flat_off] of a flat signal of flat_n floats (zero outside it): a strided Conv1d(18 -> C, k, stride s, pad p) over
+    // [F][18] rows IS that 1-tap convolution with Cin = 18 k, ld_in = 18 s, flat_off = -18 p (consecutive windows overlap)
+    int ld_in; long flat_off, flat_n;
 };
 
 #define CV_BT 128
@@ -203,6 +207,16 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
                 const int it = it0 + 256 * u;
                 const int r = it >> 4, c = c0 + (it & 15) * 4, t = t0 - a.pad_left + r;
                 q[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (a.ld_in) {                                      // flat windows (block-uniform branch): rows overlap, 8-byte alignment at best
+                    if (it < rows * 16) {
+                        const long base = (long)t * a.ld_in + a.flat_off + c;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const long ix = base + e;
+                            if (c + e < a.Cin && ix >= 0 && ix < a.flat_n) q[u][e] = a.x[ix];
+                        }
+                    }
+                } else
                 if (it < rows * 16 && t >= 0 && t < a.L_in) {
                     const float* src = a.x + (size_t)t * a.Cin + c;
                     if (c + 3 < a.Cin) q[u] = *reinterpret_cast<const f32x4*>(src);
@@ -344,19 +358,34 @@ __global__ __launch_bounds__(256) void k_f0_head(const float* x, const float* w,
 //   rad_h[i] = (f0[i] * h / 24000) % 1     (the 1/480 linear down-interpolation of the nearest-upsampled signal returns
 //   exactly the frame value: both taps, samples 480 i + 239 and + 240, lie inside frame i, so rand_ini at sample 0 never matters)
 //   phase = cumsum(rad) (float64 accumulate like torch's CPU cumsum) -> fp32 -> * 2 pi -> * 480
-__global__ void k_phase(const float* f0, float* phase, int T, long zs) {
+// One block per lane: the per-element work (multiply, divide, fmod; the final two multiplies) by all threads over tiles of PH_TILE frames,
+// the float64 running sums by nine threads walking the tile's values in LDS -- the same operations in the same order per harmonic as the
+// nine-thread loop this replaces (106 us at 500 frames: every iteration paid a global load, a division and an fmod before its one addition).
+#define PH_TILE 512
+__global__ __launch_bounds__(256) void k_phase(const float* f0, float* phase, int T, long zs) {
+    __shared__ float rad[PH_TILE * 9];
+    __shared__ float cs[PH_TILE * 9];
     f0 += (size_t)blockIdx.z * zs; phase += (size_t)blockIdx.z * zs;
-    const int h = threadIdx.x;            // 9 threads
-    if (h >= 9) return;
-    double acc = 0.0;
-    const float hm = (float)(h + 1);
-    for (int i = 0; i < T; i++) {
-        const float fn = __fmul_rn(f0[i], hm);
-        const float q = __fdiv_rn(fn, 24000.0f);
-        const float rad = fmodf(q, 1.0f);
-        acc += (double)rad;
-        const float c = (float)acc;
-        phase[i * 9 + h] = __fmul_rn(__fmul_rn(c, 6.283185307179586f), 480.0f);
+    const int tid = threadIdx.x;
+    double acc = 0.0;                       // threads 0 .. 8: harmonic tid + 1
+    for (int t0 = 0; t0 < T; t0 += PH_TILE) {
+        const int n = min(PH_TILE, T - t0);
+        for (int e = tid; e < n * 9; e += 256) {
+            const int i = e / 9, h = e - 9 * i;
+            const float fn = __fmul_rn(f0[t0 + i], (float)(h + 1));
+            const float q = __fdiv_rn(fn, 24000.0f);
+            rad[e] = fmodf(q, 1.0f);
+        }
+        __syncthreads();
+        if (tid < 9) {
+            for (int i = 0; i < n; i++) {
+                acc += (double)rad[i * 9 + tid];
+                cs[i * 9 + tid] = (float)acc;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < n * 9; e += 256) phase[(size_t)t0 * 9 + e] = __fmul_rn(__fmul_rn(cs[e], 6.283185307179586f), 480.0f);
+        __syncthreads();
     }
 }
 
@@ -583,8 +612,11 @@ extern "C" const float* cv2_hift_debug_buffer(cv2_hift* h, int32_t which) {
 }
 
 static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out, int ldo, long out_off, int L_out, int pre,
-                       const float* alpha, float slope, const float* res, int ldres, int post, int acc, hipStream_t s) {
+                       const float* alpha, float slope, const float* res, int ldres, int post, int acc, hipStream_t s,
+                       int ld_in = 0, long flat_off = 0, long flat_n = 0) {
     ConvArgs a{};
+    a.ld_in = ld_in; a.flat_off = flat_off; a.flat_n = flat_n;
+    CV2_CHECK(ld_in == 0 || (cw.w3 && cw.taps == 1), "hift conv: flat windows need the three-plane weights and one tap");
     a.x = x; a.L_in = L_in; a.Cin = cw.cin; a.wp = cw.w; a.bias = cw.b; a.CinP = cw.cin_pad; a.CoutP = cw.cout_pad;
     a.Cout_store = cw.cout; a.taps = cw.taps; a.dil = cw.dil; a.pad_left = cw.pad_left; a.pre = pre; a.alpha = alpha; a.slope = slope;
     a.L_out = L_out; a.out = out; a.ldo = ldo; a.out_off = out_off; a.res = res; a.ldres = ldres; a.post = post; a.acc = acc;
@@ -745,7 +777,7 @@ static int hift_run(cv2_hift* h, const float* mel, int32_t T, const float* cache
         hipLaunchKernelGGL(k_f0_head, dim3((T + 3) / 4, 1, Z), dim3(256), 0, s, in, w.f0_w, w.f0_b, h->f0, (int)T, zs);
     }
     // source
-    hipLaunchKernelGGL(k_phase, dim3(1, 1, Z), dim3(64), 0, s, (const float*)h->f0, h->phase, (int)T, zs);
+    hipLaunchKernelGGL(k_phase, dim3(1, 1, Z), dim3(256), 0, s, (const float*)h->f0, h->phase, (int)T, zs);
     {
         SrcArgs a{h->f0, h->phase, T, noise, (uint32_t)seed, (uint32_t)(seed >> 32), seed_dev, w.src_w, w.src_b, cache_source, n_cache, source, zs};
         hipLaunchKernelGGL(k_source, dim3((Ls + 255) / 256, 1, Z), dim3(256), 0, s, a);
@@ -767,8 +799,15 @@ static int hift_run(cv2_hift* h, const float* mel, int32_t T, const float* cache
         // source branch: source_down -> source_resblock, added into x
         {
             CV2_CHECK((F + 2 * sd_p[i] - sd_k[i]) / sd_s[i] + 1 == L, "hift: source_down length %d != %d", (F + 2 * sd_p[i] - sd_k[i]) / sd_s[i] + 1, L);
-            SdArgs a{h->sstft, F, w.sd_w[i], w.sd_b[i], C, sd_k[i], sd_s[i], sd_p[i], h->sd, L, zs};
-            hipLaunchKernelGGL(k_source_down, dim3(((long)L * C + 255) / 256, 1, Z), dim3(256), 0, s, a);
+            static const bool sd_scalar = getenv("CV2_HIFT_SD_SCALAR") && getenv("CV2_HIFT_SD_SCALAR")[0] == '1';      // A/B switch (diagnostics)
+            if (w.sd_conv[i].w3 && !sd_scalar) {
+                // the strided convolution over [F][18] rows as a 1-tap convolution over flat windows of 18 k floats on the matrix cores (k_conv6)
+                if (conv_launch(w.sd_conv[i], h->sstft, L, h->sd, C, 0, L, PRE_NONE, nullptr, 0.f, nullptr, 0, POST_NONE, ACC_STORE, s,
+                                18 * sd_s[i], -18l * sd_p[i], 18l * F)) return -1;
+            } else {
+                SdArgs a{h->sstft, F, w.sd_w[i], w.sd_b[i], C, sd_k[i], sd_s[i], sd_p[i], h->sd, L, zs};
+                hipLaunchKernelGGL(k_source_down, dim3(((long)L * C + 255) / 256, 1, Z), dim3(256), 0, s, a);
+            }
             if (resblock(h, w.src_rb[i], h->sd, L, C, h->x, ACC_ADD, s)) return -1;
         }
         // MRF: mean of 3 ResBlocks

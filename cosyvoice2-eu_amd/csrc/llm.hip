@@ -2554,6 +2554,11 @@ static int launch_sample(cv2_llm* h, int nblocks, int prefill_seq, int row, int 
     return 0;
 }
 
+extern "C" int cv2_llm_debug_sample(cv2_llm* h, int32_t n_rows, void* stream) {
+    CV2_CHECK(h && n_rows >= 1 && n_rows <= h->d.max_seqs, "cv2_llm_debug_sample: bad arguments");
+    return launch_sample(h, n_rows, -1, 0, 0, (hipStream_t)stream);
+}
+
 extern "C" int cv2_llm_prefill(cv2_llm* h, int32_t seq, const float* embeds, int32_t len, void* stream) {
     CV2_CHECK(h && embeds, "cv2_llm_prefill: null argument");
     CV2_CHECK(seq >= 0 && seq < h->d.max_seqs, "cv2_llm_prefill: bad slot %d", seq);

@@ -24,7 +24,7 @@ class ResBlock(C.Structure):
 
 class HiftWeights(C.Structure):
     _fields_ = [('f0_conv', Conv * 5), ('f0_w', C.c_void_p), ('f0_b', C.c_void_p), ('src_w', C.c_void_p), ('src_b', C.c_void_p),
-                ('conv_pre', Conv), ('ups', Conv * 3), ('sd_w', C.c_void_p * 3), ('sd_b', C.c_void_p * 3),
+                ('conv_pre', Conv), ('ups', Conv * 3), ('sd_w', C.c_void_p * 3), ('sd_b', C.c_void_p * 3), ('sd_conv', Conv * 3),
                 ('src_rb', ResBlock * 3), ('rb', ResBlock * 9), ('conv_post', Conv)]
 
 
@@ -170,6 +170,9 @@ class HiftEngine:
             w.ups[i] = conv(polyphase(wt, u, (k - u) // 2), b.repeat(u), 1, 1)
             w.sd_w[i] = f32(sd[f'source_downs.{i}.weight'].float().permute(2, 1, 0))      # [C][18][k] -> [k][18][C]
             w.sd_b[i] = f32(sd[f'source_downs.{i}.bias'])
+            # the same convolution over flat windows of the [F][18] rows: [C][18][k] -> [C][18 k][1] with input index j * 18 + c
+            wsd = sd[f'source_downs.{i}.weight'].float()
+            w.sd_conv[i] = conv(wsd.permute(0, 2, 1).reshape(wsd.shape[0], -1, 1), sd[f'source_downs.{i}.bias'], 1, 0)
             w.src_rb[i] = resblock(f'source_resblocks.{i}', (7, 7, 11)[i])
             for j, k2 in enumerate((3, 7, 11)):
                 w.rb[i * 3 + j] = resblock(f'resblocks.{i * 3 + j}', k2)

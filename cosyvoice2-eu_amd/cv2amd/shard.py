@@ -66,25 +66,28 @@ def scatter_texts(texts, src=0):
 
 def gather_waves(waves, indices, n_total, dst=0):
     """waves: this rank's list of 1-D float32 waveforms with their global indices.  Rank `dst` gets the full list in the
-    original order; the other ranks get None."""
+    original order (CPU tensors); the other ranks get None.  Waveforms that are still on the rank's device (tts(device_output=True))
+    go into the gather buffer device to device, and rank `dst` makes ONE device-to-host copy of what it gathered (CPU waveforms used to be
+    copied back to the device for the collective: ~250 MB bounced twice at configs[3])."""
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = _dev()
-    lens = torch.tensor([w.numel() for w in waves], dtype=torch.int64)
+    lens = [int(w.numel()) for w in waves]
     meta = [None] * world
-    dist.all_gather_object(meta, (indices, lens.tolist()))
+    dist.all_gather_object(meta, (indices, lens))
     per = max(len(m[0]) for m in meta)
     maxlen = max([l for m in meta for l in m[1]] + [1])
     buf = torch.zeros(per, maxlen, dtype=torch.float32, device=dev)
     for j, w in enumerate(waves):
-        buf[j, :w.numel()] = w.to(dev)
+        buf[j, :lens[j]].copy_(w.reshape(-1), non_blocking=True)
     out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, out, dst=dst)
     if rank != dst:
         return None
+    host = torch.stack(out).cpu()                          # [world][per][maxlen]
     res = [None] * n_total
     for r, (idxs, ls) in enumerate(meta):
         for j, (idx, l) in enumerate(zip(idxs, ls)):
-            res[idx] = out[r][j, :l].cpu()
+            res[idx] = host[r, j, :l].clone()
     return res
 
 

@@ -148,11 +148,17 @@ int cv2_llm_decode_rows(cv2_llm* h, const int32_t* slots, int32_t n_rows, int32_
 /* 1 when decode steps of up to 24 rows of this engine run as one launch (k_step / k_step2 / k_step4), 0 when they run as launches (dims
  * outside k_step's limits, or CV2_LLM_CHAIN=0). */
 int cv2_llm_one_launch_step(const cv2_llm* h);
-/* test hook: from now on Q-role block `q_block` of layer `layer` of every one-launch step does not publish its results (layer < 0: off),
- * so the blocks behind it end in their bounded waits and the step reports CV2_ST_ERR = 3 without committing anything. */
+/* test hook: from now on Q-role block `q_block` of layer `layer` of every one-launch step does not publish its results (layer < 0: off; the
+ * same (layer, block) key in every one-launch form), so the blocks behind it end in their bounded waits and EVERY row of the block's chain
+ * reports CV2_ST_ERR = 3 without committing anything. */
 int cv2_llm_debug_skip_publish(cv2_llm* h, int32_t layer, int32_t q_block);
 /* test / diagnostic hook: device addresses of the decode workspaces and the granule layout (16 values; tools/dbg_chain_vals.py) */
 int cv2_llm_debug_ptrs(cv2_llm* h, uint64_t* out);
+/* test hook: ONE sampler launch (k_sample) over slots 0 .. n_rows - 1 from whatever the caller has put into logits[row], state[slot] and
+ * out_tokens[slot] -- TransformerLM.sampling_ids + ras_sampling (llm/llm.py:235-250, utils/common.py:111-139) on their own, so that
+ * tests/golden/sampler_ras.npz (decisions of the reference's functions under a committed table of uniforms = this sampler's Philox draws)
+ * can be replayed on the device.  Updates the slots exactly as a decode step's draw does. */
+int cv2_llm_debug_sample(cv2_llm* h, int32_t n_rows, void* stream);
 
 /* Stand-alone skinny GEMM used by the LLM (exported for unit tests and for the flow time-MLP):
  * out[r][n] = sum_k W[n][k] x[r][k] (+bias[n]); rows <= 32; W packed; K % 32 == 0; N % 16 == 0. */
@@ -285,7 +291,9 @@ int cv2_flow_inference_chunk(cv2_flow* h, const cv2_flow_utt* utts, const cv2_fl
 int cv2_flow_cache_copy(const cv2_flow* h, const void* src, int32_t src_frames, void* dst, int32_t dst_frames, int32_t n_frames, void* stream);
 
 /* Test hook: 1 / 0 = the estimator attention of large batches (>= 4096 rows) with / without LDS DMA staging of its key / value tiles
- * (same matrix-core sequence: outputs agree bit for bit), -1 = the default. */
+ * (the DMA form permutes a tile's keys among the score rows: the same products summed in another order inside a matrix-core k group --
+ * the two forms agree to fp32 round-off, 3-4e-3 of the mel range after the 10 Euler steps, NOT bit for bit; batches of >= 4096 rows
+ * therefore differ from the same utterances run alone by that margin), -1 = the default. */
 int cv2_flow_debug_attn_dma(int32_t on);
 
 /* The estimator alone behind the reference's TensorRT seam (flow_matching.py:125-150): six contiguous device
@@ -329,7 +337,9 @@ typedef struct {
     const float* src_w; const float* src_b; /* m_source.l_linear [9], [1] */
     cv2_conv conv_pre;
     cv2_conv ups[3];
-    const float* sd_w[3]; const float* sd_b[3];  /* source_downs weights re-ordered [k][18][C] */
+    const float* sd_w[3]; const float* sd_b[3];  /* source_downs weights re-ordered [k][18][C] (the scalar kernel; used when sd_conv[i].w3 is NULL) */
+    cv2_conv sd_conv[3];                  /* source_downs.{0,1,2} (generator.py:468-479) as 1-tap convolutions over flat windows of the [F][18] STFT rows:
+                                             cin = 18 k with input index j * 18 + c for tap j, channel c; taps = 1; w3 given -> they run on the matrix cores */
     cv2_resblock src_rb[3];
     cv2_resblock rb[9];
     cv2_conv conv_post;

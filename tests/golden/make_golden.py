@@ -356,8 +356,9 @@ def gen_sampler_ras():
     ignore_eos, RuntimeError after 100).  Only the RNG is replaced: `Tensor.multinomial` draws by inverse CDF from a committed
     table of uniforms (first index whose float64 cumulative sum exceeds u * total) -- the nucleus draw of trial t takes
     u[t][0], the full-vocabulary re-draw of that trial (when the repetition rule fires) u[t][1] -- exactly like torch.rand /
-    randn_like are replaced for HiFT above.  Stored per case: logp, the decoded window, ignore_eos, the uniforms, and the id the
-    reference returned (-1: it raised the RuntimeError)."""
+    randn_like are replaced for HiFT above.  The table of a case is Philox4x32-10 under a stored (seed, step) -- the function k_sample
+    draws with (cv2amd/philox.py) -- so the GPU test needs no injection: the device draws the same numbers by itself.  Stored per case: logp,
+    the decoded window, ignore_eos, the uniforms, (seed, step), and the id the reference returned (-1: it raised the RuntimeError)."""
     from cosyvoice.utils.common import ras_sampling
     from cosyvoice.llm.llm import TransformerLM
     EOS = 6561
@@ -390,10 +391,23 @@ def gen_sampler_ras():
         return top, state['trial'] + 1, state['draws']
 
     cases = []
+    from cv2amd import philox
+    seed_ctr = [1000]
 
-    def add(kind, logp, window, ignore_eos, u=None):
-        u = torch.rand(102, 2, generator=g, dtype=torch.float64) if u is None else u
-        cases.append((kind, logp.float().log_softmax(0), list(window), bool(ignore_eos), u))
+    def table(seed, step):
+        """The uniforms the device's sampler draws for (slot 0, step, trial 0 .. 101) under `seed` (cv2amd/philox.py = k_sample's Philox):
+        the committed table IS what the GPU test's k_sample will use."""
+        return torch.tensor([philox.uniforms(0, step, t, seed) for t in range(102)], dtype=torch.float64)
+
+    def add(kind, logp, window, ignore_eos, want=None):
+        """want(u) -> bool: take the first seed whose table has the property the case was built for"""
+        while True:
+            seed_ctr[0] += 1
+            seed, step = seed_ctr[0] * 7919 + 13, 1 + seed_ctr[0] % 37
+            u = table(seed, step)
+            if want is None or want(u):
+                break
+        cases.append((kind, logp.float().log_softmax(0), list(window), bool(ignore_eos), u, seed, step))
 
     def peaked(ids, vals, base=-14.0, noise=0.3):
         x = torch.full((6564,), base) + noise * torch.randint(-8, 9, (6564,), generator=g).float() / 4      # (few distinct values: the fixture compresses)
@@ -419,14 +433,13 @@ def gen_sampler_ras():
     # (d) EOS (almost) certain while ignore_eos: 101 trials, then the RuntimeError (kind 3); one case escapes on a late trial through the full-vocabulary draw
     for i in range(8):
         x = peaked([EOS], [40.0], base=-40.0, noise=0.0)
-        u = torch.rand(102, 2, generator=g, dtype=torch.float64)
         window = [EOS] if i >= 4 else []           # EOS in the window: every trial also takes the full-vocabulary draw (EOS again)
-        add(3, x, window, True, u)
+        add(3, x, window, True)
     for i in range(4):
         x = peaked([EOS, 17 + i], [6.0, 0.0], base=-30.0, noise=0.0)        # EOS holds 0.9975 of the mass (> top_p: the only nucleus candidate) and sits in the window:
-        u = 0.5 + 0.5 * torch.rand(102, 2, generator=g, dtype=torch.float64)  # every trial goes to the full-vocabulary draw, which returns EOS for u >= 0.0025 ...
-        u[60 + 7 * i, 1] = 0.001                                              # ... except on one late trial (id 17 + i)
-        add(3, x, [EOS], True, u)
+        # every trial goes to the full-vocabulary draw, which returns EOS for u >= 0.0025 and id 17 + i below: a seed whose first such u comes on a late trial
+        first = lambda u: next((t for t in range(101) if float(u[t, 1]) < 0.0024), -1)
+        add(3, x, [EOS], True, want=lambda u: 50 < first(u) <= 100 and all(not (0.0024 <= float(u[t, 1]) < 0.0026) for t in range(101)))
     # (e) ties: equal top logits (the stable sort keeps the lower id first), exactly 25 candidates, one candidate holding > top_p (kind 4)
     for i in range(8):
         x = torch.full((6564,), -20.0)
@@ -437,9 +450,9 @@ def gen_sampler_ras():
         else:
             x[1234] = 5.0
         add(4, x, [50] if i == 1 else [], i % 2)
-    out = dict(logp=[], window=[], window_len=[], ignore_eos=[], uniforms=[], kind=[], top=[], trials=[], draws=[])
+    out = dict(logp=[], window=[], window_len=[], ignore_eos=[], uniforms=[], kind=[], top=[], trials=[], draws=[], seed=[], step=[])
     hist = {}
-    for kind, logp, window, ign, u in cases:
+    for kind, logp, window, ign, u, seed, step in cases:
         top, trials, draws = run(logp, window, ign, u)
         uni = lambda s_, t_: (float(u[t_, 0]), float(u[t_, 1]))
         try:
@@ -451,6 +464,7 @@ def gen_sampler_ras():
         w[:len(window)] = window
         out['logp'].append(logp.numpy()); out['window'].append(w); out['window_len'].append(len(window)); out['ignore_eos'].append(int(ign))
         out['uniforms'].append(u.numpy()); out['kind'].append(kind); out['top'].append(top); out['trials'].append(trials); out['draws'].append(draws)
+        out['seed'].append(seed); out['step'].append(step)
         hist.setdefault(kind, []).append((top, trials, draws))
     # the cases cover what they were built for
     assert all(t == 1 and d == 1 for _, t, d in hist[0])                          # no repetition: one trial, one draw

@@ -197,3 +197,71 @@ def test_speed_changes_length(cv):
     a = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr', speed=1.0))[0]['tts_speech']
     b = list(cv.inference_zero_shot('bonjour', 'salut', None, zero_shot_spk_id='fr', speed=2.0))[0]['tts_speech']
     assert abs(b.shape[1] - a.shape[1] // 2) <= 480
+
+
+def test_evaluation_harness_contract(cv):
+    """SURVEY §8(c) last row: `CosyVoice2` driven the way `evaluation/cosyvoice_synthesizer.py:183-302` drives the reference (pattern
+    restated in tests/_harness_replay.py): `_ensure_prompt_cached` registers the prompt ONCE through add_zero_shot_spk, a warm-up call
+    "warmup.", a pool of 8 workers over 12 samples with the language hint, one sample whose frontend raises -> ITS row carries `error`
+    and no audio while the other eleven succeed (the coalesced batch it rode in is not poisoned), result keys and per-utterance rtf
+    as the pipeline computes it, every per-call state released.  Then a caller that stops waiting (`future.result(timeout)` -- the
+    reference's as_completed loop only ever sees finished futures, so its FuturesTimeout row needs a waiter outside that loop): the
+    abandoned call keeps its slot, finishes on its own, and a second batch runs on a model with every slot free again."""
+    import math
+    from concurrent.futures import ThreadPoolExecutor, TimeoutError as FuturesTimeout
+    from _harness_replay import SynthesizerReplay, rtf
+    fe = cv.frontend
+    calls = {'extract': 0}
+    real_zero_shot = fe.frontend_zero_shot
+
+    def zero_shot(tts_text, prompt_text, prompt_speech_16k, resample_rate, zero_shot_spk_id):
+        if zero_shot_spk_id == '':             # "feature extraction" of the prompt audio: the pre-extracted dict, counted
+            calls['extract'] += 1
+            return real_zero_shot(tts_text, prompt_text, prompt_speech_16k, resample_rate, 'fr')
+        return real_zero_shot(tts_text, prompt_text, prompt_speech_16k, resample_rate, zero_shot_spk_id)
+    real_tok = fe.tokenize
+
+    def tokenize(t):
+        if 'kaputt' in t:
+            raise KeyError('tokenizer: unknown piece in ' + t)
+        return real_tok(t.replace('<|fr|><|endofprompt|> ', ''))
+    fe.frontend_zero_shot, fe.tokenize = zero_shot, tokenize
+    try:
+        h = SynthesizerReplay(cv, prompt_speech=torch.zeros(1, 16000))
+        cfg = {'method': 'zero_shot', 'prompt_text': 'salut', 'zero_shot_spk_id': 'eval_cached_prompt', 'warmup': True, 'workers': 8,
+               'timeout_s': 30, 'add_language_hint': True, 'language': 'fr', 'text_frontend': False, 'speed': 1.0}
+        texts = ['bonjour', 'guten tag', 'bonjour', 'autre', 'guten tag', 'kaputt', 'bonjour', 'guten tag', 'autre', 'bonjour', 'guten tag', 'autre']
+        samples = [{'utterance_id': f'utt_{i:03d}', 'text': t} for i, t in enumerate(texts)]
+        rows = h.synthesize_batch(samples, cfg)
+        assert calls['extract'] == 1 and h.cached_spk_id == 'eval_cached_prompt' and 'eval_cached_prompt' in cv.list_available_spks()
+        assert [r['utterance_id'] for r in rows] == [s['utterance_id'] for s in samples]
+        for i, r in enumerate(rows):
+            if texts[i] == 'kaputt':
+                assert set(r) == {'utterance_id', 'audio_tensor', 'audio_path', 'sample_rate', 'synthesis_time', 'error'}
+                assert r['audio_tensor'] is None and r['sample_rate'] is None and r['synthesis_time'] == 0.0 and 'unknown piece' in r['error']
+                assert math.isnan(rtf(r))
+            else:
+                assert set(r) == {'utterance_id', 'audio_tensor', 'audio_path', 'sample_rate', 'synthesis_time'}
+                w = r['audio_tensor']
+                assert w.dtype == torch.float32 and w.device.type == 'cpu' and w.shape[0] == 1 and w.shape[1] % 960 == 0 and w.shape[1] > 0
+                assert r['sample_rate'] == 24000 and r['synthesis_time'] > 0 and 0 < rtf(r) < 50
+        # the same text gives the same audio whichever batch it rode in (greedy ids; flow / HiFT noise is per call and seeded)
+        same = [r['audio_tensor'].shape for r, t in zip(rows, texts) if t == 'bonjour']
+        assert len(set(same)) == 1
+        m = cv.model
+        assert m.tts_speech_token_dict == {} and m.hift_cache_dict == {} and len(m._slot_free) == m.max_batch and not m._active_slots
+        # a waiter that gives up: its call goes on, holds its slot until it finishes, then releases it
+        with ThreadPoolExecutor(max_workers=2) as ex:
+            fut = ex.submit(h.synthesize_single, 'guten tag', cfg)
+            try:
+                fut.result(timeout=1e-4)
+                timed_out = False
+            except FuturesTimeout:
+                timed_out = True
+            others = h.synthesize_batch(samples[:4], dict(cfg, warmup=False, workers=4))
+            late = fut.result(timeout=60)
+        assert timed_out and late.shape[1] > 0 and all(r['audio_tensor'] is not None for r in others)
+        assert m.tts_speech_token_dict == {} and len(m._slot_free) == m.max_batch and not m._active_slots
+    finally:
+        fe.frontend_zero_shot, fe.tokenize = real_zero_shot, real_tok
+        cv.frontend.spk2info.pop('eval_cached_prompt', None)

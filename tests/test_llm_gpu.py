@@ -379,6 +379,43 @@ def test_ras_sampling_matches_oracle_with_same_noise(small):
         assert ids == want
 
 
+def test_sampler_decisions_vs_reference_fixture(small):
+    """k_sample on its own (test hook cv2_llm_debug_sample) replays tests/golden/sampler_ras.npz: logp, decoded window and ignore_eos of 64
+    cases go into the engine's logits / out_tokens / state, the slot's (seed, step) are the ones the fixture's table of uniforms was made
+    with (Philox: the device draws the table itself), and the id drawn -- or the 100-re-draw error -- must be what the REFERENCE's
+    `TransformerLM.sampling_ids` + `ras_sampling` returned under that table (llm/llm.py:235-250, utils/common.py:111-139).  Both candidate
+    selection paths (mode 1, and 5 = the extract-max path)."""
+    import os
+    from cv2amd import lib as L
+    from cv2amd.llm import MODE_RAS
+    sd, sdr, eng = small
+    gd = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'sampler_ras.npz'))
+    n = len(gd['top'])
+    for mode in (MODE_RAS, 5):
+        for i in range(n):                                    # (the tables are drawn for slot 0: one case per launch)
+            step, seed, wl = int(gd['step'][i]), int(gd['seed'][i]), int(gd['window_len'][i])
+            st = torch.zeros(L.STATE_STRIDE, dtype=torch.int32)
+            st[L.ST_POS], st[L.ST_STEP], st[L.ST_NOUT] = 40, step, wl
+            st[L.ST_MINLEN] = step + 1 if gd['ignore_eos'][i] else 0             # ignore_eos = step < min_len (llm.py:697)
+            st[L.ST_MAXLEN], st[L.ST_MODE] = 10_000, mode
+            st[L.ST_SEED_LO], st[L.ST_SEED_HI] = seed & 0x7FFFFFFF, 0
+            toks = torch.zeros(eng.max_out, dtype=torch.int32)
+            toks[:wl] = torch.from_numpy(gd['window'][i][:wl]).int()
+            lg = torch.zeros(eng.logits.shape[1])
+            lg[:6564] = torch.from_numpy(gd['logp'][i])
+            eng.state[0].copy_(st); eng.out_tokens[0].copy_(toks); eng.logits[0].copy_(lg)
+            L.check(eng.lib.cv2_llm_debug_sample(eng.handle, 1, L.stream_ptr()))
+            got = eng.state[0].cpu()
+            want = int(gd['top'][i])
+            if want < 0:
+                assert int(got[L.ST_ERR]) == 1, f'case {i}: expected the 100-re-draw error'
+            else:
+                assert int(got[L.ST_ERR]) == 0 and int(got[L.ST_LAST]) == want, \
+                    f'case {i} (kind {int(gd["kind"][i])}, mode {mode}): device {int(got[L.ST_LAST])}, reference {want}'
+                assert int(got[L.ST_STEP]) == step + 1
+    eng.park()
+
+
 def test_ras_candidate_selection_paths_agree(small):
     """The nucleus candidates come from a bound + rank-by-counting selection; massively tied logits fall back to 25 extract-max
     rounds.  Sampler mode 5 forces that fallback: both must draw the same ids from the same Philox stream."""

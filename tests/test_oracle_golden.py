@@ -98,6 +98,35 @@ def test_sampler_candidates(golden):
         assert len(idx) <= 25 and (float(p[:-1].sum()) < 0.8 or len(idx) == 1)
 
 
+def test_sampler_decisions_vs_reference(golden):
+    """oracle.llm.sampling_ids against the decisions of the reference's own `TransformerLM.sampling_ids` + `ras_sampling`
+    (llm/llm.py:235-250, utils/common.py:111-139) under a committed table of uniforms (tests/golden/make_golden.py gen_sampler_ras: only
+    `Tensor.multinomial` is replaced, by an inverse-CDF draw from the table): no repetition, the repetition rule's full-vocabulary re-draw,
+    EOS re-draws while ignore_eos, the RuntimeError after 100 re-draws (top = -1), ties."""
+    gd = golden('sampler_ras.npz')
+    n = len(gd['top'])
+    assert n >= 64 and set(gd['kind'].tolist()) == {0, 1, 2, 3, 4}
+    fired = errors = redraws = 0
+    for i in range(n):
+        u = gd['uniforms'][i]
+        window = gd['window'][i][:int(gd['window_len'][i])].tolist()
+        trials = []
+
+        def uni(step, trial):
+            trials.append(trial)
+            return float(u[trial, 0]), float(u[trial, 1])
+        try:
+            top = OL.sampling_ids(torch.from_numpy(gd['logp'][i]), window, bool(gd['ignore_eos'][i]), 'ras', uni, 0)
+        except RuntimeError:
+            top = -1
+        assert top == int(gd['top'][i]), f'case {i} (kind {int(gd["kind"][i])}): oracle {top}, reference {int(gd["top"][i])}'
+        assert len(trials) == int(gd['trials'][i])
+        fired += int(gd['draws'][i]) > int(gd['trials'][i])
+        errors += top == -1
+        redraws += int(gd['trials'][i]) > 1
+    assert fired >= 8 and errors >= 8 and redraws >= 12          # the fixture exercises every branch
+
+
 def test_ras_repetition_and_eos_guard():
     logp = torch.full((6564,), -20.0)
     logp[5] = 0.0
