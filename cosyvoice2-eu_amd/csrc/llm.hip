@@ -116,9 +116,13 @@ __global__ __launch_bounds__(512) void k_qkv(QkvArgs a) {
             if (rot) { b1 = a.bias[head * 64 + (f ^ 32)]; c = a.cosT[pos * 32 + (f & 31)]; sn = a.sinT[pos * 32 + (f & 31)]; }
         }
         const float rs = scaled ? rs_s[r] : 1.f;
-        float v = res[(w * 16 + i16) * ld + r] * rs + b0;
+        // (the scaled value is rounded BEFORE the bias is added, as in the <= 16-row form where skinny_core applies the row's rstd: hipcc would
+        // contract the two into one fma)
+        float t0 = res[(w * 16 + i16) * ld + r] * rs, t1 = res[((1 - w) * 16 + i16) * ld + r] * rs;
+        asm volatile("" : "+v"(t0), "+v"(t1));
+        float v = t0 + b0;
         if (rot) {                                         // rotate-half RoPE on q and k heads
-            const float vp = res[((1 - w) * 16 + i16) * ld + r] * rs + b1;
+            const float vp = t1 + b1;
             v = (f < 32) ? (v * c - vp * sn) : (v * c + vp * sn);
         }
         if (head < a.n_q) a.q[(size_t)r * a.n_q * 64 + head * 64 + f] = v;
@@ -541,6 +545,7 @@ struct StoreArgs {
     // order onto the residual stream and runs the NEXT epilogue for the following layer's QKV kernel (what k_prep<false> did as a launch
     // of its own).  arrive = [N / 16] counters, zero between launches
     int* arrive;
+    const float* sq; float eps;                 // PRE operand left un-normalised by k_prep (the head's final norm): out = (W (g . x)) rsqrt(sq[row] / K + eps) (+ bias)
 };
 template <int NB, int MAXKS, bool ATT = false, bool PRE = false, bool NEXT = false, bool LAST = false>
 __global__ __launch_bounds__(256) void k_store(StoreArgs a) {
@@ -563,6 +568,7 @@ __global__ __launch_bounds__(256) void k_store(StoreArgs a) {
     for (int e = threadIdx.x; e < a.rows * 16; e += blockDim.x) {
         const int r = e >> 4, i = e & 15;
         float v = res[i * ld + r];
+        if (PRE && a.sq) { v *= rsqrtf(a.sq[r] / (float)a.K + a.eps); asm volatile("" : "+v"(v)); }      // (rounded before the bias, as skinny_core's deferred scale)
         if (a.bias && blockIdx.y == 0) v += a.bias[n0 + i];
         if (LAST) st_agent(&out[(size_t)r * a.N + n0 + i], v);
         else if (NEXT) next(r, i, v + a.resid[(size_t)r * a.N + n0 + i]);
@@ -2455,8 +2461,8 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
     int np = 0;
     bool ready = false;                                  // the layer's QKV operand was left by the previous down projection (planes in xp, shares in sqp2, x1 written)
     auto prep = [&](const SkinnyX& X, int K, bool att) {
-        if (att) hipLaunchKernelGGL(k_prep<true>, dim3(rows), dim3(256), 0, s, X, K, h->xp);
-        else hipLaunchKernelGGL(k_prep<false>, dim3(rows), dim3(256), 0, s, X, K, h->xp);
+        if (att) hipLaunchKernelGGL(k_prep<true>, dim3(rows), dim3(256), 0, s, X, K, h->xp, (float*)nullptr);
+        else hipLaunchKernelGGL(k_prep<false>, dim3(rows), dim3(256), 0, s, X, K, h->xp, h->sqp2);      // (one share per row: the sum of squares)
     };
     SkinnyX pre{};
     pre.pre = h->xp;
@@ -2470,7 +2476,7 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
             a.KS = KSH; a.rows = rows; a.K = H; a.n_q = d.n_q; a.n_kv = d.n_kv;
             a.cosT = h->w.rope_cos; a.sinT = h->w.rope_sin;
             a.q = h->q; a.kc = h->kc + l * cache_l; a.vc = h->vc + l * cache_l; a.max_pos = d.max_pos; a.rm = rm;
-            if (ready) { a.sq = h->sqp2; a.nsq = H / 16; a.eps = d.rms_eps; }
+            a.sq = h->sqp2; a.nsq = ready ? H / 16 : 1; a.eps = d.rms_eps;     // the rows' sums of squares: the down projection's shares, or k_prep's total
             { const size_t sm = skinny_smem_bytes<2, 2, 4>(KSH); hipLaunchKernelGGL((k_qkv<2, true>), dim3(2 * (d.n_q + 2 * d.n_kv), 1), dim3(512), sm, s, a); }
         }
         {   // attention; the last split of a (row, kv head) combines the splits and leaves the O projection's operand planes
@@ -2519,6 +2525,7 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
         StoreArgs a{};
         a.W = h->w.wdec; a.bias = h->w.bdec; a.X = pre;
         a.KS = KSH; a.rows = rows; a.K = H; a.N = d.vocab_pad; a.out = h->io.logits;
+        a.sq = h->sqp2; a.eps = d.rms_eps;
         { const size_t sm = skinny_smem_bytes<2, 1, 4>(KSH); hipLaunchKernelGGL((k_store<2, 8, false, true>), dim3(d.vocab_pad / 16, 1), dim3(256), sm, s, a); }
     }
     CV2_LAUNCH_CHECK();

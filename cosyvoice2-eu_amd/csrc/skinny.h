@@ -375,34 +375,40 @@ __device__ __forceinline__ float* skinny_core(const uint16_t* __restrict__ W, in
     return res;
 }
 
-// Operand preparation for many-row launches (rows > 16): fold + RMSNorm + hi/lo split ONCE per row instead of once per
-// block, written in the LDS B-operand order the PRE kernels copy.  One block per row; K % 8 == 0.
+// Operand preparation for many-row launches (rows > 16): fold + RMSNorm weight + hi/lo split ONCE per row instead of once per
+// block, written in the LDS B-operand order the PRE kernels copy.  One block per row; K % 8 == 0, K <= 8 * 256.
+// RMSNorm in the DEFERRED form of the <= 16-row kernels (skinny_core, step 2): the planes hold g . x, the row's sum of squares goes to
+// sq_out[row] and the consumer scales its OUTPUTS by rsqrt(sq / K + eps) -- W (g . x) rs, the arithmetic every other form of the decode
+// step uses.  (Until round 5 this kernel staged g . (x rs): the normalised value was rounded to its hi / lo planes, a 2^-17 difference
+// against the other forms where everything else differs by fp32 round-off.)  The sum of squares runs in skinny_core's order: per item
+// ((v0^2 + v1^2) + (v2^2 + v3^2)) + ((v4^2 + v5^2) + (v6^2 + v7^2)), lane l of one wave adds items l, l + 64, .., then wave_sum.
 template <bool ATT>
-__global__ __launch_bounds__(256) void k_prep(SkinnyX X, int K, uint16_t* pre) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(256) void k_prep(SkinnyX X, int K, uint16_t* pre, float* sq_out) {
+    __shared__ float isq[256];
     const int r = blockIdx.x, tid = threadIdx.x;
     const int nitem = K / 8;
-    float sq = 0.f;
-    if (X.norm_w) {
-        for (int it = tid; it < nitem; it += 256) {
-            const f32x8 v = sk_load_x<ATT>(X, r, K, it * 8);
-            sq += ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
-        }
-        sq = wave_sum(sq);
-        if ((tid & 63) == 0) red[tid >> 6] = sq;
-        __syncthreads();
-        sq = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + X.eps);
-    }
     for (int it = tid; it < nitem; it += 256) {
         f32x8 v = sk_load_x<ATT>(X, r, K, it * 8);
         if (X.x_out) *reinterpret_cast<f32x8*>(X.x_out + (size_t)r * K + it * 8) = v;
-        if (X.norm_w) v = *reinterpret_cast<const f32x8*>(X.norm_w + it * 8) * (v * sq);
+        if (X.norm_w) {
+            isq[it] = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+            v = *reinterpret_cast<const f32x8*>(X.norm_w + it * 8) * v;
+        }
         bf16x8 hi, lo;
         split8(v, hi, lo);
         const int s = it >> 2, hq = it & 3, t = r >> 4;
         bf16x8* dst = reinterpret_cast<bf16x8*>(pre + ((size_t)(s * 2 + t) * 2) * 512) + hq * 16 + (r & 15);
         dst[0] = hi;
         dst[64] = lo;
+    }
+    if (X.norm_w) {
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.f;
+            for (int i = tid; i < nitem; i += 64) s += isq[i];
+            s = wave_sum(s);
+            if (tid == 0) sq_out[r] = s;
+        }
     }
 }
 

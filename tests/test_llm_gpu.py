@@ -315,6 +315,33 @@ def test_many_row_decode_path(small):
         assert ids == OL.inference(sdr, text, ptxt, ptok, force_len=8)
 
 
+def test_many_row_launches_normalise_like_the_other_forms(small):
+    """The 17 .. 32-row launches prepare every row's operand once (k_prep).  Since round 5 that preparation is the DEFERRED RMSNorm of every
+    other form of the decode step -- planes of g . x, the consumer scales its outputs by the row's rstd -- instead of planes of the
+    normalised value g . (x rstd), an extra hi / lo rounding of the operand that no other form has.  The forms still are different
+    kernels (matrix-core attention up to 8 rows, the scalar one above; tile merges of the one-launch forms): the same three requests as
+    rows 0 .. 2 of a 3-row and of a 20-row step, logits after 7 steps, relative to the largest logit -- measured (tools/dbg_rows_forms.py)
+    3 vs 8 rows 0, vs 12 / 16 rows 4.6e-6 (the attention kernels), vs 17 .. 32 rows 4.5e-6 (6.1e-6 with the old preparation), launches vs
+    one-launch forms 5.1 - 5.4e-6.  Greedy ids agree across the forms by margin (top-1 margins: profiles/r3_llm_margin_histogram.json),
+    not by construction; the bar holds the many-row form to the class of the others."""
+    from _bars import bar
+    sd, sdr, eng = small
+    reqs = _requests(20, seed=900)
+    xs = [eng.build_lm_input(*r) for r in reqs]
+    out = {}
+    for n in (3, 20):
+        eng.park()
+        eng.add_requests(list(range(n)), xs[:n], [(12, 12)] * n, 0, 0, True)
+        eng.step(n, 6, shared=True)
+        torch.cuda.synchronize()
+        st, toks = eng.read(n)
+        out[n] = (toks[:3], eng.logits[:3, :eng.vocab].clone())
+    assert out[3][0] == out[20][0]
+    scale = out[3][1].abs().max().item()
+    bar('llm 20-row vs 3-row launches, logits after 7 steps (rel to max)', (out[3][1] - out[20][1]).abs().max().item() / scale, 5.5e-6)
+    eng.park()
+
+
 def test_many_row_launches_with_fused_combines_are_reproducible(dev, small, monkeypatch):
     """The measured-and-rejected form of the 17 .. 32-row step, kept behind CV2_PRE_FUSE=1 for the A/B (llm.hip, run_layers_pre): 5
     launches per layer -- the attention's last split of a (row, kv head) combines the splits and leaves the O projection's operand; the

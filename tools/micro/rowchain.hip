@@ -13,11 +13,11 @@
 #include <vector>
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-#define NH 7
+#define NH 8                                   // hops per layer at most (Args::nh are used)
 #define THREADS 512
 struct Hop { int nb; int rd_bytes; int rd_whole; int wr_total; int w_bytes; };   // blocks; operand bytes per block (whole prev buffer or own slice); bytes of this hop's output; weight bytes per block
 struct Args {
-    Hop hop[NH]; int per_layer; int layers;
+    Hop hop[NH]; int nh; int per_layer; int layers;
     float* out[NH]; int out_stride[NH];       // per layer (floats)
     unsigned* flags; int flag_off[NH];        // [layer][sum nb]
     const f32x4* w; unsigned epoch; unsigned* err; float* sink; int single_hop; int single_layer;
@@ -34,12 +34,12 @@ __global__ __launch_bounds__(THREADS) void k_rows(Args a) {
     if (CHAIN) {
         l = blockIdx.x / a.per_layer;
         int r = blockIdx.x - l * a.per_layer;
-        for (h = 0; h < NH - 1 && r >= a.hop[h].nb; h++) r -= a.hop[h].nb;
+        for (h = 0; h < a.nh - 1 && r >= a.hop[h].nb; h++) r -= a.hop[h].nb;
         i = r;
     } else { l = a.single_layer; h = a.single_hop; i = blockIdx.x; }
     const Hop H = a.hop[h];
     const int gidx = l * a.per_layer + a.flag_off[h] + i;                        // the block's index in dependency order (= blockIdx.x of the one-launch form)
-    const int ph = h == 0 ? NH - 1 : h - 1, pl = h == 0 ? l - 1 : l;              // producer hop / layer
+    const int ph = h == 0 ? a.nh - 1 : h - 1, pl = h == 0 ? l - 1 : l;              // producer hop / layer
     // ---- weights first
     f32x4 wr[8];
     float wsum = 0.f;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(THREADS) void k_rows(Args a) {
     float tot = 0.f;
     for (int k = 0; k < THREADS / 64; k++) tot += red[k];
     if (pl >= 0) {
-        const float want = (float)(H.rd_bytes / 4) * (float)(1 + ((pl * NH + ph + a.epoch) & 7));      // (the constant moves with the epoch: a stale line fails)
+        const float want = (float)(H.rd_bytes / 4) * (float)(1 + ((pl * a.nh + ph + a.epoch) & 7));      // (the constant moves with the epoch: a stale line fails)
         if (tid == 0 && tot != want) atomicCAS(a.err, 0u, 1000u + h);                 // (the first error stays)
     }
     if (WEIGHTS) {
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(THREADS) void k_rows(Args a) {
     {
         const int slice = (H.wr_total / H.nb) & ~15;
         float* dst = a.out[h] + (size_t)l * a.out_stride[h] + (size_t)i * (slice / 4);
-        const float c = (float)(1 + ((l * NH + h + a.epoch) & 7));
+        const float c = (float)(1 + ((l * a.nh + h + a.epoch) & 7));
         const f32x4 v = {c, c, c, c};
         if (CHAIN && SC1) {
             for (int k = tid; k < slice / 16; k += THREADS) {
@@ -133,32 +133,22 @@ __global__ __launch_bounds__(THREADS) void k_rows(Args a) {
     }
 }
 
-int main() {
-    const int R = 32, Hd = 896, I = 4864, LAYERS = 24;
-    const int xb = R * Hd * 4;                          // one activation vector set as hi / lo bf16 planes (or fp32): 114 688 B
-    // hop: blocks, operand bytes per block, whole?, output bytes, weight bytes per block
-    Hop hops[NH] = {
-        {36, xb, 1, R * 1152 * 4, 57344},             // Q: x planes -> q, k, v (147 KB); 2.06 MB of W_qkv
-        {128, 4608, 0, 2 * xb, 65536},                // A: (row, kv head, 2 tiles): its q slice; K / V tile as the "weights"; partials
-        {32, 2 * 3584, 0, xb, 0},                     // C: combine a row's tiles -> attention planes
-        {56, xb, 1, xb, 28672},                       // O: attention planes -> x_mid; 1.6 MB of W_o
-        {152, xb, 1, R * I * 4, 114688},              // GU: x_mid planes -> h (622 KB); 17.4 MB
-        {280, R * I * 4 / 5, 0, 5 * xb, 31232},       // D: K slice of h -> 5 partial sets; 8.7 MB
-        {32, 6 * 3584, 0, xb, 0},                     // F: fold + norm of a row -> x planes
-    };
+static int run_table(const char* title, const Hop* hops, int nh) {
+    const int LAYERS = 24;
     Args a{};
+    a.nh = nh;
     int per = 0;
-    for (int h = 0; h < NH; h++) { a.hop[h] = hops[h]; a.flag_off[h] = per; per += hops[h].nb; }
+    for (int h = 0; h < nh; h++) { a.hop[h] = hops[h]; a.flag_off[h] = per; per += hops[h].nb; }
     a.per_layer = per; a.layers = LAYERS;
-    for (int h = 0; h < NH; h++) {
+    for (int h = 0; h < nh; h++) {
         const int slice = (hops[h].wr_total / hops[h].nb) & ~15;
         a.hop[h].wr_total = slice * hops[h].nb;       // what the blocks really write
         a.out_stride[h] = a.hop[h].wr_total / 4;
         CK(hipMalloc(&a.out[h], (size_t)LAYERS * a.hop[h].wr_total));
         CK(hipMemset(a.out[h], 0, (size_t)LAYERS * a.hop[h].wr_total));
     }
-    for (int h = 0; h < NH; h++) {                    // operands never exceed what the producer hop wrote
-        const int ph = h == 0 ? NH - 1 : h - 1;
+    for (int h = 0; h < nh; h++) {                    // operands never exceed what the producer hop wrote
+        const int ph = h == 0 ? nh - 1 : h - 1;
         if (a.hop[h].rd_bytes > a.hop[ph].wr_total) a.hop[h].rd_bytes = a.hop[ph].wr_total;
         a.hop[h].rd_bytes &= ~15;
     }
@@ -169,27 +159,19 @@ int main() {
     const size_t wbytes = (size_t)LAYERS * per * 16 * THREADS * 16;
     f32x4* w; CK(hipMalloc(&w, wbytes)); CK(hipMemset(w, 0, wbytes));
     a.w = w;
-    printf("many-row chain skeleton: %d layers x %d blocks (%d hops), weight buffer %.1f MB\n", LAYERS, per, NH, wbytes / 1e6);
+    long wsum = 0, rsum = 0;
+    for (int h = 0; h < nh; h++) { wsum += (long)a.hop[h].nb * a.hop[h].w_bytes; rsum += (long)a.hop[h].nb * a.hop[h].rd_bytes; }
+    printf("%s: %d layers x %d blocks (%d hops); per layer %.1f MB of weights, %.1f MB of operand reads\n", title, LAYERS, per, nh, wsum / 1e6, rsum / 1e6);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    unsigned epoch = 0;
+    static unsigned epoch = 0;
     auto report = [&](const char* name, float ms, int reps) {
         unsigned err = 0; (void)hipMemcpy(&err, a.err, 4, hipMemcpyDeviceToHost);
-        printf("%-58s %8.1f us per step  %6.2f us per layer%s\n", name, ms * 1e3 / reps, ms * 1e3 / reps / LAYERS, err ? "   ERROR" : "");
+        printf("  %-58s %8.1f us per step  %6.2f us per layer%s\n", name, ms * 1e3 / reps, ms * 1e3 / reps / LAYERS, err ? "   ERROR" : "");
         if (err) { printf("   error code %u\n", err); (void)hipMemset(a.err, 0, 4); }
     };
     for (int weights = 0; weights < 2; weights++) {
         const int reps = 20;
-        for (int warm = 0; warm < 2; warm++) {
-            CK(hipEventRecord(e0));
-            for (int r = 0; r < reps; r++) {
-                a.epoch = ++epoch;
-                if (weights) hipLaunchKernelGGL((k_rows<true, true>), dim3(LAYERS * per), dim3(THREADS), 0, 0, a);
-                else hipLaunchKernelGGL((k_rows<true, false>), dim3(LAYERS * per), dim3(THREADS), 0, 0, a);
-            }
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-        }
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        report(weights ? "ONE launch, flags + release / acquire fences, weight stream" : "ONE launch, flags + release / acquire fences, no weights", ms, reps);
+        float ms;
         for (int warm = 0; warm < 2; warm++) {
             CK(hipEventRecord(e0));
             for (int r = 0; r < reps; r++) {
@@ -206,7 +188,7 @@ int main() {
             for (int r = 0; r < reps; r++) {
                 a.epoch = ++epoch;
                 for (int l = 0; l < LAYERS; l++)
-                    for (int h = 0; h < NH; h++) {
+                    for (int h = 0; h < nh; h++) {
                         a.single_layer = l; a.single_hop = h;
                         if (weights) hipLaunchKernelGGL((k_rows<false, true>), dim3(a.hop[h].nb), dim3(THREADS), 0, 0, a);
                         else hipLaunchKernelGGL((k_rows<false, false>), dim3(a.hop[h].nb), dim3(THREADS), 0, 0, a);
@@ -215,7 +197,43 @@ int main() {
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         }
         CK(hipEventElapsedTime(&ms, e0, e1));
-        report(weights ? "one launch per hop (7 per layer), with the weight stream" : "one launch per hop (7 per layer), no weights", ms, reps);
+        report(weights ? "one launch per hop, with the weight stream" : "one launch per hop, no weights", ms, reps);
     }
+    for (int h = 0; h < nh; h++) (void)hipFree(a.out[h]);
+    (void)hipFree(a.flags); (void)hipFree(a.err); (void)hipFree(a.sink); (void)hipFree(w);
+    return 0;
+}
+
+int main() {
+    const int R = 32, Hd = 896, I = 4864;
+    const int xb = R * Hd * 4;                          // one activation vector set as hi / lo bf16 planes (or fp32): 114 688 B
+    // hop: blocks, operand bytes per block, whole?, output bytes, weight bytes per block
+    const Hop today[7] = {
+        {36, xb, 1, R * 1152 * 4, 57344},             // Q: x planes -> q, k, v (147 KB); 2.06 MB of W_qkv
+        {128, 4608, 0, 2 * xb, 65536},                // A: (row, kv head, 2 tiles): its q slice; K / V tile as the "weights"; partials
+        {32, 2 * 3584, 0, xb, 0},                     // C: combine a row's tiles -> attention planes
+        {56, xb, 1, xb, 28672},                       // O: attention planes -> x_mid; 1.6 MB of W_o
+        {152, xb, 1, R * I * 4, 114688},              // GU: x_mid planes -> h (622 KB); 17.4 MB
+        {280, R * I * 4 / 5, 0, 5 * xb, 31232},       // D: K slice of h -> 5 partial sets; 8.7 MB
+        {32, 6 * 3584, 0, xb, 0},                     // F: fold + norm of a row -> x planes
+    };
+    if (run_table("today's many-row step (round 3 table)", today, 7)) return 1;
+    // K-sliced QKV (round-4 review): a block = 64 features x K / 4 -- 18 feature tiles x 4 slices = 72 blocks, each ingests a QUARTER of the
+    // operand planes (28.7 KB) and 28.7 KB of weights instead of 115 + 57 KB; the four partial sets are folded by the consumer (an attention
+    // block reads its q slice from four sets: 18.4 KB instead of 4.6)
+    Hop ksq[7];
+    for (int h = 0; h < 7; h++) ksq[h] = today[h];
+    ksq[0] = Hop{72, xb / 4, 0, 4 * R * 1152 * 4, 28672};
+    ksq[1] = Hop{128, 4 * 4608, 0, 2 * xb, 65536};
+    if (run_table("K-sliced QKV (72 blocks of 64 features x K / 4, the attention folds four partial sets)", ksq, 7)) return 1;
+    // ... and the O projection K-sliced too: 14 feature tiles x 4 slices = 56 blocks of 28.7 + 28.7 KB; its four partial sets + the residual
+    // cannot be folded by gate/up (every one of its 152 blocks needs whole rows: 5 x 115 KB each), so a fold hop of 32 row blocks follows
+    // (what the O projection's NEXT epilogue does in-kernel today): eight hops
+    Hop kso[8];
+    kso[0] = ksq[0]; kso[1] = ksq[1]; kso[2] = today[2];
+    kso[3] = Hop{56, xb / 4, 0, 4 * xb, 28672};
+    kso[4] = Hop{32, 5 * 3584, 0, xb, 0};
+    kso[5] = today[4]; kso[6] = today[5]; kso[7] = today[6];
+    if (run_table("K-sliced QKV and O (+ a fold hop behind the O projection: 8 hops)", kso, 8)) return 1;
     return 0;
 }
