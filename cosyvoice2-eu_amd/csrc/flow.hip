@@ -925,7 +925,8 @@ extern "C" int cv2_flow_destroy(cv2_flow* h) { delete h; return 0; }
 
 // ------------------------------------------------------------------ estimator core
 struct EstCtx { cv2_flow* h; const Layout* L; const float* temb; int chunk; hipStream_t s;
-                const IncTabs* inc = nullptr; int step = 0, conv_i = 0, tb_i = 0; };      // cached streaming: tables, Euler step, site counters
+                const IncTabs* inc = nullptr; int step = 0, conv_i = 0, tb_i = 0;         // cached streaming: tables, Euler step, site counters
+                bool qkv_chained = false; };                                              // the next transformer block's q / k / v^T are already there (k_tail_rows2<true>)
 
 // cached streaming: hand the conv at this site its left context and keep this call's last two input rows
 static int est_conv_tail(EstCtx& c, uint16_t* buf, int C) {
@@ -974,10 +975,14 @@ static int est_resnet(EstCtx& c, const cv2_resnet& rn, int ridx, uint16_t* A, in
 static std::atomic<int> g_att_dma{-1};
 extern "C" int cv2_flow_debug_attn_dma(int32_t on) { g_att_dma = on < 0 ? -1 : (on != 0); return 0; }
 
-// transformer block; next_ln == null: last of its group -> bf16 copy of x goes to (xout, ldx)
-static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, uint16_t* xout, long ldx) {
+// transformer block; next_ln == null: last of its group -> bf16 copy of x goes to (xout, ldx).  have_qkv: the block's q / k / v^T are
+// there already (the previous block's tail kernel chained this block's QKV projection on); next_tb != null: the block that follows in the
+// group -- its QKV projection may be chained onto this block's tail (c.qkv_chained says whether it was).
+static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, uint16_t* xout, long ldx, const cv2_tblock* next_tb = nullptr) {
     cv2_flow* h = c.h; const int M = c.L->rows;
-    {
+    const bool have_qkv = c.qkv_chained;
+    c.qkv_chained = false;
+    if (!have_qkv) {
         GemmArgs a = gemm_args(GB(h->lnb, 256), 256, 0, tb.qkv.w, M, 1536, 256);
         a.out_bf16 = GB(h->qk, 1024); a.ldo16 = 1024; a.n_store = 1024;
         a.vt = h->vt + GUARD; a.vt_ld = h->R + GUARD + 8; a.vt_n0 = 1024;
@@ -1026,7 +1031,16 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         t.seq = c.L->tab(); t.M_valid = M;
         t.part = h->tail_part; t.ticket = h->tail_ticket;
         t.row0 = c.inc && M > INC_LEAD ? INC_LEAD : 0;           // (cached chunks: skip the lead panels, see TailArgs::row0)
-        return (long)(M / 64) < tail_rows_min ? tail_panel_go(t, M, c.s) : tail_rows_go(t, M, c.s);
+        if ((long)(M / 64) < tail_rows_min) return tail_panel_go(t, M, c.s);
+        // batches: k_tail_rows2 (round 5); CV2_FLOW_TAIL_ROWS2=0: k_tail_rows<4>, =1: k_tail_rows2 without the chained QKV projection (A/B, diagnostics)
+        static const int rows2 = getenv("CV2_FLOW_TAIL_ROWS2") ? atoi(getenv("CV2_FLOW_TAIL_ROWS2")) : 2;
+        if (rows2 == 0) return tail_rows_go(t, M, c.s);
+        const bool chain = rows2 >= 2 && next_tb && next_ln && !c.inc;      // (cached streaming chunks file their keys / values in the QKV GEMM's epilogue)
+        if (chain) {
+            t.Wqkv = next_tb->qkv.w; t.qk = GB(h->qk, 1024); t.vt = h->vt + GUARD; t.vt_ld = h->R + GUARD + 8;
+            c.qkv_chained = true;
+        }
+        return tail_rows2_go(t, M, chain, c.s);
     }
     {
         GemmArgs a = gemm_args(GB(h->att, 512), 512, 0, tb.out.w, M, 256, 512);
@@ -1054,7 +1068,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
 static int est_block(EstCtx& c, const cv2_unet_block& b, int ridx, uint16_t* A, int cin, uint16_t* xout, long ldx) {
     if (est_resnet(c, b.rn, ridx, A, cin, b.tb[0].norm1)) return -1;
     for (int j = 0; j < 4; j++)
-        if (est_tblock(c, b.tb[j], j < 3 ? &b.tb[j + 1].norm1 : nullptr, xout, ldx)) return -1;
+        if (est_tblock(c, b.tb[j], j < 3 ? &b.tb[j + 1].norm1 : nullptr, xout, ldx, j < 3 ? &b.tb[j + 1] : nullptr)) return -1;
     return 0;
 }
 

@@ -59,16 +59,18 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
         case ACT_GELU: {                                   // exact-erf GELU; erf by Abramowitz-Stegun 7.1.26 (|err| < 7e-7 in fp32, one exp + one rcp)
             const float z = v * 0.70710678118654752f, az = fabsf(z);
-            const float t = __fdividef(1.f, 1.f + 0.3275911f * az);
+            const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * az);      // v_rcp_f32 (1 ulp): __fdividef / a plain division compile to the ten-instruction IEEE
+                                                                               // sequence (v_div_scale x 2, v_rcp, 4 fma, v_div_fmas, v_div_fixup) -- a third of this function,
+                                                                               // and the feed-forward's GELU is the largest VALU item of the batch tail kernel
             const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
             const float e = 1.f - poly * __expf(-az * az);
             return 0.5f * v * (1.f + copysignf(e, z));
         }
-        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_SILU: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
         case ACT_MISH: {                                   // x * tanh(softplus(x)); tanh(log(1 + e^x)) = n / (n + 2), n = e^x (e^x + 2)
             const float e = __expf(fminf(v, 20.f));        // torch's softplus switches to the identity above 20: the ratio is 1 there
             const float nn = e * (e + 2.f);
-            return v * __fdividef(nn, nn + 2.f);
+            return v * (nn * __builtin_amdgcn_rcpf(nn + 2.f));
         }
         case ACT_LRELU: return v > 0.f ? v : v * slope;
         default: return v;
@@ -549,6 +551,10 @@ struct TailArgs {
     uint16_t* out_x; long ldo_x;                             // gn == null: x as bf16
     SeqTable seq; int M_valid;
     float* part; int* ticket;                                // k_tail_panel<S > 1>: partial FF2 tiles [panels][S][16][256] and the panels' arrival counters (zero between launches)
+    // k_tail_rows2<true>: the NEXT transformer block's QKV projection chained on (row-local like the rest: K = 256, N = 1536, no bias): Q / K
+    // features [0, 1024) -> qk [M][1024] bf16, V features -> vt[(n - 1024) * vt_ld + m] (transposed for the attention), rows beyond their
+    // sequence as zeros -- what k_gemm<.., EPI = 1> + its transposed-V path store; out_ln is not written then (nothing else reads it)
+    const uint16_t* Wqkv; uint16_t* qk; uint16_t* vt; long vt_ld;
     int row0;                                                // k_tail_panel: first row of the launch (cached streaming chunks: the 128 lead rows in front of the first sequence
                                                              // hold nothing but the convolution tails -- 8 padding panels that pushed 8 streams' 128 real panels over the S = 2 limit)
 };
@@ -885,6 +891,294 @@ __global__ __launch_bounds__(1024) void k_tail_rows(TailArgs a) {
         }
     }
 }
+// ---- round 5: the same chain with 32-column wave tiles and ONE weight stream (k_tail_rows2)
+// k_tail_rows<4> spends ~1 400 cycles per 32-wide k-step where its matrix-core work is 256: 16 waves x (16 columns x 64 rows) re-read the
+// block's four activation row tiles from LDS once per 16 columns (64 KB per k-step = 512 cycles of LDS bandwidth), every GEMM of the chain
+// starts with its weight fragments' L2 round trip exposed, and every phase ends in a block barrier with all 16 waves in step.  Here:
+//   * 8 waves, wave w owns columns [32 w, 32 w + 32) x 64 rows: two weight fragments and four activation fragments feed eight MFMAs, so a
+//     k-step moves 32 KB through LDS (256 cycles), 16 KB of weights through the CU's vector-memory path (256 cycles) and holds the matrix
+//     cores 256 cycles -- balanced instead of LDS-bound;
+//   * the block's GEMMs (O projection, 4 x {FF1 quarter, FF2 quarter}, optionally six 256-column tiles of the next block's QKV projection)
+//     are ONE sequence for the weight ring: a slot freed at k-step kb is refilled with the fragment 8 k-steps on, whichever GEMM that
+//     belongs to, so the stream runs through the epilogues and barriers;
+//   * the hidden quarters are double-buffered (in the LDS of the attention panel, dead by then): one barrier per quarter, FF2 of quarter
+//     q and FF1 of quarter q + 1 run back to back, and the two waves of a SIMD drift apart (one in GELU, one in MFMAs).
+// Every sum keeps k_tail_rows<4>'s order (k-steps in order in one accumulator per output tile), the epilogue expressions are the same:
+// the results are bit-identical to it (tests/test_flow_gpu.py), and the chained QKV projection is k_gemm's sum (8 k-steps in order).
+#define TR2_CH 8
+// LDS hand-offs only: wait for this wave's LDS operations, then the block barrier.  __syncthreads() also waits for every outstanding
+// global operation (s_waitcnt vmcnt(0)): the weight ring would be drained at each of the kernel's ~20 barriers and every barrier behind a
+// store phase would sit out the stores' completion (phase stamps: 6 300 cycles per chained QKV tile around 2 200 of MFMAs).
+#define TR2_BARRIER do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+struct Tr2Ring { s16x8 r0[TR2_CH], r1[TR2_CH]; };
+// fragment `frag` (1 KiB) behind a wave-uniform pointer, this lane's 16 bytes: scalar base + ONE per-lane byte offset (written as
+// w[frag * 64 + lane] hipcc materialises a VGPR offset per distinct fragment index: 60 of them live across the kernel, 370 spilled)
+__device__ __forceinline__ s16x8 tr2_ld(const s16x8* w, int frag, unsigned lane16) {
+    const char* base = reinterpret_cast<const char*>(w) + (size_t)frag * 1024;
+    return *reinterpret_cast<const s16x8*>(base + lane16);
+}
+// fragments kb = 0 .. min(CH, NKS) - 1 of a GEMM's two column tiles into the ring (the very first GEMM of the block)
+template <int NKS>
+__device__ __forceinline__ void tr2_prime(Tr2Ring& R, const s16x8* w0, const s16x8* w1, unsigned lane16) {
+#pragma unroll
+    for (int i = 0; i < (NKS < TR2_CH ? NKS : TR2_CH); i++) { R.r0[i] = tr2_ld(w0, i, lane16); R.r1[i] = tr2_ld(w1, i, lane16); }
+}
+// acc[ct][rt] += W tiles (w0, w1: this wave's two 16-column tiles, NKS k-steps) x panel rows; ring slots are refilled with this GEMM's
+// later fragments, then with the NEXT GEMM's first ones (nw0 / nw1, NNKS k-steps; null: nothing follows).  PH = ring phase: the slot of
+// this GEMM's k-step 0 (the sequence's k-steps are numbered through: slot = (PH + kb) % CH).
+struct Tr2NoHook { __device__ __forceinline__ void operator()(int) const {} };
+// `side(kb)`: other work of the wave issued beside k-step kb's MFMAs, inside the same scheduling region (the feed-forward's GELU of the NEXT
+// hidden quarter rides on FF2's k-steps: VALU instructions issue while the matrix cores work on the eight MFMAs)
+template <int NKS, int NNKS, int PH, class SIDE = Tr2NoHook>
+__device__ __forceinline__ void tr2_gemm(Tr2Ring& R, const s16x8* w0, const s16x8* w1, const s16x8* nw0, const s16x8* nw1,
+                                         const char* panel, int a_off, unsigned lane16, f32x4 (&acc)[2][4], SIDE side = SIDE()) {
+    // software pipeline, fenced per k-step (left to itself hipcc hoists the fully unrolled loop's LDS reads and weight loads far ahead:
+    // 256 VGPRs + 370 spilled): the NEXT k-step's four activation fragments and this slot's refill are requested, then this k-step's
+    // eight MFMAs run
+    bf16x8 af[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; rt++) af[0][rt] = *reinterpret_cast<const bf16x8*>(panel + (size_t)rt * 1024 + a_off);
+#pragma unroll
+    for (int kb = 0; kb < NKS; kb++) {
+        const int sl = (PH + kb) % TR2_CH;
+        const bf16x8 f0 = __builtin_bit_cast(bf16x8, R.r0[sl]), f1 = __builtin_bit_cast(bf16x8, R.r1[sl]);
+        if (kb + 1 < NKS) {
+#pragma unroll
+            for (int rt = 0; rt < 4; rt++) af[(kb + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(panel + (size_t)((kb + 1) * 4 + rt) * 1024 + a_off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++) {
+#ifndef TR2_DIAG_NOMFMA
+            acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, af[kb & 1][rt], acc[0][rt], 0, 0, 0);
+            acc[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, af[kb & 1][rt], acc[1][rt], 0, 0, 0);
+#else
+            acc[0][rt] += __builtin_bit_cast(f32x4, f0) + __builtin_bit_cast(f32x4, af[kb & 1][rt]);
+            acc[1][rt] += __builtin_bit_cast(f32x4, f1);
+#endif
+        }
+        side(kb);
+        // (both column tiles' accumulator chains pass through one opaque statement per k-step: hipcc otherwise runs tile 0's chain over all
+        // k-steps first and keeps every activation fragment for tile 1's pass -- in scratch)
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+        // (the slot is free once its fragments sit in the MFMAs' operands)
+        if (kb + TR2_CH < NKS) { R.r0[sl] = tr2_ld(w0, kb + TR2_CH, lane16); R.r1[sl] = tr2_ld(w1, kb + TR2_CH, lane16); }
+        else if (NNKS > 0 && kb + TR2_CH - NKS < NNKS) { R.r0[sl] = tr2_ld(nw0, kb + TR2_CH - NKS, lane16); R.r1[sl] = tr2_ld(nw1, kb + TR2_CH - NKS, lane16); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <bool QKV>
+__global__ __launch_bounds__(512) void k_tail_rows2(TailArgs a) {
+    constexpr int RT = 4, LDC = 260, KS0 = 16, KS1 = 8, KS2 = 32;
+    constexpr size_t P_BYTES = 68 * 1024, X_OFF = P_BYTES, PAR_OFF = X_OFF + 32 * 1024;     // P: attention panel 64 K | C tile 65 K | hidden quarters 2 x 32 K | QKV staging 2 x 33 K
+    constexpr int SLD = 264;                                                              // bf16 per staging row (256 + 8)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xs = smem + X_OFF;
+    float* par = reinterpret_cast<float*>(smem + PAR_OFF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * 64, n = lane * 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    SK_STAMP_DECL;
+    SK_STAMP(0);
+    {   // attention panel: piece (kb, rt) = 16 rows x 32 k; wave w fetches k-steps w and w + 8 of every row tile
+        const int srow = lane >> 2, schunk = (lane & 3) ^ ((lane >> 5) << 1);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const int kb = wave + 8 * h;
+                const uint16_t* src = a.att + (long)(m0 + rt * 16 + srow) * a.lda + kb * 32 + schunk * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + (size_t)(kb * RT + rt) * 1024), 16, 0, 0);
+            }
+    }
+    if (wave < 6) {                                          // per-column vectors: bo, g3, b3, b2, gn, bn
+        const float* src = wave == 0 ? a.bo : wave == 1 ? a.g3 : wave == 2 ? a.b3 : wave == 3 ? a.b2 : wave == 4 ? a.gn : a.bn;
+        if (src)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(par) + wave * 1024), 16, 0, 0);
+    }
+    f32x4 xrow[8];                                            // this wave's rows of the residual stream: rows wave + 8 i
+#pragma unroll
+    for (int i = 0; i < 8; i++) xrow[i] = *reinterpret_cast<const f32x4*>(a.xf + (size_t)(m0 + wave + 8 * i) * 256 + n);
+    __builtin_amdgcn_s_barrier();
+    // packed weights: fragment (16-column tile t, k-step kb) of a [N][K] matrix = 1 KiB at ((t * K / 32 + kb) * 64 + lane) * 16 B
+    // (wave-uniform pointers: the loads take the scalar base + lane offset form; per-lane pointers for all 30 weight tiles cost 60 VGPRs)
+    const s16x8* wo0 = reinterpret_cast<const s16x8*>(a.Wo) + ((size_t)(2 * wave) * KS0) * 64;
+    const s16x8* wo1 = wo0 + (size_t)KS0 * 64;
+    auto w1p = [&](int hq, int ct) { return reinterpret_cast<const s16x8*>(a.W1) + ((size_t)(hq * 16 + 2 * wave + ct) * KS1) * 64; };
+    auto w2p = [&](int hq, int ct) { return reinterpret_cast<const s16x8*>(a.W2) + ((size_t)(2 * wave + ct) * KS2 + hq * 8) * 64; };
+    auto wqp = [&](int j, int ct) { return reinterpret_cast<const s16x8*>(a.Wqkv) + ((size_t)(j * 16 + 2 * wave + ct) * KS1) * 64; };
+    Tr2Ring R;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    tr2_prime<KS0>(R, wo0, wo1, lane16);
+    int ep_start = 0, ep_len = a.M_valid;
+    if (a.seq.tile_seq) {
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) i32x4_t k_i32x4;
+        const i32x4_t ti = *reinterpret_cast<k_i32x4*>(reinterpret_cast<uintptr_t>(a.seq.tile_info + (m0 >> 6)));
+        ep_start = ti.y; ep_len = ti.z;
+    }
+    vmcnt_wait<2 * TR2_CH>();                                // everything older than the ring's loads: the panel, the vectors, the residual rows
+    __builtin_amdgcn_s_barrier();
+    SK_STAMP(1);                                             // panel, vectors and residual rows arrived
+    const int a_off = subtile_off(lane & 15, lane >> 4);
+    const f32x4* pv = reinterpret_cast<const f32x4*>(par) + lane;
+    float* C = reinterpret_cast<float*>(smem);
+    auto zero = [&](f32x4 (&acc)[2][4]) {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int rt = 0; rt < 4; rt++) acc[c][rt] = z4;
+    };
+    auto to_c = [&](const f32x4 (&acc)[2][4]) {              // accumulators -> C tile [64][LDC]
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int rt = 0; rt < 4; rt++)
+                *reinterpret_cast<f32x4*>(&C[(rt * 16 + (lane & 15)) * LDC + wave * 32 + c * 16 + 4 * (lane >> 4)]) = acc[c][rt];
+    };
+    // ---- GEMM 0: O projection (ring phase 0; followed by FF1 quarter 0)
+    f32x4 acc[2][4], acc2[2][4];
+    zero(acc);
+    tr2_gemm<KS0, KS1, 0>(R, wo0, wo1, w1p(0, 0), w1p(0, 1), smem, a_off, lane16, acc);
+    SK_STAMP(2);                                             // O projection's MFMAs issued
+    TR2_BARRIER;                                         // attention panel fully read: its LDS becomes the C tile
+    to_c(acc);
+    TR2_BARRIER;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {   // x += o + bo ; y = LN3(x) -> x panel (bf16, operand layout of FF1)
+        const int r = wave + 8 * i;
+        const bool valid = (m0 + r - ep_start) < ep_len;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&C[r * LDC + n]) + pv[0] + xrow[i];
+        if (!valid) v = z4;
+        xrow[i] = v;
+        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256);
+        const f32x4 d = v - mean;
+        const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256);
+        f32x4 y = d * rsqrtf(var + a.eps3) * pv[64] + pv[128];
+        if (!valid) y = z4;
+        char* dst = xs + (size_t)((n >> 5) * RT + (r >> 4)) * 1024 + subtile_off(r & 15, (n & 31) >> 3) + (n & 7) * 2;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+    }
+    TR2_BARRIER;                                         // x panel complete; the C tile is consumed: its LDS becomes the hidden quarters
+    // ---- feed-forward, one hidden quarter at a time; FF2 accumulates over the quarters (in order: the sums are k_tail_rows<4>'s).  The
+    // GELU of a quarter is the block's largest VALU item (32 values per thread: ~7 000 cycles per quarter beside 4 400 of MFMAs when it runs
+    // on its own): quarter q's GELU rides on the k-steps of FF2(q - 1) -- one accumulator tile per k-step -- so only quarter 0's is exposed.
+    // GEMM order for the weight ring: FF1(0), FF1(1), FF2(0), FF1(2), FF2(1), FF1(3), FF2(2), FF2(3)[, QKV tiles]; every one 8 k-steps, phase 0.
+    SK_STAMP(3);                                             // norm3 rows done, x panel complete
+    zero(acc2);
+    f32x4 b1v[2];
+    auto gelu_tile = [&](int hq, int c, int rt) {            // acc[c][rt] (+ b1) -> GELU -> hidden quarter hq's panel (operand layout of FF2)
+        char* hs = smem + (size_t)(hq & 1) * 32 * 1024;
+        const int cq = wave * 32 + c * 16 + 4 * (lane >> 4);
+        f32x4 v = acc[c][rt] + b1v[c];
+#ifndef TR2_DIAG_NOGELU                                     // (diagnostic builds: where does the feed-forward phase spend its time?)
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = act_apply(v[e], ACT_GELU, 0.f);
+#endif
+        char* d = hs + (size_t)((cq >> 5) * RT + rt) * 1024 + subtile_off(lane & 15, (cq & 31) >> 3) + (cq & 7) * 2;
+        *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    };
+    auto load_b1 = [&](int hq) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) b1v[c] = *reinterpret_cast<const f32x4*>(a.b1 + hq * 256 + wave * 32 + c * 16 + 4 * (lane >> 4));
+    };
+    load_b1(0);
+    zero(acc);
+    tr2_gemm<KS1, KS1, 0>(R, w1p(0, 0), w1p(0, 1), w1p(1, 0), w1p(1, 1), xs, a_off, lane16, acc);
+#pragma unroll
+    for (int t = 0; t < 8; t++) gelu_tile(0, t >> 2, t & 3);
+    TR2_BARRIER;                                             // hidden quarter 0 complete
+#define TR2_STEP(HQ, NW0, NW1, NNKS)   /* FF1(HQ), then FF2(HQ - 1) with GELU(HQ) beside it; next in the ring: NW */                   \
+    {                                                                                                                               \
+        load_b1(HQ);                                                                                                                 \
+        zero(acc);                                                                                                                   \
+        tr2_gemm<KS1, KS1, 0>(R, w1p(HQ, 0), w1p(HQ, 1), w2p((HQ) - 1, 0), w2p((HQ) - 1, 1), xs, a_off, lane16, acc);                  \
+        tr2_gemm<KS1, NNKS, 0>(R, w2p((HQ) - 1, 0), w2p((HQ) - 1, 1), NW0, NW1, smem + (size_t)(((HQ) - 1) & 1) * 32 * 1024, a_off, lane16, acc2, \
+                               [&](int kb) { gelu_tile(HQ, kb >> 2, kb & 3); });                                                      \
+        TR2_BARRIER;                                         /* hidden quarter HQ complete, quarter HQ - 1 consumed */              \
+    }
+    TR2_STEP(1, w1p(2, 0), w1p(2, 1), KS1)
+    TR2_STEP(2, w1p(3, 0), w1p(3, 1), KS1)
+    TR2_STEP(3, w2p(3, 0), w2p(3, 1), KS1)
+#undef TR2_STEP
+    if (QKV) tr2_gemm<KS1, KS1, 0>(R, w2p(3, 0), w2p(3, 1), wqp(0, 0), wqp(0, 1), smem + 32 * 1024, a_off, lane16, acc2);
+    else tr2_gemm<KS1, 0, 0>(R, w2p(3, 0), w2p(3, 1), (const s16x8*)nullptr, (const s16x8*)nullptr, smem + 32 * 1024, a_off, lane16, acc2);
+    SK_STAMP(4);                                             // feed-forward quarters done
+    TR2_BARRIER;                                         // the last hidden quarter is consumed: the LDS becomes the C tile again
+    to_c(acc2);
+    TR2_BARRIER;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {   // x += ff + b2 ; stores
+        const int r = wave + 8 * i, m = m0 + r;
+        const bool valid = (m - ep_start) < ep_len;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&C[r * LDC + n]) + pv[192] + xrow[i];
+        if (!valid) v = z4;
+        if (a.gn) {
+            *reinterpret_cast<f32x4*>(a.xf + (size_t)m * 256 + n) = v;
+            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256);
+            const f32x4 d = v - mean;
+            const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256);
+            f32x4 y = d * rsqrtf(var + a.epsn) * pv[256] + pv[320];
+            if (!valid) y = z4;
+            const uint2 yb = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+            if (QKV) *reinterpret_cast<uint2*>(xs + (size_t)((n >> 5) * RT + (r >> 4)) * 1024 + subtile_off(r & 15, (n & 31) >> 3) + (n & 7) * 2) = yb;
+            else *reinterpret_cast<uint2*>(a.out_ln + (size_t)m * a.ldo_ln + n) = yb;
+        } else {
+            *reinterpret_cast<uint2*>(a.out_x + (size_t)m * a.ldo_x + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+    }
+    if (!QKV) {
+        SK_STAMP(5);
+        SK_STAMP_FLUSH_RING(((unsigned long long)0x7A11 << 32) | 256u, ((unsigned long long)64 << 48) | ((unsigned long long)32 << 32) | (unsigned)gridDim.y);
+        return;
+    }
+    TR2_BARRIER;                                         // y panel complete (and the C tile consumed: its LDS becomes the staging tiles)
+    // ---- the next block's QKV projection: six tiles of 256 features; a tile is staged as bf16 [64][SLD] (two buffers) and stored by the
+    // whole block in full rows (Q / K: 512 B per row) or full columns (V^T: 128 B per feature)
+#define TR2_QKV(J, NW0, NW1, NNKS)                                                                                                   \
+    {                                                                                                                               \
+        uint16_t* S = reinterpret_cast<uint16_t*>(smem + (size_t)((J) & 1) * 34 * 1024);                                              \
+        zero(acc);                                                                                                                   \
+        tr2_gemm<KS1, NNKS, 0>(R, wqp(J, 0), wqp(J, 1), NW0, NW1, xs, a_off, lane16, acc);                                                    \
+        _Pragma("unroll") for (int c = 0; c < 2; c++)                                                                                \
+            _Pragma("unroll") for (int rt = 0; rt < 4; rt++) {                                                                       \
+                const int r = rt * 16 + (lane & 15);                                                                                 \
+                f32x4 v = acc[c][rt];                                                                                                \
+                if ((m0 + r - ep_start) >= ep_len) v = z4;                                                                           \
+                *reinterpret_cast<uint2*>(S + (size_t)r * SLD + wave * 32 + c * 16 + 4 * (lane >> 4)) =                               \
+                    make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));                                                    \
+            }                                                                                                                       \
+        TR2_BARRIER;                                                                                                             \
+        if ((J) < 4) {                                       /* Q / K features 256 J ..: rows of 512 B, 32 threads x 16 B each */   \
+            _Pragma("unroll") for (int it = 0; it < 4; it++) {                                                                       \
+                const int e = tid + 512 * it, r = e >> 5, ch = e & 31;                                                               \
+                *reinterpret_cast<uint4*>(a.qk + (size_t)(m0 + r) * 1024 + (J) * 256 + ch * 8) = *reinterpret_cast<const uint4*>(S + (size_t)r * SLD + ch * 8); \
+            }                                                                                                                       \
+        } else {                                             /* V features: feature f of the tile, rows 8 g .. 8 g + 7 -> 16 B of its V^T row */ \
+            _Pragma("unroll") for (int it = 0; it < 4; it++) {                                                                       \
+                const int e = tid + 512 * it, f = e >> 3, g = e & 7;                                                                 \
+                uint32_t pk[4];                                                                                                      \
+                _Pragma("unroll") for (int q = 0; q < 4; q++)                                                                        \
+                    pk[q] = (uint32_t)S[(size_t)(8 * g + 2 * q) * SLD + f] | ((uint32_t)S[(size_t)(8 * g + 2 * q + 1) * SLD + f] << 16);   \
+                *reinterpret_cast<uint4*>(a.vt + (size_t)(((J) - 4) * 256 + f) * a.vt_ld + m0 + 8 * g) = make_uint4(pk[0], pk[1], pk[2], pk[3]); \
+            }                                                                                                                       \
+        }                                                                                                                           \
+    }
+    TR2_QKV(0, wqp(1, 0), wqp(1, 1), KS1)
+    TR2_QKV(1, wqp(2, 0), wqp(2, 1), KS1)
+    TR2_QKV(2, wqp(3, 0), wqp(3, 1), KS1)
+    TR2_QKV(3, wqp(4, 0), wqp(4, 1), KS1)
+    TR2_QKV(4, wqp(5, 0), wqp(5, 1), KS1)
+    TR2_QKV(5, (const s16x8*)nullptr, (const s16x8*)nullptr, 0)
+#undef TR2_QKV
+    SK_STAMP(5);
+    SK_STAMP_FLUSH_RING(((unsigned long long)0x7A11 << 32) | 1536u, ((unsigned long long)64 << 48) | ((unsigned long long)32 << 32) | (unsigned)gridDim.y);
+}
+constexpr size_t tail_rows2_smem() { return (size_t)(68 + 32 + 6) * 1024; }
+
 template <int RT>
 constexpr size_t tail_rows_smem() {
     constexpr size_t c = (size_t)RT * 16 * 260 * 4, att = (size_t)16 * RT * 1024;

@@ -62,6 +62,20 @@ static int tail_rows_go(const TailArgs& a, int M, hipStream_t s) {
     CV2_LAUNCH_CHECK();
     return 0;
 }
+// round 5: 8 waves x (32 columns x 64 rows), one weight stream through the block's GEMMs; qkv: the next block's QKV projection chained on
+static int tail_rows2_go(const TailArgs& a, int M, bool qkv, hipStream_t s) {
+    constexpr size_t sm = tail_rows2_smem();
+    static std::atomic<bool> once{false};
+    if (!once) {
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_rows2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_rows2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        once = true;
+    }
+    if (qkv) hipLaunchKernelGGL(k_tail_rows2<true>, dim3(1, M / 64, 1), dim3(512), sm, s, a);
+    else hipLaunchKernelGGL(k_tail_rows2<false>, dim3(1, M / 64, 1), dim3(512), sm, s, a);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
 static int tail_panel_go(const TailArgs& a, int M, hipStream_t s) {
     constexpr size_t sm = tail_panel_smem();
     static std::atomic<bool> once{false};    // idempotent attribute call: a second thread repeats it rather than launch before it is in place
