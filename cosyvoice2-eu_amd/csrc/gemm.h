@@ -533,6 +533,10 @@ __global__ __launch_bounds__(1024) void k_gemm_panel(GemmArgs a) {
                         ((unsigned long long)BM << 48) | ((unsigned long long)BN << 32) | (unsigned)(gridDim.x * gridDim.y * gridDim.z));
 }
 
+// LDS hand-offs only: wait for this wave's LDS operations, then the block barrier.  __syncthreads() also waits for every outstanding
+// global operation (s_waitcnt vmcnt(0)): weight fragments requested to fly through an epilogue would be waited for at the epilogue's first barrier,
+// and a barrier behind a store phase would sit out the stores' completion.
+#define TR2_BARRIER do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 // ------------------------------------------------------------------ transformer-block tail for few rows (one utterance)
 // Everything of a BasicTransformerBlock after the attention is row-local: x += att Wo^T + bo; y = LN3(x); x += GELU(y W1^T + b1) W2^T
 // + b2; next = LN(x).  One launch per 16-row panel chains the three GEMMs (K = 512, 256, 1024) with the weights streamed
@@ -906,10 +910,6 @@ __global__ __launch_bounds__(1024) void k_tail_rows(TailArgs a) {
 // Every sum keeps k_tail_rows<4>'s order (k-steps in order in one accumulator per output tile), the epilogue expressions are the same:
 // the results are bit-identical to it (tests/test_flow_gpu.py), and the chained QKV projection is k_gemm's sum (8 k-steps in order).
 #define TR2_CH 8
-// LDS hand-offs only: wait for this wave's LDS operations, then the block barrier.  __syncthreads() also waits for every outstanding
-// global operation (s_waitcnt vmcnt(0)): the weight ring would be drained at each of the kernel's ~20 barriers and every barrier behind a
-// store phase would sit out the stores' completion (phase stamps: 6 300 cycles per chained QKV tile around 2 200 of MFMAs).
-#define TR2_BARRIER do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 struct Tr2Ring { s16x8 r0[TR2_CH], r1[TR2_CH]; };
 // fragment `frag` (1 KiB) behind a wave-uniform pointer, this lane's 16 bytes: scalar base + ONE per-lane byte offset (written as
 // w[frag * 64 + lane] hipcc materialises a VGPR offset per distinct fragment index: 60 of them live across the kernel, 370 spilled)

@@ -60,6 +60,13 @@ __device__ __forceinline__ float pre_apply(float v, int pre, float al, float slo
     return v;
 }
 
+// the same with 1 / (alpha + 1e-9) computed by the caller (the same division, once per channel: bit-identical)
+__device__ __forceinline__ float pre_apply_inv(float v, int pre, float al, float inv_al, float slope) {
+    if (pre == PRE_SNAKE) { const float s = __sinf(v * al); return v + inv_al * (s * s); }
+    if (pre == PRE_LRELU) return v > 0.f ? v : v * slope;
+    return v;
+}
+
 // FT = frame tiles of 32 per wave (2: blocks of 128 frames = CV_BT; 1: of 64 frames, for grids that leave CUs idle; see k_conv6)
 template <int FT>
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
@@ -147,23 +154,35 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #undef CV_MMA
     }
     // epilogue: lane holds channel co (li) of its output tile and 16 frames of each of its two frame tiles
-#pragma unroll
-    for (int tile = 0; tile < FT; tile++) {
+    // Every residual value and every accumulate-mode output value of the lane (16 frames per tile) is requested BEFORE any is used, from
+    // clamped addresses instead of behind a per-frame branch: with `if (t >= L_out) continue` in front of each element hipcc kept the loads
+    // where they were -- 32 dependent global round trips per lane (phase stamps: 33-46 000 cycles of epilogue around 8-38 000 of MFMAs).
+    {
         const int co = co0 + cw * 32 + li;
-        if (co >= a.Cout_store) continue;
-        const float b = a.bias ? a.bias[co] : 0.f;
+        const bool cok = co < a.Cout_store;
+        const int coc = cok ? co : 0;
+        const float b = a.bias ? a.bias[coc] : 0.f;
+        float rv[FT][16], ov[FT][16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int t = t0 + fw * (32 * FT) + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (t >= a.L_out) continue;
-            float v = (tile == 0 ? acc0[r] : acc1[r]) + b;
-            if (a.res) v += a.res[(size_t)t * a.ldres + co];
-            if (a.post == POST_ELU) v = v > 0.f ? v : expm1f(v);
-            float* o = a.out + (size_t)t * a.ldo + a.out_off + co;
-            if (a.acc == ACC_ADD) v = *o + v;
-            else if (a.acc == ACC_ADD_DIV3) v = (*o + v) / 3.0f;
-            *o = v;
-        }
+        for (int tile = 0; tile < FT; tile++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int t = min(t0 + fw * (32 * FT) + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, a.L_out - 1);
+                rv[tile][r] = a.res ? a.res[(size_t)t * a.ldres + coc] : 0.f;
+                ov[tile][r] = a.acc != ACC_STORE ? a.out[(size_t)t * a.ldo + a.out_off + coc] : 0.f;
+            }
+#pragma unroll
+        for (int tile = 0; tile < FT; tile++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int t = t0 + fw * (32 * FT) + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                float v = (tile == 0 ? acc0[r] : acc1[r]) + b;
+                if (a.res) v += rv[tile][r];
+                if (a.post == POST_ELU) v = v > 0.f ? v : expm1f(v);
+                if (a.acc == ACC_ADD) v = ov[tile][r] + v;
+                else if (a.acc == ACC_ADD_DIV3) v = (ov[tile][r] + v) / 3.0f;
+                if (cok && t < a.L_out) a.out[(size_t)t * a.ldo + a.out_off + co] = v;
+            }
     }
 }
 
@@ -198,12 +217,21 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
     const int li = lane & 31, lk = lane >> 5;
     const int fw = wave >> 1, cw = wave & 1;                        // frame half (32 FT frames), 32-channel output tile
     const size_t kbstride = (size_t)ntile * 3 * 512;                // elements between consecutive 16-channel blocks of one tap
+    SK_STAMP_DECL;
+    SK_STAMP(0);
     for (int c0 = 0; c0 < a.CinP; c0 += CV_CK) {
         __syncthreads();
-        for (int it0 = tid; it0 < rows * 16; it0 += 256 * 4) {
-            f32x4 q[4];
+        // (a thread's items share their column group -- 1024 is a multiple of 16 --: the Snake alphas of its four channels are fetched once per
+        // chunk, not once per element of every item)
+        f32x4 al4 = {0.f, 0.f, 0.f, 0.f}, ia4 = {0.f, 0.f, 0.f, 0.f};      // alpha and 1 / (alpha + 1e-9) (activation.py:84): one division per channel, not per element
+        if (a.pre == PRE_SNAKE) {
+            const int ca = c0 + (tid & 15) * 4;
+            for (int e = 0; e < 4; e++) if (ca + e < a.Cin) { al4[e] = a.alpha[ca + e]; ia4[e] = 1.0f / (al4[e] + 1e-9f); }
+        }
+        for (int it0 = tid; it0 < rows * 16; it0 += 256 * 6) {      // (six items per thread requested before the first is used: two round trips for the longest
+            f32x4 q[6];                                               //  line buffer, 178 rows = 11.1 items per thread; four, as until round 5: three)
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 6; u++) {
                 const int it = it0 + 256 * u;
                 const int r = it >> 4, c = c0 + (it & 15) * 4, t = t0 - a.pad_left + r;
                 q[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -224,14 +252,14 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 6; u++) {
                 const int it = it0 + 256 * u;
                 if (it >= rows * 16) break;
                 const int r = it >> 4, c4 = (it & 15) * 4, c = c0 + c4, t = t0 - a.pad_left + r;
                 f32x4 v = q[u];
                 if (a.pre != PRE_NONE && t >= 0 && t < a.L_in)
                     for (int e = 0; e < 4; e++)
-                        if (c + e < a.Cin) v[e] = pre_apply(v[e], a.pre, a.pre == PRE_SNAKE ? a.alpha[c + e] : 0.f, a.slope);
+                        if (c + e < a.Cin) v[e] = pre_apply_inv(v[e], a.pre, al4[e], ia4[e], a.slope);
                 uint32_t h0[4], h1[4], h2[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) split3t(v[e], h0[e], h1[e], h2[e]);
@@ -242,6 +270,7 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
             }
         }
         __syncthreads();
+        SK_STAMP(1);                                                 // (last chunk's) line buffer staged
         // one 16-channel step = weight fragments of the three planes (3 x 16 B per lane, global / L2) + the two frame tiles' activation
         // fragments of the three planes (LDS) + 12 MFMAs; the next step's weights are requested before the current step's MFMAs
         const uint16_t* wb = a.w3 + ((size_t)(c0 / 16) * ntile + co0 / 32 + cw) * 3 * 512 + (size_t)lane * 8;
@@ -293,26 +322,42 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
         }
 #undef C6_LOAD
 #undef C6_MMA
+        SK_STAMP(2);                                                 // (last chunk's) MFMAs issued
     }
     // epilogue: identical to k_conv
-#pragma unroll
-    for (int tile = 0; tile < FT; tile++) {
+    // Every residual value and every accumulate-mode output value of the lane (16 frames per tile) is requested BEFORE any is used, from
+    // clamped addresses instead of behind a per-frame branch: with `if (t >= L_out) continue` in front of each element hipcc kept the loads
+    // where they were -- 32 dependent global round trips per lane (phase stamps: 33-46 000 cycles of epilogue around 8-38 000 of MFMAs).
+    {
         const int co = co0 + cw * 32 + li;
-        if (co >= a.Cout_store) continue;
-        const float b = a.bias ? a.bias[co] : 0.f;
+        const bool cok = co < a.Cout_store;
+        const int coc = cok ? co : 0;
+        const float b = a.bias ? a.bias[coc] : 0.f;
+        float rv[FT][16], ov[FT][16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int t = t0 + fw * (32 * FT) + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (t >= a.L_out) continue;
-            float v = (tile == 0 ? acc0[r] : acc1[r]) + b;
-            if (a.res) v += a.res[(size_t)t * a.ldres + co];
-            if (a.post == POST_ELU) v = v > 0.f ? v : expm1f(v);
-            float* o = a.out + (size_t)t * a.ldo + a.out_off + co;
-            if (a.acc == ACC_ADD) v = *o + v;
-            else if (a.acc == ACC_ADD_DIV3) v = (*o + v) / 3.0f;
-            *o = v;
-        }
+        for (int tile = 0; tile < FT; tile++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int t = min(t0 + fw * (32 * FT) + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, a.L_out - 1);
+                rv[tile][r] = a.res ? a.res[(size_t)t * a.ldres + coc] : 0.f;
+                ov[tile][r] = a.acc != ACC_STORE ? a.out[(size_t)t * a.ldo + a.out_off + coc] : 0.f;
+            }
+#pragma unroll
+        for (int tile = 0; tile < FT; tile++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int t = t0 + fw * (32 * FT) + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                float v = (tile == 0 ? acc0[r] : acc1[r]) + b;
+                if (a.res) v += rv[tile][r];
+                if (a.post == POST_ELU) v = v > 0.f ? v : expm1f(v);
+                if (a.acc == ACC_ADD) v = ov[tile][r] + v;
+                else if (a.acc == ACC_ADD_DIV3) v = (ov[tile][r] + v) / 3.0f;
+                if (cok && t < a.L_out) a.out[(size_t)t * a.ldo + a.out_off + co] = v;
+            }
     }
+    SK_STAMP(3);
+    SK_STAMP_FLUSH_RING(((unsigned long long)a.taps << 48) | ((unsigned long long)a.dil << 32) | (unsigned)a.CinP,
+                        ((unsigned long long)(64 * FT) << 48) | ((unsigned long long)a.CoutP << 32) | (unsigned)(gridDim.x * gridDim.y * gridDim.z));
 }
 
 // source_downs: Conv1d(18 -> C, k, stride, pad) over s_stft [F][18] (generator.py:468-479); tiny, direct
@@ -606,6 +651,13 @@ extern "C" int cv2_hift_destroy(cv2_hift* h) {
     delete h;
     return 0;
 }
+#ifdef CV2_STAMPS
+extern "C" int cv2_debug_stamps_hift(unsigned long long* out_host) {       // this translation unit's copy of the stamp ring
+    CV2_HIP(hipDeviceSynchronize());
+    CV2_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 8));
+    return 0;
+}
+#endif
 // test hook: device pointers of intermediate buffers (0 melT, 1 f0, 2 s_stft, 3 conv_pre out, 4 x (last stage out), 5 conv_post out)
 extern "C" const float* cv2_hift_debug_buffer(cv2_hift* h, int32_t which) {
     switch (which) { case 0: return h->melT; case 1: return h->f0; case 2: return h->sstft; case 3: return h->xpre; case 4: return h->sum; case 5: return h->post; default: return nullptr; }
