@@ -175,7 +175,11 @@ __device__ int g_stamp_slot;
 #define SK_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_[i] = t_; } while (0)
 #define SK_ACC(i, expr) do { unsigned long long t0_, t1_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); expr; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory"); st_[i] += t1_ - t0_; } while (0)
 #define SK_STAMP_FLUSH do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && g_stamp_slot < 64) for (int i_ = 0; i_ < 8; i_++) g_stamps[g_stamp_slot][i_] = st_[i_]; } while (0)
+#define SK_TICK(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#define SK_ADD(i, d) do { st_[i] += (d); } while (0)
 #else
+#define SK_TICK(v) do { } while (0)
+#define SK_ADD(i, d) do { } while (0)
 #define SK_STAMP_DECL
 #define SK_STAMP(i) do { } while (0)
 #define SK_ACC(i, expr) do { expr; } while (0)

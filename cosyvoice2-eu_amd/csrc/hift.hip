@@ -228,46 +228,64 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
             const int ca = c0 + (tid & 15) * 4;
             for (int e = 0; e < 4; e++) if (ca + e < a.Cin) { al4[e] = a.alpha[ca + e]; ia4[e] = 1.0f / (al4[e] + 1e-9f); }
         }
-        for (int it0 = tid; it0 < rows * 16; it0 += 256 * 6) {      // (six items per thread requested before the first is used: two round trips for the longest
-            f32x4 q[6];                                               //  line buffer, 178 rows = 11.1 items per thread; four, as until round 5: three)
+        // A thread's items are rows r_b, r_b + 16, ..: of its column group: one base pointer and constant increments (the address arithmetic per
+        // item -- 64-bit products, bounds, the item -> (row, column) split -- was 6 000 of a single-chunk block's 17 000 staging cycles).  Six
+        // items are requested before the first is used: two round trips for the longest line buffer (178 rows = 11.1 items per thread).
+        const int r_b = tid >> 4, c4 = (tid & 15) * 4, c = c0 + c4;
+        const int t_b = t0 - a.pad_left + r_b;
+        const bool cfull = c + 3 < a.Cin;
+        const float* src_b = a.ld_in ? a.x : a.x + (long)t_b * a.Cin + c;             // (dereferenced only where the row is inside the signal)
+        const long rstep = 16l * a.Cin;
+        const long flat_b = (long)t_b * a.ld_in + a.flat_off + c, flat_step = 16l * a.ld_in;
+        uint16_t* xo = xp[0] + (size_t)r_b * C6_LD + c4;
+        const size_t plane = (size_t)rows * C6_LD;
+        const int n_it = (rows - r_b + 15) >> 4;                  // items of this thread
+        for (int u0 = 0; u0 < n_it; u0 += 6) {
+            f32x4 q[6];
+            SK_TICK(ta_);
 #pragma unroll
-            for (int u = 0; u < 6; u++) {
-                const int it = it0 + 256 * u;
-                const int r = it >> 4, c = c0 + (it & 15) * 4, t = t0 - a.pad_left + r;
-                q[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int uu = 0; uu < 6; uu++) {
+                const int u = u0 + uu, t = t_b + 16 * u;
+                q[uu] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (u >= n_it) continue;
                 if (a.ld_in) {                                      // flat windows (block-uniform branch): rows overlap, 8-byte alignment at best
-                    if (it < rows * 16) {
-                        const long base = (long)t * a.ld_in + a.flat_off + c;
+                    const long base = flat_b + u * flat_step;
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const long ix = base + e;
-                            if (c + e < a.Cin && ix >= 0 && ix < a.flat_n) q[u][e] = a.x[ix];
-                        }
+                    for (int e = 0; e < 4; e++) {
+                        const long ix = base + e;
+                        if (c + e < a.Cin && ix >= 0 && ix < a.flat_n) q[uu][e] = a.x[ix];
                     }
-                } else
-                if (it < rows * 16 && t >= 0 && t < a.L_in) {
-                    const float* src = a.x + (size_t)t * a.Cin + c;
-                    if (c + 3 < a.Cin) q[u] = *reinterpret_cast<const f32x4*>(src);
-                    else for (int e = 0; e < 4; e++) if (c + e < a.Cin) q[u][e] = src[e];
+                } else if (t >= 0 && t < a.L_in) {
+                    const float* src = src_b + u * rstep;
+                    if (cfull) q[uu] = *reinterpret_cast<const f32x4*>(src);
+                    else for (int e = 0; e < 4; e++) if (c + e < a.Cin) q[uu][e] = src[e];
                 }
             }
+            SK_TICK(tb_);
 #pragma unroll
-            for (int u = 0; u < 6; u++) {
-                const int it = it0 + 256 * u;
-                if (it >= rows * 16) break;
-                const int r = it >> 4, c4 = (it & 15) * 4, c = c0 + c4, t = t0 - a.pad_left + r;
-                f32x4 v = q[u];
-                if (a.pre != PRE_NONE && t >= 0 && t < a.L_in)
-                    for (int e = 0; e < 4; e++)
-                        if (c + e < a.Cin) v[e] = pre_apply_inv(v[e], a.pre, al4[e], ia4[e], a.slope);
+            for (int uu = 0; uu < 6; uu++) {
+                const int u = u0 + uu, t = t_b + 16 * u;
+                if (u >= n_it) break;
+                f32x4 v = q[uu];
+                if (a.pre != PRE_NONE && t >= 0 && t < a.L_in) {
+                    if (cfull) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = pre_apply_inv(v[e], a.pre, al4[e], ia4[e], a.slope);
+                    } else
+                        for (int e = 0; e < 4; e++)
+                            if (c + e < a.Cin) v[e] = pre_apply_inv(v[e], a.pre, al4[e], ia4[e], a.slope);
+                }
                 uint32_t h0[4], h1[4], h2[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) split3t(v[e], h0[e], h1[e], h2[e]);
-                const size_t o = (size_t)r * C6_LD + c4;
-                *reinterpret_cast<uint2*>(xp[0] + o) = make_uint2(pack_hi(h0[0], h0[1]), pack_hi(h0[2], h0[3]));
-                *reinterpret_cast<uint2*>(xp[1] + o) = make_uint2(pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3]));
-                *reinterpret_cast<uint2*>(xp[2] + o) = make_uint2(pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3]));
+                uint16_t* o = xo + (size_t)u * 16 * C6_LD;
+                *reinterpret_cast<uint2*>(o) = make_uint2(pack_hi(h0[0], h0[1]), pack_hi(h0[2], h0[3]));
+                *reinterpret_cast<uint2*>(o + plane) = make_uint2(pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3]));
+                *reinterpret_cast<uint2*>(o + 2 * plane) = make_uint2(pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3]));
             }
+            SK_TICK(tc_);
+            SK_ADD(4, tb_ - ta_);                                    // (diagnostic builds) issue of the batch's loads
+            SK_ADD(5, tc_ - tb_);                                    // wait for them + activation + planes + LDS writes
         }
         __syncthreads();
         SK_STAMP(1);                                                 // (last chunk's) line buffer staged
@@ -328,31 +346,36 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
     // Every residual value and every accumulate-mode output value of the lane (16 frames per tile) is requested BEFORE any is used, from
     // clamped addresses instead of behind a per-frame branch: with `if (t >= L_out) continue` in front of each element hipcc kept the loads
     // where they were -- 32 dependent global round trips per lane (phase stamps: 33-46 000 cycles of epilogue around 8-38 000 of MFMAs).
+    // Frame of (tile, r) = tb + 32 tile + (r & 3) + 8 (r >> 2): row pointers by constant increments of the leading dimensions.
     {
         const int co = co0 + cw * 32 + li;
         const bool cok = co < a.Cout_store;
         const int coc = cok ? co : 0;
         const float b = a.bias ? a.bias[coc] : 0.f;
+        const int tb = t0 + fw * (32 * FT) + 4 * lk;
+        float* const ob = a.out + a.out_off + coc;
+        const float* const rb = a.res ? a.res + coc : nullptr;
+        const int last = a.L_out - 1;
         float rv[FT][16], ov[FT][16];
 #pragma unroll
         for (int tile = 0; tile < FT; tile++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int t = min(t0 + fw * (32 * FT) + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, a.L_out - 1);
-                rv[tile][r] = a.res ? a.res[(size_t)t * a.ldres + coc] : 0.f;
-                ov[tile][r] = a.acc != ACC_STORE ? a.out[(size_t)t * a.ldo + a.out_off + coc] : 0.f;
+                const int t = min(tb + tile * 32 + (r & 3) + 8 * (r >> 2), last);
+                rv[tile][r] = rb ? rb[(long)t * a.ldres] : 0.f;
+                ov[tile][r] = a.acc != ACC_STORE ? ob[(long)t * a.ldo] : 0.f;
             }
 #pragma unroll
         for (int tile = 0; tile < FT; tile++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int t = t0 + fw * (32 * FT) + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int t = tb + tile * 32 + (r & 3) + 8 * (r >> 2);
                 float v = (tile == 0 ? acc0[r] : acc1[r]) + b;
                 if (a.res) v += rv[tile][r];
                 if (a.post == POST_ELU) v = v > 0.f ? v : expm1f(v);
                 if (a.acc == ACC_ADD) v = ov[tile][r] + v;
                 else if (a.acc == ACC_ADD_DIV3) v = (ov[tile][r] + v) / 3.0f;
-                if (cok && t < a.L_out) a.out[(size_t)t * a.ldo + a.out_off + co] = v;
+                if (cok && t <= last) ob[(long)t * a.ldo] = v;
             }
     }
     SK_STAMP(3);

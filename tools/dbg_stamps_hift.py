@@ -19,8 +19,8 @@ for k in range(56):
     t = [buf[k * 8 + i] for i in range(8)]
     if not t[0]: continue
     key = (t[6] >> 48, (t[6] >> 32) & 0xffff, t[6] & 0xffffffff, t[7] >> 48, (t[7] >> 32) & 0xffff, t[7] & 0xffffffff)
-    groups[key].append([t[1] - t[0], t[2] - t[1], t[3] - t[2]])
+    groups[key].append([t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4], t[5]])
 for key, rows in sorted(groups.items()):
     n = len(rows)
-    avg = [sum(r[i] for r in rows) / n for i in range(3)]
-    print(f'taps {key[0]:2d} dil {key[1]} C_in {key[2]:4d} frames/block {key[3]:3d} C_out {key[4]:4d} blocks {key[5]:5d} launches {n:2d}: to staged(last chunk) {avg[0]:7.0f}  MFMAs {avg[1]:7.0f}  epilogue {avg[2]:7.0f}  total {sum(avg):7.0f} cycles')
+    avg = [sum(r[i] for r in rows) / n for i in range(5)]
+    print(f'taps {key[0]:2d} dil {key[1]} C_in {key[2]:4d} frames/block {key[3]:3d} C_out {key[4]:4d} blocks {key[5]:5d} launches {n:2d}: to staged(last chunk) {avg[0]:7.0f}  MFMAs {avg[1]:7.0f}  epilogue {avg[2]:7.0f}  total {sum(avg[:3]):7.0f} cycles; staging over all chunks: load issue {avg[3]:6.0f}, wait + activation + planes {avg[4]:6.0f}')
