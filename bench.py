@@ -252,7 +252,7 @@ def pmc_stage_file(stage):
     """The newest committed profiles/r<N>_pmc_<stage>.json (tools/pmc_stages.sh: rocprofv3 --pmc passes of one stage alone) or None.
     The dict carries its own file name ('_file'): counters cannot be read from inside the bench, so every field derived from them is
     stamped with where it came from and 'measured_in_this_run': False."""
-    for rnd in (4, 3):
+    for rnd in (5, 4, 3):
         p = os.path.join(ROOT, 'profiles', f'r{rnd}_pmc_{stage}.json')
         if os.path.exists(p):
             d = json.load(open(p))
@@ -726,7 +726,7 @@ def n1_reference(per_rank, steps):
     rates = sorted(r['audio_s_per_step'] * steps / max(r['work_s'], 1e-9) for r in per_rank)
     ref = {'unit': 'audio-s/s per GPU', 'per_rank_shard_rate_median': round(rates[len(rates) // 2], 2), 'per_rank_shard_rate_min': round(rates[0], 2),
            'source': "each rank's own shard inside this run, collectives excluded"}
-    for name in ('r4_bench_b1.json', 'r3_bench_b1.json'):
+    for name in ('r5_bench_b1.json', 'r4_bench_b1.json', 'r3_bench_b1.json'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             with open(path) as f:

@@ -434,7 +434,10 @@ class CosyVoice2Model:
                 t_cap = t_sub + self.first_round_hold_cap * hold              # (arrivals that never stop must not hold a chunk for ever)
                 while not c.done and not c.taken:                             # (taken: a round has this chunk -- get in line)
                     now = time.perf_counter()
-                    if now >= t_cap or not any(now - t0 < hold for t0 in list(self._first_pending.values())):
+                    # (from three calls on: two calls 30 ms apart are as well off with a round each -- measured 73 / 121 ms p50 / max either way)
+                    n_new = sum(1 for t0 in list(self._first_pending.values()) if now - t0 < hold)
+                    n_wait = sum(1 for q in list(self._chunk_q) if q.offset == 0 and q.stream and not q.finalize)
+                    if now >= t_cap or n_new == 0 or n_new + max(n_wait, 1) < 3:
                         break
                     held = True
                     time.sleep(0.0002)
