@@ -369,7 +369,13 @@ __device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t*
                                                                          (((8 * (q16 >> 2) + (q16 & 3)) * 128 + ((g ^ att_kswz(q16)) << 4)) ^ (ks << 6)))
                                       : *reinterpret_cast<const bf16x8*>(&Kt[(16 * k4 + q16) * AK_LD + ks * 32 + g * 8]);
 #pragma unroll
-                for (int u = 0; u < QS; u++) sacc[u][k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][k4], 0, 0, 0);
+                for (int u = 0; u < QS; u++) {
+#if defined(ATT_DIAG) && (ATT_DIAG & 4)
+                    sacc[u][k4][0] += __builtin_bit_cast(f32x4, kf)[u];
+#else
+                    sacc[u][k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][k4], 0, 0, 0);
+#endif
+                }
             }
         }
         bf16x8 pf[QS][2];
@@ -379,6 +385,15 @@ __device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t*
         constexpr float SC = 0.125f * 1.4426950408889634f;
 #pragma unroll
         for (int u = 0; u < QS; u++) {
+#if defined(ATT_DIAG) && (ATT_DIAG & 8)
+            for (int kp = 0; kp < 2; kp++) {
+                typedef __attribute__((ext_vector_type(8))) float f32x8;
+                const f32x8 pv = {sacc[u][2 * kp][0], sacc[u][2 * kp][1], sacc[u][2 * kp][2], sacc[u][2 * kp][3],
+                                  sacc[u][2 * kp + 1][0], sacc[u][2 * kp + 1][1], sacc[u][2 * kp + 1][2], sacc[u][2 * kp + 1][3]};
+                pf[u][kp] = __builtin_convertvector(pv, bf16x8);
+            }
+            continue;
+#endif
             if (!__all(kt * 64 + 64 <= kmax_q[u])) {
 #pragma unroll
                 for (int k4 = 0; k4 < 4; k4++)
@@ -395,8 +410,8 @@ __device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t*
             mloc = fmaxf(fmaxf(mloc, sacc[u][2][3]), sacc[u][3][0]);
             mloc = fmaxf(fmaxf(mloc, sacc[u][3][1]), sacc[u][3][2]);
             mloc = fmaxf(mloc, sacc[u][3][3]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-            const float mnew = fmaxf(fmaxf(mrun[u], mloc), __shfl_xor(mloc, 32));      // raw-score domain
+            // over the query's four lanes (q16 + 16 g): two v_permlane*_swap instead of two LDS-routed shuffles with a wait behind each
+            const float mnew = fmaxf(mrun[u], rows4_max(mloc));      // raw-score domain
             const float msafe = mnew == -INFINITY ? 0.f : mnew;
             const float mc = msafe * SC;
             const float alpha = __builtin_amdgcn_exp2f((mrun[u] - msafe) * SC);     // mrun = -inf -> 0
@@ -404,7 +419,14 @@ __device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t*
 #pragma unroll
             for (int k4 = 0; k4 < 4; k4++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) { const float p = __builtin_amdgcn_exp2f(fmaf(sacc[u][k4][r], SC, -mc)); sacc[u][k4][r] = p; psum += p; }
+                for (int r = 0; r < 4; r++) {
+#if defined(ATT_DIAG) && (ATT_DIAG & 1)
+                    const float p = fmaf(sacc[u][k4][r], SC, -mc);
+#else
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[u][k4][r], SC, -mc));
+#endif
+                    sacc[u][k4][r] = p; psum += p;
+                }
             lrun[u] = lrun[u] * alpha + psum;
             mrun[u] = mnew;
             if (__any(alpha != 1.f)) {
@@ -434,7 +456,13 @@ __device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t*
                     vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
                 }
 #pragma unroll
-                for (int u = 0; u < QS; u++) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][kp], o[u][dt], 0, 0, 0);
+                for (int u = 0; u < QS; u++) {
+#if defined(ATT_DIAG) && (ATT_DIAG & 2)
+                    o[u][dt][0] += __builtin_bit_cast(f32x4, vf)[u] + __builtin_bit_cast(f32x4, pf[u][kp])[dt];
+#else
+                    o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][kp], o[u][dt], 0, 0, 0);
+#endif
+                }
             }
 }
 // QS query sub-tiles of 16 rows per wave, NW waves (block = 16*NW*QS rows): K / V^T fragments read from LDS once serve QS MFMAs;
@@ -638,6 +666,9 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
 // instruction writes 1 KiB = 8 rows of 128 B; lane l fetches chunk (l & 7) ^ (l >> 3) of row l >> 3, so the chunk c of row r lands in
 // slot c ^ (r & 7) and the fragment reads (att_est_tile<.., true>) are conflict-free without padding.  The tile's keys are permuted among the
 // score rows (att_est_tile): same products, another order inside a k group -- agreement with k_attn_est to fp32 round-off, not bit for bit.
+#ifndef ATT_STAMP_BLOCK
+#define ATT_STAMP_BLOCK 0
+#endif
 template <int QS, bool CACHE = false>
 __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
     constexpr int NW = 4, RB = 16 * NW;
@@ -695,6 +726,15 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
         }
     }
     kstep = CACHE ? 64 * 512 : 64 * 1024;
+#if defined(ATT_DIAG_SRC)        // (timing experiments on the tiles' source patterns; the data is wrong)
+    long vstep_ = 64;
+    if (ATT_DIAG_SRC == 1) { for (int j = 0; j < 2; j++) ksrc[j] = vsrc[j] + 32 * a.R; kstep = 64; }            // K tiles fetched with the V^T pattern
+    if (ATT_DIAG_SRC == 2) { for (int j = 0; j < 2; j++) vsrc[j] = ksrc[j] - 512; vstep_ = kstep; }             // V^T tiles fetched with the K pattern (the q half)
+    if (ATT_DIAG_SRC == 3) { for (int j = 0; j < 2; j++) ksrc[j] = a.qk + ((size_t)h * a.R + start + 8 * (w + 4 * j) + rr) * 64 + gc * 8; kstep = 64 * 64; }   // K head-major, tiles contiguous
+#define ATT_VSTEP vstep_
+#else
+#define ATT_VSTEP 64
+#endif
     // The DMA instructions are inline asm on purpose: hipcc orders every LDS read that may alias the destination of a DMA builtin behind
     // vmcnt(0) (here: each tile's fragment reads behind the DMA issued just before them, i.e. no tile in flight).  Written this way the
     // compiler knows nothing of the LDS writes and the waits below are the only ones; m0 is used by nothing else in this kernel (it is a
@@ -705,7 +745,7 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
             const unsigned kd = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(&Ks[st][(w + 4 * j) * 512]);
             const unsigned vd = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(&Vs[st][(w + 4 * j) * 512]);
             asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(kd), "v"(ksrc[j] + (long)kt * kstep) : "memory");
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(vd), "v"(vsrc[j] + (long)kt * 64) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(vd), "v"(vsrc[j] + (long)kt * ATT_VSTEP) : "memory");
         }
     };
     f32x4 o[QS][4];
@@ -717,6 +757,8 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
         for (int dt = 0; dt < 4; dt++) o[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const int last = ntiles - 1;
+    SK_STAMP_DECL;
+    SK_STAMP(0);
     dma(0, 0);
     dma(min(1, last), 1);
     // q fragments: loaded AFTER the first DMAs and consumed (empty asm) before the loop, so that the compiler's own wait for these loads sits
@@ -732,16 +774,24 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) asm volatile("" : "+v"(qf[u][ks]));
     int st = 0;
+    SK_STAMP(1);
     for (int kt = 0; kt < ntiles; kt++) {
         // four DMA instructions per tile and wave, always (a tile index past the end re-fetches the last tile): tile kt has landed when at
         // most the four of tile kt + 1 are outstanding; the barrier makes that true for every wave's share and says that every wave is
         // done with tile kt - 1 (its fragment reads have returned: lgkmcnt), whose stage the next DMA overwrites
+        SK_TICK(ta_);
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        SK_TICK(tb_);
         __builtin_amdgcn_s_barrier();            // (no fence: __syncthreads() would add waits of its own)
+        SK_TICK(tc_);
         dma(min(kt + 2, last), st >= 1 ? st - 1 : 2);
+        SK_TICK(td_);
         att_est_tile<QS, true>(Ks[st], Vs[st], qf, o, mrun, lrun, kmax_q, kt, q16, g);
+        SK_TICK(te_);
+        SK_ADD(2, tb_ - ta_); SK_ADD(3, tc_ - tb_); SK_ADD(6, td_ - tc_); SK_ADD(7, te_ - td_);
         st = st == 2 ? 0 : st + 1;
     }
+    SK_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the look-ahead DMAs target this block's LDS: they land before it is released)
 #pragma unroll
     for (int u = 0; u < QS; u++) {
@@ -753,6 +803,13 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
         for (int dt = 0; dt < 4; dt++)
             *reinterpret_cast<uint2*>(orow[u] + 16 * dt) = make_uint2(pack_bf16x2(o[u][dt][0] * inv, o[u][dt][1] * inv), pack_bf16x2(o[u][dt][2] * inv, o[u][dt][3] * inv));
     }
+#ifdef CV2_STAMPS
+    SK_STAMP(5);
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == ATT_STAMP_BLOCK) {
+        for (int i_ = 0; i_ < 8; i_++) g_stamps[61][i_] = st_[i_];       // slot 61: last DMA attention launch (tools/dbg_stamps_flow.py)
+        g_stamps[62][0] = ntiles; g_stamps[62][1] = gridDim.x * gridDim.y;
+    }
+#endif
 }
 
 // =========================================================================== host side

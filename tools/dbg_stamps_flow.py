@@ -25,6 +25,10 @@ L.check(L.lib().cv2_debug_stamps_flow(buf))
 ph = ['issue', 'first stage', 'K loop', 'C stage', 'row epilogue']
 t = [buf[60 * 8 + i] for i in range(8)]
 print(f'k_attn_est block 0: prologue={t[1]-t[0]}  staging+wait(sum)={t[2]}  compute(sum)={t[3]}  loop total={t[4]-t[1]}  store={t[5]-t[4]}  tiles={t[6]} blocks={t[7]}')
+t = [buf[61 * 8 + i] for i in range(8)]
+if t[0]:
+    print(f'k_attn_est_dma block 0 (s_memtime ticks): prologue={t[1]-t[0]}  loop total={t[4]-t[1]} = wait for the tile (sum) {t[2]} + barrier (sum) {t[3]} + DMA issue (sum) {t[6]} '
+          f'+ tile body (sum) {t[7]}  store={t[5]-t[4]}  tiles={buf[62 * 8]} blocks={buf[62 * 8 + 1]}')
 groups = collections.defaultdict(list)
 for k in range(56):
     t = [buf[k * 8 + i] for i in range(8)]
