@@ -346,124 +346,116 @@ struct AttnEstArgs {
 };
 #define AK_LD 72    // K tile row stride (bf16 elements): 64 + 8
 #define AV_LD 68    // V^T tile row stride: 64 + 4
-// one 64-key tile of the flash loop: scores, running softmax, O^T update (Kt / Vt = the staged tile in LDS)
+// one 64-key tile of the flash loop in three phases: scores, running softmax, O^T update (Kt / Vt = the staged tile in LDS)
 // SWZ: the tile was written by LDS DMA (k_attn_est_dma): rows of 128 B without padding; chunk c (16 B) of V^T row d sits in slot c ^ (d & 7),
 // chunk c of K row r in slot c ^ att_kswz-of-its-score-row.  The score rows are a permutation of the tile's keys, chosen so that the eight
 // P entries a lane holds per key-pair tile are eight consecutive keys: the V^T operand of the second product is then ONE 16-byte read
 // (the register-staged form reads two 8-byte halves 16 keys apart and moves them together).  Same products, another order inside a
 // matrix-core k group: the two forms agree to fp32 round-off, not bit for bit.
 __device__ __forceinline__ int att_kswz(int i) { return (i >> 2) * 2 + ((i >> 1) & 1); }      // i = score row (0 .. 15): two rows per value
-template <int QS, bool SWZ = false>
-__device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t* Vt, const bf16x8 (&qf)[QS][2], f32x4 (&o)[QS][4],
-                                             float (&mrun)[QS], float (&lrun)[QS], const int (&kmax_q)[QS], int kt, int q16, int g) {
-        // S^T: 4 key tiles x (d = 64 in two k-steps), K fragments shared by the QS query sub-tiles
-        f32x4 sacc[QS][4];
+// S^T: 4 key tiles x (d = 64 in two k-steps), K fragments shared by the QS query sub-tiles
+template <int QS, bool SWZ>
+__device__ __forceinline__ void att_qk(const uint16_t* Kt, const bf16x8 (&qf)[QS][2], f32x4 (&sacc)[QS][4], int q16, int g) {
 #pragma unroll
-        for (int k4 = 0; k4 < 4; k4++) {
+    for (int k4 = 0; k4 < 4; k4++) {
 #pragma unroll
-            for (int u = 0; u < QS; u++) sacc[u][k4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < QS; u++) sacc[u][k4] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                // SWZ: score row i = q16 of key tile k4 is key 32 (k4 / 2) + 8 (i / 4) + 4 (k4 % 2) + i % 4 (see the V^T read below)
-                const bf16x8 kf = SWZ ? *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Kt) + (k4 >> 1) * 4096 + (k4 & 1) * 512 +
-                                                                         (((8 * (q16 >> 2) + (q16 & 3)) * 128 + ((g ^ att_kswz(q16)) << 4)) ^ (ks << 6)))
-                                      : *reinterpret_cast<const bf16x8*>(&Kt[(16 * k4 + q16) * AK_LD + ks * 32 + g * 8]);
+        for (int ks = 0; ks < 2; ks++) {
+            // SWZ: score row i = q16 of key tile k4 is key 32 (k4 / 2) + 8 (i / 4) + 4 (k4 % 2) + i % 4 (see the V^T read in att_pv)
+            const bf16x8 kf = SWZ ? *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Kt) + (k4 >> 1) * 4096 + (k4 & 1) * 512 +
+                                                                     (((8 * (q16 >> 2) + (q16 & 3)) * 128 + ((g ^ att_kswz(q16)) << 4)) ^ (ks << 6)))
+                                  : *reinterpret_cast<const bf16x8*>(&Kt[(16 * k4 + q16) * AK_LD + ks * 32 + g * 8]);
 #pragma unroll
-                for (int u = 0; u < QS; u++) {
-#if defined(ATT_DIAG) && (ATT_DIAG & 4)
-                    sacc[u][k4][0] += __builtin_bit_cast(f32x4, kf)[u];
-#else
-                    sacc[u][k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][k4], 0, 0, 0);
-#endif
-                }
+            for (int u = 0; u < QS; u++) {
+                sacc[u][k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][k4], 0, 0, 0);
             }
         }
-        bf16x8 pf[QS][2];
-        // softmax in the exp2 domain on the RAW scores: p = 2^(s C - m C), C = log2(e) / sqrt(64), one FMA + one v_exp_f32 per score.
-        // Masking and the rescale of O are wave-uniform branches: only the last tile(s) of a sequence mask, and the running maximum
-        // stops moving after the first few tiles.
-        constexpr float SC = 0.125f * 1.4426950408889634f;
+    }
+}
+// softmax in the exp2 domain on the RAW scores: p = 2^(s C - m C), C = log2(e) / sqrt(64), one FMA + one v_exp_f32 per score.
+// Masking and the rescale of O are wave-uniform branches: only the last tile(s) of a sequence mask, and the running maximum
+// stops moving after the first few tiles.
+template <int QS, bool SWZ>
+__device__ __forceinline__ void att_softmax(f32x4 (&sacc)[QS][4], bf16x8 (&pf)[QS][2], f32x4 (&o)[QS][4], float (&mrun)[QS], float (&lrun)[QS],
+                                            const int (&kmax_q)[QS], int kt, int g) {
+    constexpr float SC = 0.125f * 1.4426950408889634f;
 #pragma unroll
-        for (int u = 0; u < QS; u++) {
-#if defined(ATT_DIAG) && (ATT_DIAG & 8)
-            for (int kp = 0; kp < 2; kp++) {
-                typedef __attribute__((ext_vector_type(8))) float f32x8;
-                const f32x8 pv = {sacc[u][2 * kp][0], sacc[u][2 * kp][1], sacc[u][2 * kp][2], sacc[u][2 * kp][3],
-                                  sacc[u][2 * kp + 1][0], sacc[u][2 * kp + 1][1], sacc[u][2 * kp + 1][2], sacc[u][2 * kp + 1][3]};
-                pf[u][kp] = __builtin_convertvector(pv, bf16x8);
-            }
-            continue;
-#endif
-            if (!__all(kt * 64 + 64 <= kmax_q[u])) {
-#pragma unroll
-                for (int k4 = 0; k4 < 4; k4++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (kt * 64 + (SWZ ? 32 * (k4 >> 1) + 8 * g + 4 * (k4 & 1) : 16 * k4 + 4 * g) + r >= kmax_q[u]) sacc[u][k4][r] = -INFINITY;
-            }
-            // 16 scores -> one maximum as a chain of three-operand maxima (8 v_max3_f32; a balanced tree of pairs compiled to 23 instructions)
-            float mloc = fmaxf(fmaxf(sacc[u][0][0], sacc[u][0][1]), sacc[u][0][2]);
-            mloc = fmaxf(fmaxf(mloc, sacc[u][0][3]), sacc[u][1][0]);
-            mloc = fmaxf(fmaxf(mloc, sacc[u][1][1]), sacc[u][1][2]);
-            mloc = fmaxf(fmaxf(mloc, sacc[u][1][3]), sacc[u][2][0]);
-            mloc = fmaxf(fmaxf(mloc, sacc[u][2][1]), sacc[u][2][2]);
-            mloc = fmaxf(fmaxf(mloc, sacc[u][2][3]), sacc[u][3][0]);
-            mloc = fmaxf(fmaxf(mloc, sacc[u][3][1]), sacc[u][3][2]);
-            mloc = fmaxf(mloc, sacc[u][3][3]);
-            // over the query's four lanes (q16 + 16 g): two v_permlane*_swap instead of two LDS-routed shuffles with a wait behind each
-            const float mnew = fmaxf(mrun[u], rows4_max(mloc));      // raw-score domain
-            const float msafe = mnew == -INFINITY ? 0.f : mnew;
-            const float mc = msafe * SC;
-            const float alpha = __builtin_amdgcn_exp2f((mrun[u] - msafe) * SC);     // mrun = -inf -> 0
-            float psum = 0.f;
+    for (int u = 0; u < QS; u++) {
+        if (!__all(kt * 64 + 64 <= kmax_q[u])) {
 #pragma unroll
             for (int k4 = 0; k4 < 4; k4++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-#if defined(ATT_DIAG) && (ATT_DIAG & 1)
-                    const float p = fmaf(sacc[u][k4][r], SC, -mc);
-#else
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[u][k4][r], SC, -mc));
-#endif
-                    sacc[u][k4][r] = p; psum += p;
-                }
-            lrun[u] = lrun[u] * alpha + psum;
-            mrun[u] = mnew;
-            if (__any(alpha != 1.f)) {
+                for (int r = 0; r < 4; r++)
+                    if (kt * 64 + (SWZ ? 32 * (k4 >> 1) + 8 * g + 4 * (k4 & 1) : 16 * k4 + 4 * g) + r >= kmax_q[u]) sacc[u][k4][r] = -INFINITY;
+        }
+        // 16 scores -> one maximum as a chain of three-operand maxima (8 v_max3_f32; a balanced tree of pairs compiled to 23 instructions)
+        float mloc = fmaxf(fmaxf(sacc[u][0][0], sacc[u][0][1]), sacc[u][0][2]);
+        mloc = fmaxf(fmaxf(mloc, sacc[u][0][3]), sacc[u][1][0]);
+        mloc = fmaxf(fmaxf(mloc, sacc[u][1][1]), sacc[u][1][2]);
+        mloc = fmaxf(fmaxf(mloc, sacc[u][1][3]), sacc[u][2][0]);
+        mloc = fmaxf(fmaxf(mloc, sacc[u][2][1]), sacc[u][2][2]);
+        mloc = fmaxf(fmaxf(mloc, sacc[u][2][3]), sacc[u][3][0]);
+        mloc = fmaxf(fmaxf(mloc, sacc[u][3][1]), sacc[u][3][2]);
+        mloc = fmaxf(mloc, sacc[u][3][3]);
+        // over the query's four lanes (q16 + 16 g): two v_permlane*_swap instead of two LDS-routed shuffles with a wait behind each
+        const float mnew = fmaxf(mrun[u], rows4_max(mloc));      // raw-score domain
+        const float msafe = mnew == -INFINITY ? 0.f : mnew;
+        const float mc = msafe * SC;
+        const float alpha = __builtin_amdgcn_exp2f((mrun[u] - msafe) * SC);     // mrun = -inf -> 0
+        float psum = 0.f;
 #pragma unroll
-                for (int dt = 0; dt < 4; dt++) o[u][dt] *= alpha;
+        for (int k4 = 0; k4 < 4; k4++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[u][k4][r], SC, -mc));
+                sacc[u][k4][r] = p; psum += p;
+            }
+        lrun[u] = lrun[u] * alpha + psum;
+        mrun[u] = mnew;
+        if (__any(alpha != 1.f)) {
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) o[u][dt] *= alpha;
+        }
+#pragma unroll
+        for (int kp = 0; kp < 2; kp++) {
+            typedef __attribute__((ext_vector_type(8))) float f32x8;
+            const f32x8 pv = {sacc[u][2 * kp][0], sacc[u][2 * kp][1], sacc[u][2 * kp][2], sacc[u][2 * kp][3],
+                              sacc[u][2 * kp + 1][0], sacc[u][2 * kp + 1][1], sacc[u][2 * kp + 1][2], sacc[u][2 * kp + 1][3]};
+            pf[u][kp] = __builtin_convertvector(pv, bf16x8);
+        }
+    }
+}
+// O^T += V^T P^T ; k slots of key-pair tile kp: j < 4 -> key 32kp + 4g + j, j >= 4 -> key 32kp + 16 + 4g + (j - 4)
+template <int QS, bool SWZ>
+__device__ __forceinline__ void att_pv(const uint16_t* Vt, const bf16x8 (&pf)[QS][2], f32x4 (&o)[QS][4], int q16, int g) {
+#pragma unroll
+    for (int kp = 0; kp < 2; kp++)
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) {
+            bf16x8 vf;
+            if (SWZ) {                       // the lane's eight P entries of key-pair tile kp are the CONSECUTIVE keys 32 kp + 8 g .. + 7: one 16-byte chunk
+                vf = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Vt) + dt * 2048 + ((q16 * 128 + ((g ^ (q16 & 7)) << 4)) ^ (kp << 6)));
+            } else {
+                const uint16_t* vrow = &Vt[(16 * dt + q16) * AV_LD + 32 * kp + 4 * g];
+                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+                vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
             }
 #pragma unroll
-            for (int kp = 0; kp < 2; kp++) {
-                typedef __attribute__((ext_vector_type(8))) float f32x8;
-                const f32x8 pv = {sacc[u][2 * kp][0], sacc[u][2 * kp][1], sacc[u][2 * kp][2], sacc[u][2 * kp][3],
-                                  sacc[u][2 * kp + 1][0], sacc[u][2 * kp + 1][1], sacc[u][2 * kp + 1][2], sacc[u][2 * kp + 1][3]};
-                pf[u][kp] = __builtin_convertvector(pv, bf16x8);
+            for (int u = 0; u < QS; u++) {
+                o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][kp], o[u][dt], 0, 0, 0);
             }
         }
-        // O^T += V^T P^T ; k slots of key-pair tile kp: j < 4 -> key 32kp + 4g + j, j >= 4 -> key 32kp + 16 + 4g + (j - 4)
-#pragma unroll
-        for (int kp = 0; kp < 2; kp++)
-#pragma unroll
-            for (int dt = 0; dt < 4; dt++) {
-                bf16x8 vf;
-                if (SWZ) {                       // the lane's eight P entries of key-pair tile kp are the CONSECUTIVE keys 32 kp + 8 g .. + 7: one 16-byte chunk
-                    vf = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Vt) + dt * 2048 + ((q16 * 128 + ((g ^ (q16 & 7)) << 4)) ^ (kp << 6)));
-                } else {
-                    const uint16_t* vrow = &Vt[(16 * dt + q16) * AV_LD + 32 * kp + 4 * g];
-                    const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
-                    vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-                }
-#pragma unroll
-                for (int u = 0; u < QS; u++) {
-#if defined(ATT_DIAG) && (ATT_DIAG & 2)
-                    o[u][dt][0] += __builtin_bit_cast(f32x4, vf)[u] + __builtin_bit_cast(f32x4, pf[u][kp])[dt];
-#else
-                    o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][kp], o[u][dt], 0, 0, 0);
-#endif
-                }
-            }
+}
+template <int QS, bool SWZ = false>
+__device__ __forceinline__ void att_est_tile(const uint16_t* Kt, const uint16_t* Vt, const bf16x8 (&qf)[QS][2], f32x4 (&o)[QS][4],
+                                             float (&mrun)[QS], float (&lrun)[QS], const int (&kmax_q)[QS], int kt, int q16, int g) {
+    f32x4 sacc[QS][4];
+    bf16x8 pf[QS][2];
+    att_qk<QS, SWZ>(Kt, qf, sacc, q16, g);
+    att_softmax<QS, SWZ>(sacc, pf, o, mrun, lrun, kmax_q, kt, g);
+    att_pv<QS, SWZ>(Vt, pf, o, q16, g);
 }
 // QS query sub-tiles of 16 rows per wave, NW waves (block = 16*NW*QS rows): K / V^T fragments read from LDS once serve QS MFMAs;
 // NW = 2 doubles the block count for single-utterance calls, whose 64-row tiles would not even fill the chip once.
@@ -662,18 +654,23 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
 }
 
 // The same attention with the K / V^T tiles going global -> LDS by DMA (4 waves, one key group): no staging registers (k_attn_est keeps
-// two tiles = 64 VGPRs in flight per thread and stores them to LDS itself), three LDS stages of 16 KB, two tiles in flight.  A wave's DMA
+// two tiles = 64 VGPRs in flight per thread and stores them to LDS itself), LDS stages of 16 KB (round 4: three, two tiles in flight, three
+// blocks per CU; round 5: two, one tile in flight, FOUR blocks per CU at 123 VGPRs -- the loop is bound by vector issue and the L2 -> LDS
+// delivery, not by the tiles' latency: 176 -> 167 us per launch on a 32-utterance batch, profiles/r5_attention_experiments.txt).  A wave's DMA
 // instruction writes 1 KiB = 8 rows of 128 B; lane l fetches chunk (l & 7) ^ (l >> 3) of row l >> 3, so the chunk c of row r lands in
 // slot c ^ (r & 7) and the fragment reads (att_est_tile<.., true>) are conflict-free without padding.  The tile's keys are permuted among the
 // score rows (att_est_tile): same products, another order inside a k group -- agreement with k_attn_est to fp32 round-off, not bit for bit.
 #ifndef ATT_STAMP_BLOCK
 #define ATT_STAMP_BLOCK 0
 #endif
+#ifndef ATT_STAGES
+#define ATT_STAGES 2     // LDS stages of the DMA attention: 2 = 32 KB per block, four blocks per CU (3: two tiles in flight, three blocks; A/B)
+#endif
 template <int QS, bool CACHE = false>
 __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
     constexpr int NW = 4, RB = 16 * NW;
-    __shared__ __attribute__((aligned(1024))) uint16_t Ks[3][64 * 64];
-    __shared__ __attribute__((aligned(1024))) uint16_t Vs[3][64 * 64];
+    __shared__ __attribute__((aligned(1024))) uint16_t Ks[ATT_STAGES][64 * 64];
+    __shared__ __attribute__((aligned(1024))) uint16_t Vs[ATT_STAGES][64 * 64];
     const int lane = threadIdx.x & 63, tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef CV2_NO_XCD
@@ -726,15 +723,6 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
         }
     }
     kstep = CACHE ? 64 * 512 : 64 * 1024;
-#if defined(ATT_DIAG_SRC)        // (timing experiments on the tiles' source patterns; the data is wrong)
-    long vstep_ = 64;
-    if (ATT_DIAG_SRC == 1) { for (int j = 0; j < 2; j++) ksrc[j] = vsrc[j] + 32 * a.R; kstep = 64; }            // K tiles fetched with the V^T pattern
-    if (ATT_DIAG_SRC == 2) { for (int j = 0; j < 2; j++) vsrc[j] = ksrc[j] - 512; vstep_ = kstep; }             // V^T tiles fetched with the K pattern (the q half)
-    if (ATT_DIAG_SRC == 3) { for (int j = 0; j < 2; j++) ksrc[j] = a.qk + ((size_t)h * a.R + start + 8 * (w + 4 * j) + rr) * 64 + gc * 8; kstep = 64 * 64; }   // K head-major, tiles contiguous
-#define ATT_VSTEP vstep_
-#else
-#define ATT_VSTEP 64
-#endif
     // The DMA instructions are inline asm on purpose: hipcc orders every LDS read that may alias the destination of a DMA builtin behind
     // vmcnt(0) (here: each tile's fragment reads behind the DMA issued just before them, i.e. no tile in flight).  Written this way the
     // compiler knows nothing of the LDS writes and the waits below are the only ones; m0 is used by nothing else in this kernel (it is a
@@ -745,7 +733,7 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
             const unsigned kd = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(&Ks[st][(w + 4 * j) * 512]);
             const unsigned vd = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(&Vs[st][(w + 4 * j) * 512]);
             asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(kd), "v"(ksrc[j] + (long)kt * kstep) : "memory");
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(vd), "v"(vsrc[j] + (long)kt * ATT_VSTEP) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(vd), "v"(vsrc[j] + (long)kt * 64) : "memory");
         }
     };
     f32x4 o[QS][4];
@@ -760,7 +748,9 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
     SK_STAMP_DECL;
     SK_STAMP(0);
     dma(0, 0);
+#if ATT_STAGES == 3
     dma(min(1, last), 1);
+#endif
     // q fragments: loaded AFTER the first DMAs and consumed (empty asm) before the loop, so that the compiler's own wait for these loads sits
     // here -- placed at their first use inside the loop it would be a vmcnt(0) in every iteration, i.e. a wait for the DMA just issued
     bf16x8 qf[QS][2];
@@ -775,6 +765,16 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
         for (int ks = 0; ks < 2; ks++) asm volatile("" : "+v"(qf[u][ks]));
     int st = 0;
     SK_STAMP(1);
+#if ATT_STAGES == 2
+    // two stages (32 KB of LDS: four blocks per CU instead of three): one tile in flight while the other is worked on
+    for (int kt = 0; kt < ntiles; kt++) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        dma(min(kt + 1, last), st ^ 1);
+        att_est_tile<QS, true>(Ks[st], Vs[st], qf, o, mrun, lrun, kmax_q, kt, q16, g);
+        st ^= 1;
+    }
+#else
     for (int kt = 0; kt < ntiles; kt++) {
         // four DMA instructions per tile and wave, always (a tile index past the end re-fetches the last tile): tile kt has landed when at
         // most the four of tile kt + 1 are outstanding; the barrier makes that true for every wave's share and says that every wave is
@@ -791,6 +791,7 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
         SK_ADD(2, tb_ - ta_); SK_ADD(3, tc_ - tb_); SK_ADD(6, td_ - tc_); SK_ADD(7, te_ - td_);
         st = st == 2 ? 0 : st + 1;
     }
+#endif
     SK_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the look-ahead DMAs target this block's LDS: they land before it is released)
 #pragma unroll
