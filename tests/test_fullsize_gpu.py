@@ -557,6 +557,71 @@ def test_hub_mixed_calls_failing_text_and_abandoned_stream(dev):
     mdl._token_log, mdl._on_call = None, None
 
 
+def test_staggered_arrivals_over_many_rounds_every_call_gets_its_own_tokens(dev):
+    """The serving pattern the aligned-start tests do not exercise: calls arrive 0-40 ms apart (seeded offsets), over 8 rounds of 6
+    calls on one model with 6 slots, so that a call joins while others are prefilling, decoding their first tokens, inside a chunk round
+    or finishing (the first-round hold, the joining bursts and the hub's rounds all see newcomers).  Each round mixes tensor-text
+    streams, generator-text (bistream) streams, one non-streaming call and one consumer that walks away after its first chunk.  Every
+    completed call must deliver exactly its own tokens (== the oracle's for its kind), no call may hang, and after every round all
+    slots and per-call dictionaries are free again."""
+    import random
+    import time
+    from cv2amd import synth, weights as W
+    from cosyvoice.cli.model import CosyVoice2Model
+    from oracle import llm as OL
+    sd = _bistream_sd(2)
+    sdr = W.round_llm_sd(sd)
+    mdl = CosyVoice2Model(sd, synth.make_flow(), synth.make_hift(), max_batch=6, max_text=64, max_prompt_tokens=64, max_new_tokens=512, sampling='greedy')
+    inp = synth.synthetic_inputs(seed=1, text_len=23, prompt_len=31, prompt_text_len=6)
+    cuts = (0, 3, 10, 15, 23)
+    pieces = [inp['text'][:, a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    want_bi, _ = OL.inference_bistream(sdr, pieces, inp['prompt_text'], inp['prompt_token'])
+    want_uni = OL.inference(sdr, inp['text'], inp['prompt_text'], inp['prompt_token'], max_ratio=20)
+    kw = dict(flow_embedding=inp['embedding'], llm_embedding=inp['embedding'], prompt_text=inp['prompt_text'],
+              llm_prompt_speech_token=inp['prompt_token'], flow_prompt_speech_token=inp['prompt_token'], prompt_speech_feat=inp['prompt_feat'])
+    rng = random.Random(5)
+    kinds = ['uni', 'bi', 'uni', 'bi', 'batch', 'quit']
+    for rnd in range(8):
+        order = kinds[:]
+        rng.shuffle(order)
+        offs = [rng.uniform(0.0, 0.040) for _ in order]
+        mdl._token_log = {}
+        uuid_of, tl = {}, threading.local()
+        mdl._on_call = lambda u: uuid_of.__setitem__(tl.i, u)
+        res, errs = {}, {}
+
+        def work(i, kind, off):
+            tl.i = i
+            time.sleep(off)
+            try:
+                if kind == 'bi':
+                    res[i] = sum(o['tts_speech'].shape[1] for o in mdl.tts(text=(p for p in pieces), stream=True, **kw))
+                elif kind == 'uni':
+                    res[i] = sum(o['tts_speech'].shape[1] for o in mdl.tts(text=inp['text'], stream=True, **kw))
+                elif kind == 'batch':
+                    res[i] = sum(o['tts_speech'].shape[1] for o in mdl.tts(text=inp['text'], stream=False, **kw))
+                else:
+                    g = mdl.tts(text=inp['text'], stream=True, **kw)
+                    res[i] = next(g)['tts_speech'].shape[1]
+                    g.close()
+            except Exception as e:      # noqa: BLE001
+                errs[i] = e
+        ths = [threading.Thread(target=work, args=(i, k, o)) for i, (k, o) in enumerate(zip(order, offs))]
+        [t.start() for t in ths]
+        [t.join(600) for t in ths]
+        assert not any(t.is_alive() for t in ths), f'round {rnd}: a call hangs'
+        assert not errs, f'round {rnd}: {errs}'
+        log = mdl._token_log
+        for i, k in enumerate(order):
+            if k == 'bi':
+                assert log[uuid_of[i]] == want_bi and res[i] == 960 * len(want_bi), f'round {rnd} call {i} ({k})'
+            elif k in ('uni', 'batch'):              # (only the hub's calls keep a token log: the length is the token count)
+                assert res[i] == 960 * len(want_uni), f'round {rnd} call {i} ({k})'
+        assert sorted(mdl._slot_free) == list(range(mdl.max_batch)) and not mdl._active_slots, f'round {rnd}: slots not released'
+        assert not mdl.tts_speech_token_dict and not mdl.hift_cache_dict, f'round {rnd}: per-call state left behind'
+    mdl._token_log, mdl._on_call = None, None
+
+
 def test_config4_eight_generator_text_streams_vs_oracle_bistream(dev):
     """BASELINE configs[4] as it is worded ("bistream LLM + chunk-CFM, batch=8"): EIGHT concurrent streaming calls whose text is a
     Python generator (llm_job's bistream branch, cli/model.py:120-128 x 8) on one model.  Every stream owns one LLM slot; the eight
