@@ -383,6 +383,191 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
                         ((unsigned long long)(64 * FT) << 48) | ((unsigned long long)a.CoutP << 32) | (unsigned)(gridDim.x * gridDim.y * gridDim.z));
 }
 
+// k_respair (round 5): one (dilated convolution, convolution) pair of a ResBlock (generator.py:94-101) in ONE launch:
+//     out = x + conv2(snake(conv1(snake(x)) + b1)) + b2          (conv1: k taps, dilation d; conv2: k taps, dilation 1; C -> C -> C)
+// for the 64- and 128-channel stages (C = 64 CT).  A block owns 128 - (k - 1) output frames and ALL channels: it stages the input rows of
+// the 128 conv1 frames it needs (its output frames + (k - 1) / 2 on either side) as k_conv6 does -- Snake, three bf16 planes, line buffer
+// --, runs conv1 on the matrix cores, and instead of writing the intermediate to HBM leaves snake(conv1 + b1) as three planes in LDS
+// (the buffer takes the place of the input's line buffer, which is dead by then; rows outside the signal are conv2's zero padding), runs
+// conv2 from there and closes with k_conv6's epilogue (residual x from global memory, store or MRF accumulate).  Per output element
+// every sum runs over the same terms in the same order as in the two k_conv6 launches (chunk, tap, 16-channel step): the waveform is
+// bit-identical.  What it saves per pair: the intermediate's write and read (2 of 5 activation passes), one launch, one staging from
+// global memory and one epilogue to it; what it costs: 128 / (128 - (k - 1)) more frame tiles (2-8 %).  The 256-channel stage keeps
+// the two launches: its intermediate (3 planes x 138 rows x 264 columns = 218 KB) does not fit the 160 KB of LDS.
+struct PairArgs {
+    const float* x; int L;                                            // input / residual rows [L][C]
+    const uint16_t* w1; const float* b1; const float* al1; int taps, dil;     // conv1: three-plane weights [taps][C/16][C/32][3][64][8], bias, Snake alpha of its input
+    const uint16_t* w2; const float* b2; const float* al2;            // conv2 (dilation 1): the same
+    float* out; int acc;                                              // out[t][C], ACC_STORE / ACC_ADD / ACC_ADD_DIV3
+    long zs;
+};
+template <int CT>
+__global__ __launch_bounds__(256 * CT) void k_respair(PairArgs a) {
+    constexpr int NT = 256 * CT, C = 64 * CT, LDB = C + 8, NTILE = 2 * CT, RP = NT / 16;      // RP = line-buffer rows per staging pass
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    { const size_t zo = (size_t)blockIdx.z * a.zs; a.x += zo; a.out += zo; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int fw = wave / NTILE, cw = wave % NTILE;                   // frame half (64 frames), 32-channel output tile
+    const int p2 = (a.taps - 1) >> 1, span1 = (a.taps - 1) * a.dil, p1 = span1 >> 1;
+    const int rows1 = 128 + span1, rowsB = 128 + a.taps - 1, BTo = 128 - (a.taps - 1);
+    const int t0 = blockIdx.x * BTo;                                  // first output frame
+    const int f0 = t0 - p2;                                           // first conv1 frame = row 0 of the intermediate
+    uint16_t* xp[3];
+    xp[0] = reinterpret_cast<uint16_t*>(smem); xp[1] = xp[0] + (size_t)rows1 * C6_LD; xp[2] = xp[1] + (size_t)rows1 * C6_LD;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    constexpr size_t kbstride = (size_t)NTILE * 3 * 512;              // elements between consecutive 16-channel blocks of one tap
+    constexpr size_t tapstride = (size_t)(C / 16) * kbstride;
+    bf16x8 wA[3 * C6_G], wB[3 * C6_G];
+#define RP_LOAD(SET, GI)                                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < C6_G; g_++) {                                                             \
+        const int si_ = (GI) * C6_G + g_;                                                                             \
+        const uint16_t* wn_ = wb + (si_ >> 2) * tapstride + (size_t)(si_ & 3) * kbstride;                             \
+        _Pragma("unroll") for (int p = 0; p < 3; p++) SET[g_ * 3 + p] = *reinterpret_cast<const bf16x8*>(wn_ + p * 512); \
+    }
+#define RP_MMA(SET, GI, BUF, LD, DIL, COL0)                                                                         \
+    _Pragma("unroll") for (int g_ = 0; g_ < C6_G; g_++) {                                                             \
+        const int si_ = (GI) * C6_G + g_;                                                                             \
+        const size_t xo_ = (size_t)(fw * 64 + li + (si_ >> 2) * (DIL)) * (LD) + (COL0) + (si_ & 3) * 16 + lk * 8;     \
+        bf16x8 x0[3], x1[3];                                                                                          \
+        _Pragma("unroll") for (int p = 0; p < 3; p++) {                                                               \
+            x0[p] = *reinterpret_cast<const bf16x8*>(BUF[p] + xo_);                                                   \
+            x1[p] = *reinterpret_cast<const bf16x8*>(BUF[p] + xo_ + 32 * (LD));                                       \
+        }                                                                                                           \
+        const bf16x8 w0_ = SET[g_ * 3], w1_ = SET[g_ * 3 + 1], w2_ = SET[g_ * 3 + 2];                                 \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[2], w0_, acc0, 0, 0, 0);                                    \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[2], w0_, acc1, 0, 0, 0);                                    \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[1], w1_, acc0, 0, 0, 0);                                    \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[1], w1_, acc1, 0, 0, 0);                                    \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[0], w2_, acc0, 0, 0, 0);                                    \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w2_, acc1, 0, 0, 0);                                    \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[1], w0_, acc0, 0, 0, 0);                                    \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[1], w0_, acc1, 0, 0, 0);                                    \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[0], w1_, acc0, 0, 0, 0);                                    \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w1_, acc1, 0, 0, 0);                                    \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[0], w0_, acc0, 0, 0, 0);                                    \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w0_, acc1, 0, 0, 0);                                    \
+    }
+#define RP_RUN(BUF, LD, DIL, COL0)                                                                                  \
+    {                                                                                                               \
+        const int ngroups = a.taps * 4 / C6_G;                                                                        \
+        RP_LOAD(wA, 0)                                                                                                \
+        for (int gi = 0; gi < ngroups; gi += 2) {                                                                     \
+            if (gi + 1 < ngroups) RP_LOAD(wB, gi + 1)                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            RP_MMA(wA, gi, BUF, LD, DIL, COL0)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            if (gi + 2 < ngroups) RP_LOAD(wA, gi + 2)                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            if (gi + 1 < ngroups) RP_MMA(wB, gi + 1, BUF, LD, DIL, COL0)                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+        }                                                                                                           \
+    }
+    // ---- conv1: per 64-channel chunk stage snake(x) as three planes (k_conv6's staging), then the chunk's MFMAs
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        __syncthreads();
+        f32x4 al4, ia4;
+        const int r_b = tid >> 4, c4 = (tid & 15) * 4, c = c0 + c4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { al4[e] = a.al1[c + e]; ia4[e] = 1.0f / (al4[e] + 1e-9f); }
+        const int t_b = f0 - p1 + r_b;
+        const float* src_b = a.x + (long)t_b * C + c;                 // (dereferenced only where the row is inside the signal)
+        uint16_t* xo = xp[0] + (size_t)r_b * C6_LD + c4;
+        const size_t plane = (size_t)rows1 * C6_LD;
+        const int n_it = (rows1 - r_b + RP - 1) / RP;                 // items of this thread: rows r_b, r_b + RP, ..
+        for (int u0 = 0; u0 < n_it; u0 += 6) {
+            f32x4 q[6];
+#pragma unroll
+            for (int uu = 0; uu < 6; uu++) {
+                const int u = u0 + uu, t = t_b + RP * u;
+                q[uu] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (u < n_it && t >= 0 && t < a.L) q[uu] = *reinterpret_cast<const f32x4*>(src_b + (long)u * RP * C);
+            }
+#pragma unroll
+            for (int uu = 0; uu < 6; uu++) {
+                const int u = u0 + uu, t = t_b + RP * u;
+                if (u >= n_it) break;
+                f32x4 v = q[uu];
+                if (t >= 0 && t < a.L) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = pre_apply_inv(v[e], PRE_SNAKE, al4[e], ia4[e], 0.f);
+                }
+                uint32_t h0[4], h1[4], h2[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) split3t(v[e], h0[e], h1[e], h2[e]);
+                uint16_t* o = xo + (size_t)u * RP * C6_LD;
+                *reinterpret_cast<uint2*>(o) = make_uint2(pack_hi(h0[0], h0[1]), pack_hi(h0[2], h0[3]));
+                *reinterpret_cast<uint2*>(o + plane) = make_uint2(pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3]));
+                *reinterpret_cast<uint2*>(o + 2 * plane) = make_uint2(pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3]));
+            }
+        }
+        __syncthreads();
+        const uint16_t* wb = a.w1 + ((size_t)(c0 / 16) * NTILE + cw) * 3 * 512 + (size_t)lane * 8;
+        RP_RUN(xp, C6_LD, a.dil, 0)
+    }
+    __syncthreads();                                                  // every wave is done with the input's line buffer
+    // ---- the intermediate: snake(conv1 + b1) as three planes, rows = conv1 frames f0 .. f0 + 127, zero outside the signal
+    uint16_t* bp[3];
+    bp[0] = reinterpret_cast<uint16_t*>(smem); bp[1] = bp[0] + (size_t)rowsB * LDB; bp[2] = bp[1] + (size_t)rowsB * LDB;
+    {
+        const int co = cw * 32 + li;
+        const float b = a.b1[co], al = a.al2[co], ia = 1.0f / (al + 1e-9f);
+#pragma unroll
+        for (int tile = 0; tile < 2; tile++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int j = fw * 64 + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int f = f0 + j;
+                uint32_t h0 = 0, h1 = 0, h2 = 0;
+                if (f >= 0 && f < a.L) split3t(pre_apply_inv((tile == 0 ? acc0[r] : acc1[r]) + b, PRE_SNAKE, al, ia, 0.f), h0, h1, h2);
+                const size_t o = (size_t)j * LDB + co;
+                bp[0][o] = (uint16_t)(h0 >> 16); bp[1][o] = (uint16_t)(h1 >> 16); bp[2][o] = (uint16_t)(h2 >> 16);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    __syncthreads();
+    // ---- conv2 from the intermediate (rows 128 .. rowsB - 1 are never written: they only reach the frames j >= BTo that are dropped below)
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const uint16_t* wb = a.w2 + ((size_t)(c0 / 16) * NTILE + cw) * 3 * 512 + (size_t)lane * 8;
+        RP_RUN(bp, LDB, 1, c0)
+    }
+#undef RP_LOAD
+#undef RP_MMA
+#undef RP_RUN
+    // ---- epilogue (k_conv6's): + b2 + x, store / accumulate; frames j >= BTo belong to the next block
+    {
+        const int co = cw * 32 + li;
+        const float b = a.b2[co];
+        const int jb = fw * 64 + 4 * lk;
+        float* const ob = a.out + co;
+        const float* const rb = a.x + co;
+        const int last = a.L - 1;
+        float rv[2][16], ov[2][16];
+#pragma unroll
+        for (int tile = 0; tile < 2; tile++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int t = min(t0 + jb + tile * 32 + (r & 3) + 8 * (r >> 2), last);
+                rv[tile][r] = rb[(long)t * C];
+                ov[tile][r] = a.acc != ACC_STORE ? ob[(long)t * C] : 0.f;
+            }
+#pragma unroll
+        for (int tile = 0; tile < 2; tile++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int j = jb + tile * 32 + (r & 3) + 8 * (r >> 2), t = t0 + j;
+                float v = (tile == 0 ? acc0[r] : acc1[r]) + b;
+                v += rv[tile][r];
+                if (a.acc == ACC_ADD) v = ov[tile][r] + v;
+                else if (a.acc == ACC_ADD_DIV3) v = (ov[tile][r] + v) / 3.0f;
+                if (j < BTo && t <= last) ob[(long)t * C] = v;
+            }
+    }
+}
+
 // source_downs: Conv1d(18 -> C, k, stride, pad) over s_stft [F][18] (generator.py:468-479); tiny, direct
 struct SdArgs { const float* x; int F; const float* w; const float* b; int C, k, stride, pad; float* out; int L_out; long zs; };
 __global__ __launch_bounds__(256) void k_source_down(SdArgs a) {
@@ -662,6 +847,8 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv6<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv6<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_respair<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_respair<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
     *out = h;
@@ -732,8 +919,44 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
     return 0;
 }
 
+// one fused (conv1, conv2) pair (k_respair); false: the shapes are not the fused kernel's
+static bool respair_ok(const cv2_conv& c1, const cv2_conv& c2, int C) {
+    return (C == 64 || C == 128) && c1.w3 && c2.w3 && c1.cin == C && c1.cout == C && c2.cin == C && c2.cout == C && c1.cin_pad == C && c1.cout_pad == C &&
+           c2.cin_pad == C && c2.cout_pad == C && c1.taps == c2.taps && (c1.taps & 1) && c1.taps <= 11 && c2.dil == 1 && c1.b && c2.b &&
+           c1.pad_left == c1.dil * (c1.taps - 1) / 2 && c2.pad_left == (c2.taps - 1) / 2;
+}
+static int respair_launch(const cv2_conv& c1, const float* al1, const cv2_conv& c2, const float* al2, const float* x, int L, int C, float* out, int acc,
+                          hipStream_t s) {
+    PairArgs a{x, L, c1.w3, c1.b, al1, c1.taps, c1.dil, c2.w3, c2.b, al2, out, acc, g_hz_zs};
+    const int BTo = 128 - (c1.taps - 1);
+    const size_t rows1 = 128 + (size_t)(c1.taps - 1) * c1.dil, rowsB = 128 + c1.taps - 1;
+    const size_t sm = std::max(rows1 * C6_LD, rowsB * (size_t)(C + 8)) * 2 * 3;
+    if (C == 64) hipLaunchKernelGGL(k_respair<1>, dim3((L + BTo - 1) / BTo, 1, g_hz_n), dim3(256), sm, s, a);
+    else hipLaunchKernelGGL(k_respair<2>, dim3((L + BTo - 1) / BTo, 1, g_hz_n), dim3(512), sm, s, a);
+    CV2_LAUNCH_CHECK();
+    return 0;
+}
+
 // ResBlock.forward (generator.py:94-101); x read-only, result accumulated into `dst` with mode `acc`
 static int resblock(cv2_hift* h, const cv2_resblock& rb, const float* x, int L, int C, float* dst, int acc, hipStream_t s) {
+    // 64- and 128-channel stages: every (dilated conv, conv) pair is ONE launch (k_respair); a block reads its neighbours' input rows, so the
+    // pairs ping-pong x -> ra -> xt -> dst instead of running in place.  CV2_HIFT_PAIR=0: the two launches per pair (A/B, diagnostics)
+    static const bool pair_on = !(getenv("CV2_HIFT_PAIR") && getenv("CV2_HIFT_PAIR")[0] == '0');
+    static const bool fp32_only = getenv("CV2_HIFT_FP32") && getenv("CV2_HIFT_FP32")[0] == '1';
+    // (a short signal leaves most CUs without a block, and a fused block's two convolutions run one after the other: below pair_min blocks
+    // the two launches with their 64-frame blocks are faster -- 90 frames: 2.25 against 2.51 ms per call with every pair fused; with the
+    // threshold at 100 blocks 500 / 250 / 150 / 90 frames take 2.93 / 2.48 / 2.27 / 2.25 ms against 3.35 / 2.66 / 2.40 / 2.25 unfused)
+    static const long pair_min = getenv("CV2_HIFT_PAIR_MIN") ? atol(getenv("CV2_HIFT_PAIR_MIN")) : 100;
+    const long pair_blocks = (long)((L + 117) / 118) * g_hz_n;
+    if (pair_on && !fp32_only && pair_blocks >= pair_min && respair_ok(rb.c1[0], rb.c2[0], C) && respair_ok(rb.c1[1], rb.c2[1], C) && respair_ok(rb.c1[2], rb.c2[2], C)) {
+        float* bufs[3] = {h->ra, h->xt, dst};
+        const float* in = x;
+        for (int i = 0; i < 3; i++) {
+            if (respair_launch(rb.c1[i], rb.a1[i], rb.c2[i], rb.a2[i], in, L, C, bufs[i], i == 2 ? acc : ACC_STORE, s)) return -1;
+            in = bufs[i];
+        }
+        return 0;
+    }
     for (int i = 0; i < 3; i++) {
         const float* in = i == 0 ? x : h->ra;
         if (conv_launch(rb.c1[i], in, L, h->xt, C, 0, L, PRE_SNAKE, rb.a1[i], 0.f, nullptr, 0, POST_NONE, ACC_STORE, s)) return -1;
