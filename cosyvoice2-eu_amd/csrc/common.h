@@ -164,6 +164,22 @@ __device__ __forceinline__ void xcd_tile_yfast(int& bx, int& by) {
     bx = Lp / gy; by = Lp - bx * gy;
 }
 
+// The same with the XCDs split nch ways over the y tiles and 8 / nch ways over the x tiles (nch = 1, 2, 4, 8; gridDim.y % nch == 0 and
+// gridDim.x % (8 / nch) == 0: the launcher pads x, blocks past x_real leave).  XCD (c, f) serves y tiles [c gy / nch, (c + 1) gy / nch) of the x
+// tiles [f gx / nfr, (f + 1) gx / nfr): what is indexed by y (a convolution's weights) is fetched by 8 / nch L2s, what is indexed by x (its
+// input rows) by nch of them.  Returns false for a padding block.
+__device__ __forceinline__ bool xcd_tile_split(int& bx, int& by, int nch, int x_real) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    bx = blockIdx.x; by = blockIdx.y;
+    if (gridDim.z != 1 || nch <= 1) { xcd_tile_yfast(bx, by); return bx < x_real; }
+    const int L = bx + by * gx, x = L & 7, n = L >> 3;
+    const int nfr = 8 / nch, hy = gy / nch, qn = gx / nfr;
+    const int c = x % nch, f = x / nch;
+    const int dx = n / hy;
+    bx = f * qn + dx; by = c * hy + (n - dx * hy);
+    return bx < x_real;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Diagnostic build only (-DCV2_STAMPS, tools/dbg_stamps.py): wave 0 of block 0 records s_memtime at the phase boundaries of

@@ -47,6 +47,7 @@ struct ConvArgs {
     // x[t * ld_in + flat_off] of a flat signal of flat_n floats (zero outside it): a strided Conv1d(18 -> C, k, stride s, pad p) over
     // [F][18] rows IS that 1-tap convolution with Cin = 18 k, ld_in = 18 s, flat_off = -18 p (consecutive windows overlap)
     int ld_in; long flat_off, flat_n;
+    int xcd_ch;                             // XCDs split this many ways over the output-channel tiles (xcd_tile_split; 0 / 1: frame tiles only)
 };
 
 #define CV_BT 128
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     float* xs = reinterpret_cast<float*>(smem);                     // [rows][CV_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx_, by_;
-    xcd_tile_yfast(bx_, by_);                                       // the output-channel tiles of one frame tile read the same input rows: one L2
+    // frame tiles of one XCD share input rows in its L2, channel tiles share weights: the launcher picks the split (conv_launch)
+    if (!xcd_tile_split(bx_, by_, a.xcd_ch, (a.L_out + BT - 1) / BT)) return;
     const int t0 = bx_ * BT, co0 = by_ * 64;
     const int span = (a.taps - 1) * a.dil;
     const int rows = BT + span;
@@ -204,7 +206,8 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
     { const size_t zo = (size_t)blockIdx.z * a.zs; a.x += zo; a.out += zo; if (a.res) a.res += zo; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx_, by_;
-    xcd_tile_yfast(bx_, by_);                                       // the output-channel tiles of one frame tile read the same input rows: one L2
+    // frame tiles of one XCD share input rows in its L2, channel tiles share weights: the launcher picks the split (conv_launch)
+    if (!xcd_tile_split(bx_, by_, a.xcd_ch, (a.L_out + BT - 1) / BT)) return;
     const int t0 = bx_ * BT, co0 = by_ * 64;
     const int span = (a.taps - 1) * a.dil;
     const int rows = BT + span;
@@ -885,6 +888,23 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
     a.zs = g_hz_zs;
     CV2_CHECK(cw.cin_pad % 64 == 0 && cw.cout_pad % 64 == 0 && cw.w, "hift conv: bad packed weight (cin_pad %d cout_pad %d)", cw.cin_pad, cw.cout_pad);
     static const bool fp32_only = getenv("CV2_HIFT_FP32") && getenv("CV2_HIFT_FP32")[0] == '1';      // A/B switch: the fp32 matrix-core kernel everywhere
+    // How the 8 XCDs (one L2 each) share a launch: split nch ways over the output-channel tiles and 8 / nch ways over the frame tiles, the
+    // weights then cross the fabric 8 / nch times and the input rows nch times (xcd_tile_split).  Round 3 always took nch = 1 (every L2
+    // pulls all the weights: 8 x 19 MB for the first upsampling layer, whose input is 1 MB).  CV2_HIFT_XCD_SPLIT=0: that form (A/B)
+    static const bool xcd_split = !(getenv("CV2_HIFT_XCD_SPLIT") && getenv("CV2_HIFT_XCD_SPLIT")[0] == '0');
+    auto grid_for = [&](int BT, bool planes) {
+        const int gx = (L_out + BT - 1) / BT, gy = cw.cout_pad / 64;
+        int nch = 1;
+        if (xcd_split && g_hz_n == 1 && gx * gy >= 16) {
+            const double W = (double)cw.taps * cw.cin_pad * cw.cout_pad * (planes ? 6 : 4), A = (double)L_in * cw.cin * 4;
+            double best = 8 * W + A;
+            for (int n = 2; n <= 8; n *= 2)
+                if (gy % n == 0 && (8 / n) * W + n * A < best) { best = (8 / n) * W + n * A; nch = n; }
+        }
+        a.xcd_ch = nch;
+        const int nfr = 8 / nch;
+        return dim3((gx + nfr - 1) / nfr * nfr, gy, g_hz_n);
+    };
     if (cw.w3 && !fp32_only) {
         a.w3 = cw.w3;
         // fewer 128-frame blocks than CUs (one utterance's 256- and 512-channel stages): 64-frame blocks; CV2_HIFT_BT64=0: A/B, diagnostics
@@ -894,12 +914,12 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
         static const long bt64_max = getenv("CV2_HIFT_BT64_MAX") ? atol(getenv("CV2_HIFT_BT64_MAX")) : 200;
         if (bt64 && blocks128 < bt64_max) {
             const size_t sm = (size_t)(64 + (cw.taps - 1) * cw.dil) * C6_LD * 2 * 3;
-            hipLaunchKernelGGL(k_conv6<1>, dim3((L_out + 63) / 64, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
+            { const dim3 g_ = grid_for(64, true); hipLaunchKernelGGL(k_conv6<1>, g_, dim3(256), sm, s, a); }      // (sets a.xcd_ch first)
             CV2_LAUNCH_CHECK();
             return 0;
         }
         const size_t sm = (size_t)(CV_BT + (cw.taps - 1) * cw.dil) * C6_LD * 2 * 3;
-        hipLaunchKernelGGL(k_conv6<2>, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
+        { const dim3 g_ = grid_for(CV_BT, true); hipLaunchKernelGGL(k_conv6<2>, g_, dim3(256), sm, s, a); }      // (sets a.xcd_ch first)
         CV2_LAUNCH_CHECK();
         return 0;
     }
@@ -908,13 +928,13 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
         const long blocks128 = (long)((L_out + CV_BT - 1) / CV_BT) * (cw.cout_pad / 64) * g_hz_n;
         if (bt64 && blocks128 < 200) {                 // (the f0 predictor's 512-channel layers at one utterance: 4 x 8 blocks)
             const size_t sm = (size_t)(64 + (cw.taps - 1) * cw.dil) * CV_LD * 4;
-            hipLaunchKernelGGL(k_conv<1>, dim3((L_out + 63) / 64, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
+            { const dim3 g_ = grid_for(64, false); hipLaunchKernelGGL(k_conv<1>, g_, dim3(256), sm, s, a); }      // (sets a.xcd_ch first)
             CV2_LAUNCH_CHECK();
             return 0;
         }
     }
     const size_t sm = (size_t)(CV_BT + (cw.taps - 1) * cw.dil) * CV_LD * 4;
-    hipLaunchKernelGGL(k_conv<2>, dim3((L_out + CV_BT - 1) / CV_BT, cw.cout_pad / 64, g_hz_n), dim3(256), sm, s, a);
+    { const dim3 g_ = grid_for(CV_BT, false); hipLaunchKernelGGL(k_conv<2>, g_, dim3(256), sm, s, a); }      // (sets a.xcd_ch first)
     CV2_LAUNCH_CHECK();
     return 0;
 }
