@@ -803,7 +803,9 @@ struct CapStream {
     explicit CapStream(hipStream_t have) : s(have) { if (!s) { own = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess; if (!own) s = nullptr; } }
     ~CapStream() { if (own && s) (void)hipStreamDestroy(s); }
 };
+#ifndef HG_MAX_T
 #define HG_MAX_T 160          // longest call that goes through a graph (frames)
+#endif
 #define HG_MAX_GRAPHS 24
 
 struct HCarver {

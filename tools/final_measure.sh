@@ -8,6 +8,8 @@ bash tools/prof_b32.sh > gpurun_out/final_prof_b32.txt 2>&1
 cd $R
 CV2_AMD_LIB=$R/cosyvoice2-eu_amd/cv2amd/libcv2amd_dbg.so python tools/dbg_chain.py > gpurun_out/final_chain_timeline.txt 2>&1
 python tools/bench_rows_sweep.py > gpurun_out/final_rows_sweep.txt 2>&1
+bash tools/prof_stream.sh 8 > gpurun_out/final_stream8.txt 2>&1
+python tools/bench_threads.py 8 3 > gpurun_out/final_threads8.txt 2>&1
 python bench.py > gpurun_out/final_bench_b1.json 2> gpurun_out/final_bench_b1.err
 python bench.py --batch 32 --steps 2 --warmup 1 --no-cpu-baseline --no-extra > gpurun_out/final_bench_b32.json 2> gpurun_out/final_bench_b32.err
 tail -1 gpurun_out/final_bench_b1.json | cut -c1-250; tail -1 gpurun_out/final_bench_b32.json | cut -c1-250
