@@ -289,12 +289,15 @@ def counter_fields(pmc_flow, pmc_hift, hift_tf):
                           'cycles = kernel-trace duration x 2.4 GHz (util_counter) or GRBM_GUI_ACTIVE / 8 (util_counter_gui_active)'}
     if pmc_hift:
         tot = (pmc_hift['hbm_read_MB_per_rep'] + pmc_hift['hbm_write_MB_per_rep']) / 1e3
-        k6 = max((r for r in pmc_hift['kernels'] if r['kernel'].startswith('k_conv6')), key=lambda r: r.get('us_per_rep') or 0, default={})     # (k_conv6<2>: the 128-frame form)
+        convs = [r for r in pmc_hift['kernels'] if r['kernel'].startswith(('k_conv6', 'k_respair'))]
+        k6 = max(convs, key=lambda r: r.get('us_per_rep') or 0, default={})     # the convolution kernel with the largest share of the stage
         hift = {'hbm_gbs': pmc_hift.get('hbm_GBs_over_kernel_time'), 'hbm_GB_per_10s_audio': round(tot, 3), 'survey_8d_GB_per_10s_audio': 0.28,
-                'k_conv6': {'hbm_gbs': k6.get('hbm_GBs'), 'mfma_util_counter': k6.get('mfma_util_wall'), 'avg_us': k6.get('avg_us')},
+                'conv_launches_per_call': round(sum(r['launches_per_rep'] for r in pmc_hift['kernels'] if r['kernel'].startswith(('k_conv', 'k_respair')))),
+                'top_conv_kernel': {'kernel': k6.get('kernel'), 'hbm_gbs': k6.get('hbm_GBs'), 'mfma_util_counter': k6.get('mfma_util_wall'), 'avg_us': k6.get('avg_us')},
                 'measured_in_this_run': False, 'source': pmc_hift['_file'] + ' (500 mel frames = 10 s of audio per rep; FETCH_SIZE x 2 + WRITE_SIZE over the stage\'s kernel time); '
-                          'SURVEY 8(d)\'s 0.28 GB assumes whole ResBlocks fused (1.4 GB unfused); here every convolution is one launch: input + halo, the '
-                          'residual / MRF accumulator read by the epilogue, and the layer\'s three weight planes once per XCD L2'}
+                          'SURVEY 8(d)\'s 0.28 GB assumes whole ResBlocks fused (1.4 GB unfused); here the (dilated conv, conv) pairs of the 64- and 128-channel '
+                          'stages are one launch each (k_respair), the 256-channel stage is one launch per convolution: input + halo, the residual / MRF '
+                          'accumulator read by the epilogue, and the weight planes once per L2 that serves the layer\'s channel tiles'}
     return flow, hift
 
 
