@@ -372,6 +372,14 @@ __device__ __host__ constexpr int r1_smem_bytes(int nks) { return R1_STAGE_BYTES
 // out[f] (f < NWR * 16) = sum_k W[(tile0 + (f / 16) * tstride) * 16 + f % 16][k] * x[k] over the k-steps [ks0, ks1),
 // x = op's vector [* RMSNorm weight, scaled by the row's rstd].  Returns feature f's value in thread f (other threads: 0).
 // 512 threads = NWR x NWK waves; every wave's weight fragments (<= MAXKS) are requested first.
+// A weight fragment by a GLOBAL load: the layer table's pointers come out of memory, so the compiler sees generic pointers and would emit
+// flat_load (which also counts in lgkmcnt: every LDS / scalar wait then waits for the weights in flight)
+typedef const __attribute__((address_space(1))) s16x8* gs16x8p;
+template <bool NT>
+__device__ __forceinline__ s16x8 ld_wfrag(const s16x8* p) {
+    gs16x8p g = (gs16x8p)(uintptr_t)p;
+    return NT ? __builtin_nontemporal_load(g) : *g;
+}
 struct R1NoHook { __device__ __forceinline__ void operator()() const {} };
 // `issued` runs right after the weight requests: the place for a role's own dependent loads (Q: position -> RoPE table).
 // NT: the weight fragments are read once per step (one row: non-temporal loads keep them out of L2); false when several rows' blocks
@@ -406,7 +414,7 @@ __device__ __forceinline__ float row1_core(const uint16_t* __restrict__ W, int t
 #pragma unroll
     for (int i = 0; i < MAXKS; i++) {
         const s16x8* wp_ = reinterpret_cast<const s16x8*>(wbase + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024 + wlane);
-        abuf[i] = NT ? __builtin_nontemporal_load(wp_) : *wp_;
+        abuf[i] = ld_wfrag<NT>(wp_);
     }
     __builtin_amdgcn_sched_barrier(0);
     issued();
@@ -526,7 +534,7 @@ __device__ __forceinline__ float row2_core(const uint16_t* __restrict__ W, int t
 #pragma unroll
     for (int i = 0; i < MAXKS; i++) {
         const s16x8* wp_ = reinterpret_cast<const s16x8*>(wbase + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024 + wlane);
-        abuf[i] = NT ? __builtin_nontemporal_load(wp_) : *wp_;       // several pairs: the sibling chains' blocks of this tile follow on this XCD -> keep it in L2
+        abuf[i] = ld_wfrag<NT>(wp_);       // several pairs: the sibling chains' blocks of this tile follow on this XCD -> keep it in L2
     }
     __builtin_amdgcn_sched_barrier(0);
     issued();
@@ -660,7 +668,7 @@ __device__ __forceinline__ float row4_core(const uint16_t* __restrict__ W, int t
 #pragma unroll
     for (int i = 0; i < MAXKS; i++) {
         const s16x8* wp_ = reinterpret_cast<const s16x8*>(wbase + (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024 + wlane);
-        abuf[i] = NT ? __builtin_nontemporal_load(wp_) : *wp_;
+        abuf[i] = ld_wfrag<NT>(wp_);
     }
     __builtin_amdgcn_sched_barrier(0);
     issued();
@@ -778,8 +786,8 @@ __device__ __forceinline__ void t2_issue(const uint16_t* __restrict__ W, int til
         const size_t o = (size_t)(i < nw ? i : (nw > 0 ? nw - 1 : 0)) * 1024;
         const s16x8* p0 = reinterpret_cast<const s16x8*>(b0 + o);
         const s16x8* p1 = reinterpret_cast<const s16x8*>(b1 + o);
-        w.a0[i] = NT ? __builtin_nontemporal_load(p0) : *p0;
-        w.a1[i] = NT ? __builtin_nontemporal_load(p1) : *p1;
+        w.a0[i] = ld_wfrag<NT>(p0);
+        w.a1[i] = ld_wfrag<NT>(p1);
     }
     __builtin_amdgcn_sched_barrier(0);
 }

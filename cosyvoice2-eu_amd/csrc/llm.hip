@@ -672,6 +672,18 @@ static int chain_rows() {                        // CV2_CHAIN_ROWS = 1 .. 24: A/
     return v;
 }
 struct StepLayer { const uint16_t *wqkv, *wo, *wgu, *wdown; const float *bqkv, *ln1, *ln2; float *kc, *vc; };
+// The table's pointers are loaded from memory, so the compiler knows them as generic pointers and would emit flat_load / flat_store for
+// everything behind them (weights, norms, biases, cache rows) -- instructions that also count in lgkmcnt, so that every LDS or scalar wait
+// waits for the weight fragments in flight.  Read through a view of the table whose members are typed as global pointers, the casts to
+// the roles' generic parameters are visible to the compiler's address-space inference: global_load / global_store.
+#define CV2_AS1 __attribute__((address_space(1)))
+struct StepLayerG { const CV2_AS1 uint16_t *wqkv, *wo, *wgu, *wdown; const CV2_AS1 float *bqkv, *ln1, *ln2; CV2_AS1 float *kc, *vc; };
+static_assert(sizeof(StepLayerG) == sizeof(StepLayer), "the global-pointer view of the layer table");
+__device__ __forceinline__ StepLayer step_layer(const StepLayer* tab, int layer) {
+    const StepLayerG g = reinterpret_cast<const StepLayerG*>(tab)[layer];
+    return StepLayer{(const uint16_t*)g.wqkv, (const uint16_t*)g.wo, (const uint16_t*)g.wgu, (const uint16_t*)g.wdown,
+                     (const float*)g.bqkv, (const float*)g.ln1, (const float*)g.ln2, (float*)g.kc, (float*)g.vc};
+}
 struct StepArgs {
     const StepLayer* layers; int n_layers;
     const uint16_t* wdec; const float* bdec; const float* final_norm; float* logits;
@@ -960,7 +972,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
         if (tid < 16) a.logits[r * 16 + tid] = out + a.bdec[r * 16 + tid];
         return;
     }
-    StepLayer L = a.layers[layer];
+    StepLayer L = step_layer(a.layers, layer);
     if (MULTI) { L.kc += a.kv_slot; L.vc += a.kv_slot; }
     OpFold xin{&G, gp, gp + a.off_dg, H, layer == 0 ? a.xin : nullptr, od, gp + a.off_hg + a.inter - 1};
     if (r < nQ) {                   // ---- Q: RMSNorm -> QKV -> + bias -> RoPE -> q granules / key, value granules + cache rows
@@ -1076,7 +1088,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step1(StepArgs a) {
         if (tid < 16) a.logits[r * 16 + tid] = out + a.bdec[r * 16 + tid];
         return;
     }
-    const StepLayer L = a.layers[layer];
+    const StepLayer L = step_layer(a.layers, layer);
     OpFold xin{&G, gp, gp + a.off_dg, H, layer == 0 ? a.xin : nullptr, od, gp + a.off_hg + a.inter - 1};
     if (r < nQ) {                   // ---- Q (QA: only the new token's key / value heads)
         const int head = (QA ? a.n_q : 0) + (r >> 1), half = r & 1;
@@ -1237,7 +1249,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step2(StepArgs a) {
         if (tid < 32 && (c16 == 0 || two)) a.logits[(size_t)(c16 ? row1 : row0) * a.ldl + r * 16 + (tid & 15)] = out + a.bdec[r * 16 + (tid & 15)];
         return;
     }
-    const StepLayer L = a.layers[layer];
+    const StepLayer L = step_layer(a.layers, layer);
     OpFold xin0{&G, go0 + gp, go0 + gp + a.off_dg, H, layer == 0 ? a.xin + (size_t)row0 * H : nullptr, -1, go0 + gp + a.off_hg + a.inter - 1};
     OpFold xin1{&G, go1 + gp, go1 + gp + a.off_dg, H, layer == 0 ? a.xin + (size_t)row1 * H : nullptr, -1, go1 + gp + a.off_hg + a.inter - 1};
     if (r < nQ) {                   // ---- Q
@@ -1358,7 +1370,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step4(StepArgs a) {
         if (tid < 64 && c16 < nv) a.logits[(size_t)sel(c16, row) * a.ldl + r * 16 + (tid & 15)] = out + a.bdec[r * 16 + (tid & 15)];
         return;
     }
-    const StepLayer L = a.layers[layer];
+    const StepLayer L = step_layer(a.layers, layer);
     OpFold xin[4];
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -2737,7 +2749,7 @@ static int get_graph(cv2_llm* h, int n_seqs, int unroll, bool one_launch, hipGra
                 const size_t sm = std::max((size_t)r1_smem_bytes(nks_max), (size_t)AT_SMEM_FLOATS * sizeof(float));
                 StepArgs a = h->step;
 #ifdef CV2_STAMPS
-                a.dbg_layer = 12;
+                a.dbg_layer = getenv("CV2_DBG_LAYER") ? atoi(getenv("CV2_DBG_LAYER")) : 12;      // (tools/dbg_chain.py: the layer whose blocks are stamped)
 #endif
                 static const bool force_multi = getenv("CV2_CHAIN_FORCE_MULTI") != nullptr;       // diagnostics: one row through k_step<true>
                 // one row: k_step, or with CV2_STEP1 = 1 / 2 / 3 k_step1 (round 5: bit 0 QA blocks that compute their query head themselves, bit 1
