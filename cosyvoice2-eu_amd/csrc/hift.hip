@@ -25,6 +25,7 @@
 #include <map>
 #include "../../include/cv2_amd.h"
 #include <math.h>
+#include <atomic>
 #include <vector>
 
 enum { PRE_NONE = 0, PRE_SNAKE = 1, PRE_LRELU = 2 };
@@ -878,6 +879,15 @@ extern "C" const float* cv2_hift_debug_buffer(cv2_hift* h, int32_t which) {
     switch (which) { case 0: return h->melT; case 1: return h->f0; case 2: return h->sstft; case 3: return h->xpre; case 4: return h->sum; case 5: return h->post; default: return nullptr; }
 }
 
+// Test hook (tests/test_hift_gpu.py): -1 = the defaults (environment), 0 / 1 = without / with the fused ResBlock pairs (k_respair) and the
+// per-layer XCD split of the convolution grids.  Calls of <= HG_MAX_T frames replay graphs captured under the mode of their first call.
+static std::atomic<int> g_pair_mode{-1}, g_xcd_mode{-1};
+extern "C" int cv2_hift_debug_modes(int32_t pair, int32_t xcd_split) {
+    g_pair_mode = pair < 0 ? -1 : (pair != 0);
+    g_xcd_mode = xcd_split < 0 ? -1 : (xcd_split != 0);
+    return 0;
+}
+
 static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out, int ldo, long out_off, int L_out, int pre,
                        const float* alpha, float slope, const float* res, int ldres, int post, int acc, hipStream_t s,
                        int ld_in = 0, long flat_off = 0, long flat_n = 0) {
@@ -893,7 +903,9 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
     // How the 8 XCDs (one L2 each) share a launch: split nch ways over the output-channel tiles and 8 / nch ways over the frame tiles, the
     // weights then cross the fabric 8 / nch times and the input rows nch times (xcd_tile_split).  Round 3 always took nch = 1 (every L2
     // pulls all the weights: 8 x 19 MB for the first upsampling layer, whose input is 1 MB).  CV2_HIFT_XCD_SPLIT=0: that form (A/B)
-    static const bool xcd_split = !(getenv("CV2_HIFT_XCD_SPLIT") && getenv("CV2_HIFT_XCD_SPLIT")[0] == '0');
+    static const bool xcd_split_env = !(getenv("CV2_HIFT_XCD_SPLIT") && getenv("CV2_HIFT_XCD_SPLIT")[0] == '0');
+    const int xcd_dbg = g_xcd_mode.load();
+    const bool xcd_split = xcd_dbg < 0 ? xcd_split_env : xcd_dbg != 0;
     auto grid_for = [&](int BT, bool planes) {
         const int gx = (L_out + BT - 1) / BT, gy = cw.cout_pad / 64;
         int nch = 1;
@@ -963,7 +975,9 @@ static int respair_launch(const cv2_conv& c1, const float* al1, const cv2_conv& 
 static int resblock(cv2_hift* h, const cv2_resblock& rb, const float* x, int L, int C, float* dst, int acc, hipStream_t s) {
     // 64- and 128-channel stages: every (dilated conv, conv) pair is ONE launch (k_respair); a block reads its neighbours' input rows, so the
     // pairs ping-pong x -> ra -> xt -> dst instead of running in place.  CV2_HIFT_PAIR=0: the two launches per pair (A/B, diagnostics)
-    static const bool pair_on = !(getenv("CV2_HIFT_PAIR") && getenv("CV2_HIFT_PAIR")[0] == '0');
+    static const bool pair_env = !(getenv("CV2_HIFT_PAIR") && getenv("CV2_HIFT_PAIR")[0] == '0');
+    const int pair_dbg = g_pair_mode.load();
+    const bool pair_on = pair_dbg < 0 ? pair_env : pair_dbg != 0;
     static const bool fp32_only = getenv("CV2_HIFT_FP32") && getenv("CV2_HIFT_FP32")[0] == '1';
     // (a short signal leaves most CUs without a block, and a fused block's two convolutions run one after the other: below pair_min blocks
     // the two launches with their 64-frame blocks are faster -- 90 frames: 2.25 against 2.51 ms per call with every pair fused; with the

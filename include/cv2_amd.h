@@ -349,6 +349,11 @@ typedef struct { int32_t max_frames; int32_t lanes; } cv2_hift_dims;   /* longes
 size_t cv2_hift_workspace_bytes(const cv2_hift_dims* d);
 int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w, void* workspace, size_t workspace_bytes, cv2_hift** out);
 int cv2_hift_destroy(cv2_hift* h);
+/* Test hook: pair / xcd_split = 1 / 0 runs the vocoder with / without the fused ResBlock pairs of the 64- and 128-channel stages (one launch
+ * per (dilated conv, conv) pair, the intermediate kept in LDS) and with / without the per-layer split of the convolution grids over the XCDs;
+ * -1 = the default.  All four combinations produce the same waveform bit for bit.  Process-wide; calls of <= 160 frames replay graphs
+ * captured under the mode of their first call. */
+int cv2_hift_debug_modes(int32_t pair, int32_t xcd_split);
 /* mel fp32 [80][T] (channel-major, the reference's speech_feat[0]); cache_source fp32 [n_cache] or NULL;
  * noise: fp32 [480 T][9] standard normals injected in place of the reference's randn_like (generator.py:334), or NULL
  * to draw them on the device from Philox(seed); wav fp32 [480 T]; source fp32 [480 T]. */

@@ -181,3 +181,33 @@ def test_split_product_convolutions_match_the_fp32_matrix_core_path(dev, hift_sd
     assert torch.equal(sa, sb)
     err = (wa - wb).abs().max().item()
     assert err < 2e-6, f'{err:.3e}'
+
+
+@pytest.mark.parametrize('T', [130, 300])
+def test_fused_resblock_pairs_and_xcd_split_leave_the_waveform_bit_identical(dev, hift_sd, T):
+    """k_respair (round 5: every (dilated conv, conv) pair of the 64- / 128-channel stages as ONE launch with the intermediate kept in LDS
+    as three bf16 planes) and the per-layer XCD split of the convolution grids are scheduling choices: per output element every sum runs
+    over the same terms in the same order as in the one-launch-per-convolution form, so all four combinations give the same waveform
+    BIT FOR BIT (T = 130: only the 64-channel stage's grid reaches the fused path's 100 blocks; T = 300: the 128-channel stage's too).
+    Noise injected -> no graph replay, so every call runs under the mode just set."""
+    from cv2amd import lib as L
+    from cv2amd.hift import HiftEngine
+    g = torch.Generator().manual_seed(23 + T)
+    mel = (torch.randn(1, 80, T, generator=g) * 2 - 4).clamp(-11.5, 2).to(dev)
+    nz = torch.randn(1, 480 * T, 9, generator=g)
+    eng = HiftEngine(hift_sd, dev, max_frames=512)
+    out = {}
+    try:
+        for pair in (0, 1):
+            for split in (0, 1):
+                L.check(L.lib().cv2_hift_debug_modes(pair, split))
+                w, s = eng.inference(mel, None, noise=nz)
+                torch.cuda.synchronize()
+                out[pair, split] = (w.clone(), s.clone())
+    finally:
+        L.check(L.lib().cv2_hift_debug_modes(-1, -1))
+    ref_w, ref_s = out[0, 0]
+    assert torch.isfinite(ref_w).all() and ref_w.abs().max() > 1e-3
+    for key, (w, s) in out.items():
+        assert torch.equal(s, ref_s), f'source differs for (pair, xcd split) = {key}'
+        assert torch.equal(w, ref_w), f'waveform differs for (pair, xcd split) = {key}: max abs {float((w - ref_w).abs().max()):.3e}'
