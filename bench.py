@@ -261,6 +261,80 @@ def pmc_stage_file(stage):
     return None
 
 
+def _pmc_pass(stage, reps, counters, timeout_s=150):
+    """One `rocprofv3 --pmc <counters>` run of tools/prof_stage_run.py <stage> <reps> as a child process (no trace domain beside --pmc; the
+    program directly behind `--`).  Returns {kernel: {'n': dispatches, 'ns': summed duration, counter: summed value}} or None."""
+    import collections, csv, glob, shutil, tempfile
+    tmp = tempfile.mkdtemp(prefix='cv2_pmc_', dir='/tmp')
+    try:
+        cmd = ['rocprofv3', '--pmc'] + list(counters) + ['--output-format', 'csv', '-d', tmp, '--', sys.executable,
+                                                         os.path.join(ROOT, 'tools', 'prof_stage_run.py'), stage, str(reps)]
+        r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        if r.returncode != 0:
+            return None
+        acc, seen = collections.defaultdict(lambda: collections.defaultdict(float)), set()
+        for f in glob.glob(tmp + '/**/*counter_collection.csv', recursive=True):
+            for row in csv.DictReader(open(f)):
+                k = row['Kernel_Name'].split('(')[0].replace('void ', '').strip()
+                acc[k][row['Counter_Name']] += float(row['Counter_Value'])
+                if (f, row['Dispatch_Id']) not in seen:
+                    seen.add((f, row['Dispatch_Id']))
+                    acc[k]['n'] += 1
+                    acc[k]['ns'] += float(row['End_Timestamp']) - float(row['Start_Timestamp'])
+        return {k: dict(v) for k, v in acc.items()} or None
+    except Exception:                   # noqa: BLE001 -- a profiler problem must not fail the benchmark
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_counters():
+    """The counter-based fields of the line measured NOW: each stage alone (tools/prof_stage_run.py) under `rocprofv3 --pmc`, one pass per
+    counter group, as child processes that finish before this process touches the GPU.  FETCH_SIZE is doubled (gfx950 tallies 128-byte
+    requests at 64 B, MI355X_MICROARCH.md); FETCH_SIZE / WRITE_SIZE are in KiB.  Returns {} when rocprofv3 is missing or the bench itself
+    runs under a profiler; a stage whose pass fails is left out (the committed counter files of profiles/ are used for it)."""
+    import shutil
+    out = {}
+    if shutil.which('rocprofv3') is None or os.environ.get('CV2_BENCH_LIVE_PMC', '1') == '0':
+        return out
+    if any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):          # already inside a profiler run (tools/prof_b1.sh)
+        return out
+    how = 'measured in this run: rocprofv3 --pmc, one pass per counter, child processes before the timed region; FETCH_SIZE x 2 (gfx950 correction)'
+    f, w = _pmc_pass('decode', 1, ['FETCH_SIZE']), None
+    if f is None:
+        return out                                                           # the profiler does not work here: do not try the other passes
+    w = _pmc_pass('decode', 1, ['WRITE_SIZE'])
+    ks = [k for k in f if k.startswith('k_step')]
+    if w is not None and ks and ks[0] in w:
+        k = ks[0]
+        per = (2.0 * f[k]['FETCH_SIZE'] / f[k]['n'] + w[k]['WRITE_SIZE'] / w[k]['n']) * 1024.0
+        out['decode'] = (int(per), f'{how}; {int(f[k]["n"])} {k} launches of the decode stage alone')
+    f, w = _pmc_pass('hift', 3, ['FETCH_SIZE']), _pmc_pass('hift', 3, ['WRITE_SIZE'])
+    if f is not None and w is not None:
+        rd = sum(2.0 * v.get('FETCH_SIZE', 0.0) for v in f.values()) * 1024.0 / 3
+        wr = sum(v.get('WRITE_SIZE', 0.0) for v in w.values()) * 1024.0 / 3
+        ns = sum(v['ns'] for v in f.values()) / 3
+        convs = {k: v for k, v in f.items() if k.startswith(('k_conv', 'k_respair'))}
+        top = max(convs, key=lambda k: convs[k]['ns'], default=None)
+        topd = None
+        if top is not None:
+            tb = (2.0 * f[top].get('FETCH_SIZE', 0.0) + w.get(top, {}).get('WRITE_SIZE', 0.0)) * 1024.0
+            topd = {'kernel': top, 'hbm_gbs': round(tb / f[top]['ns'], 1), 'avg_us': round(f[top]['ns'] / f[top]['n'] / 1e3, 2)}
+        out['hift'] = {'hbm_gbs': round((rd + wr) / ns, 1), 'hbm_GB_per_10s_audio': round((rd + wr) / 1e9, 3), 'survey_8d_GB_per_10s_audio': 0.28,
+                       'conv_launches_per_call': round(sum(v['n'] for v in convs.values()) / 3), 'top_conv_kernel': topd, 'measured_in_this_run': True,
+                       'source': how + '; 500 mel frames = 10 s of audio per call, 3 calls; bytes over the summed kernel time'}
+    m = _pmc_pass('flow', 3, ['SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'])
+    if m is not None:
+        busy = sum(v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for v in m.values())
+        ns = sum(v['ns'] for v in m.values())
+        gui = sum(v.get('GRBM_GUI_ACTIVE', 0.0) for v in m.values()) / 8.0
+        out['flow'] = {'util_counter': round(busy / (4 * 256 * ns * 2.4), 4), 'util_counter_gui_active': round(busy / (4 * 256 * gui), 4) if gui else None,
+                       'measured_in_this_run': True,
+                       'source': how + '; one utterance (T = 1010), 3 calls: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x 256 CU x cycles) over all kernels of the stage; '
+                                 'cycles = kernel duration x 2.4 GHz (util_counter) or GRBM_GUI_ACTIVE / 8 (util_counter_gui_active)'}
+    return out
+
+
 def pmc_decode_traffic(desc):
     """HBM bytes per decode-step launch from the committed counter files: the one-launch step (k_step) of round 3, else the older
     per-step totals."""
@@ -324,6 +398,9 @@ def build_model(dev, max_batch):
 
 # ------------------------------------------------------------------------------------------------ N = 1
 def run_single(args):
+    # the live counter passes run first: child processes, done before this process initialises the GPU
+    live = live_counters() if (args.batch == 1 and not args.no_extra and 'RANK' not in os.environ) else {}
+    live_traffic = live.get('decode')
     import torch
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the hot path has no CPU fallback)'
     dev_index = int(os.environ.get('CV2_BENCH_DEVICE', os.environ.get('LOCAL_RANK', 0)))
@@ -382,7 +459,7 @@ def run_single(args):
     hift_tf = 30.6e9 * audio_per_step * args.steps / (hift_t.ms() * 1e-3) / 1e12
     traffic, traffic_src = None, None
     if B == 1:          # PMC counters cannot be read from inside the bench: committed rocprofv3 --pmc measurements of the same kernels
-        traffic, traffic_src = pmc_decode_traffic(model.llm.decode_kernel_desc(B))
+        traffic, traffic_src = live_traffic if live_traffic is not None else pmc_decode_traffic(model.llm.decode_kernel_desc(B))
     pmc_flow, pmc_hift = pmc_stage_file('flow'), pmc_stage_file('hift')
     out = {
         'metric': 'audio-sec/sec, CosyVoice2-0.5B-EU zero-shot FR', 'value': round(value, 3), 'unit': 'audio-s/s',
@@ -408,6 +485,10 @@ def run_single(args):
                                               'instructions run on'}},
     }
     cf, ch = counter_fields(pmc_flow, pmc_hift, hift_tf)
+    if B == 1 and live.get('flow'):               # the live passes profile the configs[1] shapes: they belong to the B=1 line
+        cf = live['flow']
+    if B == 1 and live.get('hift'):
+        ch = live['hift']
     if cf:
         out['stages']['flow_mfma'].update(cf)
     if ch:
