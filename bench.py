@@ -300,7 +300,7 @@ def live_counters():
     if any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):          # already inside a profiler run (tools/prof_b1.sh)
         return out
     how = 'measured in this run: rocprofv3 --pmc, one pass per counter, child processes before the timed region; FETCH_SIZE x 2 (gfx950 correction)'
-    f, w = _pmc_pass('decode', 1, ['FETCH_SIZE']), None
+    f, w = _pmc_pass('decode', 1, ['FETCH_SIZE'], timeout_s=300), None       # (the first child also pays a fresh box's first `import torch`)
     if f is None:
         return out                                                           # the profiler does not work here: do not try the other passes
     w = _pmc_pass('decode', 1, ['WRITE_SIZE'])
