@@ -1062,6 +1062,16 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         // below 4096 rows the keys are split over four wave groups of a 64-row block (one 10 s utterance: flow 26.5 -> 24.9 ms against two
         // groups of a 32-row block; a stream's chunk alone: first chunk 51.3 -> 50.8 ms); CV2_ATT_KSP=2 (A/B, diagnostics): the two-group form
         static const bool ksp4 = !(getenv("CV2_ATT_KSP") && getenv("CV2_ATT_KSP")[0] == '2');
+        // (without the DMA forms: two key groups of four waves put two blocks on a CU above 256 blocks; CV2_ATT_KSP=4: four groups regardless)
+        // One utterance above 2 048 packed rows (10.2 .. 20 s: 257 .. 511 blocks of the four-group form): a 1024-thread block fills a CU, so that
+        // grid ran in TWO rounds (attention 13 -> 26 us per launch from 2 048 to 2 304 rows: flow 24.6 -> 33.5 ms for 6 % more frames).  From 257
+        // blocks on the one-group DMA form runs (four 256-thread blocks per CU): 33.5 / 36.3 / 39.3 / 41.8 ms at 1 070 / 1 310 / 1 610 / 1 910
+        // frames -> 28.7 / 31.5 / 35.0 / 37.3 (two key groups of a 512-thread block, the other candidate: 30.2 / 33.0 / 36.0 / 38.7);
+        // tools/exp_flow_len.py.  Full-context calls only: a streaming call's chunk-masked recompute keeps the four-group form, the one its
+        // cached continuation runs (k_attn_est<.., CACHE>), so that recomputed and cached chunks of a stream stay bit-identical -- any other
+        // summation order moves the mel by ~3e-3 of its range through the 10 Euler steps.  CV2_ATT_DMA1_MIN=512: the round-4 threshold (A/B)
+        static const int dma1_min = getenv("CV2_ATT_DMA1_MIN") ? atoi(getenv("CV2_ATT_DMA1_MIN")) : 257;
+        static const bool ksp42 = !(getenv("CV2_ATT_KSP") && getenv("CV2_ATT_KSP")[0] == '4');
         const int dma_dbg = g_att_dma.load();
         const bool dma = dma_dbg < 0 ? dma_env : dma_dbg != 0;
         if (c.inc) {
@@ -1071,8 +1081,9 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
             else hipLaunchKernelGGL((k_attn_est<1, 2, 2, true>), dim3(8, M / 32), dim3(256), 0, c.s, a);
         }
         else if (M / 128 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<2>), dim3(8, M / 128), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(8, M / 128), dim3(256), 0, c.s, a); }   // enough blocks to fill the chip twice
-        else if (M / 64 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<1>), dim3(8, M / 64), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(8, M / 64), dim3(256), 0, c.s, a); }
-        else if (ksp4) hipLaunchKernelGGL((k_attn_est<1, 4, 4>), dim3(8, M / 64), dim3(1024), 0, c.s, a);   // one utterance: the keys split over four wave groups of a 64-row block
+        else if (M / 64 * 8 >= (c.chunk > 0 ? 512 : dma1_min)) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<1>), dim3(8, M / 64), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(8, M / 64), dim3(256), 0, c.s, a); }
+        else if (ksp4 && (M / 64 * 8 <= 256 || !ksp42 || c.chunk > 0)) hipLaunchKernelGGL((k_attn_est<1, 4, 4>), dim3(8, M / 64), dim3(1024), 0, c.s, a);   // one utterance: the keys split over four wave groups of a 64-row block
+        else if (ksp4) hipLaunchKernelGGL((k_attn_est<1, 4, 2>), dim3(8, M / 64), dim3(512), 0, c.s, a);     // more blocks than CUs (a 1024-thread block fills one): two groups, two blocks per CU
         else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(8, M / 32), dim3(256), 0, c.s, a);       // (over two groups of a 32-row block)
     }
     static const bool tail_rows_off = getenv("CV2_FLOW_TAIL_ROWS") && getenv("CV2_FLOW_TAIL_ROWS")[0] == '0';     // A/B switch (diagnostics)
