@@ -1077,7 +1077,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         if (c.inc) {
             if (M / 128 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<2, true>), dim3(8, M / 128), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<2, 4, 1, true>), dim3(8, M / 128), dim3(256), 0, c.s, a); }
             else if (M / 64 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<1, true>), dim3(8, M / 64), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<1, 4, 1, true>), dim3(8, M / 64), dim3(256), 0, c.s, a); }
-            else if (ksp4) hipLaunchKernelGGL((k_attn_est<1, 4, 4, true>), dim3(8, M / 64), dim3(1024), 0, c.s, a);
+            else if (ksp4) hipLaunchKernelGGL((k_attn_est<1, 4, 4, true>), dim3(8, M / 64), dim3(1024), 0, c.s, a);     // (9 .. 15 streams' chunks, 257 .. 511 blocks: two groups of a 512-thread block measured +1 %: 12 streams 165 -> 167 audio-s/s; not taken)
             else hipLaunchKernelGGL((k_attn_est<1, 2, 2, true>), dim3(8, M / 32), dim3(256), 0, c.s, a);
         }
         else if (M / 128 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<2>), dim3(8, M / 128), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(8, M / 128), dim3(256), 0, c.s, a); }   // enough blocks to fill the chip twice

@@ -12,7 +12,7 @@ _a = [x for i, x in enumerate(sys.argv[1:]) if not x.startswith('--') and sys.ar
 N = int(_a[0]) if len(_a) > 0 else 8
 R = int(_a[1]) if len(_a) > 1 else 4
 m = CosyVoice2Model(synth.make_llm(), synth.make_flow(), synth.make_hift(), max_text=128, max_prompt_tokens=320, max_new_tokens=1100,
-                    max_batch=8)
+                    max_batch=max(8, N))
 m.stream_live_rows = os.environ.get('CV2_STREAM_LOCKSTEP', '0') != '1'      # A/B switch
 inp = synth.synthetic_inputs(seed=1986, text_len=12, prompt_len=255, prompt_text_len=20)     # 12 text tokens -> <= 240 speech tokens
 kw = dict(text=inp['text'], prompt_text=inp['prompt_text'], llm_prompt_speech_token=inp['prompt_token'],
