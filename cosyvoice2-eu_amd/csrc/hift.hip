@@ -925,7 +925,7 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
         static const bool bt64 = !(getenv("CV2_HIFT_BT64") && getenv("CV2_HIFT_BT64")[0] == '0');
         const long blocks128 = (long)((L_out + CV_BT - 1) / CV_BT) * (cw.cout_pad / 64) * g_hz_n;
         // (measured, 500 frames: below 200 blocks 4.61 ms, below 400 -- the 128-channel stage too -- 4.55, below 600 4.64; 5.34 without)
-        static const long bt64_max = getenv("CV2_HIFT_BT64_MAX") ? atol(getenv("CV2_HIFT_BT64_MAX")) : 200;
+        static const long bt64_max = getenv("CV2_HIFT_BT64_MAX") ? atol(getenv("CV2_HIFT_BT64_MAX")) : 200;     // (260, one 128-frame block per CU: a lone 900-frame call 5.07 -> 4.76 ms, but 32 utterances on the pool's four streams 81.0 -> 83.5 ms: kept at 200)
         if (bt64 && blocks128 < bt64_max) {
             const size_t sm = (size_t)(64 + (cw.taps - 1) * cw.dil) * C6_LD * 2 * 3;
             { const dim3 g_ = grid_for(64, true); hipLaunchKernelGGL(k_conv6<1>, g_, dim3(256), sm, s, a); }      // (sets a.xcd_ch first)
