@@ -581,7 +581,7 @@ def test_staggered_arrivals_over_many_rounds_every_call_gets_its_own_tokens(dev)
               llm_prompt_speech_token=inp['prompt_token'], flow_prompt_speech_token=inp['prompt_token'], prompt_speech_feat=inp['prompt_feat'])
     rng = random.Random(5)
     kinds = ['uni', 'bi', 'uni', 'bi', 'batch', 'quit']
-    for rnd in range(8):
+    for rnd in range(int(os.environ.get('CV2_SOAK_ROUNDS', '8'))):        # (a longer soak: CV2_SOAK_ROUNDS=100 pytest -k staggered_arrivals)
         order = kinds[:]
         rng.shuffle(order)
         offs = [rng.uniform(0.0, 0.040) for _ in order]
