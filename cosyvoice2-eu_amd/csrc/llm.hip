@@ -1594,6 +1594,14 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
 #pragma unroll
         for (int i = 0; i < ST; i++) sv[i] = stc[i];
     }
+    // the first trial's uniforms depend on the state record only (counter = (slot, step, 0), key = seed): one lane of wave 1 draws them
+    // while the logits are still on their way -- the ten Philox rounds were ~500 cycles of the sampling lane's serial draw phase
+    __shared__ double s_u0[2];
+    if (tid == 64) {
+        uint32_t rn[4];
+        philox4x32((uint32_t)seq, (uint32_t)sv[CV2_ST_STEP], 0u, 0u, (uint32_t)sv[CV2_ST_SEED_LO], (uint32_t)sv[CV2_ST_SEED_HI], rn);
+        s_u0[0] = u53(rn[0], rn[1]); s_u0[1] = u53(rn[2], rn[3]);
+    }
     // CV2_ST_ERR == 3: a hand-off of this step's k_step timed out (chain.h) -- the logits are not this step's: nothing is drawn and
     // nothing committed (state, tokens and the pending input stay as they were; the epoch still advances), so the host can clear the
     // flag and run the step again on the launches
@@ -1776,22 +1784,33 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                 if (tid < 64) {                                                // wave 0: lane 0 draws, all lanes check the window
                     int top_l = 0;
                     if (tid == 0) {
-                        uint32_t rn[4];
-                        philox4x32((uint32_t)seq, (uint32_t)step, (uint32_t)trial, 0u, (uint32_t)sv[CV2_ST_SEED_LO], (uint32_t)sv[CV2_ST_SEED_HI], rn);
-                        const double u1 = u53(rn[0], rn[1]);
-                        s_u2 = u53(rn[2], rn[3]);
-                        // nucleus draw: inverse cdf over the candidate probabilities (float64 running sum); the probabilities are
-                        // fetched from LDS together, not one dependent read per step of the serial sums
+                        double u1;
+                        if (trial == 0) { u1 = s_u0[0]; s_u2 = s_u0[1]; }      // (drawn at kernel entry; the barriers since then order the LDS write)
+                        else {
+                            uint32_t rn[4];
+                            philox4x32((uint32_t)seq, (uint32_t)step, (uint32_t)trial, 0u, (uint32_t)sv[CV2_ST_SEED_LO], (uint32_t)sv[CV2_ST_SEED_HI], rn);
+                            u1 = u53(rn[0], rn[1]);
+                            s_u2 = u53(rn[2], rn[3]);
+                        }
+                        // nucleus draw: inverse cdf over the candidate probabilities (float64 running sums in the reference's order); the
+                        // probabilities are fetched from LDS together, and both passes are straight-line selects: with a branch per candidate
+                        // the two 25-step loops were most of this phase's 5 700 cycles
                         float cp[SM_TOPK];
 #pragma unroll
                         for (int c = 0; c < SM_TOPK; c++) cp[c] = candp[c];
                         double csum = 0.0;
 #pragma unroll
-                        for (int c = 0; c < SM_TOPK; c++) if (c < ncand) csum += (double)cp[c];
+                        for (int c = 0; c < SM_TOPK; c++) { const double nx = csum + (double)cp[c]; csum = c < ncand ? nx : csum; }
                         const double thr = u1 * csum; double run = 0.0; int pick = ncand - 1; bool found = false;
 #pragma unroll
-                        for (int c = 0; c < SM_TOPK; c++)
-                            if (c < ncand && !found) { run += (double)cp[c]; if (run > thr) { pick = c; found = true; } }
+                        for (int c = 0; c < SM_TOPK; c++) {
+                            const bool in = c < ncand && !found;
+                            const double nr = run + (double)cp[c];
+                            run = in ? nr : run;
+                            const bool take = in && nr > thr;
+                            pick = take ? c : pick;
+                            found = found || take;
+                        }
                         top_l = candi[pick];
                     }
                     const int top = __builtin_amdgcn_readfirstlane(top_l);     // lane 0 is the first active lane
