@@ -1693,6 +1693,7 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
             }
             __syncthreads();
             const int ncnd = s_cnt;
+            int ncand_r = 0;                                                  // nucleus size, kept by thread 0 (the only reader)
             SK_STAMP(3);                                                      // candidates compacted
             if (ncnd <= SM_CAP && mode != 5) {                                // mode 5 (tests): force the extract-max path
                 if (tid < ncnd) {
@@ -1708,17 +1709,28 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                     if (r < a.top_k) { candi[r] = mi; candp[r] = __expf(fkey_inv(mk)); }
                 }
                 if (tid >= ncnd && tid < SM_TOPK) { candi[tid] = 0; candp[tid] = 0.f; }   // vocabulary smaller than the nucleus
-                __syncthreads();
+                // the candidate lists are written by threads < max(ncnd, 25) and read by thread 0 alone (here and in the draw below): with
+                // at most 64 survivors -- the usual ~40 -- all of that is wave 0, whose LDS operations execute in order: no block barrier
+                // (each cost the sampling lane the arrival skew of 16 waves; the block meets again at the draw's barrier)
+                if (ncnd > 64) __syncthreads();
+                else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (tid == 0) {
                     float cp[SM_TOPK];
 #pragma unroll
                     for (int c = 0; c < SM_TOPK; c++) cp[c] = candp[c];        // all reads in flight, then the serial fp32 sum of the reference
-                    int nc = 0; float cum = 0.f;
+                    // the nucleus grows while the mass BEFORE a candidate is < top_p (common.py:127-131): the reference's running fp32 sum is
+                    // computed once as a chain of 25 additions (the same additions in the same order: equal bits up to where it stops, unused
+                    // beyond), and since it never decreases the size is a COUNT of independent comparisons instead of a 25-step chain of
+                    // compare -> select -> add on one lane
+                    int nc = 0; float before = 0.f;
 #pragma unroll
-                    for (int c = 0; c < SM_TOPK; c++) if (nc == c && c < a.top_k && cum < a.top_p) { cum += cp[c]; nc++; }
+                    for (int c = 0; c < SM_TOPK; c++) {
+                        nc += (c < a.top_k && before < a.top_p) ? 1 : 0;
+                        before += cp[c];
+                    }
+                    ncand_r = nc;
                     s_ncand = nc;
                 }
-                __syncthreads();
             } else {
                 // Two stages, one block barrier: every wave extracts the top 25 of its own 1/16 of the vocabulary, wave 0 merges the
                 // 16 sorted lists.  Cross-lane maxima go through DPP row operations instead of LDS-routed shuffles.
@@ -1769,12 +1781,12 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                     if (lane == 0) {
                         int nc = 0; float cum = 0.f;
                         while (nc < a.top_k && cum < a.top_p) { cum += candp[nc]; nc++; }
+                        ncand_r = nc;
                         s_ncand = nc;
                     }
                 }
-                __syncthreads();
             }
-            const int ncand = s_ncand;
+            const int ncand = ncand_r;                                        // (thread 0's own count; nobody else uses it)
             SK_STAMP(4);                                                      // candidates ranked
             if (mode == 4) { if (tid == 0) s_top = 0; goto sample_done; }       // after the candidate selection
             const int chunk = (V + SM_T - 1) / SM_T;
@@ -1798,19 +1810,21 @@ __global__ __launch_bounds__(SM_T) void k_sample(SampleArgs a) {
                         float cp[SM_TOPK];
 #pragma unroll
                         for (int c = 0; c < SM_TOPK; c++) cp[c] = candp[c];
+                        // ONE chain of 25 float64 additions gives every prefix sum P[c] (the reference's running sum: same additions, same
+                        // order); the total is P[ncand - 1], and as the sums never decrease the pick -- the first c < ncand with P[c] > u1 * total --
+                        // is the COUNT of the c < ncand with P[c] <= threshold: independent comparisons, no second chain
+                        double P[SM_TOPK];
+                        double run = 0.0;
+#pragma unroll
+                        for (int c = 0; c < SM_TOPK; c++) { run += (double)cp[c]; P[c] = run; }
                         double csum = 0.0;
 #pragma unroll
-                        for (int c = 0; c < SM_TOPK; c++) { const double nx = csum + (double)cp[c]; csum = c < ncand ? nx : csum; }
-                        const double thr = u1 * csum; double run = 0.0; int pick = ncand - 1; bool found = false;
+                        for (int c = 0; c < SM_TOPK; c++) csum = c == ncand - 1 ? P[c] : csum;
+                        const double thr = u1 * csum;
+                        int below = 0;
 #pragma unroll
-                        for (int c = 0; c < SM_TOPK; c++) {
-                            const bool in = c < ncand && !found;
-                            const double nr = run + (double)cp[c];
-                            run = in ? nr : run;
-                            const bool take = in && nr > thr;
-                            pick = take ? c : pick;
-                            found = found || take;
-                        }
+                        for (int c = 0; c < SM_TOPK; c++) below += (c < ncand && !(P[c] > thr)) ? 1 : 0;
+                        const int pick = below < ncand - 1 ? below : ncand - 1;
                         top_l = candi[pick];
                     }
                     const int top = __builtin_amdgcn_readfirstlane(top_l);     // lane 0 is the first active lane
