@@ -191,8 +191,9 @@ def test_attention_with_dma_staged_tiles_agrees_with_the_register_staged_form(de
                 L.check(L.lib().cv2_flow_debug_attn_dma(-1))
         return out
 
-    for n_utts in (8, 3):                                   # 8 x 2 x ~1000 rows: the 128-row query tiles; 3: the 64-row ones
-        utts = [utt(i, 430 + 11 * i, 35 + 4 * i) for i in range(n_utts)]
+    for n_utts in (8, 3, 1):                                # 8 x 2 x ~1000 rows: the 128-row query tiles; 3: the 64-row ones; 1 utterance of
+        # 1 110 frames (2 304 rows = 288 blocks of the four-group form: round 5 sends full-context calls above 256 blocks to the 64-row DMA form)
+        utts = [utt(i, 520 if n_utts == 1 else 430 + 11 * i, 35 + 4 * i) for i in range(n_utts)]
         for streaming in (False, True):
             a, b = both(lambda: [m.clone() for m in big.inference_batch(utts, streaming=streaming)])
             assert all(torch.isfinite(x).all() for x in a)
