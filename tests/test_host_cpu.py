@@ -503,3 +503,66 @@ def test_bench_caller_pool_runs_every_call_once_in_both_modes():
         assert sorted(i for i, _ in seen) == [0, 2]
     finally:
         bench.CallerPool.fresh = keep
+
+
+def test_xcd_split_block_mapping_is_a_bijection():
+    """csrc/common.h xcd_tile_split / hift.hip conv_launch: the convolution grids are dealt to the 8 XCDs `nch` ways over the output-channel
+    tiles and 8 / nch ways over the frame tiles; consecutive block ids go round the XCDs, the launcher pads x to a multiple of 8 / nch and
+    blocks past x_real leave.  Restated here: every real (x, y) tile is visited exactly once, padding blocks only land on x >= x_real, and
+    all tiles of one XCD lie in its (channel part, frame part)."""
+    def mapping(gx, gy, nch, x_real):
+        nfr, hy, qn = 8 // nch, gy // nch, gx // (8 // nch)
+        out = {}
+        for L in range(gx * gy):
+            x, n = L & 7, L >> 3
+            c, f = x % nch, x // nch
+            dx = n // hy
+            out[L] = (f * qn + dx, c * hy + (n - dx * hy), x)
+        return out
+    for gy in (2, 4, 8, 32):
+        for nch in (2, 4, 8):
+            if gy % nch:
+                continue
+            nfr = 8 // nch
+            for x_real in (1, 3, 7, 8, 63, 75, 314):
+                gx = (x_real + nfr - 1) // nfr * nfr
+                m = mapping(gx, gy, nch, x_real)
+                tiles = [(bx, by) for bx, by, _ in m.values()]
+                assert len(set(tiles)) == gx * gy and all(0 <= bx < gx and 0 <= by < gy for bx, by in tiles)        # a bijection of the padded grid
+                real = [(bx, by) for bx, by in tiles if bx < x_real]
+                assert sorted(real) == [(x, y) for x in range(x_real) for y in range(gy)]                          # every real tile exactly once
+                hy, qn = gy // nch, gx // nfr
+                for bx, by, x in m.values():                                                                      # an XCD's tiles: one channel part, one frame part
+                    assert by // hy == x % nch and bx // qn == x // nch
+
+
+def test_bench_live_counter_fields(monkeypatch):
+    """bench.live_counters: the arithmetic of the counter passes (FETCH_SIZE doubled, KiB units, per-launch / per-call division, MFMA busy over
+    4 SIMDs x 256 CUs x duration x 2.4 GHz) on made-up pass results; a failing first pass gives {} (the committed files are the fallback)."""
+    import shutil
+    import bench
+    monkeypatch.setattr(shutil, 'which', lambda name: '/opt/rocm/bin/rocprofv3')
+    for k in list(os.environ):
+        if k.startswith(('ROCPROF', 'ROCP_')):
+            monkeypatch.delenv(k)
+    monkeypatch.delenv('CV2_BENCH_LIVE_PMC', raising=False)
+
+    def fake(stage, reps, counters, timeout_s=150):
+        c = counters[0]
+        if stage == 'decode':
+            return {'k_step<false, true>': {'n': 40.0, 'ns': 40 * 330e3, c: 40 * (380000.0 if c == 'FETCH_SIZE' else 2000.0)}, 'k_sample': {'n': 40.0, 'ns': 4e5, c: 40.0}}
+        if stage == 'hift':
+            return {'k_conv6<1>': {'n': 81.0, 'ns': 3 * 1.2e6, c: 3 * 300000.0}, 'k_respair<1>': {'n': 36.0, 'ns': 3 * 0.6e6, c: 3 * 100000.0}, 'k_phase': {'n': 3.0, 'ns': 5e4, c: 3.0}}
+        return {'k_gemm<64>': {'n': 100.0, 'ns': 1e6, 'SQ_VALU_MFMA_BUSY_CYCLES': 4 * 256 * 1e6 * 2.4 * 0.1, 'GRBM_GUI_ACTIVE': 8 * 4e6}}
+    monkeypatch.setattr(bench, '_pmc_pass', fake)
+    out = bench.live_counters()
+    per, src = out['decode']
+    assert per == int((2 * 380000.0 + 2000.0) * 1024) and 'measured in this run' in src and '40 k_step' in src
+    h = out['hift']
+    assert h['measured_in_this_run'] and h['conv_launches_per_call'] == 39
+    assert abs(h['hbm_GB_per_10s_audio'] - (2 * 400003.0 + 400003.0) * 1024 / 1e9) < 1e-3
+    assert h['top_conv_kernel']['kernel'] == 'k_conv6<1>'
+    f = out['flow']
+    assert abs(f['util_counter'] - 0.1) < 1e-4 and abs(f['util_counter_gui_active'] - 4 * 256 * 1e6 * 2.4 * 0.1 / (4 * 256 * 4e6)) < 1e-4
+    monkeypatch.setattr(bench, '_pmc_pass', lambda *a, **k: None)
+    assert bench.live_counters() == {}
