@@ -929,7 +929,10 @@ __device__ __forceinline__ void tr2_prime(Tr2Ring& R, const s16x8* w0, const s16
 struct Tr2NoHook { __device__ __forceinline__ void operator()(int) const {} };
 // `side(kb)`: other work of the wave issued beside k-step kb's MFMAs, inside the same scheduling region (the feed-forward's GELU of the NEXT
 // hidden quarter rides on FF2's k-steps: VALU instructions issue while the matrix cores work on the eight MFMAs)
-template <int NKS, int NNKS, int PH, class SIDE = Tr2NoHook>
+// SWAP: the activation fragment is the MFMA's first operand and the weight fragment its second -- the same products summed over k in the same
+// order (bit-identical values), but the accumulator tile comes out TRANSPOSED: a lane then holds four consecutive ROWS of one column (the
+// chained V projection stages its tile as V^T with 8-byte writes instead of gathering 2-byte elements, k_tail_rows2)
+template <int NKS, int NNKS, int PH, class SIDE = Tr2NoHook, bool SWAP = false>
 __device__ __forceinline__ void tr2_gemm(Tr2Ring& R, const s16x8* w0, const s16x8* w1, const s16x8* nw0, const s16x8* nw1,
                                          const char* panel, int a_off, unsigned lane16, f32x4 (&acc)[2][4], SIDE side = SIDE()) {
     // software pipeline, fenced per k-step (left to itself hipcc hoists the fully unrolled loop's LDS reads and weight loads far ahead:
@@ -950,8 +953,10 @@ __device__ __forceinline__ void tr2_gemm(Tr2Ring& R, const s16x8* w0, const s16x
 #pragma unroll
         for (int rt = 0; rt < 4; rt++) {
 #ifndef TR2_DIAG_NOMFMA
-            acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, af[kb & 1][rt], acc[0][rt], 0, 0, 0);
-            acc[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, af[kb & 1][rt], acc[1][rt], 0, 0, 0);
+            acc[0][rt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb & 1][rt], f0, acc[0][rt], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, af[kb & 1][rt], acc[0][rt], 0, 0, 0);
+            acc[1][rt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb & 1][rt], f1, acc[1][rt], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, af[kb & 1][rt], acc[1][rt], 0, 0, 0);
 #else
             acc[0][rt] += __builtin_bit_cast(f32x4, f0) + __builtin_bit_cast(f32x4, af[kb & 1][rt]);
             acc[1][rt] += __builtin_bit_cast(f32x4, f1);
@@ -1138,7 +1143,7 @@ __global__ __launch_bounds__(512) void k_tail_rows2(TailArgs a) {
     TR2_BARRIER;                                         // y panel complete (and the C tile consumed: its LDS becomes the staging tiles)
     // ---- the next block's QKV projection: six tiles of 256 features; a tile is staged as bf16 [64][SLD] (two buffers) and stored by the
     // whole block in full rows (Q / K: 512 B per row) or full columns (V^T: 128 B per feature)
-#define TR2_QKV(J, NW0, NW1, NNKS)                                                                                                   \
+#define TR2_QKV(J, NW0, NW1, NNKS)                                    /* Q / K features 256 J ..: staged [64 rows][SLD], stored in rows of 512 B */ \
     {                                                                                                                               \
         uint16_t* S = reinterpret_cast<uint16_t*>(smem + (size_t)((J) & 1) * 34 * 1024);                                              \
         zero(acc);                                                                                                                   \
@@ -1152,27 +1157,43 @@ __global__ __launch_bounds__(512) void k_tail_rows2(TailArgs a) {
                     make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));                                                    \
             }                                                                                                                       \
         TR2_BARRIER;                                                                                                             \
-        if ((J) < 4) {                                       /* Q / K features 256 J ..: rows of 512 B, 32 threads x 16 B each */   \
-            _Pragma("unroll") for (int it = 0; it < 4; it++) {                                                                       \
-                const int e = tid + 512 * it, r = e >> 5, ch = e & 31;                                                               \
-                *reinterpret_cast<uint4*>(a.qk + (size_t)(m0 + r) * 1024 + (J) * 256 + ch * 8) = *reinterpret_cast<const uint4*>(S + (size_t)r * SLD + ch * 8); \
+        _Pragma("unroll") for (int it = 0; it < 4; it++) {                                              /* 32 threads x 16 B per row */ \
+            const int e = tid + 512 * it, r = e >> 5, ch = e & 31;                                                                   \
+            *reinterpret_cast<uint4*>(a.qk + (size_t)(m0 + r) * 1024 + (J) * 256 + ch * 8) = *reinterpret_cast<const uint4*>(S + (size_t)r * SLD + ch * 8); \
+        }                                                                                                                           \
+    }
+    // V features: the accumulators come out transposed (tr2_gemm<.., SWAP>: a lane holds four consecutive rows of one feature), so the tile is
+    // staged AS V^T [256 features][TLD] with 8-byte writes and leaves in 16-byte pieces (8 rows of a feature: 8 threads cover the 128 B of a
+    // feature's 64 rows).  Staged [64][SLD] like Q / K, every 16-byte piece was eight 2-byte LDS reads a row apart -- all on one bank: the
+    // two V tiles cost 12 us of a 207 us launch more than the four Q / K tiles' way of storing.
+#define TR2_V(J, NW0, NW1, NNKS)                                                                                                     \
+    {                                                                                                                               \
+        constexpr int TLD = 68;                              /* bf16 per staged V^T row: 64 + 4 (256 x 68 x 2 B = the 34 KB staging buffer) */ \
+        uint16_t* S = reinterpret_cast<uint16_t*>(smem + (size_t)((J) & 1) * 34 * 1024);                                              \
+        zero(acc);                                                                                                                   \
+        tr2_gemm<KS1, NNKS, 0, Tr2NoHook, true>(R, wqp(J, 0), wqp(J, 1), NW0, NW1, xs, a_off, lane16, acc);                          \
+        _Pragma("unroll") for (int c = 0; c < 2; c++)                                                                                \
+            _Pragma("unroll") for (int rt = 0; rt < 4; rt++) {                                                                       \
+                const int r0 = rt * 16 + 4 * (lane >> 4);        /* this lane's rows r0 .. r0 + 3 of feature f */                    \
+                const int f = wave * 32 + c * 16 + (lane & 15);                                                                      \
+                f32x4 v = acc[c][rt];                                                                                                \
+                _Pragma("unroll") for (int e = 0; e < 4; e++) if ((m0 + r0 + e - ep_start) >= ep_len) v[e] = 0.f;                     \
+                *reinterpret_cast<uint2*>(S + (size_t)f * TLD + r0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));  \
             }                                                                                                                       \
-        } else {                                             /* V features: feature f of the tile, rows 8 g .. 8 g + 7 -> 16 B of its V^T row */ \
-            _Pragma("unroll") for (int it = 0; it < 4; it++) {                                                                       \
-                const int e = tid + 512 * it, f = e >> 3, g = e & 7;                                                                 \
-                uint32_t pk[4];                                                                                                      \
-                _Pragma("unroll") for (int q = 0; q < 4; q++)                                                                        \
-                    pk[q] = (uint32_t)S[(size_t)(8 * g + 2 * q) * SLD + f] | ((uint32_t)S[(size_t)(8 * g + 2 * q + 1) * SLD + f] << 16);   \
-                *reinterpret_cast<uint4*>(a.vt + (size_t)(((J) - 4) * 256 + f) * a.vt_ld + m0 + 8 * g) = make_uint4(pk[0], pk[1], pk[2], pk[3]); \
-            }                                                                                                                       \
+        TR2_BARRIER;                                                                                                             \
+        _Pragma("unroll") for (int it = 0; it < 4; it++) {                                                                           \
+            const int e = tid + 512 * it, f = e >> 3, g = e & 7;                                                                     \
+            const uint2 lo = *reinterpret_cast<const uint2*>(S + (size_t)f * TLD + 8 * g), hi = *reinterpret_cast<const uint2*>(S + (size_t)f * TLD + 8 * g + 4); \
+            *reinterpret_cast<uint4*>(a.vt + (size_t)(((J) - 4) * 256 + f) * a.vt_ld + m0 + 8 * g) = make_uint4(lo.x, lo.y, hi.x, hi.y); \
         }                                                                                                                           \
     }
     TR2_QKV(0, wqp(1, 0), wqp(1, 1), KS1)
     TR2_QKV(1, wqp(2, 0), wqp(2, 1), KS1)
     TR2_QKV(2, wqp(3, 0), wqp(3, 1), KS1)
     TR2_QKV(3, wqp(4, 0), wqp(4, 1), KS1)
-    TR2_QKV(4, wqp(5, 0), wqp(5, 1), KS1)
-    TR2_QKV(5, (const s16x8*)nullptr, (const s16x8*)nullptr, 0)
+    TR2_V(4, wqp(5, 0), wqp(5, 1), KS1)
+    TR2_V(5, (const s16x8*)nullptr, (const s16x8*)nullptr, 0)
+#undef TR2_V
 #undef TR2_QKV
     SK_STAMP(5);
     SK_STAMP_FLUSH_RING(((unsigned long long)0x7A11 << 32) | 1536u, ((unsigned long long)64 << 48) | ((unsigned long long)32 << 32) | (unsigned)gridDim.y);
