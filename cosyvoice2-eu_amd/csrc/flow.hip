@@ -576,6 +576,13 @@ __global__ __launch_bounds__(64 * NW * KSP) void k_attn_est(AttnEstArgs a) {
     ATT_GLOAD(A, min(kgrp, last))
     ATT_GLOAD(B, min(kgrp + KSP, last))
     SK_STAMP(1);
+    // Both sets are consumed here (an empty statement the compiler has to wait in front of): hipcc issues the prologue's loads in an order
+    // of its own, set A's after set B's, and the wait it places at the loop header covers the entry path too -- vmcnt(0) in EVERY
+    // iteration, i.e. a wait for the set requested half an iteration earlier instead of the one requested two tiles ago (phase stamps at
+    // one utterance: staging + wait 11 100 of a block's 23 500 cycles).  With nothing outstanding at the entry the header's wait is the
+    // back edge's: the four loads of the other set stay in flight.
+    asm volatile("" :: "v"(kregA0.x), "v"(kregA1.x), "v"(kregA2.x), "v"(kregA3.x), "v"(vregA0.x), "v"(vregA1.x), "v"(vregA2.x), "v"(vregA3.x),
+                       "v"(kregB0.x), "v"(kregB1.x), "v"(kregB2.x), "v"(kregB3.x), "v"(vregB0.x), "v"(vregB1.x), "v"(vregB2.x), "v"(vregB3.x));
     for (int r = 0; r < rounds; r += 2) {
         {
             const int kt = r * KSP + kgrp;
