@@ -820,6 +820,117 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
 #endif
 }
 
+// One utterance, full context (round 5): the four-key-group form (k_attn_est<1, 4, 4>: 64 query rows x one head per 1024-thread block, group
+// g works on the key tiles g, g + 4, ..., the four states merged through LDS) with its tiles by LDS DMA like k_attn_est_dma: no staging
+// registers, no register -> LDS copies (phase stamps of the register-staged form at one utterance: staging + waits 9 800 of a block's 23 500
+// cycles), two 16 KB stages per group.  The tile body is att_est_tile<1, true> (the DMA form's key permutation): agreement with k_attn_est to
+// fp32 round-off, so -- like the other DMA forms -- it serves full-context calls only; a stream's chunk-masked recompute keeps the arithmetic
+// of its cached continuation.
+__global__ __launch_bounds__(1024) void k_attn_est_dma4(AttnEstArgs a) {
+    constexpr int NW = 4, KSP = 4, RB = 64;
+    __shared__ __attribute__((aligned(1024))) uint16_t Ts[KSP][2][2][64 * 64];          // [group][stage][K | V^T]: 128 KB
+    const int lane = threadIdx.x & 63;
+    const int kgrp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    const int tid = threadIdx.x & 255;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * RB, h = blockIdx.x;
+    const int q16 = lane & 15, g = lane >> 4;
+    const int s = a.seq.tile_seq[m0 >> 6];
+    uint16_t* orow[1] = {a.out + (size_t)(m0 + 16 * w + q16) * 512 + h * 64 + 4 * g};
+    if (s < 0) {
+        if (kgrp == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) *reinterpret_cast<uint2*>(orow[0] + 16 * dt) = make_uint2(0u, 0u);
+        }
+        return;
+    }
+    const int start = a.seq.seq_start[s], len = a.seq.seq_len[s];
+    const int t0 = m0 - start;
+    const int klen = len;
+    int tq[1], kmax_q[1];
+    tq[0] = t0 + 16 * w + q16;
+    kmax_q[0] = a.chunk > 0 ? min(klen, (tq[0] / a.chunk + 1) * a.chunk) : klen;
+    const int kmax_blk = a.chunk > 0 ? min(klen, ((t0 + RB - 1) / a.chunk + 1) * a.chunk) : klen;
+    const int ntiles = (kmax_blk + 63) / 64;
+    const int rounds = (ntiles + KSP - 1) / KSP, last = ntiles - 1;
+    // this lane's DMA sources of tile 0 (wave w of the group, instruction j: rows 8 (w + 4 j) .. + 7 of the tile), as in k_attn_est_dma
+    const int rr = lane >> 3, gc = (lane & 7) ^ rr;
+    const uint16_t* ksrc[2]; const uint16_t* vsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int r = 8 * (w + 4 * j) + rr;
+        const int gck = (lane & 7) ^ att_kswz(4 * ((r >> 3) & 3) + (r & 3));
+        ksrc[j] = a.qk + (size_t)(start + r) * 1024 + 512 + h * 64 + gck * 8;
+        vsrc[j] = a.vt + (size_t)(h * 64 + r) * a.R + start + gc * 8;
+    }
+    auto dma = [&](int kt, int st) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const unsigned kd = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(&Ts[kgrp][st][0][(w + 4 * j) * 512]);
+            const unsigned vd = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(&Ts[kgrp][st][1][(w + 4 * j) * 512]);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(kd), "v"(ksrc[j] + (long)kt * (64 * 1024)) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(vd), "v"(vsrc[j] + (long)kt * 64) : "memory");
+        }
+    };
+    f32x4 o[1][4];
+    float mrun[1] = {-INFINITY}, lrun[1] = {0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) o[0][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dma(min(kgrp, last), 0);
+    bf16x8 qf[1][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+        qf[0][ks] = *reinterpret_cast<const bf16x8*>(a.qk + (size_t)(m0 + 16 * w + q16) * 1024 + h * 64 + ks * 32 + g * 8);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) asm volatile("" : "+v"(qf[0][ks]));          // (the compiler's wait for q sits here, not inside the loop)
+    int st = 0;
+    for (int r = 0; r < rounds; r++) {
+        const int kt = r * KSP + kgrp;                        // a tile index past the end re-fetches the last tile and is fully masked
+        int kmask_q[1] = {kt < ntiles ? kmax_q[0] : 0};
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // every wave's share of tile r has landed; every wave is done with tile r - 1
+        dma(min(kt + KSP, last), st ^ 1);
+        att_est_tile<1, true>(Ts[kgrp][st][0], Ts[kgrp][st][1], qf, o, mrun, lrun, kmask_q, kt, q16, g);
+        st ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // merge: the groups 1 .. 3 park (m, l, O) in their own tile buffers (free now), group 0 folds them in, in group order (k_attn_est's merge)
+    constexpr float SC = 0.125f * 1.4426950408889634f;
+    static_assert((size_t)64 * NW * 18 * sizeof(float) <= sizeof(Ts[0]), "a group's tile buffers hold its parked state");
+    __syncthreads();
+    if (kgrp != 0) {
+        float* d = reinterpret_cast<float*>(&Ts[kgrp][0][0][0]) + (size_t)tid * 18;
+        d[0] = mrun[0]; d[1] = lrun[0];
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) d[2 + dt * 4 + e] = o[0][dt][e];
+    }
+    __syncthreads();
+    if (kgrp != 0) return;
+#pragma unroll
+    for (int gq = 1; gq < KSP; gq++) {
+        const float* d = reinterpret_cast<const float*>(&Ts[gq][0][0][0]) + (size_t)tid * 18;
+        const float m1 = d[0], l1 = d[1];
+        const float M = fmaxf(mrun[0], m1);
+        const float ms = M == -INFINITY ? 0.f : M;
+        const float a0 = __builtin_amdgcn_exp2f((mrun[0] - ms) * SC), a1 = __builtin_amdgcn_exp2f((m1 - ms) * SC);
+        lrun[0] = lrun[0] * a0 + l1 * a1;
+        mrun[0] = M;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[0][dt][e] = o[0][dt][e] * a0 + d[2 + dt * 4 + e] * a1;
+    }
+    float l = lrun[0];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = (tq[0] < len && l > 0.f) ? 1.f / l : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)
+        *reinterpret_cast<uint2*>(orow[0] + 16 * dt) = make_uint2(pack_bf16x2(o[0][dt][0] * inv, o[0][dt][1] * inv), pack_bf16x2(o[0][dt][2] * inv, o[0][dt][3] * inv));
+}
+
 // =========================================================================== host side
 struct Layout {
     int S = 0, rows = 0;
@@ -1078,6 +1189,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         // cached continuation runs (k_attn_est<.., CACHE>), so that recomputed and cached chunks of a stream stay bit-identical -- any other
         // summation order moves the mel by ~3e-3 of its range through the 10 Euler steps.  CV2_ATT_DMA1_MIN=512: the round-4 threshold (A/B)
         static const int dma1_min = getenv("CV2_ATT_DMA1_MIN") ? atoi(getenv("CV2_ATT_DMA1_MIN")) : 257;
+        static const bool dma4 = !(getenv("CV2_ATT_DMA4") && getenv("CV2_ATT_DMA4")[0] == '0');      // (A/B: the register-staged four-group form)
         static const bool ksp42 = !(getenv("CV2_ATT_KSP") && getenv("CV2_ATT_KSP")[0] == '4');
         const int dma_dbg = g_att_dma.load();
         const bool dma = dma_dbg < 0 ? dma_env : dma_dbg != 0;
@@ -1089,6 +1201,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         }
         else if (M / 128 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<2>), dim3(8, M / 128), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(8, M / 128), dim3(256), 0, c.s, a); }   // enough blocks to fill the chip twice
         else if (M / 64 * 8 >= (c.chunk > 0 ? 512 : dma1_min)) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<1>), dim3(8, M / 64), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(8, M / 64), dim3(256), 0, c.s, a); }
+        else if (ksp4 && dma && dma4 && c.chunk == 0) hipLaunchKernelGGL(k_attn_est_dma4, dim3(8, M / 64), dim3(1024), 0, c.s, a);      // one utterance, full context: tiles by LDS DMA
         else if (ksp4 && (M / 64 * 8 <= 256 || !ksp42 || c.chunk > 0)) hipLaunchKernelGGL((k_attn_est<1, 4, 4>), dim3(8, M / 64), dim3(1024), 0, c.s, a);   // one utterance: the keys split over four wave groups of a 64-row block
         else if (ksp4) hipLaunchKernelGGL((k_attn_est<1, 4, 2>), dim3(8, M / 64), dim3(512), 0, c.s, a);     // more blocks than CUs (a 1024-thread block fills one): two groups, two blocks per CU
         else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(8, M / 32), dim3(256), 0, c.s, a);       // (over two groups of a 32-row block)
