@@ -826,6 +826,7 @@ __global__ __launch_bounds__(256) void k_attn_est_dma(AttnEstArgs a) {
 // cycles), two 16 KB stages per group.  The tile body is att_est_tile<1, true> (the DMA form's key permutation): agreement with k_attn_est to
 // fp32 round-off, so -- like the other DMA forms -- it serves full-context calls only; a stream's chunk-masked recompute keeps the arithmetic
 // of its cached continuation.
+template <bool CACHE = false>
 __global__ __launch_bounds__(1024) void k_attn_est_dma4(AttnEstArgs a) {
     constexpr int NW = 4, KSP = 4, RB = 64;
     __shared__ __attribute__((aligned(1024))) uint16_t Ts[KSP][2][2][64 * 64];          // [group][stage][K | V^T]: 128 KB
@@ -846,11 +847,20 @@ __global__ __launch_bounds__(1024) void k_attn_est_dma4(AttnEstArgs a) {
     }
     const int start = a.seq.seq_start[s], len = a.seq.seq_len[s];
     const int t0 = m0 - start;
-    const int klen = len;
+    if (CACHE && t0 >= len) {                          // padding rows of the sequence's last tile(s): zeros, as for a padding tile
+        if (kgrp == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) *reinterpret_cast<uint2*>(orow[0] + 16 * dt) = make_uint2(0u, 0u);
+        }
+        return;
+    }
+    // cached streaming (CACHE): keys / values come from the sequence's cache slot, the queries are the call's new frames at pos0 + t
+    const int p0 = CACHE ? a.pos0[s] : 0;
+    const int klen = p0 + len;
     int tq[1], kmax_q[1];
     tq[0] = t0 + 16 * w + q16;
-    kmax_q[0] = a.chunk > 0 ? min(klen, (tq[0] / a.chunk + 1) * a.chunk) : klen;
-    const int kmax_blk = a.chunk > 0 ? min(klen, ((t0 + RB - 1) / a.chunk + 1) * a.chunk) : klen;
+    kmax_q[0] = a.chunk > 0 ? min(klen, ((p0 + tq[0]) / a.chunk + 1) * a.chunk) : klen;
+    const int kmax_blk = a.chunk > 0 ? min(klen, ((p0 + t0 + RB - 1) / a.chunk + 1) * a.chunk) : klen;
     const int ntiles = (kmax_blk + 63) / 64;
     const int rounds = (ntiles + KSP - 1) / KSP, last = ntiles - 1;
     // this lane's DMA sources of tile 0 (wave w of the group, instruction j: rows 8 (w + 4 j) .. + 7 of the tile), as in k_attn_est_dma
@@ -860,15 +870,22 @@ __global__ __launch_bounds__(1024) void k_attn_est_dma4(AttnEstArgs a) {
     for (int j = 0; j < 2; j++) {
         const int r = 8 * (w + 4 * j) + rr;
         const int gck = (lane & 7) ^ att_kswz(4 * ((r >> 3) & 3) + (r & 3));
-        ksrc[j] = a.qk + (size_t)(start + r) * 1024 + 512 + h * 64 + gck * 8;
-        vsrc[j] = a.vt + (size_t)(h * 64 + r) * a.R + start + gc * 8;
+        if (CACHE) {
+            const long fr = a.kv_frames[s];
+            ksrc[j] = a.kv[s] + a.slot * fr * 1024 + h * 64 + (long)r * 512 + gck * 8;
+            vsrc[j] = a.kv[s] + a.slot * fr * 1024 + fr * 512 + (long)(h * 64 + r) * fr + gc * 8;
+        } else {
+            ksrc[j] = a.qk + (size_t)(start + r) * 1024 + 512 + h * 64 + gck * 8;
+            vsrc[j] = a.vt + (size_t)(h * 64 + r) * a.R + start + gc * 8;
+        }
     }
+    const long kstep = CACHE ? 64 * 512 : 64 * 1024;
     auto dma = [&](int kt, int st) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const unsigned kd = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(&Ts[kgrp][st][0][(w + 4 * j) * 512]);
             const unsigned vd = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(&Ts[kgrp][st][1][(w + 4 * j) * 512]);
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(kd), "v"(ksrc[j] + (long)kt * (64 * 1024)) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(kd), "v"(ksrc[j] + (long)kt * kstep) : "memory");
             asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(vd), "v"(vsrc[j] + (long)kt * 64) : "memory");
         }
     };
@@ -1189,6 +1206,7 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         // cached continuation runs (k_attn_est<.., CACHE>), so that recomputed and cached chunks of a stream stay bit-identical -- any other
         // summation order moves the mel by ~3e-3 of its range through the 10 Euler steps.  CV2_ATT_DMA1_MIN=512: the round-4 threshold (A/B)
         static const int dma1_min = getenv("CV2_ATT_DMA1_MIN") ? atoi(getenv("CV2_ATT_DMA1_MIN")) : 257;
+        static const bool dma4s = !(getenv("CV2_ATT_DMA4S") && getenv("CV2_ATT_DMA4S")[0] == '0');    // (A/B: streaming calls keep the register-staged form)
         static const bool dma4 = !(getenv("CV2_ATT_DMA4") && getenv("CV2_ATT_DMA4")[0] == '0');      // (A/B: the register-staged four-group form)
         static const bool ksp42 = !(getenv("CV2_ATT_KSP") && getenv("CV2_ATT_KSP")[0] == '4');
         const int dma_dbg = g_att_dma.load();
@@ -1196,12 +1214,15 @@ static int est_tblock(EstCtx& c, const cv2_tblock& tb, const cv2_ln* next_ln, ui
         if (c.inc) {
             if (M / 128 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<2, true>), dim3(8, M / 128), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<2, 4, 1, true>), dim3(8, M / 128), dim3(256), 0, c.s, a); }
             else if (M / 64 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<1, true>), dim3(8, M / 64), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<1, 4, 1, true>), dim3(8, M / 64), dim3(256), 0, c.s, a); }
+            else if (ksp4 && dma && dma4 && dma4s) hipLaunchKernelGGL(k_attn_est_dma4<true>, dim3(8, M / 64), dim3(1024), 0, c.s, a);
             else if (ksp4) hipLaunchKernelGGL((k_attn_est<1, 4, 4, true>), dim3(8, M / 64), dim3(1024), 0, c.s, a);     // (9 .. 15 streams' chunks, 257 .. 511 blocks: two groups of a 512-thread block measured +1 %: 12 streams 165 -> 167 audio-s/s; not taken)
             else hipLaunchKernelGGL((k_attn_est<1, 2, 2, true>), dim3(8, M / 32), dim3(256), 0, c.s, a);
         }
         else if (M / 128 * 8 >= 512) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<2>), dim3(8, M / 128), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<2, 4>), dim3(8, M / 128), dim3(256), 0, c.s, a); }   // enough blocks to fill the chip twice
         else if (M / 64 * 8 >= (c.chunk > 0 ? 512 : dma1_min)) { if (dma) hipLaunchKernelGGL((k_attn_est_dma<1>), dim3(8, M / 64), dim3(256), 0, c.s, a); else hipLaunchKernelGGL((k_attn_est<1, 4>), dim3(8, M / 64), dim3(256), 0, c.s, a); }
-        else if (ksp4 && dma && dma4 && c.chunk == 0) hipLaunchKernelGGL(k_attn_est_dma4, dim3(8, M / 64), dim3(1024), 0, c.s, a);      // one utterance, full context: tiles by LDS DMA
+        // below 512 blocks: the four-group form with its tiles by LDS DMA.  Chunk-masked (streaming) calls take it together with their cached
+        // continuation (dma4s) over this whole range, so that recomputed and cached chunks of a stream keep ONE arithmetic whatever their row counts
+        else if (ksp4 && dma && dma4 && (c.chunk == 0 || dma4s)) hipLaunchKernelGGL(k_attn_est_dma4<false>, dim3(8, M / 64), dim3(1024), 0, c.s, a);
         else if (ksp4 && (M / 64 * 8 <= 256 || !ksp42 || c.chunk > 0)) hipLaunchKernelGGL((k_attn_est<1, 4, 4>), dim3(8, M / 64), dim3(1024), 0, c.s, a);   // one utterance: the keys split over four wave groups of a 64-row block
         else if (ksp4) hipLaunchKernelGGL((k_attn_est<1, 4, 2>), dim3(8, M / 64), dim3(512), 0, c.s, a);     // more blocks than CUs (a 1024-thread block fills one): two groups, two blocks per CU
         else hipLaunchKernelGGL((k_attn_est<1, 2, 2>), dim3(8, M / 32), dim3(256), 0, c.s, a);       // (over two groups of a 32-row block)
