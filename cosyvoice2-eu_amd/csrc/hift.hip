@@ -200,7 +200,11 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 // (split3t / pack_hi: common.h)
 // FT = frame tiles of 32 per wave: 2 -> blocks of 128 frames (CV_BT), 1 -> blocks of 64 frames for convolutions whose 128-frame grid leaves
 // half the CUs idle (one utterance: the 256-channel stage is 32 x 4 = 128 blocks)
-template <int FT>
+// TAPS > 0: the tap count at compile time (3 / 7 / 11 cover every layer but the 1-tap flat windows; 0 = run-time a.taps).  With it the loop
+// over the taps' weight register sets is straight-line code and the waits hipcc places are counted ones: around the run-time loop it put
+// s_waitcnt vmcnt(0) in front of every set's MFMAs -- behind the request for the OTHER set, i.e. no weight fragment was ever in flight
+// beside the matrix cores (the same effect and the same remedy as k_gemm_panel's compile-time K).
+template <int FT, int TAPS = 0>
 __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
     constexpr int BT = 64 * FT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -330,8 +334,10 @@ __global__ __launch_bounds__(256) void k_conv6(ConvArgs a) {
             if (FT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[0], w0_, acc1, 0, 0, 0);                                \
         }
         static_assert(4 % C6_G == 0, "a register set must not straddle taps");
-        const int ngroups = a.taps * 4 / C6_G;
+        const int ngroups = (TAPS ? TAPS : a.taps) * 4 / C6_G;
         C6_LOAD(wA, 0)
+        constexpr int UNR = TAPS ? 8 : 1;                           // (straight-line code when the tap count is a compile-time constant)
+#pragma unroll UNR
         for (int gi = 0; gi < ngroups; gi += 2) {
             if (gi + 1 < ngroups) C6_LOAD(wB, gi + 1)
             __builtin_amdgcn_sched_barrier(0);
@@ -405,7 +411,7 @@ struct PairArgs {
     float* out; int acc;                                              // out[t][C], ACC_STORE / ACC_ADD / ACC_ADD_DIV3
     long zs;
 };
-template <int CT>
+template <int CT, int TAPS = 0>                     // TAPS: as k_conv6's (compile-time tap count: counted waits around the weight sets)
 __global__ __launch_bounds__(256 * CT) void k_respair(PairArgs a) {
     constexpr int NT = 256 * CT, C = 64 * CT, LDB = C + 8, NTILE = 2 * CT, RP = NT / 16;      // RP = line-buffer rows per staging pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -425,6 +431,7 @@ __global__ __launch_bounds__(256 * CT) void k_respair(PairArgs a) {
     constexpr size_t kbstride = (size_t)NTILE * 3 * 512;              // elements between consecutive 16-channel blocks of one tap
     constexpr size_t tapstride = (size_t)(C / 16) * kbstride;
     bf16x8 wA[3 * C6_G], wB[3 * C6_G];
+    constexpr int RP_UNR = TAPS ? 8 : 1;                             // (straight-line weight-set loop when the tap count is a compile-time constant)
 #define RP_LOAD(SET, GI)                                                                                            \
     _Pragma("unroll") for (int g_ = 0; g_ < C6_G; g_++) {                                                             \
         const int si_ = (GI) * C6_G + g_;                                                                             \
@@ -456,9 +463,9 @@ __global__ __launch_bounds__(256 * CT) void k_respair(PairArgs a) {
     }
 #define RP_RUN(BUF, LD, DIL, COL0)                                                                                  \
     {                                                                                                               \
-        const int ngroups = a.taps * 4 / C6_G;                                                                        \
+        const int ngroups = (TAPS ? TAPS : a.taps) * 4 / C6_G;                                                        \
         RP_LOAD(wA, 0)                                                                                                \
-        for (int gi = 0; gi < ngroups; gi += 2) {                                                                     \
+        _Pragma("unroll RP_UNR") for (int gi = 0; gi < ngroups; gi += 2) {                                            \
             if (gi + 1 < ngroups) RP_LOAD(wB, gi + 1)                                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                        \
             RP_MMA(wA, gi, BUF, LD, DIL, COL0)                                                                        \
@@ -851,10 +858,12 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
     if (!once) {
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv6<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv6<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_respair<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_respair<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define CV2_BIG_LDS(K) CV2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        CV2_BIG_LDS((k_conv6<2, 0>)); CV2_BIG_LDS((k_conv6<2, 3>)); CV2_BIG_LDS((k_conv6<2, 7>)); CV2_BIG_LDS((k_conv6<2, 11>));
+        CV2_BIG_LDS((k_conv6<1, 0>)); CV2_BIG_LDS((k_conv6<1, 3>)); CV2_BIG_LDS((k_conv6<1, 7>)); CV2_BIG_LDS((k_conv6<1, 11>));
+        CV2_BIG_LDS((k_respair<1, 3>)); CV2_BIG_LDS((k_respair<1, 7>)); CV2_BIG_LDS((k_respair<1, 11>)); CV2_BIG_LDS((k_respair<1, 0>));
+        CV2_BIG_LDS((k_respair<2, 3>)); CV2_BIG_LDS((k_respair<2, 7>)); CV2_BIG_LDS((k_respair<2, 11>)); CV2_BIG_LDS((k_respair<2, 0>));
+#undef CV2_BIG_LDS
         once = true;
     }
     *out = h;
@@ -921,6 +930,9 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
     };
     if (cw.w3 && !fp32_only) {
         a.w3 = cw.w3;
+        // the kernels with the tap count at compile time (counted waits around the weight register sets); CV2_HIFT_TAPS_CT=0: the run-time loop (A/B)
+        static const bool taps_env = !(getenv("CV2_HIFT_TAPS_CT") && getenv("CV2_HIFT_TAPS_CT")[0] == '0');
+        const int taps_ct = taps_env ? cw.taps : 0;
         // fewer 128-frame blocks than CUs (one utterance's 256- and 512-channel stages): 64-frame blocks; CV2_HIFT_BT64=0: A/B, diagnostics
         static const bool bt64 = !(getenv("CV2_HIFT_BT64") && getenv("CV2_HIFT_BT64")[0] == '0');
         const long blocks128 = (long)((L_out + CV_BT - 1) / CV_BT) * (cw.cout_pad / 64) * g_hz_n;
@@ -928,12 +940,20 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
         static const long bt64_max = getenv("CV2_HIFT_BT64_MAX") ? atol(getenv("CV2_HIFT_BT64_MAX")) : 200;     // (260, one 128-frame block per CU: a lone 900-frame call 5.07 -> 4.76 ms, but 32 utterances on the pool's four streams 81.0 -> 83.5 ms: kept at 200)
         if (bt64 && blocks128 < bt64_max) {
             const size_t sm = (size_t)(64 + (cw.taps - 1) * cw.dil) * C6_LD * 2 * 3;
-            { const dim3 g_ = grid_for(64, true); hipLaunchKernelGGL(k_conv6<1>, g_, dim3(256), sm, s, a); }      // (sets a.xcd_ch first)
+            const dim3 g_ = grid_for(64, true);                // (sets a.xcd_ch first)
+            if (taps_ct == 3) hipLaunchKernelGGL((k_conv6<1, 3>), g_, dim3(256), sm, s, a);
+            else if (taps_ct == 7) hipLaunchKernelGGL((k_conv6<1, 7>), g_, dim3(256), sm, s, a);
+            else if (taps_ct == 11) hipLaunchKernelGGL((k_conv6<1, 11>), g_, dim3(256), sm, s, a);
+            else hipLaunchKernelGGL((k_conv6<1, 0>), g_, dim3(256), sm, s, a);
             CV2_LAUNCH_CHECK();
             return 0;
         }
         const size_t sm = (size_t)(CV_BT + (cw.taps - 1) * cw.dil) * C6_LD * 2 * 3;
-        { const dim3 g_ = grid_for(CV_BT, true); hipLaunchKernelGGL(k_conv6<2>, g_, dim3(256), sm, s, a); }      // (sets a.xcd_ch first)
+        const dim3 g_ = grid_for(CV_BT, true);                 // (sets a.xcd_ch first)
+        if (taps_ct == 3) hipLaunchKernelGGL((k_conv6<2, 3>), g_, dim3(256), sm, s, a);
+        else if (taps_ct == 7) hipLaunchKernelGGL((k_conv6<2, 7>), g_, dim3(256), sm, s, a);
+        else if (taps_ct == 11) hipLaunchKernelGGL((k_conv6<2, 11>), g_, dim3(256), sm, s, a);
+        else hipLaunchKernelGGL((k_conv6<2, 0>), g_, dim3(256), sm, s, a);
         CV2_LAUNCH_CHECK();
         return 0;
     }
@@ -965,8 +985,19 @@ static int respair_launch(const cv2_conv& c1, const float* al1, const cv2_conv& 
     const int BTo = 128 - (c1.taps - 1);
     const size_t rows1 = 128 + (size_t)(c1.taps - 1) * c1.dil, rowsB = 128 + c1.taps - 1;
     const size_t sm = std::max(rows1 * C6_LD, rowsB * (size_t)(C + 8)) * 2 * 3;
-    if (C == 64) hipLaunchKernelGGL(k_respair<1>, dim3((L + BTo - 1) / BTo, 1, g_hz_n), dim3(256), sm, s, a);
-    else hipLaunchKernelGGL(k_respair<2>, dim3((L + BTo - 1) / BTo, 1, g_hz_n), dim3(512), sm, s, a);
+    static const bool taps_env = !(getenv("CV2_HIFT_TAPS_CT") && getenv("CV2_HIFT_TAPS_CT")[0] == '0');
+    const int t = taps_env ? c1.taps : 0;
+    const dim3 g((L + BTo - 1) / BTo, 1, g_hz_n);
+#define CV2_RP_GO(CT, NT)                                                                                       \
+    do {                                                                                                          \
+        if (t == 3) hipLaunchKernelGGL((k_respair<CT, 3>), g, dim3(NT), sm, s, a);                                  \
+        else if (t == 7) hipLaunchKernelGGL((k_respair<CT, 7>), g, dim3(NT), sm, s, a);                             \
+        else if (t == 11) hipLaunchKernelGGL((k_respair<CT, 11>), g, dim3(NT), sm, s, a);                           \
+        else hipLaunchKernelGGL((k_respair<CT, 0>), g, dim3(NT), sm, s, a);                                         \
+    } while (0)
+    if (C == 64) CV2_RP_GO(1, 256);
+    else CV2_RP_GO(2, 512);
+#undef CV2_RP_GO
     CV2_LAUNCH_CHECK();
     return 0;
 }
