@@ -833,12 +833,15 @@ def main():
     ap.add_argument('--fresh-threads', action='store_true', help='concurrent calls from new threads per round instead of persistent workers (CallerPool)')
     args = ap.parse_args()
     CallerPool.fresh = bool(args.fresh_threads)
-    if args.steps is None:
-        args.steps = 6 if args.gpus == 1 else 2
-    if args.warmup is None:
-        args.warmup = 2 if args.gpus == 1 else 1
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus > 1 and 'RANK' not in os.environ:
+    # CV2_BENCH_FORCE_SHARDED=1 --gpus 1: the configs[3] path (run_sharded: RCCL process group, broadcast / scatter / gather on device tensors,
+    # tts(device_output=True)) with a world of ONE rank -- the only way to execute the `nccl` branch of cv2amd/shard.py on a one-GPU box
+    force_sharded = os.environ.get('CV2_BENCH_FORCE_SHARDED') == '1'
+    if args.steps is None:
+        args.steps = 6 if (args.gpus == 1 and not force_sharded) else 2
+    if args.warmup is None:
+        args.warmup = 2 if (args.gpus == 1 and not force_sharded) else 1
+    if (args.gpus > 1 or force_sharded) and 'RANK' not in os.environ:
         # started without a launcher: spawn one rank per GPU as CHILD processes before anything in this process touches the GPU
         # (a process that has initialised the GPU must never exec another program on this pool)
         port = os.environ.get('MASTER_PORT', '29531')
@@ -852,7 +855,7 @@ def main():
     if not os.path.exists(L.LIB_PATH) and os.environ.get('CV2_BENCH_FAKE_SYNTH') != '1':
         import __graft_entry__
         __graft_entry__.build()
-    if world == 1:
+    if world == 1 and not force_sharded:
         run_single(args)
     else:
         run_sharded(args)

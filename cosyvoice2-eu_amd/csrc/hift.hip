@@ -897,18 +897,25 @@ extern "C" int cv2_hift_debug_modes(int32_t pair, int32_t xcd_split) {
     return 0;
 }
 
+// CV2_HIFT_FP32=1: the fp32 matrix-core kernel (k_conv) for every convolution (A/B switch)
+static bool hift_fp32_only() {
+    static const bool v = getenv("CV2_HIFT_FP32") && getenv("CV2_HIFT_FP32")[0] == '1';
+    return v;
+}
+
 static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out, int ldo, long out_off, int L_out, int pre,
                        const float* alpha, float slope, const float* res, int ldres, int post, int acc, hipStream_t s,
                        int ld_in = 0, long flat_off = 0, long flat_n = 0) {
     ConvArgs a{};
     a.ld_in = ld_in; a.flat_off = flat_off; a.flat_n = flat_n;
-    CV2_CHECK(ld_in == 0 || (cw.w3 && cw.taps == 1), "hift conv: flat windows need the three-plane weights and one tap");
+    const bool fp32_only = hift_fp32_only();
+    // (k_conv ignores ld_in / flat_off: with a flat window it would read x[t * Cin + c] past the source STFT)
+    CV2_CHECK(ld_in == 0 || (cw.w3 && cw.taps == 1 && !fp32_only), "hift conv: flat windows need the three-plane kernel (k_conv6) and one tap");
     a.x = x; a.L_in = L_in; a.Cin = cw.cin; a.wp = cw.w; a.bias = cw.b; a.CinP = cw.cin_pad; a.CoutP = cw.cout_pad;
     a.Cout_store = cw.cout; a.taps = cw.taps; a.dil = cw.dil; a.pad_left = cw.pad_left; a.pre = pre; a.alpha = alpha; a.slope = slope;
     a.L_out = L_out; a.out = out; a.ldo = ldo; a.out_off = out_off; a.res = res; a.ldres = ldres; a.post = post; a.acc = acc;
     a.zs = g_hz_zs;
     CV2_CHECK(cw.cin_pad % 64 == 0 && cw.cout_pad % 64 == 0 && cw.w, "hift conv: bad packed weight (cin_pad %d cout_pad %d)", cw.cin_pad, cw.cout_pad);
-    static const bool fp32_only = getenv("CV2_HIFT_FP32") && getenv("CV2_HIFT_FP32")[0] == '1';      // A/B switch: the fp32 matrix-core kernel everywhere
     // How the 8 XCDs (one L2 each) share a launch: split nch ways over the output-channel tiles and 8 / nch ways over the frame tiles, the
     // weights then cross the fabric 8 / nch times and the input rows nch times (xcd_tile_split).  Round 3 always took nch = 1 (every L2
     // pulls all the weights: 8 x 19 MB for the first upsampling layer, whose input is 1 MB).  CV2_HIFT_XCD_SPLIT=0: that form (A/B)
@@ -925,7 +932,7 @@ static int conv_launch(const cv2_conv& cw, const float* x, int L_in, float* out,
                 if (gy % n == 0 && (8 / n) * W + n * A < best) { best = (8 / n) * W + n * A; nch = n; }
         }
         a.xcd_ch = nch;
-        const int nfr = 8 / nch;
+        const int nfr = nch > 1 ? 8 / nch : 1;                   // (the unsplit order takes any grid: no padding blocks for short chunks)
         return dim3((gx + nfr - 1) / nfr * nfr, gy, g_hz_n);
     };
     if (cw.w3 && !fp32_only) {
@@ -1009,7 +1016,7 @@ static int resblock(cv2_hift* h, const cv2_resblock& rb, const float* x, int L, 
     static const bool pair_env = !(getenv("CV2_HIFT_PAIR") && getenv("CV2_HIFT_PAIR")[0] == '0');
     const int pair_dbg = g_pair_mode.load();
     const bool pair_on = pair_dbg < 0 ? pair_env : pair_dbg != 0;
-    static const bool fp32_only = getenv("CV2_HIFT_FP32") && getenv("CV2_HIFT_FP32")[0] == '1';
+    const bool fp32_only = hift_fp32_only();
     // (a short signal leaves most CUs without a block, and a fused block's two convolutions run one after the other: below pair_min blocks
     // the two launches with their 64-frame blocks are faster -- 90 frames: 2.25 against 2.51 ms per call with every pair fused; with the
     // threshold at 100 blocks 500 / 250 / 150 / 90 frames take 2.93 / 2.48 / 2.27 / 2.25 ms against 3.35 / 2.66 / 2.40 / 2.25 unfused)
@@ -1165,7 +1172,7 @@ static int hift_run(cv2_hift* h, const float* mel, int32_t T, const float* cache
         {
             CV2_CHECK((F + 2 * sd_p[i] - sd_k[i]) / sd_s[i] + 1 == L, "hift: source_down length %d != %d", (F + 2 * sd_p[i] - sd_k[i]) / sd_s[i] + 1, L);
             static const bool sd_scalar = getenv("CV2_HIFT_SD_SCALAR") && getenv("CV2_HIFT_SD_SCALAR")[0] == '1';      // A/B switch (diagnostics)
-            if (w.sd_conv[i].w3 && !sd_scalar) {
+            if (w.sd_conv[i].w3 && !sd_scalar && !hift_fp32_only()) {      // (CV2_HIFT_FP32=1: k_conv knows no flat windows -> the scalar kernel)
                 // the strided convolution over [F][18] rows as a 1-tap convolution over flat windows of 18 k floats on the matrix cores (k_conv6)
                 if (conv_launch(w.sd_conv[i], h->sstft, L, h->sd, C, 0, L, PRE_NONE, nullptr, 0.f, nullptr, 0, POST_NONE, ACC_STORE, s,
                                 18 * sd_s[i], -18l * sd_p[i], 18l * F)) return -1;

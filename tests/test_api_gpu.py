@@ -265,3 +265,33 @@ def test_evaluation_harness_contract(cv):
     finally:
         fe.frontend_zero_shot, fe.tokenize = real_zero_shot, real_tok
         cv.frontend.spk2info.pop('eval_cached_prompt', None)
+
+
+def test_sharded_path_over_rccl_world_of_one():
+    """configs[3]'s code path on the one GPU of this box: `CV2_BENCH_FORCE_SHARDED=1 bench.py --gpus 1` spawns ONE rank under
+    torch.distributed.run with backend `nccl` (= RCCL), so cv2amd/shard.py's device branch runs for real: broadcast_prompt on device
+    tensors, scatter_texts from a device list, 4 utterances through tts(device_output=True), gather_waves device to device and ONE
+    copy to the host.  bench.py itself asserts the gathered waveforms' lengths against the forced-length rule
+    (the harness pattern: evaluation/cosyvoice_synthesizer.py:219,260)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, CV2_BENCH_FORCE_SHARDED='1', CV2_BENCH_PER_GPU='4', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'CV2_BENCH_BACKEND', 'CV2_BENCH_FAKE_SYNTH'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '1'], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['backend'].startswith('nccl = RCCL') and out['ranks_seen'] == 1 and out['n_gpus'] == 1
+    assert 'configs[3]' in out['config']['workload'] and out['config']['batch_per_gpu'] == 4 and out['data'] == 'synthetic'
+    assert out['per_rank'][0]['utts_per_step'] == 4 and out['per_rank'][0]['device'].startswith('cuda:') and out['value'] > 0
