@@ -111,6 +111,13 @@ class CosyVoice2:
             yield model_output
             start_time = time.time()
 
+    def inference_sft(self, tts_text, spk_id, stream=False, speed=1.0, text_frontend=True):
+        """cli/cosyvoice.py:81-90 (inherited by CosyVoice2): a speaker of spk2info by id, no prompt.  A CosyVoice2 model dir has no
+        spk2info.pt, so an unknown `spk_id` raises the reference's KeyError (frontend.py:487)."""
+        for i in self.frontend.text_normalize(tts_text, split=True, text_frontend=text_frontend):
+            model_input = self.frontend.frontend_sft(i, spk_id)
+            yield from self._run(model_input, stream, speed, i)
+
     def inference_zero_shot(self, tts_text, prompt_text, prompt_speech_16k, zero_shot_spk_id='', stream=False, speed=1.0, text_frontend=True):
         prompt_text = self.frontend.text_normalize(prompt_text, split=False, text_frontend=text_frontend)
         for i in self.frontend.text_normalize(tts_text, split=True, text_frontend=text_frontend):

@@ -55,6 +55,13 @@ class PrecomputedFrontEnd:
         t = torch.tensor([ids], dtype=torch.int32)
         return t, torch.tensor([t.shape[1]], dtype=torch.int32)
 
+    def frontend_sft(self, tts_text, spk_id):
+        """frontend.py:485-489: text ids + the stored speaker embedding of `spk_id` (spk2info.pt of an SFT model dir).  A CosyVoice2 model
+        dir ships no spk2info: an unknown id raises KeyError exactly as the reference's `self.spk2info[spk_id]` does."""
+        tts_text_token, tts_text_token_len = self._extract_text_token(tts_text)
+        embedding = self.spk2info[spk_id]['embedding']
+        return {'text': tts_text_token, 'text_len': tts_text_token_len, 'llm_embedding': embedding, 'flow_embedding': embedding}
+
     def frontend_zero_shot(self, tts_text, prompt_text, prompt_speech_16k, resample_rate, zero_shot_spk_id):
         if zero_shot_spk_id == '':
             raise FrontEndUnavailable('prompt feature extraction needs onnxruntime + whisper + the model_dir ONNX files; '

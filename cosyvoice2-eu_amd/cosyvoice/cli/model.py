@@ -109,6 +109,10 @@ class CosyVoice2Model:
         # their way (their prefills and shared decode bursts run meanwhile, this stream's rows included).  0: off.
         self.first_round_hold_ms = float(os.environ.get('CV2_FIRST_ROUND_HOLD_MS', '80'))
         self.first_round_hold_cap = float(os.environ.get('CV2_FIRST_ROUND_HOLD_CAP', '1.5'))      # longest hold of one chunk, in units of first_round_hold_ms
+        # ... and only for newcomers that are CLOSE to their first chunk: a newcomer is expected to submit as long after its call as the
+        # holding call took (call -> first submit); the hold covers newcomers expected within this window, the others meet the next round.
+        # Under sustained arrivals (there is always a newcomer) a first chunk then pays at most the window, not the cap, for lock-step
+        self.first_round_hold_window_ms = float(os.environ.get('CV2_FIRST_ROUND_HOLD_WINDOW_MS', '40'))
         self._first_pending = {}               # uuid -> time of the call, until its first chunk is submitted
         self._chunks_active = 0                # chunk rounds (flow + HiFT) in progress: decode bursts beside them take the launches
         self._bi_incoming = 0                  # generator-text calls that have entered tts() but not yet joined the hub
@@ -427,16 +431,21 @@ class CosyVoice2Model:
         if self._sched_log is not None:
             self._sched_log.append((time.perf_counter(), 'submit', dict(queued=len(self._chunk_q), offset=offset)))
         if stream and not finalize and offset == 0:
-            self._first_pending.pop(this_uuid, None)
+            with self.lock:
+                t_call = self._first_pending.pop(this_uuid, None)
             hold = self.first_round_hold_ms * 1e-3
             if hold > 0:
                 t_sub, held = time.perf_counter(), False
                 t_cap = t_sub + self.first_round_hold_cap * hold              # (arrivals that never stop must not hold a chunk for ever)
+                own = t_sub - t_call if t_call is not None else hold          # what this call took from tts() to its first chunk
+                window = self.first_round_hold_window_ms * 1e-3
                 while not c.done and not c.taken:                             # (taken: a round has this chunk -- get in line)
                     now = time.perf_counter()
+                    with self.lock:                                           # (one consistent view of the newcomers and of the queue)
+                        pend = list(self._first_pending.values())
+                        n_wait = sum(1 for q in self._chunk_q if q.offset == 0 and q.stream and not q.finalize)
                     # (from three calls on: two calls 30 ms apart are as well off with a round each -- measured 73 / 121 ms p50 / max either way)
-                    n_new = sum(1 for t0 in list(self._first_pending.values()) if now - t0 < hold)
-                    n_wait = sum(1 for q in list(self._chunk_q) if q.offset == 0 and q.stream and not q.finalize)
+                    n_new = sum(1 for t0 in pend if now - t0 < hold and t0 + own - now <= window)
                     if now >= t_cap or n_new == 0 or n_new + max(n_wait, 1) < 3:
                         break
                     held = True
@@ -1039,7 +1048,8 @@ class CosyVoice2Model:
                 if self.flow_cache and self.prompt_cache_max > 0:              # identity of the prompt: tokens + checksums of mel and embedding
                     pkey = (tuple(flow_prompt_speech_token.flatten().tolist()), float(prompt_speech_feat.double().sum()),
                             float(flow_embedding.double().sum()))
-                self._first_pending[this_uuid] = t_call
+                with self.lock:
+                    self._first_pending[this_uuid] = t_call
                 self._llm_start(slot, text_d, ptext_d, lptok_d, force_len)     # prefill draws token 0; the first pass of the loop below
                 while True:                                                    # requests the rest of the first chunk's tokens
                     this_tok, finished = None, False
@@ -1088,7 +1098,8 @@ class CosyVoice2Model:
                 with torch.cuda.stream(self.llm_stream):
                     self.llm.park(slot)
                 self.llm_stream.synchronize()
-            self._first_pending.pop(this_uuid, None)
+            with self.lock:
+                self._first_pending.pop(this_uuid, None)
             self._exit_shared(slot)
             with self.lock:
                 self.tts_speech_token_dict.pop(this_uuid, None)

@@ -38,7 +38,7 @@ int cv2_fail(const char* fmt, ...) {
     return -1;
 }
 extern "C" const char* cv2_last_error(void) { return g_cv2_err.c_str(); }
-extern "C" int cv2_version(void) { return 1; }
+extern "C" int cv2_version(void) { return CV2_ABI_VERSION; }
 
 #define ST CV2_LLM_STATE_STRIDE
 

@@ -100,3 +100,54 @@ def validate(llm_sd, flow_sd, hift_sd):
     check(flow_sd, 'flow', strict=True)
     check(hift_sd, 'hift', strict=True)
     return llm_sd, flow_sd, hift_sd
+
+
+def verify_dir(model_dir, final=True, out=print):
+    """`python -m cv2amd.checkpoint --verify <model_dir>`: the strict key / shape diff of llm.pt, flow.pt, hift.pt (`final=False`:
+    the `-original` files of cli/cosyvoice.py:240-265) against the architecture the HIP engines implement, without touching a GPU.
+    The first person with real weights learns from ONE command whether `load_state_dict(strict=True)` of the reference's classes would
+    hold — in particular whether the estimator's attention projections carry biases (diffusers `Attention(bias=...)`, matcha
+    transformer.py:168,201: the q / k / v-without-bias reading of SURVEY.md §8(c) is confirmed or refuted here).  Returns the number of
+    problems found."""
+    import os
+    bad = 0
+    suffix = '' if final else '-original'
+    for kind in ('llm', 'flow', 'hift'):
+        path = os.path.join(model_dir, '{}{}.pt'.format(kind, suffix))
+        if not os.path.exists(path):
+            out('{}: MISSING FILE {}'.format(kind, path))
+            bad += 1
+            continue
+        sd = strip(torch.load(path, map_location='cpu', weights_only=True), kind)
+        missing, unexpected, mism = check(sd, kind, strict=False)
+        n_par = sum(v.numel() for v in sd.values() if torch.is_tensor(v))
+        out('{}: {} tensors, {:.1f} M parameters in {}'.format(kind, sum(torch.is_tensor(v) for v in sd.values()), n_par / 1e6, path))
+        unused = [k for k in missing if kind == 'llm' and k in LLM_UNUSED]
+        missing = [k for k in missing if k not in unused]
+        qkv_bias = [k for k in unexpected if any(k.endswith('attn1.to_{}.bias'.format(x)) for x in 'qkv')]
+        for k in unused:
+            out('  note: {} absent (not read by the decode path)'.format(k))
+        for k in missing:
+            out('  MISSING    {}'.format(k))
+        for k in unexpected:
+            out('  UNEXPECTED {} {}'.format(k, tuple(sd[k].shape) if torch.is_tensor(sd[k]) else type(sd[k]).__name__))
+        for m in mism:
+            out('  ' + m)
+        if qkv_bias:
+            out('  => the estimator was built with attention_bias=True ({} q/k/v bias tensors): the HIP kernels implement q / k / v WITHOUT '
+                'bias (DESIGN.md section 2) and refuse this checkpoint'.format(len(qkv_bias)))
+        elif kind == 'flow' and not (missing or unexpected or mism):
+            out('  => strict load holds: q / k / v projections carry no bias, to_out carries one (the reading of SURVEY.md 8(c) is confirmed)')
+        bad += len(missing) + len(unexpected) + len(mism)
+    out('OK: the three checkpoints match the architecture key for key, shape for shape' if bad == 0 else '{} problem(s)'.format(bad))
+    return bad
+
+
+if __name__ == '__main__':
+    import argparse
+    import sys
+    ap = argparse.ArgumentParser(description='strict key / shape check of a CosyVoice2 model directory against the MI355X engines (CPU only)')
+    ap.add_argument('--verify', metavar='MODEL_DIR', required=True)
+    ap.add_argument('--original', action='store_true', help='check llm-original.pt / flow-original.pt / hift-original.pt (setting="original")')
+    a = ap.parse_args()
+    sys.exit(1 if verify_dir(a.verify, final=not a.original) else 0)

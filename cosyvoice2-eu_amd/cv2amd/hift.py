@@ -209,6 +209,12 @@ class HiftEngine:
                                             L.ptr(nz), C.c_uint64(seed), L.ptr(wav), L.ptr(src), L.stream_ptr()))
         return wav, src
 
+    def debug_f0(self, T):
+        """Test hook: the f0 track [T] (Hz) of the last inference() call of this engine (the graph path of short calls keeps its own)."""
+        out = torch.empty(T, dtype=torch.float32, device=self.device)
+        L.check(self.lib.cv2_hift_debug_f0(self.handle, L.ptr(out), T, L.stream_ptr()))
+        return out
+
     def change_speed(self, mel, speed):
         """cli/model.py:328-330: F.interpolate(tts_mel, size=int(T / speed), mode='linear') on the device (cv2_interp_linear);
         mel [1, 80, T] fp32."""

@@ -7,6 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CV2_AMD_LIB') or os.path.join(_HERE, 'libcv2amd.so')   # CV2_AMD_LIB: diagnostic builds (tools/)
+ABI_VERSION = 2          # include/cv2_amd.h: CV2_ABI_VERSION the ctypes mirrors of this package (lib.py, llm.py, flow.py, hift.py) were written against
 _lib = None
 
 STATE_STRIDE = 16
@@ -45,6 +46,9 @@ def lib():
             raise Cv2Error(f'{LIB_PATH} not found: the HIP extension is not built; there is no CPU fallback')
         L = C.CDLL(LIB_PATH)
         L.cv2_last_error.restype = C.c_char_p
+        got = L.cv2_version()
+        if got != ABI_VERSION:              # a stale build: its structs differ from the mirrors here (pointers would be misread silently)
+            raise Cv2Error(f'{LIB_PATH} has ABI revision {got}, this package needs {ABI_VERSION}: rebuild it (python __graft_entry__.py)')
         L.cv2_llm_workspace_bytes.restype = C.c_size_t
         L.cv2_llm_workspace_bytes.argtypes = [C.POINTER(LlmDims)]
         L.cv2_llm_create.argtypes = [C.POINTER(LlmDims), C.POINTER(LlmWeights), C.POINTER(LlmIO), C.c_void_p, C.c_size_t,
@@ -60,6 +64,8 @@ def lib():
         L.cv2_llm_debug_sample.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.cv2_flow_debug_attn_dma.argtypes = [C.c_int32]
         L.cv2_hift_debug_modes.argtypes = [C.c_int32, C.c_int32]
+        L.cv2_hift_debug_precision.argtypes = [C.c_int32]
+        L.cv2_hift_debug_f0.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.cv2_llm_extend.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.cv2_llm_prefill_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]
         L.cv2_llm_extend_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]
@@ -90,5 +96,5 @@ def ptr(t):
 EXPORTS = ['cv2_last_error', 'cv2_version', 'cv2_llm_workspace_bytes', 'cv2_llm_create', 'cv2_llm_destroy',
            'cv2_llm_prefill', 'cv2_llm_prefill_batch', 'cv2_llm_extend', 'cv2_llm_extend_batch', 'cv2_llm_decode', 'cv2_llm_decode_ex', 'cv2_llm_decode_rows', 'cv2_llm_one_launch_step', 'cv2_llm_debug_ptrs', 'cv2_llm_debug_skip_publish', 'cv2_llm_debug_sample', 'cv2_skinny_gemm', 'cv2_gemm_bf16',
            'cv2_flow_workspace_bytes', 'cv2_flow_create', 'cv2_flow_destroy', 'cv2_flow_inference', 'cv2_flow_inference_chunk', 'cv2_flow_cache_bytes', 'cv2_flow_cache_copy', 'cv2_flow_debug_attn_dma', 'cv2_flow_estimator',
-           'cv2_flow_encoder', 'cv2_hift_workspace_bytes', 'cv2_hift_create', 'cv2_hift_destroy', 'cv2_hift_inference', 'cv2_hift_inference_batch', 'cv2_hift_debug_modes',
+           'cv2_flow_encoder', 'cv2_hift_workspace_bytes', 'cv2_hift_create', 'cv2_hift_destroy', 'cv2_hift_inference', 'cv2_hift_inference_batch', 'cv2_hift_debug_modes', 'cv2_hift_debug_precision', 'cv2_hift_debug_f0',
            'cv2_fade_in_out', 'cv2_interp_linear', 'cv2_melspec', 'cv2_resample', 'cv2_framefeat', 'cv2_whisper_post', 'cv2_sub_col_mean', 'cv2_dbg_act', 'cv2_dbg_pre']

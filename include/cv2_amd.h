@@ -24,6 +24,10 @@ extern "C" {
 #endif
 
 const char* cv2_last_error(void);
+/* ABI revision of the structs and entry points below; bumped whenever a struct's layout or a signature changes (2: cv2_hift_weights gained
+ * sd_conv[3] in front of src_rb).  cv2_version() returns the library's; a binding built against another revision must refuse to run
+ * (cv2amd/lib.py does) -- a stale libcv2amd.so would otherwise misread every pointer behind the changed field without any error. */
+#define CV2_ABI_VERSION 2
 int cv2_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -354,6 +358,12 @@ int cv2_hift_destroy(cv2_hift* h);
  * -1 = the default.  All four combinations produce the same waveform bit for bit.  Process-wide; calls of <= 160 frames replay graphs
  * captured under the mode of their first call. */
 int cv2_hift_debug_modes(int32_t pair, int32_t xcd_split);
+/* Test hook: how the convolutions with plane weights multiply.  2 = two bf16 planes per operand, three products (~2^-15 of a term; the
+ * default since round 6), 0 = three planes, six products (fp32-equivalent; CV2_HIFT_PLANES=3), 1 = the fp32 matrix-core kernel everywhere
+ * (CV2_HIFT_FP32=1), -1 = what the environment says.  Process-wide; graphs as for cv2_hift_debug_modes. */
+int cv2_hift_debug_precision(int32_t mode);
+/* Test hook: the f0 track [T] (Hz; ConvRNNF0Predictor.forward, f0_predictor.py:55-58) of the engine's last cv2_hift_inference call. */
+int cv2_hift_debug_f0(cv2_hift* h, float* out, int32_t T, void* stream);
 /* mel fp32 [80][T] (channel-major, the reference's speech_feat[0]); cache_source fp32 [n_cache] or NULL;
  * noise: fp32 [480 T][9] standard normals injected in place of the reference's randn_like (generator.py:334), or NULL
  * to draw them on the device from Philox(seed); wav fp32 [480 T]; source fp32 [480 T]. */

@@ -236,6 +236,21 @@ def gen_fullsize():
          wav_absmax=wav.abs().max(), mel_absmax=mel.abs().max())
 
 
+def gen_chain_rounded():
+    """Scale for the chain-level waveform tolerance (tests/test_fullsize_gpu.py::test_chain_tokens_to_waveform_vs_reference_chain): the mel of
+    fullsize.npz's tokens from the ORACLE flow in rounded-operand mode (every matrix-product operand rounded to bf16 where the HIP path
+    rounds, everything else fp32) -- what bf16 operand rounding alone does in the reference's arithmetic.  ~100 s of CPU, hence a fixture."""
+    gd = np.load(os.path.join(HERE, 'fullsize.npz'))
+    inp = synth.synthetic_inputs(prompt_len=int(gd['prompt_len']))
+    fsd = synth.make_flow()
+    with torch.inference_mode():
+        mo = OF.inference(fsd, torch.from_numpy(gd['token']), inp['prompt_token'], inp['prompt_feat'], inp['embedding'], False, True)
+        assert (mo[0] - torch.from_numpy(gd['mel'])).abs().max() < 5e-5, 'oracle flow no longer reproduces the reference mel of fullsize.npz'
+        with OF.rounded_operands():
+            mr = OF.inference(fsd, torch.from_numpy(gd['token']), inp['prompt_token'], inp['prompt_feat'], inp['embedding'], False, True)
+    save('chain_rounded.npz', mel_rounded=mr[0])
+
+
 TEXT_SAMPLES = [
     "Bonjour, je m'appelle Claire et j'habite à Lyon. Aujourd'hui nous allons parler de la synthèse vocale ! Est-ce que vous êtes prêts ? "
     "La première partie concerne les modèles de langage : ils prédisent des jetons de parole; la seconde partie concerne le vocodeur. "

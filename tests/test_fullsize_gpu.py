@@ -131,6 +131,68 @@ def test_hift_500_frames_vs_reference_golden(golden, dev):
     assert ew < 5e-4, f'waveform abs err {ew:.3e} (range {float(gd["wav_absmax"]):.3f})'
 
 
+def test_chain_tokens_to_waveform_vs_reference_chain(golden, flow1, dev):
+    """THE waveform tolerance of the chain (north_star: "waveforms match within a stated fp tolerance"), at the configs[1] shape: the same 250
+    tokens + FR prompt through HIP flow -> HIP HiFT, against the REFERENCE's chain -- the reference's own flow.inference mel of those tokens
+    (tests/golden/fullsize.npz) through oracle.hift, which reproduces the reference's HiFTGenerator bit for bit (checked here against the
+    fixture's stored samples) -- with the same injected noise.  Sample-wise the two decorrelate (the sine source integrates f0 to ~1e5 rad;
+    a mel difference at the bf16 level moves the phase), so the distance is taken in the domain the reference's evaluation uses:
+    log-mel spectral distance (evaluation/metrics_computer.py:311 compute_lsd_mel_db) and the f0 tracks' gross pitch error / RMSE /
+    correlation / voicing mismatch (:550 compute_pitch_metrics), tests/_metrics.py.  For scale the same distances between two REFERENCE
+    renderings that differ only in their noise draws (what two runs of the reference itself differ by) are recorded beside them."""
+    import _metrics as M
+    from cv2amd import synth
+    from cv2amd.hift import HiftEngine
+    from oracle import hift as OH
+    gd = golden('fullsize.npz')
+    T = 500
+    g = torch.Generator().manual_seed(int(gd['noise_seed']))
+    ri, nz = torch.rand(1, 9, generator=g), torch.randn(1, 480 * T, 9, generator=g)
+    hsd = synth.make_hift()
+    inp = synth.synthetic_inputs(prompt_len=int(gd['prompt_len']))
+    # the HIP chain
+    mel, _ = flow1.inference(torch.from_numpy(gd['token']), None, inp['prompt_token'], None, inp['prompt_feat'], None, inp['embedding'], False, True)
+    eng = HiftEngine(hsd, dev, max_frames=512)
+    wav, _src = eng.inference(mel, None, noise=nz)
+    f0_hip = eng.debug_f0(T).cpu()
+    torch.cuda.synchronize()
+    wav = wav.cpu()[0]
+    # the reference chain
+    mel_ref = torch.from_numpy(gd['mel']).unsqueeze(0)
+    wav_ref, _ = OH.inference(hsd, mel_ref, torch.zeros(1, 1, 0), ri, nz)
+    wav_ref = wav_ref[0]
+    # (bit-equal on the CPU that made the fixture; another CPU's conv / FFT summation orders move the 1e5-rad source phase: 1.4e-4 on the GPU box)
+    assert (wav_ref[::8] - torch.from_numpy(gd['wav8'])).abs().max().item() < 5e-4, 'oracle HiFT on the fixture mel is not the reference waveform'
+    f0_ref = OH.f0_predictor(hsd, mel_ref).reshape(-1)
+    g2 = torch.Generator().manual_seed(int(gd['noise_seed']) + 1)
+    ri2, nz2 = torch.rand(1, 9, generator=g2), torch.randn(1, 480 * T, 9, generator=g2)
+    wav_ref2 = OH.inference(hsd, mel_ref, torch.zeros(1, 1, 0), ri2, nz2)[0][0]
+    lsd, lsd_floor = M.lsd_mel_db(wav_ref, wav), M.lsd_mel_db(wav_ref, wav_ref2)
+    pm = M.pitch_metrics(f0_ref.numpy(), f0_hip.numpy())
+    # ... and what bf16 operand rounding ALONE does to the chain in the reference's arithmetic: the oracle flow in rounded-operand mode
+    # (every matrix-product operand rounded to bf16 where the HIP path rounds, fp32 everything else) -> oracle HiFT, same noise
+    # (tests/golden/chain_rounded.npz, make_golden.py gen_chain_rounded: ~100 s of CPU, hence a fixture)
+    mel_rnd = torch.from_numpy(golden('chain_rounded.npz')['mel_rounded']).unsqueeze(0)
+    wav_rnd = OH.inference(hsd, mel_rnd, torch.zeros(1, 1, 0), ri, nz)[0][0]
+    lsd_rnd = M.lsd_mel_db(wav_ref, wav_rnd)
+    pm_rnd = M.pitch_metrics(f0_ref.numpy(), OH.f0_predictor(hsd, mel_rnd).reshape(-1).numpy())
+    rec = {'lsd_mel_db': lsd, 'lsd_mel_db_two_reference_noise_draws': lsd_floor, 'lsd_mel_db_bf16_operand_rounding_in_the_oracle': lsd_rnd,
+           'pitch': pm, 'pitch_bf16_operand_rounding_in_the_oracle': pm_rnd, 'mel_rel_max_rounded_oracle': rel(mel_rnd, mel_ref),
+           'sample_max_abs': float((wav - wav_ref).abs().max()), 'sample_corr': float(np.corrcoef(wav.numpy(), wav_ref.numpy())[0, 1]),
+           'wav_absmax': float(wav_ref.abs().max()), 'mel_rel_max': rel(mel.cpu(), mel_ref)}
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, 'chain_tolerance.json'), 'w') as f:
+        json.dump(rec, f)
+    assert pm['voiced_pairs'] >= 400, pm
+    # bars = what the first run measured (profiles/r6_chain_tolerance.json) plus margin; DESIGN.md section 2 states them
+    bar('chain: log-mel spectral distance HIP vs reference chain, dB', lsd, 1.0)
+    bar('chain: LSD relative to bf16 operand rounding alone in the oracle', lsd / max(lsd_rnd, 1e-9), 1.5)
+    bar('chain: gross pitch error of the f0 tracks, %', pm['gpe'], 0.5)
+    bar('chain: f0 RMSE on voiced frames, Hz', pm['f0_rmse_hz'], 3.0)
+    bar('chain: 1 - f0 correlation', 1.0 - pm['f0_corr'], 1e-2)
+    bar('chain: voiced / unvoiced mismatch, %', pm['vuv'], 0.5)
+
+
 # ------------------------------------------------------------------------------------------------ configs[2]: B = 32, FR + DE
 def _b32_requests():
     from cv2amd import synth

@@ -49,6 +49,69 @@ def test_hift_vs_reference_golden(golden, eng, dev, name, T):
     assert torch.isfinite(wav).all()
     assert es < 2e-3, f'source max abs err {es:.3e}'
     assert ew < 5e-4, f'wav max abs err {ew:.3e}'
+    # the f0 track itself (ConvRNNF0Predictor.forward, f0_predictor.py:55-58; the reference's is in the fixture): five fp32 matrix-core
+    # convolutions + the classifier.  Values are 100-300 Hz; 5e-3 Hz abs is what the source's 2e-3 bar allows for the integrated phase
+    # (measured value recorded by bar())
+    from _bars import bar
+    f0 = eng.debug_f0(T).cpu()
+    want = torch.from_numpy(gd['f0']).reshape(-1)
+    bar(f'hift f0 vs reference fixture ({name}), Hz', (f0 - want).abs().max().item(), 5e-3)
+    bar(f'hift f0 vs reference fixture ({name}), relative', ((f0 - want).abs() / want.abs().clamp_min(1.0)).max().item(), 2e-5)
+
+
+def test_precision_modes(golden, dev, hift_sd):
+    """cv2_hift_debug_precision: the fp32 matrix-core kernels everywhere (CV2_HIFT_FP32=1; the flat-window source_downs then take the
+    scalar kernel -- k_conv knows no flat windows) against the three-plane products: waveform 2e-6 abs, source identical.  And the
+    round-6 measurement that made TWO planes per operand (three products) the default: both forms against the reference fixtures, errors
+    recorded by bar() (profiles/r6_bars.jsonl: the same 4e-5 .. 1.4e-4 for both -- the f0 track's share --, 2e-6 .. 7e-6 between them)."""
+    from _bars import bar
+    from cv2amd.hift import HiftEngine
+    from cv2amd import lib as L
+    eng = HiftEngine(hift_sd, dev, max_frames=512)
+    lib = L.lib()
+    T = 300
+    g = torch.Generator().manual_seed(11)
+    mel = (torch.randn(1, 80, T, generator=g) * 2 - 4).clamp(-11.5, 2).to(dev)
+    _, nz = _noise(31, T)
+    try:
+        L.check(lib.cv2_hift_debug_precision(0))
+        w0, s0 = eng.inference(mel, None, noise=nz)
+        L.check(lib.cv2_hift_debug_precision(1))
+        w1, s1 = eng.inference(mel, None, noise=nz)
+        L.check(lib.cv2_hift_debug_precision(2))
+        w2, s2 = eng.inference(mel, None, noise=nz)
+        torch.cuda.synchronize()
+        assert torch.equal(s0, s1) and torch.equal(s0, s2)             # the source never goes through the plane products
+        bar('hift fp32-only kernels vs three planes, waveform abs', (w0 - w1).abs().max().item(), 2e-6)
+        bar('hift two planes vs three planes, waveform abs (T = 300)', (w0 - w2).abs().max().item(), 1e-4)
+        # two planes against the REFERENCE's waveforms (the bars of the default path: 5e-4 / 2e-3)
+        for name, Tg in (('hift_T24.npz', 24), ('hift_T16_cache.npz', 16)):
+            gd = golden(name)
+            _, nzg = _noise(int(gd['noise_seed']), Tg)
+            melg = torch.from_numpy(gd['mel']).to(dev)
+            cs = torch.from_numpy(gd['cache_source'])
+            wav2, src2 = eng.inference(melg, cs, noise=nzg)
+            L.check(lib.cv2_hift_debug_precision(0))
+            wav3, _ = eng.inference(melg, cs, noise=nzg)
+            L.check(lib.cv2_hift_debug_precision(2))
+            torch.cuda.synchronize()
+            bar(f'hift two planes vs reference fixture ({name}), waveform abs', (wav2.cpu() - torch.from_numpy(gd['wav'])).abs().max().item(), 5e-4)
+            bar(f'hift three planes vs reference fixture ({name}), waveform abs', (wav3.cpu() - torch.from_numpy(gd['wav'])).abs().max().item(), 5e-4)
+            bar(f'hift two planes vs reference fixture ({name}), source abs', (src2.cpu() - torch.from_numpy(gd['source'])).abs().max().item(), 2e-3)
+        gd = golden('fullsize.npz')
+        g = torch.Generator().manual_seed(int(gd['noise_seed']))
+        _ri, nzf = torch.rand(1, 9, generator=g), torch.randn(1, 480 * 500, 9, generator=g)
+        melf = torch.from_numpy(gd['mel']).unsqueeze(0).to(dev)
+        wav2, _ = eng.inference(melf, None, noise=nzf)
+        L.check(lib.cv2_hift_debug_precision(0))
+        wav3, _ = eng.inference(melf, None, noise=nzf)
+        torch.cuda.synchronize()
+        want = torch.from_numpy(gd['wav8'])
+        bar('hift two planes vs reference (500 frames), waveform abs', (wav2.cpu()[0, ::8] - want).abs().max().item(), 5e-4)
+        bar('hift three planes vs reference (500 frames), waveform abs', (wav3.cpu()[0, ::8] - want).abs().max().item(), 5e-4)
+        bar('hift two planes vs three planes (500 frames), waveform abs', (wav2 - wav3).abs().max().item(), 1e-4)
+    finally:
+        L.check(lib.cv2_hift_debug_precision(-1))
 
 
 def test_hift_vs_oracle_longer(eng, dev, hift_sd):
@@ -165,9 +228,13 @@ def test_decoder_at_real_checkpoint_ranges(dev):
 
 
 def test_split_product_convolutions_match_the_fp32_matrix_core_path(dev, hift_sd):
-    """k_conv6 (three bf16 planes per operand, six MFMA products per term) against k_conv (fp32 MFMA, exact fp32 FMA chains) on the
-    same inputs: the waveform agrees to fp32 round-off accumulated over the stack (the dropped products are below 2^-23 of a term),
-    far inside the 5e-5 bar both paths meet against the oracle; the source (f0 predictor on the fp32 matrix cores in both) is identical."""
+    """k_conv6 against k_conv (fp32 MFMA, exact fp32 FMA chains) on the same inputs.  Three bf16 planes per operand (six products per term;
+    cv2_hift_debug_precision(0)): the waveform agrees to fp32 round-off accumulated over the stack (the dropped products are below 2^-23
+    of a term).  Two planes (three products; the default since round 6): the dropped products are ~2^-15 of a term -- measured 6e-6 abs
+    on the waveform, bar 2e-5, far inside the 5e-5 both forms meet against the oracle with its source injected.  The source (f0 predictor
+    on the fp32 matrix cores in every form) is identical."""
+    from _bars import bar
+    from cv2amd import lib as L
     from cv2amd.hift import HiftEngine
     T = 130
     g = torch.Generator().manual_seed(11)
@@ -175,12 +242,18 @@ def test_split_product_convolutions_match_the_fp32_matrix_core_path(dev, hift_sd
     nz = torch.randn(1, 480 * T, 9, generator=g)
     split = HiftEngine(hift_sd, dev, max_frames=256)
     fp32 = HiftEngine(hift_sd, dev, max_frames=256, split_products=False)
-    wa, sa = split.inference(mel, None, noise=nz)
     wb, sb = fp32.inference(mel, None, noise=nz)
+    w2, s2 = split.inference(mel, None, noise=nz)                     # the default: two planes
+    try:
+        L.check(L.lib().cv2_hift_debug_precision(0))
+        w3, s3 = split.inference(mel, None, noise=nz)                 # three planes
+    finally:
+        L.check(L.lib().cv2_hift_debug_precision(-1))
     torch.cuda.synchronize()
-    assert torch.equal(sa, sb)
-    err = (wa - wb).abs().max().item()
-    assert err < 2e-6, f'{err:.3e}'
+    assert torch.equal(s3, sb) and torch.equal(s2, sb)
+    bar('hift three-plane products vs fp32 matrix cores, waveform abs', (w3 - wb).abs().max().item(), 2e-6)
+    bar('hift two-plane products (default) vs fp32 matrix cores, waveform abs', (w2 - wb).abs().max().item(), 2e-5)
+    assert not torch.equal(w2, w3)                                     # (the default really is the two-plane form)
 
 
 @pytest.mark.parametrize('T', [130, 300])

@@ -33,7 +33,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, name), f'{name} is declared in include/cv2_amd.h but not exported by libcv2amd.so'
     assert set(L.EXPORTS) <= set(declared)
     cdll.cv2_last_error.restype = ctypes.c_char_p
-    assert cdll.cv2_version() >= 1
+    import re
+    hdr = open(os.path.join(ROOT, 'include', 'cv2_amd.h')).read()
+    abi = int(re.search(r'#define\s+CV2_ABI_VERSION\s+(\d+)', hdr).group(1))
+    assert cdll.cv2_version() == abi == L.ABI_VERSION          # header, library and ctypes mirrors agree
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """A library of another ABI revision (struct layouts differ from the ctypes mirrors) must not be used."""
+    from cv2amd import lib as L
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'ABI_VERSION', L.ABI_VERSION + 1)
+    with pytest.raises(L.Cv2Error, match='ABI revision'):
+        L.lib()
 
 
 def test_product_path_refuses_to_run_without_the_library(monkeypatch):
@@ -178,6 +190,8 @@ def test_api_surface_matches_reference_signatures():
                                                 ('flow_run_id', None), ('hifigan_run_id', None), ('final', False), ('backbone', None)]
     assert params(CosyVoice2.inference_zero_shot) == [('tts_text', inspect._empty), ('prompt_text', inspect._empty), ('prompt_speech_16k', inspect._empty),
                                                      ('zero_shot_spk_id', ''), ('stream', False), ('speed', 1.0), ('text_frontend', True)]
+    assert params(CosyVoice2.inference_sft) == [('tts_text', inspect._empty), ('spk_id', inspect._empty), ('stream', False), ('speed', 1.0),
+                                                ('text_frontend', True)]                                  # cli/cosyvoice.py:81
     assert params(CosyVoice2.inference_cross_lingual) == [('tts_text', inspect._empty), ('prompt_speech_16k', inspect._empty), ('zero_shot_spk_id', ''),
                                                          ('stream', False), ('speed', 1.0), ('text_frontend', True)]
     assert params(CosyVoice2.inference_instruct2) == [('tts_text', inspect._empty), ('instruct_text', inspect._empty), ('prompt_speech_16k', inspect._empty),
@@ -203,6 +217,12 @@ def test_frontend_modes_build_the_reference_model_input():
     fe = PrecomputedFrontEnd(lambda t: [ord(c) for c in t], {'a': spk})
     z = fe.frontend_zero_shot('hi', 'x', None, 24000, 'a')
     assert set(z) == set(spk) | {'text', 'text_len'} and z['text'].tolist() == [[104, 105]] and z['text'].dtype == torch.int32
+    # frontend_sft (frontend.py:485-489): text + the stored embedding; a CosyVoice2 model dir has no spk2info -> the reference's KeyError
+    fe.spk2info['sft'] = {'embedding': torch.ones(1, 192)}
+    sft = fe.frontend_sft('hi', 'sft')
+    assert set(sft) == {'text', 'text_len', 'llm_embedding', 'flow_embedding'} and torch.equal(sft['llm_embedding'], torch.ones(1, 192))
+    with pytest.raises(KeyError):
+        fe.frontend_sft('hi', 'nobody')
     c = fe.frontend_cross_lingual('hi', None, 24000, 'a')
     assert set(c) == set(z) - {'prompt_text', 'prompt_text_len', 'llm_prompt_speech_token', 'llm_prompt_speech_token_len'}
     i2 = fe.frontend_instruct2('hi', 'speak fast', None, 24000, 'a')

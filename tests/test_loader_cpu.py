@@ -197,3 +197,30 @@ def test_text_normalize_splits_long_text_and_passes_generators_through():
     gen = (t for t in ['a', 'b'])
     assert fe.text_normalize(gen, split=True) == [gen]
     assert fe.text_normalize('Bonjour tout le monde', split=False) == 'Bonjour tout le monde.'
+
+
+def test_verify_cli_prints_the_strict_diff(tmp_path, monkeypatch):
+    """`python -m cv2amd.checkpoint --verify <model_dir>` (cv2amd/checkpoint.py:verify_dir): the key / shape diff of the three checkpoints
+    against the engines' architecture, incl. the q / k / v-bias refusal (matcha transformer.py:168,201).  The checkpoint files are stood in
+    for by meta-tensor dicts (a real llm.pt is 2 GB): torch.load is patched per file name."""
+    llm, flow, hift = synth.make_llm(layers=24, meta=True), synth.make_flow(meta=True), synth.make_hift(meta=True)
+    files = {'llm.pt': dict(llm, epoch=1, step=2), 'flow.pt': flow, 'hift.pt': {'generator.' + k: v for k, v in hift.items()}}
+    for n in files:
+        (tmp_path / n).write_bytes(b'')
+    monkeypatch.setattr(torch, 'load', lambda path, **kw: files[path.rsplit('/', 1)[1]])
+    lines = []
+    assert CK.verify_dir(str(tmp_path), out=lines.append) == 0
+    assert lines[-1].startswith('OK') and any('strict load holds' in l for l in lines)
+    # a checkpoint trained with attention_bias=True, a missing tensor, a wrong shape, a missing file
+    files['flow.pt'] = dict(flow)
+    for x in 'qkv':
+        files['flow.pt'][f'decoder.estimator.mid_blocks.0.1.0.attn1.to_{x}.bias'] = torch.empty(512, device='meta')
+    files['hift.pt'] = dict(hift)
+    del files['hift.pt']['conv_post.bias']
+    files['hift.pt']['conv_pre.bias'] = torch.empty(511, device='meta')
+    (tmp_path / 'llm.pt').unlink()
+    lines = []
+    assert CK.verify_dir(str(tmp_path), out=lines.append) == 1 + 3 + 1 + 1
+    text = '\n'.join(lines)
+    assert 'MISSING FILE' in text and 'attention_bias=True (3 q/k/v bias tensors)' in text and 'MISSING    conv_post.bias' in text
+    assert 'size mismatch for conv_pre.bias' in text and lines[-1] == '6 problem(s)'
