@@ -44,9 +44,42 @@ MFMA_BF16_PEAK = 2500.0   # TFLOP/s dense
 FP32_MFMA_PEAK = 157.3
 
 
-def llm_step_bytes(weight_bytes, kv_positions_sum, layers=24, n_kv=2):
-    # bf16 weights once per step + fp32 KV read: layers x {k, v} x kv heads x 64 x 4 B per cached position
-    return weight_bytes + layers * 2 * n_kv * 64 * 4 * kv_positions_sum
+def llm_step_bytes(weight_bytes, kv_positions_sum, layers=24, n_kv=2, kv_elem_bytes=4):
+    # bf16 weights once per step + the KV read: layers x {k, v} x kv heads x 64 x element size per cached position.
+    # kv_elem_bytes = 4: what this implementation reads (fp32 cache, 24 576 B per position); 2: SURVEY.md §8(d)'s figure (bf16 cache, 12 288 B)
+    return weight_bytes + layers * 2 * n_kv * 64 * kv_elem_bytes * kv_positions_sum
+
+
+def hift_products():
+    """bf16 MFMA products the vocoder's convolutions issue per fp32-equivalent term: 3 (two planes per operand, the default), 6 (CV2_HIFT_PLANES=3);
+    None with CV2_HIFT_FP32=1 (fp32 matrix cores)."""
+    if os.environ.get('CV2_HIFT_FP32', '0')[:1] == '1':
+        return None
+    return 6 if os.environ.get('CV2_HIFT_PLANES', '2')[:1] == '3' else 3
+
+
+def hift_mfma_fields(alg_tflops):
+    """The conv stack's matrix-core rate: issued FLOP/s (algorithmic x products per term) against the roof of the instructions it issues."""
+    n = hift_products()
+    if n is None:
+        return {'achieved': round(alg_tflops, 2), 'peak': FP32_MFMA_PEAK, 'unit': 'TFLOP/s', 'frac': round(alg_tflops / FP32_MFMA_PEAK, 4),
+                'note': 'CV2_HIFT_FP32=1: fp32 matrix cores, algorithmic FLOP/s against the fp32 MFMA roof'}
+    return {'achieved': round(n * alg_tflops, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(n * alg_tflops / MFMA_BF16_PEAK, 4),
+            'algorithmic_tflops': round(alg_tflops, 2), 'products_per_term': n,
+            'note': f'issued bf16 MFMA FLOP/s of the conv stack ({n} plane products per fp32-equivalent term of the 30.6 GFLOP per audio-second) against '
+                    'the bf16 roof its instructions run on; the f0 predictor (3.3 of the 30.6) runs on the fp32 matrix cores'}
+
+
+def rows_breakdown(rec):
+    """Decode bursts by live-row count: {group: {'steps', 'avg_step_us'}} for the row-count families of the decode step (<= 8 rows: k_step /
+    k_step2, 9-24: k_step4, 25-32: the launches); rec = StepTimer.rec after a device synchronize."""
+    groups = (('rows_25_32', 25, 32), ('rows_9_24', 9, 24), ('rows_1_8', 1, 8))
+    out = {}
+    for name, lo, hi in groups:
+        sel = [(e0.elapsed_time(e1), k) for e0, e1, n, k in rec if lo <= n <= hi]
+        steps = sum(k for _, k in sel)
+        out[name] = {'steps': steps, 'avg_step_us': round(sum(ms for ms, _ in sel) / steps * 1e3, 1) if steps else None}
+    return out
 
 
 def flow_flops(T):
@@ -252,7 +285,7 @@ def pmc_stage_file(stage):
     """The newest committed profiles/r<N>_pmc_<stage>.json (tools/pmc_stages.sh: rocprofv3 --pmc passes of one stage alone) or None.
     The dict carries its own file name ('_file'): counters cannot be read from inside the bench, so every field derived from them is
     stamped with where it came from and 'measured_in_this_run': False."""
-    for rnd in (5, 4, 3):
+    for rnd in (6, 5, 4, 3):
         p = os.path.join(ROOT, 'profiles', f'r{rnd}_pmc_{stage}.json')
         if os.path.exists(p):
             d = json.load(open(p))
@@ -475,6 +508,7 @@ def run_single(args):
     assert dec_steps == n_steps * args.steps, (dec_steps, n_steps, args.steps)
     step_us = dec_ms / dec_steps * 1e3
     step_bytes = llm_step_bytes(model.llm.weight_bytes, kv_mean)
+    step_bytes_8d = llm_step_bytes(model.llm.weight_bytes, kv_mean, kv_elem_bytes=2)
     achieved = step_bytes / (step_us * 1e-6) / 1e9
     Ts = [2 * (r['flow_prompt_speech_token'].numel() + f) for r, f in zip(reqs, forces)]
     flow_tf = sum(flow_flops(T) for T in Ts) * args.steps / (flow_t.ms() * 1e-3) / 1e12
@@ -491,20 +525,20 @@ def run_single(args):
         'config': {'workload': f'configs[{1 if B == 1 else 2}]: zero-shot FR{"+DE" if B > 1 else ""}, batch={B}, non-streaming, through CosyVoice2Model.tts() '
                                f'(scheduler + D2H of the waveform inside the timed region), P=255{"/310" if B > 1 else ""} prompt tokens, '
                                f'{TEXT_LEN} text tokens, {"250" if B == 1 else "U{150..500}"} generated tokens (forced), 10 Euler steps + CFG, RAS sampler; '
-                               f'LLM bf16 weights / fp32 KV, flow bf16 MFMA, HiFT fp32 data with three-plane bf16 MFMA products (fp32-equivalent) and fp32 MFMA for the f0 predictor', 'batch_per_gpu': B,
+                               f'LLM bf16 weights / fp32 KV, flow bf16 MFMA, HiFT fp32 data with two-plane bf16 MFMA products (three per term, ~2^-15; CV2_HIFT_PLANES=3: six, fp32-equivalent) and fp32 MFMA for the f0 predictor', 'batch_per_gpu': B,
                    'audio_s_per_step_per_gpu': round(audio_per_step, 3)},
         'roofline': {'bound': 'hbm', 'kernel': model.llm.decode_kernel_desc(B),
                      'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                     'traffic': traffic, 'traffic_source': traffic_src, 'bytes_per_launch': int(step_bytes), 'avg_launch_us': round(step_us, 2)},
+                     'traffic': traffic, 'traffic_source': traffic_src, 'bytes_per_launch': int(step_bytes), 'avg_launch_us': round(step_us, 2),
+                     # both byte counts: `achieved` / `frac` use what THIS implementation must read (fp32 KV cache: 24 576 B per cached
+                     # position); SURVEY.md 8(d) prices a bf16 cache (12 288 B per position)
+                     'bytes_per_launch_survey_8d': int(step_bytes_8d),
+                     'frac_survey_8d_bytes': round(step_bytes_8d / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
         'stages': {'ms_per_step': {'llm_decode': round(dec_ms / args.steps, 3), 'flow': round(flow_t.ms() / args.steps, 3),
                                    'hift': round(hift_t.ms() / args.steps, 3),
                                    'rest (prefill, scheduler, D2H)': round((dt * 1e3 - dec_ms - flow_t.ms() - hift_t.ms()) / args.steps, 3)},
                    'flow_mfma': {'achieved': round(flow_tf, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(flow_tf / MFMA_BF16_PEAK, 4)},
-                   'hift_fp32_mfma': {'achieved': round(hift_tf, 2), 'peak': FP32_MFMA_PEAK, 'unit': 'TFLOP/s', 'frac': round(hift_tf / FP32_MFMA_PEAK, 4),
-                                      'note': 'algorithmic (fp32-equivalent) FLOP/s against the fp32 matrix roof; k_conv6 issues 6 bf16 MFMAs per term'},
-                   'hift_bf16_mfma': {'achieved': round(6 * hift_tf, 1), 'peak': MFMA_BF16_PEAK, 'unit': 'TFLOP/s', 'frac': round(6 * hift_tf / MFMA_BF16_PEAK, 4),
-                                      'note': 'issued bf16 MFMA FLOP/s of the conv stack (6 plane products per fp32-equivalent term) against the bf16 roof its '
-                                              'instructions run on'}},
+                   'hift_mfma': hift_mfma_fields(hift_tf)},
     }
     cf, ch = counter_fields(pmc_flow, pmc_hift, hift_tf)
     if B == 1 and live.get('flow'):               # the live passes profile the configs[1] shapes: they belong to the B=1 line
@@ -551,16 +585,20 @@ def extras(model, st, flow_t, hift_t, dev):
     kv_mean, _ = kv_positions_mean([lm_rows(r) for r in reqs], forces)
     step_us = dec_ms / dec_steps * 1e3
     sb = llm_step_bytes(model.llm.weight_bytes, kv_mean)
+    sb8d = llm_step_bytes(model.llm.weight_bytes, kv_mean, kv_elem_bytes=2)
     Ts = [2 * (r['flow_prompt_speech_token'].numel() + f) for r, f in zip(reqs, forces)]
     ex['batch32'] = {'workload': 'configs[2]: 32 concurrent tts() calls on one model (16 FR P=255 + 16 DE P=310, U{150..500} forced tokens), coalesced',
                      'value': round(audio * K / dt, 2), 'unit': 'audio-s/s', 'rtf': round(dt / (audio * K), 5), 'ms_per_step': round(dt / K * 1e3, 1),
                      'batch_sizes': model.batch_sizes[n0:],
                      'roofline': {'bound': 'hbm', 'kernel': model.llm.decode_kernel_desc(32), 'achieved': round(sb / (step_us * 1e-6) / 1e9, 1),
                                   'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(sb / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                  'bytes_per_launch': int(sb), 'avg_launch_us': round(step_us, 1)},
+                                  'bytes_per_launch': int(sb), 'avg_launch_us': round(step_us, 1),
+                                  'bytes_per_launch_survey_8d': int(sb8d), 'frac_survey_8d_bytes': round(sb8d / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                  # the batch's steps by live-row count (finished requests leave the decode rows): each family is its own kernel form
+                                  'by_rows': rows_breakdown(st.rec)},
                      'stages_ms': {'llm_decode': round(dec_ms / K, 1), 'flow': round(flow_t.ms() / K, 1), 'hift': round(hift_t.ms() / K, 1)},
                      'flow_mfma_frac': round(sum(flow_flops(T) for T in Ts) * K / (flow_t.ms() * 1e-3) / 1e12 / MFMA_BF16_PEAK, 4),
-                     'hift_fp32_mfma_frac': round(30.6e9 * audio * K / (hift_t.ms() * 1e-3) / 1e12 / FP32_MFMA_PEAK, 4)}
+                     'hift_mfma_frac': hift_mfma_fields(30.6e9 * audio * K / (hift_t.ms() * 1e-3) / 1e12)['frac']}
     # ---- configs[4]: streaming, 8 concurrent calls on one model; 12 text tokens -> at most 240 speech tokens per stream (EOS is live)
     sreq = request(1986, P_TOK, 12, dev)
     out = {}
@@ -832,7 +870,7 @@ def n1_reference(per_rank, steps):
     rates = sorted(r['audio_s_per_step'] * steps / max(r['work_s'], 1e-9) for r in per_rank)
     ref = {'unit': 'audio-s/s per GPU', 'per_rank_shard_rate_median': round(rates[len(rates) // 2], 2), 'per_rank_shard_rate_min': round(rates[0], 2),
            'source': "each rank's own shard inside this run, collectives excluded"}
-    for name in ('r5_bench_b1.json', 'r4_bench_b1.json', 'r3_bench_b1.json'):
+    for name in ('r6_bench_b1.json', 'r5_bench_b1.json', 'r4_bench_b1.json', 'r3_bench_b1.json'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             with open(path) as f:

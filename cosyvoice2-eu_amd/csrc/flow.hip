@@ -982,7 +982,15 @@ struct cv2_flow {
     int* itab;                   // int tables region
     void* ptab;                  // pointer tables region
     std::vector<char> host_stage;
+    // hipGraph replay of whole cv2_flow_inference calls (round 6): every kernel argument of a call is a function of its shape key -- the
+    // utterances' token / prompt lengths, the flags -- and of engine-owned device addresses (the callers' pointers and the layouts travel
+    // through device tables uploaded before the launches), so the ~2 300 launches of a call with a shape seen before are ONE graph launch.
+    struct FlowGraph { hipGraphExec_t exec = nullptr; unsigned long last = 0; };
+    std::map<std::vector<int>, FlowGraph> graphs;       // captured shapes (LRU, FG_MAX)
+    std::map<std::vector<int>, int> seen;               // uses of shapes not captured yet (bounded)
+    unsigned long graph_tick = 0;
 };
+#define FG_MAX 6
 
 struct Carver {
     char* base; size_t off = 0;
@@ -1114,7 +1122,11 @@ extern "C" int cv2_flow_create(const cv2_flow_dims* d, const cv2_flow_weights* w
     *out = h;
     return 0;
 }
-extern "C" int cv2_flow_destroy(cv2_flow* h) { delete h; return 0; }
+extern "C" int cv2_flow_destroy(cv2_flow* h) {
+    if (h) for (auto& g : h->graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+    delete h;
+    return 0;
+}
 
 // ------------------------------------------------------------------ estimator core
 struct EstCtx { cv2_flow* h; const Layout* L; const float* temb; int chunk; hipStream_t s;
@@ -1645,6 +1657,7 @@ extern "C" int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t
         CV2_HIP(hipMemcpyAsync(ibase, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice, s));
         CV2_HIP(hipStreamSynchronize(s));
         const void* const* dp = (const void* const*)h->ptab;
+        auto launches = [&](hipStream_t s) -> int {
         // speaker projection
         SpkArgs sp{(const float* const*)dp, h->w.spk_w, h->w.spk_b, h->spk};
         hipLaunchKernelGGL(k_spk, dim3(U), dim3(128), 0, s, sp);
@@ -1677,6 +1690,54 @@ extern "C" int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t
         for (int u = 0; u < U; u++) maxn2 = std::max(maxn2, lens2[u] - utts[u].n_prompt_feat);
         MelOutArgs mo{h->xs, (float* const*)(dp + 2 * U), ibase, L2.tab()};
         hipLaunchKernelGGL(k_mel_out, dim3(((long)maxn2 * 80 + 255) / 256, U), dim3(256), 0, s, mo);
+        return 0;
+        };
+        // ---- one graph launch for a shape seen before.  A shape is captured at its (CV2_FLOW_GRAPH_AFTER + 1)-th use (default: the second),
+        // so a workload whose lengths never repeat pays nothing; CV2_FLOW_GRAPH=0: always the launches (A/B).  The key holds everything the
+        // launches' arguments and kernel choices depend on beside engine-owned addresses.
+        static const bool graph_on = !(getenv("CV2_FLOW_GRAPH") && getenv("CV2_FLOW_GRAPH")[0] == '0');
+        static const int graph_after = getenv("CV2_FLOW_GRAPH_AFTER") ? atoi(getenv("CV2_FLOW_GRAPH_AFTER")) : 1;
+        if (!graph_on) { if (launches(s)) return -1; CV2_LAUNCH_CHECK(); return 0; }
+        std::vector<int> key{U, streaming, finalize, g_att_dma.load()};
+        for (int u = 0; u < U; u++) { key.push_back(utts[u].n_tok); key.push_back(utts[u].n_prompt_feat); }
+        auto it = h->graphs.find(key);
+        if (it == h->graphs.end()) {
+            int& n = h->seen[key];
+            if (n++ < graph_after) {
+                if (h->seen.size() > 256) h->seen.clear();
+                if (launches(s)) return -1;
+                CV2_LAUNCH_CHECK();
+                return 0;
+            }
+            h->seen.erase(key);
+            CV2_HIP(hipStreamSynchronize(s));                 // (the capture stream's work must follow what `s` holds; it is replayed on `s` below)
+            hipStream_t cs = nullptr;
+            CV2_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+            int rc = -1;
+            if (e == hipSuccess) {
+                rc = launches(cs);
+                e = hipStreamEndCapture(cs, &g);
+            }
+            (void)hipStreamDestroy(cs);
+            if (rc) return rc;
+            CV2_HIP(e);
+            hipGraphExec_t ge = nullptr;
+            e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            CV2_HIP(e);
+            if ((int)h->graphs.size() >= FG_MAX) {            // drop the least recently used shape
+                auto old = h->graphs.begin();
+                for (auto j = h->graphs.begin(); j != h->graphs.end(); ++j) if (j->second.last < old->second.last) old = j;
+                (void)hipGraphExecDestroy(old->second.exec);
+                h->graphs.erase(old);
+            }
+            cv2_flow::FlowGraph fg; fg.exec = ge;
+            it = h->graphs.emplace(key, fg).first;
+        }
+        it->second.last = ++h->graph_tick;
+        CV2_HIP(hipGraphLaunch(it->second.exec, s));
     }
     CV2_LAUNCH_CHECK();
     return 0;

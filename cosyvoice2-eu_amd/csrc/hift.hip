@@ -882,6 +882,10 @@ extern "C" int cv2_hift_create(const cv2_hift_dims* d, const cv2_hift_weights* w
         CV2_BIG_LDS((k_conv6<1, 0>)); CV2_BIG_LDS((k_conv6<1, 3>)); CV2_BIG_LDS((k_conv6<1, 7>)); CV2_BIG_LDS((k_conv6<1, 11>));
         CV2_BIG_LDS((k_respair<1, 3>)); CV2_BIG_LDS((k_respair<1, 7>)); CV2_BIG_LDS((k_respair<1, 11>)); CV2_BIG_LDS((k_respair<1, 0>));
         CV2_BIG_LDS((k_respair<2, 3>)); CV2_BIG_LDS((k_respair<2, 7>)); CV2_BIG_LDS((k_respair<2, 11>)); CV2_BIG_LDS((k_respair<2, 0>));
+        CV2_BIG_LDS((k_conv6<2, 0, 2>)); CV2_BIG_LDS((k_conv6<2, 3, 2>)); CV2_BIG_LDS((k_conv6<2, 7, 2>)); CV2_BIG_LDS((k_conv6<2, 11, 2>));
+        CV2_BIG_LDS((k_conv6<1, 0, 2>)); CV2_BIG_LDS((k_conv6<1, 3, 2>)); CV2_BIG_LDS((k_conv6<1, 7, 2>)); CV2_BIG_LDS((k_conv6<1, 11, 2>));
+        CV2_BIG_LDS((k_respair<1, 3, 2>)); CV2_BIG_LDS((k_respair<1, 7, 2>)); CV2_BIG_LDS((k_respair<1, 11, 2>)); CV2_BIG_LDS((k_respair<1, 0, 2>));
+        CV2_BIG_LDS((k_respair<2, 3, 2>)); CV2_BIG_LDS((k_respair<2, 7, 2>)); CV2_BIG_LDS((k_respair<2, 11, 2>)); CV2_BIG_LDS((k_respair<2, 0, 2>));
 #undef CV2_BIG_LDS
         once = true;
     }

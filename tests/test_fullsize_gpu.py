@@ -184,12 +184,15 @@ def test_chain_tokens_to_waveform_vs_reference_chain(golden, flow1, dev):
     with open(os.path.join(OUT, 'chain_tolerance.json'), 'w') as f:
         json.dump(rec, f)
     assert pm['voiced_pairs'] >= 400, pm
-    # bars = what the first run measured (profiles/r6_chain_tolerance.json) plus margin; DESIGN.md section 2 states them
-    bar('chain: log-mel spectral distance HIP vs reference chain, dB', lsd, 1.0)
-    bar('chain: LSD relative to bf16 operand rounding alone in the oracle', lsd / max(lsd_rnd, 1e-9), 1.5)
+    # bars = what the first runs measured (profiles/r6_chain_tolerance.json) plus margin; DESIGN.md section 2 states them.  Measured: LSD 3.15 dB
+    # where bf16 operand rounding alone gives 3.40 dB in the oracle (two reference renderings with different noise: 0.18 dB -- the measure
+    # clips at -80 dB and synthetic-weight waveforms have many bands near that floor); f0 RMSE 0.27 Hz (0.28), no gross pitch error,
+    # correlation 0.99997, no voicing mismatch
+    bar('chain: log-mel spectral distance HIP vs reference chain, dB', lsd, 4.0)
+    bar('chain: LSD relative to bf16 operand rounding alone in the oracle', lsd / max(lsd_rnd, 1e-9), 1.25)
     bar('chain: gross pitch error of the f0 tracks, %', pm['gpe'], 0.5)
-    bar('chain: f0 RMSE on voiced frames, Hz', pm['f0_rmse_hz'], 3.0)
-    bar('chain: 1 - f0 correlation', 1.0 - pm['f0_corr'], 1e-2)
+    bar('chain: f0 RMSE on voiced frames, Hz', pm['f0_rmse_hz'], 0.5)
+    bar('chain: 1 - f0 correlation', 1.0 - pm['f0_corr'], 1e-4)
     bar('chain: voiced / unvoiced mismatch, %', pm['vuv'], 0.5)
 
 
