@@ -1179,6 +1179,9 @@ static int est_resnet(EstCtx& c, const cv2_resnet& rn, int ridx, uint16_t* A, in
 // -1 = the default (CV2_ATT_DMA)
 static std::atomic<int> g_att_dma{-1};
 extern "C" int cv2_flow_debug_attn_dma(int32_t on) { g_att_dma = on < 0 ? -1 : (on != 0); return 0; }
+// test hook: 1 / 0 = cv2_flow_inference replays / does not replay a hipGraph for repeated shapes, -1 = the environment (CV2_FLOW_GRAPH, default off)
+static std::atomic<int> g_flow_graph{-1};
+extern "C" int cv2_flow_debug_graph(int32_t on) { g_flow_graph = on < 0 ? -1 : (on != 0); return 0; }
 
 // transformer block; next_ln == null: last of its group -> bf16 copy of x goes to (xout, ldx).  have_qkv: the block's q / k / v^T are
 // there already (the previous block's tail kernel chained this block's QKV projection on); next_tb != null: the block that follows in the
@@ -1692,11 +1695,15 @@ extern "C" int cv2_flow_inference(cv2_flow* h, const cv2_flow_utt* utts, int32_t
         hipLaunchKernelGGL(k_mel_out, dim3(((long)maxn2 * 80 + 255) / 256, U), dim3(256), 0, s, mo);
         return 0;
         };
-        // ---- one graph launch for a shape seen before.  A shape is captured at its (CV2_FLOW_GRAPH_AFTER + 1)-th use (default: the second),
-        // so a workload whose lengths never repeat pays nothing; CV2_FLOW_GRAPH=0: always the launches (A/B).  The key holds everything the
-        // launches' arguments and kernel choices depend on beside engine-owned addresses.
-        static const bool graph_on = !(getenv("CV2_FLOW_GRAPH") && getenv("CV2_FLOW_GRAPH")[0] == '0');
+        // ---- CV2_FLOW_GRAPH=1 / cv2_flow_debug_graph(1): one graph launch for a shape seen before.  A shape is captured at its
+        // (CV2_FLOW_GRAPH_AFTER + 1)-th use (default: the second), so a workload whose lengths never repeat pays nothing.  The key holds
+        // everything the launches' arguments and kernel choices depend on beside engine-owned addresses.  OFF by default: measured at
+        // configs[1] (profiles/r6_flow_graph_ab.txt) the replay is 0.4 ms SLOWER than the 2 300 launches (flow 24.73 against 24.32 ms; the
+        // host stays ahead of the device with plain launches, and a graph's kernel nodes follow each other no faster than stream launches do)
+        static const bool graph_env = getenv("CV2_FLOW_GRAPH") && getenv("CV2_FLOW_GRAPH")[0] == '1';
         static const int graph_after = getenv("CV2_FLOW_GRAPH_AFTER") ? atoi(getenv("CV2_FLOW_GRAPH_AFTER")) : 1;
+        const int graph_dbg = g_flow_graph.load();
+        const bool graph_on = graph_dbg < 0 ? graph_env : graph_dbg != 0;
         if (!graph_on) { if (launches(s)) return -1; CV2_LAUNCH_CHECK(); return 0; }
         std::vector<int> key{U, streaming, finalize, g_att_dma.load()};
         for (int u = 0; u < U; u++) { key.push_back(utts[u].n_tok); key.push_back(utts[u].n_prompt_feat); }

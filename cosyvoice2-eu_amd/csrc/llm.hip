@@ -708,6 +708,10 @@ struct StepArgs {
 #ifdef CV2_STAMPS
 __device__ unsigned long long g_chain_t[1024][8] = {};      // per block of one layer: start, result, published, operand ready (100 MHz ticks)
 #define CH_T(i) do { if (dbg && threadIdx.x == 0) g_chain_t[r_dbg][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// slot 7 (round 6, tools/dbg_chain_tails.py): where the block ran -- XCC_ID (the XCD) in bits 32.., HW_ID (CU_ID 11:8, SH_ID 12, SE_ID 15:13) below
+#define CH_WHERE() do { if (dbg && threadIdx.x == 0) { unsigned xcc_, hw_;                                              \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc_), "=s"(hw_));  \
+        g_chain_t[r_dbg][7] = ((unsigned long long)(xcc_ & 15u) << 32) | hw_ | (1ull << 48); } } while (0)
 extern "C" int cv2_debug_chain(unsigned long long* out_host) {
     CV2_HIP(hipDeviceSynchronize());
     CV2_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_chain_t), sizeof(unsigned long long) * 1024 * 8));
@@ -715,6 +719,7 @@ extern "C" int cv2_debug_chain(unsigned long long* out_host) {
 }
 #else
 #define CH_T(i) do { } while (0)
+#define CH_WHERE() do { } while (0)
 #endif
 
 // Attention of one 128-key tile for the rep query heads of kv head g over the keys ALREADY in the cache (positions < pos): eight waves
@@ -962,6 +967,7 @@ __global__ __launch_bounds__(R1_THREADS) void k_step(StepArgs a) {
     const bool dbg = layer == a.dbg_layer;
     const int r_dbg = r, od = dbg ? r : -1; (void)r_dbg; (void)dbg;
     CH_T(0);
+    CH_WHERE();
     Gran G;
     G.init(a.gran, a.gran_bytes, *a.epoch, a.err, MULTI && a.spec != 0);
     const unsigned gl = (unsigned)min(layer, a.n_layers - 1) * a.gl;        // this layer's granules (head: the last layer's)

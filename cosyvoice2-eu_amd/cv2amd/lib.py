@@ -63,6 +63,7 @@ def lib():
         L.cv2_llm_debug_skip_publish.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.cv2_llm_debug_sample.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.cv2_flow_debug_attn_dma.argtypes = [C.c_int32]
+        L.cv2_flow_debug_graph.argtypes = [C.c_int32]
         L.cv2_hift_debug_modes.argtypes = [C.c_int32, C.c_int32]
         L.cv2_hift_debug_precision.argtypes = [C.c_int32]
         L.cv2_hift_debug_f0.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
@@ -95,6 +96,6 @@ def ptr(t):
 
 EXPORTS = ['cv2_last_error', 'cv2_version', 'cv2_llm_workspace_bytes', 'cv2_llm_create', 'cv2_llm_destroy',
            'cv2_llm_prefill', 'cv2_llm_prefill_batch', 'cv2_llm_extend', 'cv2_llm_extend_batch', 'cv2_llm_decode', 'cv2_llm_decode_ex', 'cv2_llm_decode_rows', 'cv2_llm_one_launch_step', 'cv2_llm_debug_ptrs', 'cv2_llm_debug_skip_publish', 'cv2_llm_debug_sample', 'cv2_skinny_gemm', 'cv2_gemm_bf16',
-           'cv2_flow_workspace_bytes', 'cv2_flow_create', 'cv2_flow_destroy', 'cv2_flow_inference', 'cv2_flow_inference_chunk', 'cv2_flow_cache_bytes', 'cv2_flow_cache_copy', 'cv2_flow_debug_attn_dma', 'cv2_flow_estimator',
+           'cv2_flow_workspace_bytes', 'cv2_flow_create', 'cv2_flow_destroy', 'cv2_flow_inference', 'cv2_flow_inference_chunk', 'cv2_flow_cache_bytes', 'cv2_flow_cache_copy', 'cv2_flow_debug_attn_dma', 'cv2_flow_debug_graph', 'cv2_flow_estimator',
            'cv2_flow_encoder', 'cv2_hift_workspace_bytes', 'cv2_hift_create', 'cv2_hift_destroy', 'cv2_hift_inference', 'cv2_hift_inference_batch', 'cv2_hift_debug_modes', 'cv2_hift_debug_precision', 'cv2_hift_debug_f0',
            'cv2_fade_in_out', 'cv2_interp_linear', 'cv2_melspec', 'cv2_resample', 'cv2_framefeat', 'cv2_whisper_post', 'cv2_sub_col_mean', 'cv2_dbg_act', 'cv2_dbg_pre']

@@ -299,6 +299,10 @@ int cv2_flow_cache_copy(const cv2_flow* h, const void* src, int32_t src_frames, 
  * the two forms agree to fp32 round-off, 3-4e-3 of the mel range after the 10 Euler steps, NOT bit for bit; batches of >= 4096 rows
  * therefore differ from the same utterances run alone by that margin), -1 = the default. */
 int cv2_flow_debug_attn_dma(int32_t on);
+/* Test hook: 1 = cv2_flow_inference captures the launches of a call into a hipGraph at the second use of a shape (token / prompt lengths, flags)
+ * and replays it from then on (bit-identical results; CV2_FLOW_GRAPH=1), 0 = always the launches, -1 = the environment (default off: measured
+ * 0.4 ms slower per configs[1] utterance, profiles/r6_flow_graph_ab.txt). */
+int cv2_flow_debug_graph(int32_t on);
 
 /* The estimator alone behind the reference's TensorRT seam (flow_matching.py:125-150): six contiguous device
  * tensors x(2,80,T) mask(2,1,T) mu(2,80,T) t(2,) spks(2,80) cond(2,80,T), result written in place into x. */

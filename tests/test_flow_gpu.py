@@ -141,6 +141,39 @@ def test_ragged_batch_equals_single(eng):
         assert torch.equal(s, b)
 
 
+def test_repeated_shapes_replay_one_graph_bit_identically(eng):
+    """cv2_flow_inference captures a call's launches into a hipGraph at the second use of a shape and replays it from then on (flow.hip,
+    `launches` / FlowGraph): first call = the launches, second = capture + replay, third and fourth = replays -- with DIFFERENT inputs of
+    the same shape (the callers' pointers travel through device tables, not through kernel arguments) and the results of a batch and of a
+    single utterance.  Every replay must equal the direct launches bit for bit."""
+    from cv2amd import synth
+
+    def utt(seed, p, n):
+        inp = synth.synthetic_inputs(seed=seed, prompt_len=p)
+        g = torch.Generator().manual_seed(seed)
+        return dict(token=torch.randint(0, 6561, (1, n), generator=g, dtype=torch.int32), prompt_token=inp['prompt_token'],
+                    prompt_feat=inp['prompt_feat'], embedding=inp['embedding'])
+    from cv2amd import lib as L
+    a, b = utt(301, 21, 47), utt(302, 21, 47)                       # same shape, different content
+    L.check(L.lib().cv2_flow_debug_graph(1))                        # (off by default: CV2_FLOW_GRAPH=1; measured slower, profiles/r6_flow_graph_ab.txt)
+    try:
+        outs = [eng.inference_batch([x])[0].clone() for x in (a, b, a, b, a)]
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[4]) and torch.equal(outs[1], outs[3])
+        assert not torch.equal(outs[0], outs[1])
+        pair = [utt(303, 9, 60), utt(304, 30, 22)]
+        first = [o.clone() for o in eng.inference_batch(pair)]
+        again = [[o.clone() for o in eng.inference_batch(pair)] for _ in range(3)]
+        torch.cuda.synchronize()
+        for r in again:
+            assert torch.equal(r[0], first[0]) and torch.equal(r[1], first[1])
+        assert torch.equal(eng.inference_batch([a])[0], outs[0])     # the single-utterance graph is still there and still right
+        L.check(L.lib().cv2_flow_debug_graph(0))
+        assert torch.equal(eng.inference_batch([a])[0], outs[0])     # ... and equals the plain launches
+    finally:
+        L.check(L.lib().cv2_flow_debug_graph(-1))
+
+
 def test_large_batch_tile_configurations_agree_with_single(dev, flow_sd):
     """Eight ~10 s utterances packed together select the large-grid kernels (k_gemm<64,256,2,4>, <128,128,2,4>, k_attn_est<2,4>);
     one utterance alone runs on the row-panel GEMM, the 64x128 tiles and the key-split attention that the golden-vector tests

@@ -13,11 +13,12 @@
 #include <vector>
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-#define NH 8                                   // hops per layer at most (Args::nh are used)
+#define NH 12                                  // hops per layer at most (Args::nh are used)
 #define THREADS 512
+#define WMAX 32                                // 16-byte weight loads per thread at most
 struct Hop { int nb; int rd_bytes; int rd_whole; int wr_total; int w_bytes; };   // blocks; operand bytes per block (whole prev buffer or own slice); bytes of this hop's output; weight bytes per block
 struct Args {
-    Hop hop[NH]; int nh; int per_layer; int layers;
+    Hop hop[NH]; int nh; int per_layer; int layers; int dep;      // dep: a hop's producer is the hop `dep` places earlier (2: two row chains interleaved)
     float* out[NH]; int out_stride[NH];       // per layer (floats)
     unsigned* flags; int flag_off[NH];        // [layer][sum nb]
     const f32x4* w; unsigned epoch; unsigned* err; float* sink; int single_hop; int single_layer;
@@ -39,13 +40,13 @@ __global__ __launch_bounds__(THREADS) void k_rows(Args a) {
     } else { l = a.single_layer; h = a.single_hop; i = blockIdx.x; }
     const Hop H = a.hop[h];
     const int gidx = l * a.per_layer + a.flag_off[h] + i;                        // the block's index in dependency order (= blockIdx.x of the one-launch form)
-    const int ph = h == 0 ? a.nh - 1 : h - 1, pl = h == 0 ? l - 1 : l;              // producer hop / layer
+    const int ph = h < a.dep ? a.nh - a.dep + h : h - a.dep, pl = h < a.dep ? l - 1 : l;      // producer hop / layer
     // ---- weights first
     f32x4 wr[8];
     float wsum = 0.f;
     const int wl = WEIGHTS ? H.w_bytes / (THREADS * 16) : 0;                     // 16-byte loads per thread (<= 16: two batches of 8)
     if (WEIGHTS) {
-        const f32x4* wp = a.w + ((size_t)gidx * 16) * THREADS + tid;
+        const f32x4* wp = a.w + ((size_t)gidx * WMAX) * THREADS + tid;
 #pragma unroll
         for (int k = 0; k < 8; k++) wr[k] = k < wl ? __builtin_nontemporal_load(wp + (size_t)k * THREADS) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -104,10 +105,10 @@ __global__ __launch_bounds__(THREADS) void k_rows(Args a) {
     if (WEIGHTS) {
 #pragma unroll
         for (int k = 0; k < 8; k++) wsum += wr[k][0] + wr[k][3];
-        if (wl > 8) {
-            const f32x4* wp = a.w + ((size_t)gidx * 16 + 8) * THREADS + tid;
+        for (int b = 8; b < wl; b += 8) {              // further batches of 8 (rows16 tables: up to 28 loads per thread)
+            const f32x4* wp = a.w + ((size_t)gidx * WMAX + b) * THREADS + tid;
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const f32x4 v = k + 8 < wl ? __builtin_nontemporal_load(wp + (size_t)k * THREADS) : (f32x4){0.f, 0.f, 0.f, 0.f}; wsum += v[0] + v[3]; }
+            for (int k = 0; k < 8; k++) { const f32x4 v = k + b < wl ? __builtin_nontemporal_load(wp + (size_t)k * THREADS) : (f32x4){0.f, 0.f, 0.f, 0.f}; wsum += v[0] + v[3]; }
         }
     }
     // ---- this block's slice of the hop's output
@@ -133,10 +134,10 @@ __global__ __launch_bounds__(THREADS) void k_rows(Args a) {
     }
 }
 
-static int run_table(const char* title, const Hop* hops, int nh) {
+static int run_table(const char* title, const Hop* hops, int nh, int dep = 1) {
     const int LAYERS = 24;
     Args a{};
-    a.nh = nh;
+    a.nh = nh; a.dep = dep;
     int per = 0;
     for (int h = 0; h < nh; h++) { a.hop[h] = hops[h]; a.flag_off[h] = per; per += hops[h].nb; }
     a.per_layer = per; a.layers = LAYERS;
@@ -148,7 +149,7 @@ static int run_table(const char* title, const Hop* hops, int nh) {
         CK(hipMemset(a.out[h], 0, (size_t)LAYERS * a.hop[h].wr_total));
     }
     for (int h = 0; h < nh; h++) {                    // operands never exceed what the producer hop wrote
-        const int ph = h == 0 ? nh - 1 : h - 1;
+        const int ph = h < dep ? nh - dep + h : h - dep;
         if (a.hop[h].rd_bytes > a.hop[ph].wr_total) a.hop[h].rd_bytes = a.hop[ph].wr_total;
         a.hop[h].rd_bytes &= ~15;
     }
@@ -156,7 +157,7 @@ static int run_table(const char* title, const Hop* hops, int nh) {
     CK(hipMemset(a.flags, 0, (size_t)LAYERS * per * 4));
     CK(hipMalloc(&a.err, 4)); CK(hipMemset(a.err, 0, 4));
     CK(hipMalloc(&a.sink, 4));
-    const size_t wbytes = (size_t)LAYERS * per * 16 * THREADS * 16;
+    const size_t wbytes = (size_t)LAYERS * per * WMAX * THREADS * 16;
     f32x4* w; CK(hipMalloc(&w, wbytes)); CK(hipMemset(w, 0, wbytes));
     a.w = w;
     long wsum = 0, rsum = 0;
@@ -204,7 +205,44 @@ static int run_table(const char* title, const Hop* hops, int nh) {
     return 0;
 }
 
-int main() {
+// Round 6 (the round-5 review's direction): 16 rows per chain -- the rows are the 16 columns of v_mfma_f32_16x16x32_bf16's B operand, every
+// weight fragment is used by 16 rows --, two chains for 32 rows interleaved hop by hop in the grid (dep = 2: chain B's hop runs while chain
+// A's next hop waits), FIVE hops per chain and layer (Q, A, O, gate/up, down: the folds and norms move into the consumers' operand loads, no
+// prep / combine hops), operands as plain hi / lo bf16 planes by 16-byte loads, one flag per producer block.  Volumes per 16-row chain:
+// x planes 57 KB; attention partials of 16 rows 115 KB (read whole by each O block: the combine is redone per block); h planes 311 KB.
+static int rows16() {
+    const int R = 16, Hd = 896, I = 4864;
+    const int xb = R * Hd * 4;
+    // (a) down K-split two ways (k_step's form): the next Q folds two partial sets + the residual = 3 x 57 KB per block
+    const Hop c5[5] = {
+        {36, 3 * xb, 1, R * 1152 * 4, 57344},         // Q: fold(2 partial sets + residual) -> norm -> QKV
+        {64, 4608, 0, 2 * xb, 65536},                 // A: (row, kv head, 2 tiles); K / V tile as the "weights"; (o, max, sum) partials
+        {56, 2 * xb, 1, xb, 28672},                   // O: combine of the 16 rows' partials inside the operand load -> O projection
+        {152, xb, 1, R * I * 4, 114688},              // GU
+        {112, R * I * 4 / 2, 0, 3 * xb, 77824},       // D: 56 tiles x 2 K halves -> two partial sets (+ the residual rows the O role wrote)
+    };
+    Hop two[10];
+    for (int h = 0; h < 5; h++) two[2 * h] = two[2 * h + 1] = c5[h];
+    if (run_table("rows16 (a): two 16-row chains interleaved, 5 hops each, down K-split x 2, consumers fold", two, 10, 2)) return 1;
+    if (run_table("rows16 (a) as ONE 16-row chain alone (a 9..16-row step)", c5, 5, 1)) return 1;
+    // (b) down unsplit (56 blocks ingest the whole 311 KB of h planes and 155 KB of weights each): Q reads one folded set
+    Hop c5b[5];
+    for (int h = 0; h < 5; h++) c5b[h] = c5[h];
+    c5b[0] = Hop{36, xb, 1, R * 1152 * 4, 57344};
+    c5b[4] = Hop{56, R * I * 4, 1, xb, 155648};
+    for (int h = 0; h < 5; h++) two[2 * h] = two[2 * h + 1] = c5b[h];
+    if (run_table("rows16 (b): the same with down unsplit (56 blocks x 311 KB of h planes), Q reads one folded set", two, 10, 2)) return 1;
+    // (c) as (a) with gate/up as 76 blocks of 128 features (half the operand reads of the largest hop)
+    Hop c5c[5];
+    for (int h = 0; h < 5; h++) c5c[h] = c5[h];
+    c5c[3] = Hop{76, xb, 1, R * I * 4, 229376};
+    for (int h = 0; h < 5; h++) two[2 * h] = two[2 * h + 1] = c5c[h];
+    if (run_table("rows16 (c): as (a) with gate/up as 76 blocks of 128 features", two, 10, 2)) return 1;
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'r') return rows16();      // ./rowchain rows16
     const int R = 32, Hd = 896, I = 4864;
     const int xb = R * Hd * 4;                          // one activation vector set as hi / lo bf16 planes (or fp32): 114 688 B
     // hop: blocks, operand bytes per block, whole?, output bytes, weight bytes per block
