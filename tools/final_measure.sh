@@ -2,7 +2,7 @@
 # the row sweep, then the default bench line (with its extras; it reads the PMC files just collected) and the B=32 line
 R=$GRAFT_REPO_ROOT
 for s in decode hift flow; do bash tools/pmc_stages.sh $s $([ $s = decode ] && echo 1 || echo 3) > gpurun_out/final_pmc_$s.txt 2>&1; done
-cp gpurun_out/r5_pmc_decode.json gpurun_out/r5_pmc_hift.json gpurun_out/r5_pmc_flow.json profiles/ 2>/dev/null
+cp gpurun_out/r6_pmc_decode.json gpurun_out/r6_pmc_hift.json gpurun_out/r6_pmc_flow.json profiles/ 2>/dev/null
 bash tools/prof_b1.sh > gpurun_out/final_prof_b1.txt 2>&1
 bash tools/prof_b32.sh > gpurun_out/final_prof_b32.txt 2>&1
 cd $R
