@@ -15,8 +15,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 #define NH 12                                  // hops per layer at most (Args::nh are used)
 #define THREADS 512
-#define WMAX 32                                // 16-byte weight loads per thread at most
-struct Hop { int nb; int rd_bytes; int rd_whole; int wr_total; int w_bytes; };   // blocks; operand bytes per block (whole prev buffer or own slice); bytes of this hop's output; weight bytes per block
+#ifndef WMAX
+#define WMAX 32                                // 16-byte weight loads per thread at most (the estimator table: -DWMAX=96)
+#endif
+struct Hop { int nb; int rd_bytes; int rd_whole; int wr_total; int w_bytes; int share; };   // share: consecutive blocks that read the SAME slice (0 / 1: every block its own)   // blocks; operand bytes per block (whole prev buffer or own slice); bytes of this hop's output; weight bytes per block
 struct Args {
     Hop hop[NH]; int nh; int per_layer; int layers; int dep;      // dep: a hop's producer is the hop `dep` places earlier (2: two row chains interleaved)
     float* out[NH]; int out_stride[NH];       // per layer (floats)
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(THREADS) void k_rows(Args a) {
     if (pl >= 0) {
         const float* src = a.out[ph] + (size_t)pl * a.out_stride[ph];
         const int total = a.hop[ph].wr_total;
-        long off = H.rd_whole ? 0 : ((long)i * H.rd_bytes) % (total - H.rd_bytes + 16);
+        long off = H.rd_whole ? 0 : ((long)(i / (H.share > 1 ? H.share : 1)) * H.rd_bytes) % (total - H.rd_bytes + 16);
         off &= ~15l;
         const f32x4* p = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src) + off);
         const int n16 = H.rd_bytes / 16;
@@ -241,8 +243,24 @@ static int rows16() {
     return 0;
 }
 
+// Round 6: the flow estimator's transformer block at ONE utterance (M = 2 048 packed rows: the CFG pair of a 10 s utterance) as a chain of
+// its three launches -- QKV projection (k_gemm 64 x 128 tiles: 384 blocks, 32 KB of x rows + 64 KB of weights each, 6 MB of q / k / v^T out),
+// attention (k_attn_est_dma4: 256 blocks = 32 query tiles x 8 heads; the 32 blocks of a head read the same 258 KB of K / V^T), tail
+// (k_tail_panel<2>: 256 workgroups, 16 KB of attention rows + 0.77 MB of weights each) -- as ONE dependency-ordered launch (flags, write-through
+// stores, sc1 loads: what an in-launch hand-off of bulk data needs on per-XCD L2s that are not coherent with each other) against one launch
+// per hop (plain stores / loads: the consumers' re-reads are served by L2).  Build with -DWMAX=96 (the tail's 0.77 MB per workgroup).
+static int estimator() {
+    const Hop est[3] = {
+        {384, 32768, 0, 2048 * 1536 * 2, 65536, 12},          // QKV: the 12 column tiles of a 64-row tile read the same x rows
+        {256, 258560, 0, 2048 * 512 * 2, 0, 32},              // attention: the 32 query tiles of a (sequence, head) share its K / V^T
+        {256, 16384, 0, 2 * 2048 * 256 * 2, 786432, 2},       // tail: the two workgroups of a 16-row panel share its attention rows
+    };
+    return run_table("flow estimator, one utterance: transformer block = QKV -> attention -> tail (3 hops)", est, 3, 1);
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && argv[1][0] == 'r') return rows16();      // ./rowchain rows16
+    if (argc > 1 && argv[1][0] == 'e') return estimator();   // ./rowchain_est estimator   (built with -DWMAX=96)
     const int R = 32, Hd = 896, I = 4864;
     const int xb = R * Hd * 4;                          // one activation vector set as hi / lo bf16 planes (or fp32): 114 688 B
     // hop: blocks, operand bytes per block, whole?, output bytes, weight bytes per block
