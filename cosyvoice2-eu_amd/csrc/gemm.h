@@ -941,6 +941,15 @@ __device__ __forceinline__ void tr2_gemm(Tr2Ring& R, const s16x8* w0, const s16x
     bf16x8 af[2][4];
 #pragma unroll
     for (int rt = 0; rt < 4; rt++) af[0][rt] = *reinterpret_cast<const bf16x8*>(panel + (size_t)rt * 1024 + a_off);
+#ifdef TR2_DIAG_MFMA32
+    // TIMING-ONLY diagnostic (round 6, the round-5 review's item 4a; results are numerically meaningless): the k-step's eight
+    // v_mfma_f32_16x16x32_bf16 (each holds the SIMD's vector issue 8 of its 16 cycles) replaced by four v_mfma_f32_32x32x16_bf16 (8 of 32)
+    // on the SAME operand and accumulator registers -- same matrix-core time, same LDS / weight traffic, half the issue cycles taken from the
+    // GELU that rides beside them.  What the feed-forward phase would gain from 32 x 32 tiles, before any layout is rewritten.
+    f32x16 t32a, t32b;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { t32a[i] = acc[0][i >> 2][i & 3]; t32b[i] = acc[1][i >> 2][i & 3]; }
+#endif
 #pragma unroll
     for (int kb = 0; kb < NKS; kb++) {
         const int sl = (PH + kb) % TR2_CH;
@@ -950,6 +959,18 @@ __device__ __forceinline__ void tr2_gemm(Tr2Ring& R, const s16x8* w0, const s16x
             for (int rt = 0; rt < 4; rt++) af[(kb + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(panel + (size_t)((kb + 1) * 4 + rt) * 1024 + a_off);
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef TR2_DIAG_MFMA32
+        t32a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, af[kb & 1][0], t32a, 0, 0, 0);
+        t32b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, af[kb & 1][1], t32b, 0, 0, 0);
+        t32a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, af[kb & 1][2], t32a, 0, 0, 0);
+        t32b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, af[kb & 1][3], t32b, 0, 0, 0);
+        side(kb);
+        asm volatile("" : "+v"(t32a), "+v"(t32b));
+        if (kb + TR2_CH < NKS) { R.r0[sl] = tr2_ld(w0, kb + TR2_CH, lane16); R.r1[sl] = tr2_ld(w1, kb + TR2_CH, lane16); }
+        else if (NNKS > 0 && kb + TR2_CH - NKS < NNKS) { R.r0[sl] = tr2_ld(nw0, kb + TR2_CH - NKS, lane16); R.r1[sl] = tr2_ld(nw1, kb + TR2_CH - NKS, lane16); }
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+#endif
 #pragma unroll
         for (int rt = 0; rt < 4; rt++) {
 #ifndef TR2_DIAG_NOMFMA
@@ -971,6 +992,10 @@ __device__ __forceinline__ void tr2_gemm(Tr2Ring& R, const s16x8* w0, const s16x
         else if (NNKS > 0 && kb + TR2_CH - NKS < NNKS) { R.r0[sl] = tr2_ld(nw0, kb + TR2_CH - NKS, lane16); R.r1[sl] = tr2_ld(nw1, kb + TR2_CH - NKS, lane16); }
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef TR2_DIAG_MFMA32
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc[0][i >> 2][i & 3] = t32a[i]; acc[1][i >> 2][i & 3] = t32b[i]; }
+#endif
 }
 template <bool QKV>
 __global__ __launch_bounds__(512) void k_tail_rows2(TailArgs a) {
