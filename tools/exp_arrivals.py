@@ -1,0 +1,46 @@
+"""Round 6 (ADVICE): the first-round hold under SUSTAINED arrivals.  The hold (cosyvoice/cli/model.py: a streaming call's first chunk waits for
+newcomers that are about to submit theirs, so that they share one chunk round) was tuned on bursts of 8 calls within 40 ms; a server sees calls
+arriving all the time.  Streaming calls arrive as a Poisson process (mean gap `gap_ms`, default 80 ms = ~8 concurrent streams) for `n` calls;
+time from each call's own start to its first chunk, per hold setting: off, the round-5 form (no window: every newcomer younger than 80 ms
+counts, cap 120 ms) and the round-6 default (only newcomers expected within 40 ms).   python tools/exp_arrivals.py [n] [gap_ms]"""
+import os, random, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cosyvoice2-eu_amd'))
+import torch
+import bench as B
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+gap = float(sys.argv[2]) if len(sys.argv) > 2 else 80.0
+dev = torch.device('cuda:0')
+model = B.build_model(dev, 32)
+sreq = B.request(1986, B.P_TOK, 12, dev)
+B.run_calls(model, [sreq] * 8, [None] * 8, stream=True)          # graphs, prompt cache
+B.run_calls(model, [sreq] * 8, [None] * 8, stream=True)
+for name, hold, window in (('hold off', 0.0, 40.0), ('hold 80 ms, no window (round 5)', 80.0, 1e6), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0),
+                           ('hold off', 0.0, 40.0), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0)):
+    model.first_round_hold_ms, model.first_round_hold_window_ms = hold, window
+    rng = random.Random(1986)
+    offs, t = [], 0.0
+    for _ in range(n):
+        t += rng.expovariate(1.0 / gap) * 1e-3
+        offs.append(t)
+    firsts, audio, errs = [None] * n, [0.0] * n, []
+    t_start = time.perf_counter()
+
+    def work(i):
+        try:
+            time.sleep(max(0.0, t_start + offs[i] - time.perf_counter()))
+            t_call = time.perf_counter()
+            for o in model.tts(**sreq, stream=True):
+                if firsts[i] is None:
+                    firsts[i] = time.perf_counter() - t_call
+                audio[i] += o['tts_speech'].shape[1] / 24000.0
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    [th.start() for th in ths]
+    [th.join() for th in ths]
+    wall = time.perf_counter() - t_start
+    assert not errs, errs[0]
+    f = sorted(x * 1e3 for x in firsts)
+    print(f'{name:38s}: {n} calls, mean gap {gap:.0f} ms: first chunk p50 {f[n // 2]:6.1f}  p90 {f[int(0.9 * n)]:6.1f}  max {f[-1]:6.1f} ms; '
+          f'{sum(audio) / wall:6.1f} audio-s/s over {wall:.1f} s', flush=True)
