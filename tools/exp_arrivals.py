@@ -8,13 +8,41 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cosyvoice2-eu_amd'))
 import torch
 import bench as B
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-gap = float(sys.argv[2]) if len(sys.argv) > 2 else 80.0
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+n = int(args[0]) if len(args) > 0 else 60
+gap = float(args[1]) if len(args) > 1 else 80.0
 dev = torch.device('cuda:0')
 model = B.build_model(dev, 32)
 sreq = B.request(1986, B.P_TOK, 12, dev)
 B.run_calls(model, [sreq] * 8, [None] * 8, stream=True)          # graphs, prompt cache
 B.run_calls(model, [sreq] * 8, [None] * 8, stream=True)
+if '--trace' in sys.argv:       # the scheduler's log between one steady-state newcomer's call and its first chunk (default hold), two newcomers
+    rng = random.Random(7)
+    offs, t = [], 0.0
+    for _ in range(n):
+        t += rng.expovariate(1.0 / gap) * 1e-3
+        offs.append(t)
+    calls, firsts_t = [None] * n, [None] * n
+    model._sched_log = []
+    t_start = time.perf_counter()
+
+    def twork(i):
+        time.sleep(max(0.0, t_start + offs[i] - time.perf_counter()))
+        calls[i] = time.perf_counter()
+        for o in model.tts(**sreq, stream=True):
+            if firsts_t[i] is None:
+                firsts_t[i] = time.perf_counter()
+    ths = [threading.Thread(target=twork, args=(i,)) for i in range(n)]
+    [th.start() for th in ths]
+    [th.join() for th in ths]
+    log, model._sched_log = sorted(model._sched_log, key=lambda e: e[0]), None
+    for i in (n // 2, n // 2 + 3):
+        print(f'--- call {i}: first chunk after {(firsts_t[i] - calls[i]) * 1e3:.1f} ms; running streams at its start: '
+              f'{sum(1 for j in range(n) if calls[j] is not None and calls[j] < calls[i] and firsts_t[j] is not None)} started before it')
+        for tt, kind, info in log:
+            if calls[i] - 0.002 <= tt <= firsts_t[i] + 0.002:
+                print(f'{(tt - calls[i]) * 1e3:8.2f} ms  {kind:7s} {info}')
+    sys.exit(0)
 for name, hold, window in (('hold off', 0.0, 40.0), ('hold 80 ms, no window (round 5)', 80.0, 1e6), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0),
                            ('hold off', 0.0, 40.0), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0)):
     model.first_round_hold_ms, model.first_round_hold_window_ms = hold, window
