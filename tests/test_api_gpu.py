@@ -54,6 +54,33 @@ def test_instruct2_runs_without_llm_prompt_tokens(cv):
     assert len(cl) == 1 and len(zs) == 1
 
 
+def test_inference_sft_uses_the_stored_embedding_and_no_prompt(cv):
+    """cli/cosyvoice.py:81-90 + frontend.py:485-489: `inference_sft` feeds tts() with the text and the speaker's stored embedding only -- no
+    prompt text, no prompt speech tokens, an EMPTY flow prompt (the defaults of CosyVoice2Model.tts).  The LLM then sees what cross-lingual
+    sees; the token count must be the oracle's, the flow and the vocoder run on a sequence without prompt frames.  An unknown speaker id is
+    the reference's KeyError (a CosyVoice2 model dir ships no spk2info)."""
+    from cv2amd import synth, weights as W
+    from oracle import llm as OL
+    inp = synth.synthetic_inputs(prompt_len=37, prompt_text_len=4)
+    cv.frontend.spk2info['sft_spk'] = {'embedding': inp['embedding']}
+    try:
+        out = list(cv.inference_sft('bonjour', 'sft_spk', stream=False))
+        assert len(out) == 1
+        wav = out[0]['tts_speech']
+        assert wav.dtype == torch.float32 and wav.device.type == 'cpu' and torch.isfinite(wav).all() and wav.abs().max() <= 0.99
+        e0 = torch.zeros(1, 0, dtype=torch.int32)
+        text = torch.tensor([TEXT_IDS['bonjour']], dtype=torch.int32)
+        want = OL.inference(W.round_llm_sd(synth.make_llm(layers=2)), text, e0, e0)
+        assert wav.shape[1] == 960 * len(want), (wav.shape, len(want))           # 2 mel frames x 480 samples per token, no prompt frames dropped
+        chunks = list(cv.inference_sft('bonjour', 'sft_spk', stream=True))
+        assert sum(c['tts_speech'].shape[1] for c in chunks) == wav.shape[1]
+        with pytest.raises(KeyError):
+            list(cv.inference_sft('bonjour', 'nobody'))
+    finally:
+        cv.frontend.spk2info.pop('sft_spk', None)
+    assert cv.model.tts_speech_token_dict == {} and cv.model.hift_cache_dict == {}
+
+
 def test_streaming_scheduler_matches_reference_logic(cv):
     """Chunking / caches / cross-fade of model.py:300-381 restated on the CPU oracle, fed with the SAME flow mels and the same
     injected noise the device run used: waveform chunks must agree to 1e-3; the flow mels themselves are checked against the
