@@ -114,6 +114,22 @@ class CosyVoice2Model:
         # Under sustained arrivals (there is always a newcomer) a first chunk then pays at most the window, not the cap, for lock-step
         self.first_round_hold_window_ms = float(os.environ.get('CV2_FIRST_ROUND_HOLD_WINDOW_MS', '40'))
         self._first_pending = {}               # uuid -> time of the call, until its first chunk is submitted
+        # Newcomers beside a chunk round (round 6; CV2_NEWCOMER_BESIDE=0 turns it off).  ONE lock (run_lock) serialises device control and
+        # a chunk round holds it from its first launch to its last device-to-host copy (40-125 ms with 8-13 chunks): a call that arrives
+        # meanwhile used to wait for the round before its prefill could even be enqueued, and the LLM stream idled for most of the round
+        # (profiles/r6_arrivals.txt: prefill at +95 ms, first chunk at +306 ms with 12 streams running).  Now (a) a tensor-text call is
+        # prefilled at once on the LLM stream whatever holds run_lock (its own small lock, as the bistream hub does), and while a round is
+        # in progress its thread keeps enqueuing the decode steps of its first chunk in short shared bursts; (b) a round's leader tops up
+        # the first-chunk tokens of the newcomers already prefilled before it launches the round's flow; (c) CV2_FIRST_CHUNK_LANE: first
+        # chunks go in a round of their own ahead of later chunks (which have ~1 s of audio in their listener's buffer).  Measured
+        # (profiles/r6_arrivals.txt, r6_beside_bench.txt): Poisson arrivals at half load first chunk p50 193 -> 167 ms, p90 265 -> 218; at
+        # capacity 350-456 -> 279 ms with the same or better throughput; 8 calls 0-40 ms apart p50 130 -> 121, max 162 -> 143 ms; the
+        # lock-step legs (8 calls at once, generator text, batches) unchanged.  Tokens never depend on any of this (tests).
+        self.newcomer_beside = os.environ.get('CV2_NEWCOMER_BESIDE', '1') != '0'
+        self.first_chunk_lane = os.environ.get('CV2_FIRST_CHUNK_LANE', '1') != '0'
+        self._prefill_lock = threading.Lock()  # one thread at a time drains _prefill_q (taken inside run_lock by the ordinary path, alone beside a round)
+        self._adv_lock = threading.Lock()      # _llm_advance's bookkeeping (it used to rely on run_lock alone)
+        self._first_need = {}                  # slot -> tokens the call's first chunk needs, until that chunk is submitted
         self._chunks_active = 0                # chunk rounds (flow + HiFT) in progress: decode bursts beside them take the launches
         self._bi_incoming = 0                  # generator-text calls that have entered tts() but not yet joined the hub
         self._sched_log = None                 # diagnostics (tools/bench_bistream.py): list receiving (t, kind, info) of hub / chunk rounds
@@ -420,7 +436,7 @@ class CosyVoice2Model:
         self._pin_rr = (self._pin_rr + 1) % len(self.hift_pool.engines)
         return self._pin_rr
 
-    def _chunk_submit(self, token, fpt, feat, femb, offset, this_uuid, stream, finalize, cap_hint=None, pkey=None):
+    def _chunk_submit(self, token, fpt, feat, femb, offset, this_uuid, stream, finalize, cap_hint=None, pkey=None, first_slot=None):
         """token2wav for one chunk of a streaming call.  The chunk is queued; whoever gets the device next runs the flow over ALL
         queued chunks as one ragged batch (streams that share decode steps become ready together), then HiFT per chunk."""
         c = self._Chunk()
@@ -433,6 +449,8 @@ class CosyVoice2Model:
         if stream and not finalize and offset == 0:
             with self.lock:
                 t_call = self._first_pending.pop(this_uuid, None)
+                if first_slot is not None:
+                    self._first_need.pop(first_slot, None)
             hold = self.first_round_hold_ms * 1e-3
             if hold > 0:
                 t_sub, held = time.perf_counter(), False
@@ -466,13 +484,27 @@ class CosyVoice2Model:
                     break
                 time.sleep(0.0001)
         with self.run_lock:
-            if not c.done:
+            while not c.done:                                                 # (one round; two when the first-chunk lane ran first without c)
                 with self.lock:
                     batch = self._chunk_q[:self.max_batch]
-                    del self._chunk_q[:len(batch)]
+                    if self.first_chunk_lane and len(batch) > 1:
+                        # first chunks in a round of their own AHEAD of the others: a later chunk of a stream has ~1 s of audio in its
+                        # listener's buffer, a first chunk is what the caller is waiting for (profiles/r6_arrivals.txt: a newcomer's
+                        # first chunk used to ride a round of 10-11 chunks, 85-125 ms)
+                        lane = [b for b in batch if b.stream and not b.finalize and b.offset == 0]
+                        if lane and len(lane) < len(batch):
+                            batch = lane
                     for b in batch:
+                        self._chunk_q.remove(b)
                         b.taken = True
+                if not batch:                                                 # (cannot happen while c is queued; never spin on an empty queue)
+                    break
                 t0 = time.perf_counter()
+                if self.newcomer_beside and self._first_need:                 # (b) newcomers already prefilled: their first chunk's tokens run
+                    with self.lock:                                           # on the LLM stream beside this round instead of after it
+                        short = [n - self._enq[sl] for sl, n in self._first_need.items() if sl in self._enq and sl not in self._joining]
+                    if short and max(short) > 0:
+                        self._llm_advance(min(max(short), 2 * self.token_hop_len), shared=True)
                 self._chunks_active += 1
                 try:
                     self._run_chunks(batch)
@@ -533,7 +565,21 @@ class CosyVoice2Model:
         p.slot, p.text, p.prompt_text, p.ptok, p.done, p.exc, p.force_len = slot, text, prompt_text, llm_prompt_speech_token, False, None, force_len
         with self.lock:
             self._prefill_q.append(p)
-        with self.run_lock:
+        if self.newcomer_beside:
+            # never behind a chunk round: the prefill goes on the LLM stream at once (run_lock is a ticket lock -- a thread that queues for it
+            # an instant before a round's leader waits the whole round), then the first chunk's decode steps keep coming while a round lasts
+            self._prefill_drain(p)
+            if p.exc is None:
+                self._first_tokens_beside(slot)
+        else:
+            with self.run_lock:
+                self._prefill_drain(p)
+        if p.exc is not None:
+            raise p.exc
+
+    def _prefill_drain(self, p):
+        """One batched prefill for every queued request (p among them), unless another thread has served p meanwhile."""
+        with self._prefill_lock:
             if not p.done:
                 # calls that have taken a slot but not queued their prompt yet (they are copying their inputs) join this prefill: one that
                 # misses it by a millisecond waits for the whole prefill + the bursts behind it (trace of 8 staggered calls: 26 ms)
@@ -565,23 +611,41 @@ class CosyVoice2Model:
                         self._slot_ready[b.slot], self._enq[b.slot] = ev, 1          # the prefill draws token 0
                         self._joining.discard(b.slot)
                     if self._sched_log is not None:
-                        self._sched_log.append((time.perf_counter(), 'prefill', dict(n=len(batch), rows=sum(x.shape[0] for x in xs))))
+                        self._sched_log.append((time.perf_counter(), 'prefill', dict(n=len(batch), rows=sum(x.shape[0] for x in xs),
+                                                                                       beside=self._chunks_active > 0)))
                 except BaseException as e:
                     for b in batch:
                         b.exc = e
                 finally:
                     for b in batch:
                         b.done = True
-        if p.exc is not None:
-            raise p.exc
 
-    # the helpers below run under self.run_lock
+    def _first_tokens_beside(self, slot):
+        """newcomer_beside (a): while a chunk round holds run_lock, enqueue the decode steps this slot's first chunk still needs, in bursts of
+        at most `open_burst` shared steps, waiting for each burst before the next so that the LLM stream stays short for the next newcomer's
+        prefill.  Every active slot advances with it (the running streams' next chunks need those tokens anyway).  Stops when the round is
+        over: the caller's ordinary loop (under run_lock) takes it from there."""
+        need = self._first_need.get(slot)
+        while need is not None and self._chunks_active > 0:
+            left = need - self._enq.get(slot, 0)
+            if left <= 0:
+                break
+            ev = self._llm_advance(min(left, self.open_burst), shared=True)
+            if ev is None:
+                break
+            ev.synchronize()
+
+    # the helpers below run under self.run_lock (newcomer_beside: _llm_advance also beside a chunk round, under its own lock)
     def _llm_advance(self, n_steps, shared=False):
         """n_steps decode steps for EVERY active slot (slots 0..highest active, parked slots in between idle; or the active slots only,
         see stream_live_rows), enqueued on the LLM stream; `_enq[slot]` = the tokens a live slot holds at most once everything enqueued so far has run.  shared: the burst runs
         beside a chunk's flow + HiFT on the other streams."""
         if n_steps <= 0:
-            return
+            return None
+        with self._adv_lock:
+            return self._llm_advance_locked(n_steps, shared or self._chunks_active > 0)
+
+    def _llm_advance_locked(self, n_steps, shared):
         with self._mode:
             act = sorted(self._active_slots)
             # a call that has taken its slot but is not prefilled yet (it started a moment after the others): its prefill queues on the
@@ -616,6 +680,7 @@ class CosyVoice2Model:
             self._enq[sl] = self._enq.get(sl, 0) + n_steps
         if self._sched_log is not None:
             self._sched_log.append((time.perf_counter(), 'burst', dict(rows=len(act), steps=n_steps, shared=bool(shared))))
+        return evs[-1] if evs else None
 
     def _llm_poll(self, this_uuid, slot, need=None):
         """Publish the tokens of the slot so far (the reference's thread appends to the same list).  need = None: wait for all the
@@ -632,7 +697,11 @@ class CosyVoice2Model:
             st, toks = self.llm.read_slot(slot)
             if need is None or len(toks) >= need or bool(st[L.ST_DONE]) or not self._bursts:
                 break
-            self._bursts.pop(0).synchronize()
+            try:
+                ev = self._bursts.pop(0)
+            except IndexError:                                                # (newcomer_beside: a pump emptied the list meanwhile)
+                continue
+            ev.synchronize()
         if not self._bursts:
             self._enq[slot] = len(toks)                                       # nothing in flight: the count is exact (ids above EOS are steps without a token)
         self.tts_speech_token_dict[this_uuid] = toks
@@ -1050,6 +1119,7 @@ class CosyVoice2Model:
                             float(flow_embedding.double().sum()))
                 with self.lock:
                     self._first_pending[this_uuid] = t_call
+                    self._first_need[slot] = hop + prompt_token_pad + la        # (model.py:353-357: what the first chunk waits for)
                 self._llm_start(slot, text_d, ptext_d, lptok_d, force_len)     # prefill draws token 0; the first pass of the loop below
                 while True:                                                    # requests the rest of the first chunk's tokens
                     this_tok, finished = None, False
@@ -1067,7 +1137,8 @@ class CosyVoice2Model:
                         else:
                             self._llm_advance(need - len(toks))                # nothing in flight any more (ids above EOS are steps without a token)
                     if this_tok is not None:
-                        speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, True, False, cap_hint, pkey)
+                        speech = self._chunk_submit(this_tok, fpt, feat, femb, token_offset, this_uuid, True, False, cap_hint, pkey,
+                                                    first_slot=slot if token_offset == 0 else None)
                         token_offset += this_token_hop_len
                         yield {'tts_speech': speech}
                     if finished:
@@ -1100,6 +1171,7 @@ class CosyVoice2Model:
                 self.llm_stream.synchronize()
             with self.lock:
                 self._first_pending.pop(this_uuid, None)
+                self._first_need.pop(slot, None)
             self._exit_shared(slot)
             with self.lock:
                 self.tts_speech_token_dict.pop(this_uuid, None)

@@ -622,8 +622,11 @@ def test_hub_mixed_calls_failing_text_and_abandoned_stream(dev):
     mdl._token_log, mdl._on_call = None, None
 
 
-def test_staggered_arrivals_over_many_rounds_every_call_gets_its_own_tokens(dev):
-    """The serving pattern the aligned-start tests do not exercise: calls arrive 0-40 ms apart (seeded offsets), over 8 rounds of 6
+@pytest.mark.parametrize('spread_ms,beside', [(40, True), (400, True), (400, False)])
+def test_staggered_arrivals_over_many_rounds_every_call_gets_its_own_tokens(dev, spread_ms, beside):
+    """(spread 400 ms: the arrivals fall INTO the earlier calls' chunk rounds; `beside` = CosyVoice2Model.newcomer_beside, round 6: such a
+    newcomer is prefilled and decodes its first tokens beside the round instead of behind it -- same tokens, same bookkeeping.)
+    The serving pattern the aligned-start tests do not exercise: calls arrive 0-40 ms apart (seeded offsets), over 8 rounds of 6
     calls on one model with 6 slots, so that a call joins while others are prefilling, decoding their first tokens, inside a chunk round
     or finishing (the first-round hold, the joining bursts and the hub's rounds all see newcomers).  Each round mixes tensor-text
     streams, generator-text (bistream) streams, one non-streaming call and one consumer that walks away after its first chunk.  Every
@@ -637,6 +640,7 @@ def test_staggered_arrivals_over_many_rounds_every_call_gets_its_own_tokens(dev)
     sd = _bistream_sd(2)
     sdr = W.round_llm_sd(sd)
     mdl = CosyVoice2Model(sd, synth.make_flow(), synth.make_hift(), max_batch=6, max_text=64, max_prompt_tokens=64, max_new_tokens=512, sampling='greedy')
+    mdl.newcomer_beside = mdl.first_chunk_lane = beside
     inp = synth.synthetic_inputs(seed=1, text_len=23, prompt_len=31, prompt_text_len=6)
     cuts = (0, 3, 10, 15, 23)
     pieces = [inp['text'][:, a:b] for a, b in zip(cuts[:-1], cuts[1:])]
@@ -649,7 +653,7 @@ def test_staggered_arrivals_over_many_rounds_every_call_gets_its_own_tokens(dev)
     for rnd in range(int(os.environ.get('CV2_SOAK_ROUNDS', '8'))):        # (a longer soak: CV2_SOAK_ROUNDS=100 pytest -k staggered_arrivals)
         order = kinds[:]
         rng.shuffle(order)
-        offs = [rng.uniform(0.0, 0.040) for _ in order]
+        offs = [rng.uniform(0.0, spread_ms * 1e-3) for _ in order]
         mdl._token_log = {}
         uuid_of, tl = {}, threading.local()
         mdl._on_call = lambda u: uuid_of.__setitem__(tl.i, u)
@@ -684,6 +688,7 @@ def test_staggered_arrivals_over_many_rounds_every_call_gets_its_own_tokens(dev)
                 assert res[i] == 960 * len(want_uni), f'round {rnd} call {i} ({k})'
         assert sorted(mdl._slot_free) == list(range(mdl.max_batch)) and not mdl._active_slots, f'round {rnd}: slots not released'
         assert not mdl.tts_speech_token_dict and not mdl.hift_cache_dict, f'round {rnd}: per-call state left behind'
+        assert not mdl._first_need and not mdl._first_pending, f'round {rnd}: newcomer bookkeeping left behind'
     mdl._token_log, mdl._on_call = None, None
 
 

@@ -23,6 +23,7 @@ if '--trace' in sys.argv:       # the scheduler's log between one steady-state n
         t += rng.expovariate(1.0 / gap) * 1e-3
         offs.append(t)
     calls, firsts_t = [None] * n, [None] * n
+    model.newcomer_beside = model.first_chunk_lane = '--beside' in sys.argv
     model._sched_log = []
     t_start = time.perf_counter()
 
@@ -43,9 +44,14 @@ if '--trace' in sys.argv:       # the scheduler's log between one steady-state n
             if calls[i] - 0.002 <= tt <= firsts_t[i] + 0.002:
                 print(f'{(tt - calls[i]) * 1e3:8.2f} ms  {kind:7s} {info}')
     sys.exit(0)
-for name, hold, window in (('hold off', 0.0, 40.0), ('hold 80 ms, no window (round 5)', 80.0, 1e6), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0),
-                           ('hold off', 0.0, 40.0), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0)):
+SETTINGS = (('hold off', 0.0, 40.0, False), ('hold 80 ms, no window (round 5)', 80.0, 1e6, False), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0, False),
+            ('hold off', 0.0, 40.0, False), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0, False))
+if '--beside' in sys.argv:      # CosyVoice2Model.newcomer_beside (a newcomer's prefill and first tokens beside the chunk round in progress) off / on
+    SETTINGS = (('default', 80.0, 40.0, 0), ('newcomer_beside', 80.0, 40.0, 1), ('newcomer_beside + first-chunk lane', 80.0, 40.0, 3),
+                ('default', 80.0, 40.0, 0), ('newcomer_beside', 80.0, 40.0, 1), ('newcomer_beside + first-chunk lane', 80.0, 40.0, 3))
+for name, hold, window, beside in SETTINGS:
     model.first_round_hold_ms, model.first_round_hold_window_ms = hold, window
+    model.newcomer_beside, model.first_chunk_lane = bool(int(beside) & 1), bool(int(beside) & 2)
     rng = random.Random(1986)
     offs, t = [], 0.0
     for _ in range(n):
