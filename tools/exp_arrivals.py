@@ -47,8 +47,8 @@ if '--trace' in sys.argv:       # the scheduler's log between one steady-state n
 SETTINGS = (('hold off', 0.0, 40.0, False), ('hold 80 ms, no window (round 5)', 80.0, 1e6, False), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0, False),
             ('hold off', 0.0, 40.0, False), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0, False))
 if '--beside' in sys.argv:      # CosyVoice2Model.newcomer_beside (a newcomer's prefill and first tokens beside the chunk round in progress) off / on
-    SETTINGS = (('default', 80.0, 40.0, 0), ('newcomer_beside', 80.0, 40.0, 1), ('newcomer_beside + first-chunk lane', 80.0, 40.0, 3),
-                ('default', 80.0, 40.0, 0), ('newcomer_beside', 80.0, 40.0, 1), ('newcomer_beside + first-chunk lane', 80.0, 40.0, 3))
+    SETTINGS = (('both switches off (rounds 1-5)', 80.0, 40.0, 0), ('newcomer_beside', 80.0, 40.0, 1), ('newcomer_beside + first-chunk lane', 80.0, 40.0, 3),
+                ('both switches off (rounds 1-5)', 80.0, 40.0, 0), ('newcomer_beside', 80.0, 40.0, 1), ('newcomer_beside + first-chunk lane', 80.0, 40.0, 3))
 for name, hold, window, beside in SETTINGS:
     model.first_round_hold_ms, model.first_round_hold_window_ms = hold, window
     model.newcomer_beside, model.first_chunk_lane = bool(int(beside) & 1), bool(int(beside) & 2)
