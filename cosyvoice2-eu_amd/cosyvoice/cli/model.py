@@ -127,6 +127,7 @@ class CosyVoice2Model:
         # lock-step legs (8 calls at once, generator text, batches) unchanged.  Tokens never depend on any of this (tests).
         self.newcomer_beside = os.environ.get('CV2_NEWCOMER_BESIDE', '1') != '0'
         self.first_chunk_lane = os.environ.get('CV2_FIRST_CHUNK_LANE', '1') != '0'
+        self.later_chunk_wait_ms = float(os.environ.get('CV2_LATER_CHUNK_WAIT_MS', '0'))       # (d) a later chunk gives way to a newcomer about to submit (see _chunk_submit)
         self._prefill_lock = threading.Lock()  # one thread at a time drains _prefill_q (taken inside run_lock by the ordinary path, alone beside a round)
         self._adv_lock = threading.Lock()      # _llm_advance's bookkeeping (it used to rely on run_lock alone)
         self._first_need = {}                  # slot -> tokens the call's first chunk needs, until that chunk is submitted
@@ -470,6 +471,22 @@ class CosyVoice2Model:
                     time.sleep(0.0002)
                 if held and self._sched_log is not None:
                     self._sched_log.append((time.perf_counter(), 'held', dict(ms=round((time.perf_counter() - t_sub) * 1e3, 1))))
+        if stream and not finalize and offset > 0 and self.later_chunk_wait_ms > 0 and self._first_need:
+            # a LATER chunk (its listener holds ~1 s of audio) gives way to a newcomer that is about to submit its FIRST chunk: when every decode
+            # step a newcomer's first chunk needs is already enqueued, its chunk arrives within one burst -- waiting for it (at most
+            # later_chunk_wait_ms) puts it into the round that is about to start (the first-chunk lane) instead of behind it
+            t_end = time.perf_counter() + self.later_chunk_wait_ms * 1e-3
+            waited = False
+            while not c.done and not c.taken and time.perf_counter() < t_end:
+                with self.lock:
+                    near = any(self._enq.get(sl, 0) >= n for sl, n in self._first_need.items() if sl not in self._joining)
+                    have_first = any(q.offset == 0 and q.stream and not q.finalize for q in self._chunk_q)
+                if not near or have_first:
+                    break
+                waited = True
+                time.sleep(0.0002)
+            if waited and self._sched_log is not None:
+                self._sched_log.append((time.perf_counter(), 'gaveway', dict(ms=round((time.perf_counter() - t_end) * 1e3 + self.later_chunk_wait_ms, 1))))
         n_streams = min(self._n_shared, self.max_batch)
         if n_streams > 1 and self.chunk_wave_ms > 0:
             t_last = time.perf_counter()

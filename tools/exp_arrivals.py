@@ -44,14 +44,17 @@ if '--trace' in sys.argv:       # the scheduler's log between one steady-state n
             if calls[i] - 0.002 <= tt <= firsts_t[i] + 0.002:
                 print(f'{(tt - calls[i]) * 1e3:8.2f} ms  {kind:7s} {info}')
     sys.exit(0)
-SETTINGS = (('hold off', 0.0, 40.0, False), ('hold 80 ms, no window (round 5)', 80.0, 1e6, False), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0, False),
-            ('hold off', 0.0, 40.0, False), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0, False))
+SETTINGS = (('hold off', 0.0, 40.0, 3), ('hold 80 ms, no window (round 5)', 80.0, 1e6, 3), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0, 3),
+            ('hold off', 0.0, 40.0, 3), ('hold 80 ms, window 40 ms (default)', 80.0, 40.0, 3))
 if '--beside' in sys.argv:      # CosyVoice2Model.newcomer_beside (a newcomer's prefill and first tokens beside the chunk round in progress) off / on
     SETTINGS = (('both switches off (rounds 1-5)', 80.0, 40.0, 0), ('newcomer_beside', 80.0, 40.0, 1), ('newcomer_beside + first-chunk lane', 80.0, 40.0, 3),
                 ('both switches off (rounds 1-5)', 80.0, 40.0, 0), ('newcomer_beside', 80.0, 40.0, 1), ('newcomer_beside + first-chunk lane', 80.0, 40.0, 3))
+if '--giveway' in sys.argv:     # (d) later chunks give way to a newcomer about to submit: off / 15 / 30 ms, on top of the defaults
+    SETTINGS = (('defaults', 80.0, 40.0, 3), ('+ later chunks give way 15 ms', 80.0, 40.0, 3 + 4 * 15), ('+ later chunks give way 30 ms', 80.0, 40.0, 3 + 4 * 30),
+                ('defaults', 80.0, 40.0, 3), ('+ later chunks give way 15 ms', 80.0, 40.0, 3 + 4 * 15), ('+ later chunks give way 30 ms', 80.0, 40.0, 3 + 4 * 30))
 for name, hold, window, beside in SETTINGS:
     model.first_round_hold_ms, model.first_round_hold_window_ms = hold, window
-    model.newcomer_beside, model.first_chunk_lane = bool(int(beside) & 1), bool(int(beside) & 2)
+    model.newcomer_beside, model.first_chunk_lane, model.later_chunk_wait_ms = bool(int(beside) & 1), bool(int(beside) & 2), float(int(beside) >> 2)
     rng = random.Random(1986)
     offs, t = [], 0.0
     for _ in range(n):
