@@ -2530,12 +2530,20 @@ static int run_layers_pre(cv2_llm* h, int rows, const float* xin, RowMap rm, hip
             a.sq = h->sqp2; a.nsq = ready ? H / 16 : 1; a.eps = d.rms_eps;     // the rows' sums of squares: the down projection's shares, or k_prep's total
             { const size_t sm = skinny_smem_bytes<2, 2, 4>(KSH); hipLaunchKernelGGL((k_qkv<2, true>), dim3(2 * (d.n_q + 2 * d.n_kv), 1), dim3(512), sm, s, a); }
         }
-        {   // attention; the last split of a (row, kv head) combines the splits and leaves the O projection's operand planes
+        // CV2_ATT_ONE_SPLIT=1 (round 6 experiment, A/B): ONE block of four 64-key tile groups per (row, kv head) walks all the keys and leaves
+        // the O projection's operand planes itself -- no key splits, no combine launch (k_prep<true>), 64 blocks instead of ~640 + 32
+        static const bool one_split = getenv("CV2_ATT_ONE_SPLIT") && getenv("CV2_ATT_ONE_SPLIT")[0] == '1';
+        if (one_split) {
+            const int kps = (d.max_pos + 255) / 256 * 256;
+            AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, 1, kps, rm, d.n_q / d.n_kv};
+            a.arrive = h->arrive_att; a.pre = h->xp;
+            hipLaunchKernelGGL(k_attn<4>, dim3(1, d.n_kv, rows), dim3(1024), 0, s, a);
+        } else {   // attention; the last split of a (row, kv head) combines the splits and leaves the O projection's operand planes
             AttnArgs a{h->q, h->kc + l * cache_l, h->vc + l * cache_l, h->att, h->att_ml, h->att_cnt, d.n_q, d.n_kv, d.max_pos, h->nsplit, h->keys_per_split, rm, d.n_q / d.n_kv};
             if (fuse) { a.arrive = h->arrive_att; a.pre = h->xp; }
             launch_attn(a, rows, s);
         }
-        if (!fuse) prep(SkinnyX{nullptr, h->att, h->nsplit, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt}, NQ, true);
+        if (!fuse && !one_split) prep(SkinnyX{nullptr, h->att, h->nsplit, nullptr, 0.f, nullptr, h->att_ml, h->att_cnt}, NQ, true);
         float* x2 = (x1 == h->xa) ? h->xb : h->xa;
         {   // O projection; its epilogue adds the residual and prepares the gate/up operand (no k_prep launch in between)
             StoreArgs a{};
