@@ -128,7 +128,7 @@ class CosyVoice2Model:
         self.newcomer_beside = os.environ.get('CV2_NEWCOMER_BESIDE', '1') != '0'
         self.first_chunk_lane = os.environ.get('CV2_FIRST_CHUNK_LANE', '1') != '0'
         self.later_chunk_wait_ms = float(os.environ.get('CV2_LATER_CHUNK_WAIT_MS', '0'))       # (d) a later chunk gives way to a newcomer about to submit (see _chunk_submit)
-        self._prefill_lock = threading.Lock()  # one thread at a time drains _prefill_q (taken inside run_lock by the ordinary path, alone beside a round)
+        self._prefill_lock = threading.Lock()  # one thread at a time drains _prefill_q (alone with newcomer_beside, inside run_lock without it)
         self._adv_lock = threading.Lock()      # _llm_advance's bookkeeping (it used to rely on run_lock alone)
         self._first_need = {}                  # slot -> tokens the call's first chunk needs, until that chunk is submitted
         self._chunks_active = 0                # chunk rounds (flow + HiFT) in progress: decode bursts beside them take the launches
